@@ -1,0 +1,308 @@
+"""CPU oracle for the kvpress score -> top-k -> gather hot path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+The product path (``kvpress_amd``) never imports, calls or falls back to anything
+in this directory; it fails loudly when the HIP extension is missing.
+
+It is a numpy restatement of the reference algorithm (NVIDIA/kvpress v0.5.4,
+``/root/reference``).  Every function cites the reference file:line it follows.
+The arithmetic is done in ``ctype`` (float64 by default: the "exact math" the
+fp32 reference and the fp32 HIP kernels both approximate to ~1e-6; float32 for
+the large cpu_baseline runs) and results are returned as float32.
+
+Parity pin: ``oracle/gen_golden.py`` runs the *real* reference (imported from
+/root/reference, torch CPU, fp32 mode and bf16 mode) on the seeded inputs of
+``tests/_inputs.py`` and commits its outputs under ``tests/golden/``;
+``tests/test_oracle_golden.py`` checks this file against those fixtures.
+Caveat stated by SURVEY.md §8(c): the reference's own tests hold no score
+values for SnapKV / ExpectedAttention and torch.topk's tie order is
+unspecified, so the pin is "reference executed here", not "reference's own
+golden vectors" (those only pin shapes / n_kept, which are checked too).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+__all__ = [
+    "n_kept",
+    "rotate_half",
+    "repeat_kv",
+    "knorm_score",
+    "snapkv_window_queries",
+    "snapkv_window_attention",
+    "snapkv_score",
+    "snapkv_score_from_attentions",
+    "ea_query_stats",
+    "ea_avg_rope",
+    "ea_score",
+    "topk_select",
+    "topk_is_valid",
+    "gather_kv",
+    "compress",
+]
+
+
+# --------------------------------------------------------------------------------------
+# ScorerPress.compress  (kvpress/presses/scorer_press.py:76-102)
+# --------------------------------------------------------------------------------------
+def n_kept(k_len: int, compression_ratio: float) -> int:
+    """``n_kept = int(k_len * (1 - compression_ratio))`` in Python double arithmetic
+    (scorer_press.py:93-94).  e.g. int(131072*(1-0.7)) == 39321, int(23*(1-0.4)) == 13."""
+    return int(k_len * (1 - compression_ratio))
+
+
+def _ordered_key(scores_f32: np.ndarray) -> np.ndarray:
+    """Monotone map float32 -> uint32 (larger float <=> larger key); -0.0 == +0.0 as in torch."""
+    s = np.ascontiguousarray(scores_f32, dtype=np.float32)
+    u = s.view(np.uint32).copy()
+    u[u == np.uint32(0x80000000)] = np.uint32(0)  # -0.0 -> +0.0
+    neg = (u >> np.uint32(31)).astype(bool)
+    u = np.where(neg, ~u, u | np.uint32(0x80000000))
+    return u
+
+
+def topk_select(scores: np.ndarray, k: int) -> np.ndarray:
+    """Top-k retained set per row of ``scores[..., S]`` (scorer_press.py:95,
+    ``scores.topk(n_kept, dim=-1).indices``).
+
+    torch.topk leaves the order among equal scores unspecified; this framework
+    defines it: **among equal scores the lowest position wins**.  Indices are
+    returned in **ascending position** order (int32) — the reference returns
+    them in descending-score order, which no reference test depends on
+    (tests/presses/test_presses.py:143-162 sort both sides); see DESIGN.md.
+    """
+    s = np.asarray(scores, dtype=np.float32)
+    lead = s.shape[:-1]
+    S = s.shape[-1]
+    assert 0 <= k <= S
+    flat = _ordered_key(s.reshape(-1, S))
+    out = np.empty((flat.shape[0], k), dtype=np.int32)
+    for r in range(flat.shape[0]):
+        # stable sort on descending key: ties keep ascending position order
+        order = np.argsort(~flat[r], kind="stable")
+        out[r] = np.sort(order[:k]).astype(np.int32)
+    return out.reshape(*lead, k)
+
+
+def topk_is_valid(scores: np.ndarray, idx: np.ndarray, k: int, rel_band: float = 0.0):
+    """Tie-tolerant check that ``idx[..., k]`` is *a* valid top-k set of ``scores``:
+    every element with score > t is present, none with score < t, the rest are
+    drawn from == t (t = k-th largest).  ``rel_band`` widens "== t" to
+    |s - t| <= rel_band*|t| for comparisons across implementations whose fp32
+    scores differ in the last bits.  Returns (ok, message)."""
+    s = np.asarray(scores, dtype=np.float64)
+    S = s.shape[-1]
+    s2 = s.reshape(-1, S)
+    i2 = np.asarray(idx).reshape(-1, k)
+    for r in range(s2.shape[0]):
+        ids = i2[r].astype(np.int64)
+        if k == 0:
+            continue
+        if len(np.unique(ids)) != k or ids.min() < 0 or ids.max() >= S:
+            return False, f"row {r}: indices not unique/in range"
+        t = np.sort(s2[r])[::-1][k - 1]
+        band = rel_band * abs(t)
+        kept = np.zeros(S, dtype=bool)
+        kept[ids] = True
+        must = s2[r] > t + band
+        never = s2[r] < t - band
+        if (must & ~kept).any():
+            j = int(np.nonzero(must & ~kept)[0][0])
+            return False, f"row {r}: position {j} (score {s2[r, j]!r} > t={t!r}) missing"
+        if (never & kept).any():
+            j = int(np.nonzero(never & kept)[0][0])
+            return False, f"row {r}: position {j} (score {s2[r, j]!r} < t={t!r}) kept"
+    return True, "ok"
+
+
+def gather_kv(keys: np.ndarray, values: np.ndarray, idx: np.ndarray):
+    """``keys.gather(2, idx.expand(..., D)).contiguous()`` for K and V (scorer_press.py:96-100)."""
+    B, H, S, D = keys.shape
+    ii = np.asarray(idx).astype(np.int64)[..., None]
+    ko = np.take_along_axis(keys, np.broadcast_to(ii, ii.shape[:-1] + (D,)), axis=2)
+    vo = np.take_along_axis(values, np.broadcast_to(ii, ii.shape[:-1] + (D,)), axis=2)
+    return np.ascontiguousarray(ko), np.ascontiguousarray(vo)
+
+
+def compress(scores: np.ndarray, keys: np.ndarray, values: np.ndarray, compression_ratio: float):
+    """ScorerPress.compress after ``score()`` (scorer_press.py:86-102): ratio 0 returns the
+    inputs unchanged; otherwise top-k (tie rule above) + gather.  Returns (K', V', idx)."""
+    if compression_ratio == 0:
+        return keys, values, None
+    k = n_kept(keys.shape[2], compression_ratio)
+    idx = topk_select(scores, k)
+    ko, vo = gather_kv(keys, values, idx)
+    return ko, vo, idx
+
+
+# --------------------------------------------------------------------------------------
+# KnormPress.score  (kvpress/presses/knorm_press.py:29-38)
+# --------------------------------------------------------------------------------------
+def knorm_score(keys: np.ndarray, ctype=np.float64) -> np.ndarray:
+    """``-keys.norm(dim=-1)`` (knorm_press.py:38)."""
+    k = np.asarray(keys).astype(ctype)
+    return (-np.sqrt((k * k).sum(-1))).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# transformers helpers the reference imports (modeling_llama.py rotate_half / repeat_kv)
+# --------------------------------------------------------------------------------------
+def rotate_half(x: np.ndarray) -> np.ndarray:
+    """transformers ``rotate_half``: cat(-x2, x1) over the last dim (used at snapkv_press.py:58)."""
+    h = x.shape[-1] // 2
+    return np.concatenate([-x[..., h:], x[..., :h]], axis=-1)
+
+
+def repeat_kv(x: np.ndarray, n_rep: int) -> np.ndarray:
+    """transformers ``repeat_kv``: [B,H,S,D] -> [B,H*n_rep,S,D], q-head j uses kv-head j//n_rep
+    (used at snapkv_press.py:61, expected_attention_press.py:148)."""
+    return np.repeat(x, n_rep, axis=1)
+
+
+# --------------------------------------------------------------------------------------
+# SnapKVPress  (kvpress/presses/snapkv_press.py:41-105)
+# --------------------------------------------------------------------------------------
+def snapkv_window_queries(hidden, wq, bq, cos, sin, num_heads, head_dim, window, ctype=np.float64):
+    """Last-``window`` queries after RoPE (snapkv_press.py:53-58 + utils.py:43-46):
+    ``q = q_proj(hidden[:, -W:])`` viewed [B,Hq,W,D]; ``q*cos + rotate_half(q)*sin`` with the
+    last W rows of cos/sin ([1 or B, S, D])."""
+    h = np.asarray(hidden)[:, -window:].astype(ctype)
+    q = h @ np.asarray(wq).astype(ctype).T
+    if bq is not None:
+        q = q + np.asarray(bq).astype(ctype)
+    B = h.shape[0]
+    q = q.reshape(B, window, num_heads, head_dim).transpose(0, 2, 1, 3)
+    c = np.asarray(cos)[:, -window:].astype(ctype)[:, None]
+    s = np.asarray(sin)[:, -window:].astype(ctype)[:, None]
+    return q * c + rotate_half(q) * s
+
+
+def snapkv_window_attention(q_win, keys, ctype=np.float64) -> np.ndarray:
+    """``compute_window_attention`` from the RoPE'd window queries on (snapkv_press.py:60-69):
+    QK^T/sqrt(D) over **all** S keys, causal mask on the last W columns
+    (``triu(-inf, diagonal=S-W+1)``: window row w sees columns <= S-W+w), softmax over S,
+    drop the last W columns.  Returns [B,Hq,W,S-W]."""
+    q = np.asarray(q_win).astype(ctype)
+    k = np.asarray(keys).astype(ctype)
+    B, Hq, W, D = q.shape
+    H, S = k.shape[1], k.shape[2]
+    G = Hq // H
+    out = np.empty((B, Hq, W, S - W), dtype=ctype)
+    col = np.arange(S)[None, :]
+    row = np.arange(W)[:, None]
+    masked = col > (S - W + row)  # strictly above the diagonal offset S-W+1
+    for b in range(B):
+        for hq in range(Hq):
+            logits = (q[b, hq] @ k[b, hq // G].T) / ctype(math.sqrt(D))
+            logits = np.where(masked, -np.inf, logits)
+            m = logits.max(-1, keepdims=True)
+            p = np.exp(logits - m)
+            p /= p.sum(-1, keepdims=True)
+            out[b, hq] = p[:, : S - W]
+    return out
+
+
+def _snapkv_from_window_attn(attn, H, window, kernel_size, ctype):
+    """snapkv_press.py:95-103: mean over the window rows, avg_pool1d(kernel, pad=kernel//2,
+    stride 1, zero padding counted in the divisor), mean over the GQA group, pad the window
+    with ``scores.max() + 1`` (max is global over B and H)."""
+    B, Hq, W, Sm = attn.shape
+    G = Hq // H
+    s = attn.mean(axis=-2)  # [B,Hq,S-W]
+    pad = kernel_size // 2
+    sp = np.pad(s, ((0, 0), (0, 0), (pad, pad)))
+    L_out = Sm + 2 * pad - kernel_size + 1
+    pooled = np.zeros((B, Hq, L_out), dtype=ctype)
+    for j in range(kernel_size):
+        pooled += sp[..., j : j + L_out]
+    pooled /= kernel_size
+    assert L_out == Sm, "even kernel_size changes the length; the reference's view() would fail too"
+    sc = pooled.reshape(B, H, G, Sm).mean(2)
+    # F.pad(value=scores.max().item() + 1): torch evaluates max()+1 in Python double and
+    # stores it in the score dtype
+    fill = float(np.float32(sc.max())) + 1.0 if sc.size else 1.0
+    out = np.concatenate([sc, np.full((B, H, window), fill, dtype=ctype)], axis=-1)
+    return out.astype(np.float32)
+
+
+def snapkv_score(q_win, keys, kernel_size: int = 5, ctype=np.float64) -> np.ndarray:
+    """SnapKVPress.score with ``attentions=None`` (snapkv_press.py:71-105) from the RoPE'd
+    window queries ``q_win [B,Hq,W,D]`` and ``keys [B,H,S,D]``.  Returns [B,H,S] float32."""
+    W = q_win.shape[2]
+    assert keys.shape[2] > W, "Query length should be greater than the window size"  # :84-86
+    attn = snapkv_window_attention(q_win, keys, ctype)
+    return _snapkv_from_window_attn(attn, keys.shape[1], W, kernel_size, ctype)
+
+
+def snapkv_score_from_attentions(attentions, H, window, kernel_size: int = 5, ctype=np.float64):
+    """SnapKVPress.score when the layer returns attention weights (snapkv_press.py:88-89):
+    ``attentions[..., -W:, :-W]``."""
+    a = np.asarray(attentions).astype(ctype)[..., -window:, :-window]
+    return _snapkv_from_window_attn(a, H, window, kernel_size, ctype)
+
+
+# --------------------------------------------------------------------------------------
+# ExpectedAttentionPress  (kvpress/presses/expected_attention_press.py:62-165)
+# --------------------------------------------------------------------------------------
+def ea_query_stats(q, use_covariance: bool = True, ctype=np.float64):
+    """Mean and covariance of the (pre-RoPE, sink-stripped) queries ``q [B,Hq,S',D]``
+    (expected_attention_press.py:74-81): mu = mean over S'; cov = (q-mu)^T (q-mu) / S'."""
+    x = np.asarray(q).astype(ctype)
+    mu = x.mean(axis=2)
+    cov = None
+    if use_covariance:
+        c = x - mu[:, :, None, :]
+        cov = np.einsum("bnsi,bnsj->bnij", c, c) / x.shape[2]
+    return mu, cov
+
+
+def ea_avg_rope(mu, cov, cos, sin, ctype=np.float64):
+    """apply_avg_rope (expected_attention_press.py:110-123) given the cos/sin [P,D] of the
+    n_future_positions positions: R_p = diag(cos_p) + P*sin_p with P[D/2:, :D/2] = I,
+    P[:D/2, D/2:] = -I (:114-118); R = mean_p R_p (:119-120); mu <- mu R^T, cov <- R cov R^T."""
+    cos = np.asarray(cos).astype(ctype)
+    sin = np.asarray(sin).astype(ctype)
+    D = cos.shape[-1]
+    h = D // 2
+    Pm = np.zeros((D, D), dtype=ctype)
+    Pm[h:, :h] = np.eye(h)
+    Pm[:h, h:] = -np.eye(h)
+    R = (cos[:, :, None] * np.eye(D, dtype=ctype)[None] + sin[:, :, None] * Pm[None]).mean(0)
+    mu2 = np.asarray(mu).astype(ctype) @ R.T
+    cov2 = None
+    if cov is not None:
+        cov2 = R @ (np.asarray(cov).astype(ctype) @ R.T)
+    return mu2, cov2
+
+
+def ea_score(keys, values, mu, cov, n_sink=4, use_vnorm=True, epsilon=0.0, ctype=np.float64):
+    """ExpectedAttentionPress.score after the query statistics (expected_attention_press.py:137-163):
+    drop n_sink keys/values; per q-head logits = k.mu/sqrt(D) + k^T cov k / D / 2; softmax over
+    the S-n_sink keys; mean over the GQA group; (s + eps) * ||v||; left-pad n_sink with max+1."""
+    k = np.asarray(keys).astype(ctype)
+    v = np.asarray(values).astype(ctype)
+    assert k.shape[2] > n_sink, f"Input should contain more tokens than n_sink={n_sink}"  # :137
+    k = k[:, :, n_sink:]
+    v = v[:, :, n_sink:]
+    B, H, Sp, D = k.shape
+    mu = np.asarray(mu).astype(ctype)
+    Hq = mu.shape[1]
+    G = Hq // H
+    kr = repeat_kv(k, G)  # [B,Hq,S',D]
+    logits = np.einsum("bhd,bhsd->bhs", mu, kr) / ctype(math.sqrt(D))
+    if cov is not None:
+        cv = np.asarray(cov).astype(ctype)
+        y = np.einsum("bhsi,bhij->bhsj", kr, cv)
+        logits = logits + (y * kr).sum(-1) / D / 2
+    m = logits.max(-1, keepdims=True)
+    p = np.exp(logits - m)
+    p /= p.sum(-1, keepdims=True)
+    sc = p.reshape(B, H, G, Sp).mean(2)
+    if use_vnorm:
+        sc = (sc + epsilon) * np.sqrt((v * v).sum(-1))
+    fill = float(np.float32(sc.max())) + 1.0
+    out = np.concatenate([np.full((B, H, n_sink), fill, dtype=ctype), sc], axis=-1)
+    return out.astype(np.float32)

@@ -1,0 +1,142 @@
+"""Seeded synthetic inputs shared by oracle/gen_golden.py (runs the real reference in the build
+container) and the tests (run here and on the GPU box, where /root/reference does not exist).
+
+Everything is generated with numpy's frozen legacy ``RandomState`` so that both machines
+reproduce the same bits.  Arrays are float32; for the half dtypes every value is rounded
+(RNE) to that dtype first, so ``.to(bf16)`` / ``.to(fp16)`` is exact and the fp32-mode
+reference ("O32") sees exactly the numbers the kernels see.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+RATIOS = (0.2, 0.5, 0.7, 0.8)
+
+
+def round_to(x: np.ndarray, dtype: str) -> np.ndarray:
+    """Round float32 values to bf16/f16 (RNE) and return them as float32."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if dtype == "f32":
+        return x
+    if dtype == "f16":
+        return x.astype(np.float16).astype(np.float32)
+    if dtype == "bf16":
+        u = x.view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.astype(np.uint32).view(np.float32)
+    raise ValueError(dtype)
+
+
+# name -> spec.  kind: knorm | snapkv | ea.   data: "A" flat N(0,1); "B" structured
+# (per-channel key scales, heavy sink rows, log-normal value norms) -- SURVEY.md §8(d).
+CASES = {
+    # ---- KnormPress -------------------------------------------------------------------
+    "kn_tiny_d6": dict(kind="knorm", B=5, H=2, G=1, S=256, D=6, dtype="f32", data="A", seed=11,
+                       ratios=(0.1, 0.2, 0.4, 0.6, 0.8)),   # [5,2,230,6] of tests/test_per_layer_compression_press.py:19
+    "kn_readme": dict(kind="knorm", B=3, H=8, G=1, S=5, D=128, dtype="f32", data="A", seed=12,
+                      ratios=(0.4,)),                        # README.md:253-258  [3,8,5,128]->[3,8,3,128]
+    "kn_opt_geom": dict(kind="knorm", B=1, H=12, G=1, S=2048, D=64, dtype="f32", data="A", seed=13,
+                        ratios=(0.5,)),                      # BASELINE config 1 geometry
+    "kn_bf16_A": dict(kind="knorm", B=2, H=8, G=4, S=4096, D=128, dtype="bf16", data="A", seed=14),
+    "kn_bf16_B": dict(kind="knorm", B=1, H=8, G=4, S=3001, D=128, dtype="bf16", data="B", seed=15),
+    "kn_f16_ragged": dict(kind="knorm", B=1, H=4, G=1, S=1000, D=128, dtype="f16", data="A", seed=16),
+    "kn_d96_bf16": dict(kind="knorm", B=2, H=3, G=1, S=515, D=96, dtype="bf16", data="B", seed=17),
+    # ---- SnapKVPress ------------------------------------------------------------------
+    "sk_tiny": dict(kind="snapkv", B=2, H=2, G=2, S=100, D=16, dtype="f32", data="A", seed=21, W=8, ks=5),
+    "sk_w2_d6": dict(kind="snapkv", B=1, H=2, G=1, S=128, D=6, dtype="f32", data="A", seed=22, W=2, ks=5),
+    "sk_s65": dict(kind="snapkv", B=1, H=2, G=4, S=65, D=128, dtype="bf16", data="A", seed=23, W=64, ks=5),
+    "sk_257_A": dict(kind="snapkv", B=2, H=2, G=4, S=257, D=128, dtype="bf16", data="A", seed=24, W=64, ks=5),
+    "sk_257_B": dict(kind="snapkv", B=1, H=2, G=4, S=257, D=128, dtype="bf16", data="B", seed=25, W=64, ks=5),
+    "sk_4096": dict(kind="snapkv", B=1, H=2, G=4, S=4096, D=128, dtype="bf16", data="B", seed=26, W=64, ks=5),
+    "sk_f16_d64": dict(kind="snapkv", B=1, H=2, G=2, S=1000, D=64, dtype="f16", data="A", seed=27, W=32, ks=7),
+    "sk_ks1": dict(kind="snapkv", B=1, H=1, G=4, S=300, D=128, dtype="bf16", data="A", seed=28, W=64, ks=1),
+    "sk_f32_d128": dict(kind="snapkv", B=1, H=2, G=4, S=700, D=128, dtype="f32", data="B", seed=29, W=64, ks=3),
+    # ---- ExpectedAttentionPress --------------------------------------------------------
+    "ea_tiny": dict(kind="ea", B=2, H=2, G=2, S=100, D=16, dtype="f32", data="A", seed=31),
+    "ea_23": dict(kind="ea", B=1, H=2, G=1, S=23, D=16, dtype="f32", data="A", seed=32,
+                  ratios=(0.4,)),                            # tests/test_pipeline.py:31-32  23 -> 13
+    "ea_257_A": dict(kind="ea", B=2, H=2, G=4, S=257, D=128, dtype="bf16", data="A", seed=33),
+    "ea_1500_B": dict(kind="ea", B=1, H=2, G=4, S=1500, D=128, dtype="bf16", data="B", seed=34),
+    "ea_nocov": dict(kind="ea", B=1, H=2, G=4, S=400, D=128, dtype="bf16", data="B", seed=35, use_covariance=False),
+    "ea_novnorm_eps": dict(kind="ea", B=1, H=2, G=2, S=333, D=64, dtype="f16", data="A", seed=36,
+                           use_vnorm=False, epsilon=0.0, n_future=64),
+    "ea_eps_sink0": dict(kind="ea", B=1, H=1, G=4, S=512, D=128, dtype="bf16", data="A", seed=37,
+                         epsilon=0.01, n_sink=0),
+    "ea_f32_d128": dict(kind="ea", B=1, H=2, G=4, S=600, D=128, dtype="f32", data="B", seed=38),
+}
+
+_DEFAULTS = dict(W=64, ks=5, n_future=512, n_sink=4, use_covariance=True, use_vnorm=True, epsilon=0.0,
+                 ratios=RATIOS)
+
+
+def spec(name: str) -> dict:
+    s = dict(_DEFAULTS)
+    s.update(CASES[name])
+    s["name"] = name
+    s["Hq"] = s["H"] * s["G"]
+    s.setdefault("hsz", 16 * s["Hq"])  # LlamaConfig wants hidden_size % num_heads == 0
+    return s
+
+
+def make_kv(B, H, S, D, dtype, data, seed):
+    """K and V [B,H,S,D] float32 (values exactly representable in ``dtype``)."""
+    rs = np.random.RandomState(seed)
+    k = rs.standard_normal((B, H, S, D)).astype(np.float32)
+    v = rs.standard_normal((B, H, S, D)).astype(np.float32)
+    if data == "B":
+        ch = np.exp(0.5 * rs.standard_normal((1, H, 1, D))).astype(np.float32)
+        k = k * ch
+        k[:, :, : min(4, S)] *= 8.0  # sink rows
+        tok = np.exp(0.7 * rs.standard_normal((B, H, S, 1))).astype(np.float32)
+        v = v * tok
+    return round_to(k, dtype), round_to(v, dtype)
+
+
+def make_case(name: str) -> dict:
+    """All numpy inputs of a case: keys, values, hidden, wq (q_proj weight [Hq*D, hidden])."""
+    s = spec(name)
+    k, v = make_kv(s["B"], s["H"], s["S"], s["D"], s["dtype"], s["data"], s["seed"])
+    rs = np.random.RandomState(s["seed"] + 1000)
+    hid = rs.standard_normal((s["B"], s["S"], s["hsz"])).astype(np.float32)
+    wq = (rs.standard_normal((s["Hq"] * s["D"], s["hsz"])) * (1.5 / math.sqrt(s["hsz"]))).astype(np.float32)
+    if s["data"] == "B":
+        # a non-zero query mean and a few dominant channels (exercises EA's centring)
+        hid = hid + 0.5
+        wq[:: max(1, s["D"] // 4)] *= 3.0
+    s.update(keys=k, values=v, hidden=round_to(hid, s["dtype"]), wq=round_to(wq, s["dtype"]))
+    return s
+
+
+def torch_dtype(name: str):
+    import torch
+
+    return {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[name]
+
+
+def build_llama_attention(s: dict, dtype, device="cpu"):
+    """A random-geometry ``LlamaAttention`` whose q_proj carries ``s['wq']``, plus the model-level
+    rotary embedding and cos/sin for positions 0..S-1 (what transformers hands the hook as
+    ``position_embeddings``).  ``dtype`` is the *module* dtype (float32 for the O32 oracle)."""
+    import torch
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaAttention, LlamaRotaryEmbedding
+
+    cfg = LlamaConfig(
+        hidden_size=s["hsz"], num_attention_heads=s["Hq"], num_key_value_heads=s["H"], head_dim=s["D"],
+        num_hidden_layers=1, intermediate_size=32, vocab_size=32, max_position_embeddings=max(4096, 2 * s["S"]),
+        attention_bias=False,
+    )
+    cfg._attn_implementation = "eager"
+    att = LlamaAttention(cfg, layer_idx=0)
+    with torch.no_grad():
+        att.q_proj.weight.copy_(torch.from_numpy(s["wq"]))
+    rot = LlamaRotaryEmbedding(cfg)
+    att = att.to(device=device, dtype=dtype)
+    rot = rot.to(device)
+    att.rotary_emb = rot  # BasePress.__call__ attaches this (base_press.py:202)
+    hidden = torch.from_numpy(s["hidden"]).to(device=device, dtype=dtype)
+    pos = torch.arange(s["S"], device=device)[None]
+    cos, sin = rot(hidden, pos)
+    return att, rot, hidden, (cos, sin)
