@@ -1,0 +1,125 @@
+/*
+ * kvpress_hip.h -- C ABI of libkvpress_hip.so: the MI355X (gfx950) implementation of the
+ * kvpress per-layer KV score -> top-k -> gather hot path.
+ *
+ * The reference (NVIDIA/kvpress v0.5.4) is pure Python and has no FFI; its boundary for this
+ * path is the Python protocol BasePress.forward_hook -> ScorerPress.compress -> score()
+ * (kvpress/presses/base_press.py:101-162, scorer_press.py:76-102).  This header is what a
+ * binding of that path binds: every entry point names the reference lines it replaces.
+ * kvpress_amd/_native.py is the ctypes binding; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only (no torch / framework types);
+ *   - all pointers are DEVICE pointers on the current HIP device unless stated otherwise;
+ *   - 4-D tensors are [B, H, S, D] views with the last dim contiguous; strides are in ELEMENTS
+ *     (sb, sh, ss) so sliced cache views (keys[:, :, n_sink:], chunk slices) need no copy;
+ *   - outputs and workspaces are caller-allocated; *_workspace_bytes() gives the size;
+ *   - every call is asynchronous on `stream` (a hipStream_t), allocates nothing, never
+ *     synchronises, keeps no global state and is thread-safe;
+ *   - return 0 (KVP_OK) or a negative KVP_E* code; kvp_last_error() returns the calling
+ *     thread's last message.
+ *   - scores are always float32 (the reference returns the model dtype; float32 is a superset
+ *     and makes the top-k well defined -- DESIGN.md "Parity contract").
+ */
+#ifndef KVPRESS_HIP_H
+#define KVPRESS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KVP_VERSION 100 /* 0.1.0 */
+
+typedef void* kvp_stream_t; /* hipStream_t */
+
+enum kvp_dtype { KVP_F32 = 0, KVP_F16 = 1, KVP_BF16 = 2 };
+enum kvp_status { KVP_OK = 0, KVP_EINVAL = -1, KVP_EUNSUPPORTED = -2, KVP_EWORKSPACE = -3, KVP_EHIP = -4 };
+/* Order of the retained indices.  POSITION: ascending token position (default; makes the gather a
+ * monotone stream).  SCORE: descending score, ties by ascending position -- the element order
+ * torch.topk(sorted=True) produces at scorer_press.py:95, for tensor-exact comparisons. */
+enum kvp_order { KVP_ORDER_POSITION = 0, KVP_ORDER_SCORE = 1 };
+
+int kvp_version(void);
+const char* kvp_last_error(void);
+
+/* ---- KnormPress.score: -keys.norm(dim=-1)  (kvpress/presses/knorm_press.py:38) -------------
+ * out[b,h,s] = scale * ||x[b,h,s,:]||_2   (scale = -1 for Knorm; +1 for ||V|| in ExpectedAttention,
+ * expected_attention_press.py:160).  out is contiguous [B,H,S] float32. */
+int kvp_rownorm_score(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D,
+                      int64_t sb, int64_t sh, int64_t ss, float scale, float* out, kvp_stream_t stream);
+
+/* ---- SnapKVPress.score (kvpress/presses/snapkv_press.py:60-105) ----------------------------
+ * q: RoPE'd queries of the last W tokens [B,Hq,W,D] (the host keeps q_proj + RoPE,
+ *    snapkv_press.py:53-58 / utils.py:43-46: q_proj is a model-owned nn.Linear);
+ * k: keys [B,Hkv,S,D].  Computes softmax(q k^T / sqrt(D)) over all S keys with the causal mask
+ * on the last W columns (:62-66), mean over the W rows (:95), avg_pool1d(kernel_size,
+ * pad=kernel_size/2, stride 1, zero padded, divisor kernel_size) (:96), mean over the
+ * Hq/Hkv group (:99-100), and fills the last W positions with max(scores)+1, max global over
+ * B and Hkv (:103) -- on the device, no host sync.  scores: [B,Hkv,S] float32, contiguous.
+ * kernel_size must be odd.  Requires S > W. */
+size_t kvp_snapkv_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D);
+int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw,
+                     const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
+                     int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
+                     float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream);
+
+/* Same, when the attention layer returned its weights (snapkv_press.py:88-89):
+ * attn is the [B,Hq,W,S-W] view attentions[..., -W:, :-W] (last dim contiguous). */
+int kvp_snapkv_score_from_attn(const void* attn, int64_t a_sb, int64_t a_sh, int64_t a_sw, int dtype,
+                               int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int kernel_size,
+                               float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream);
+
+/* ---- ExpectedAttentionPress (kvpress/presses/expected_attention_press.py) -------------------
+ * kvp_ea_qstats: mean and covariance of the pre-RoPE queries q [B,Hq,Sq,D] (sinks already
+ * stripped by the host, :70-71): mu[b,h,:] = mean_s q; cov = (q-mu)^T (q-mu) / Sq (:74-80).
+ * mu [B,Hq,D], cov [B,Hq,D,D] float32 contiguous; cov may be NULL (use_covariance=False).
+ * The averaged-RoPE step (:110-123) is 128x128 host-side math on mu/cov and stays in the host. */
+size_t kvp_ea_qstats_workspace_bytes(int64_t B, int64_t Hq, int64_t Sq, int64_t D);
+int kvp_ea_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int dtype,
+                  int64_t B, int64_t Hq, int64_t Sq, int64_t D,
+                  float* mu, float* cov, void* ws, size_t ws_bytes, kvp_stream_t stream);
+
+/* kvp_ea_score (:137-163): with the post-RoPE mu [B,Hq,D] / cov [B,Hq,D,D] (float32, cov may be
+ * NULL): for keys/values [B,Hkv,S,D] drop the first n_sink positions; logits = k.mu/sqrt(D) +
+ * k^T cov k / (2D) per q-head; softmax over the S-n_sink keys; mean over the group;
+ * (s + epsilon) * ||v||_2 if use_vnorm; positions < n_sink get max(scores)+1 (global max).
+ * scores [B,Hkv,S] float32. */
+size_t kvp_ea_score_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t D);
+int kvp_ea_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
+                 const void* v, int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype,
+                 const float* mu, const float* cov,
+                 int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t D,
+                 int64_t n_sink, int use_vnorm, float epsilon,
+                 float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream);
+
+/* ---- ScorerPress.compress: top-k + gather (kvpress/presses/scorer_press.py:94-100) ----------
+ * kvp_topk_select: for each of the R rows of scores[R, S] (row stride in elements) write the
+ * indices of the k largest scores to idx[R, k] (int32).  torch.topk leaves ties unspecified;
+ * here the LOWEST POSITION wins among equal scores, and -0.0 == +0.0.  0 <= k <= S. */
+size_t kvp_topk_workspace_bytes(int64_t R, int64_t S, int64_t k);
+int kvp_topk_select(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int order,
+                    int32_t* idx, void* ws, size_t ws_bytes, kvp_stream_t stream);
+
+/* kvp_gather_kv: k_out[b,h,j,:] = k[b,h,idx[b*H+h, j],:], same for v (scorer_press.py:96-100).
+ * Outputs are contiguous [B,H,n,D] in the input dtype; inputs are not modified. */
+int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
+                  const void* v, int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype,
+                  int64_t B, int64_t H, int64_t S, int64_t D,
+                  const int32_t* idx, int64_t n, void* k_out, void* v_out, kvp_stream_t stream);
+
+/* ---- measurement aid (not part of the reference boundary) ------------------------------------
+ * kvp_prof_enable(1) makes every kernel launch of the calling thread record a HIP event pair on
+ * its launch stream; after synchronising, kvp_prof_get(i) returns kernel i's name and duration.
+ * kvp_prof_enable(0) turns it off and drops the records.  Used by bench.py for roofline.achieved. */
+int kvp_prof_enable(int on);
+int kvp_prof_count(void);
+int kvp_prof_get(int i, const char** name, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVPRESS_HIP_H */

@@ -1,0 +1,249 @@
+"""ctypes binding of libkvpress_hip.so (include/kvpress_hip.h) for torch tensors on a HIP device.
+
+There is deliberately NO fallback: if the shared library is missing, or a tensor is not on a
+GPU, the call raises.  PyTorch is used for device memory (outputs / workspaces come from the
+caching allocator, so they are stream-ordered) and for the current stream only.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from typing import Optional
+
+import torch  # must be imported before the .so so that it binds to torch's libamdhip64.so.7
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkvpress_hip.so")
+
+KVP_F32, KVP_F16, KVP_BF16 = 0, 1, 2
+ORDER_POSITION, ORDER_SCORE = 0, 1
+_DTYPES = {torch.float32: KVP_F32, torch.float16: KVP_F16, torch.bfloat16: KVP_BF16}
+
+# name -> (restype, argtypes); mirrors include/kvpress_hip.h line by line
+_I64 = c_int64
+SIGNATURES = {
+    "kvp_version": (c_int, []),
+    "kvp_last_error": (c_char_p, []),
+    "kvp_rownorm_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_float, c_void_p, c_void_p]),
+    "kvp_snapkv_workspace_bytes": (c_size_t, [_I64] * 6),
+    "kvp_snapkv_score": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int,
+                                 _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "kvp_snapkv_score_from_attn": (c_int, [c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, c_int,
+                                           c_void_p, c_void_p, c_size_t, c_void_p]),
+    "kvp_ea_qstats_workspace_bytes": (c_size_t, [_I64] * 4),
+    "kvp_ea_qstats": (c_int, [c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, c_void_p, c_void_p,
+                              c_void_p, c_size_t, c_void_p]),
+    "kvp_ea_score_workspace_bytes": (c_size_t, [_I64] * 5),
+    "kvp_ea_score": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, c_void_p, c_void_p,
+                             _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "kvp_topk_workspace_bytes": (c_size_t, [_I64] * 3),
+    "kvp_topk_select": (c_int, [c_void_p, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "kvp_gather_kv": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64,
+                              c_void_p, _I64, c_void_p, c_void_p, c_void_p]),
+    "kvp_prof_enable": (c_int, [c_int]),
+    "kvp_prof_count": (c_int, []),
+    "kvp_prof_get": (c_int, [c_int, ctypes.POINTER(c_char_p), ctypes.POINTER(c_float)]),
+}
+
+_lib = None
+
+
+class KvpressHipError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load libkvpress_hip.so (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KvpressHipError(
+                f"{LIB_PATH} not found: build it with `python -m kvpress_amd.build` (hipcc, gfx950). "
+                "kvpress_amd has no CPU / pure-PyTorch fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().kvp_last_error()
+        raise KvpressHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def _dev(t: torch.Tensor):
+    if not t.is_cuda:
+        raise KvpressHipError(
+            f"kvpress_amd kernels need tensors on a HIP device, got {t.device} (no CPU fallback exists)")
+    if t.dtype not in _DTYPES:
+        raise KvpressHipError(f"unsupported dtype {t.dtype} (float32 / float16 / bfloat16)")
+    return t
+
+
+def _rows_last_contig(t: torch.Tensor) -> torch.Tensor:
+    """[..., D] view whose last dim is contiguous (sliced cache views pass through untouched)."""
+    return t if (t.shape[-1] == 1 or t.stride(-1) == 1) else t.contiguous()
+
+
+def _st(t: torch.Tensor, i: int) -> int:
+    """Element stride of dim i; 0 for size-1 dims (torch reports arbitrary strides there)."""
+    return 0 if t.shape[i] == 1 else t.stride(i)
+
+
+def _stream(t: torch.Tensor):
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ws(nbytes: int, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+# ------------------------------------------------------------------------------------------------
+def rownorm_score(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """out[b,h,s] = scale * ||x[b,h,s,:]||_2, float32 [B,H,S]."""
+    x = _rows_last_contig(_dev(x))
+    B, H, S, D = x.shape
+    out = torch.empty((B, H, S), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().kvp_rownorm_score(_p(x), _DTYPES[x.dtype], B, H, S, D, _st(x, 0), _st(x, 1), _st(x, 2),
+                                       float(scale), _p(out), _stream(x)), "kvp_rownorm_score")
+    return out
+
+
+def snapkv_score(q_win: torch.Tensor, keys: torch.Tensor, kernel_size: int) -> torch.Tensor:
+    """SnapKV scores [B,Hkv,S] float32 from RoPE'd window queries [B,Hq,W,D] and keys [B,Hkv,S,D]."""
+    keys = _rows_last_contig(_dev(keys))
+    q_win = _rows_last_contig(_dev(q_win))
+    if q_win.dtype != keys.dtype:
+        q_win = q_win.to(keys.dtype)
+    B, Hq, W, D = q_win.shape
+    Bk, Hkv, S, Dk = keys.shape
+    assert B == Bk and D == Dk and Hq % Hkv == 0, (q_win.shape, keys.shape)
+    scores = torch.empty((B, Hkv, S), dtype=torch.float32, device=keys.device)
+    with torch.cuda.device(keys.device):
+        nws = lib().kvp_snapkv_workspace_bytes(B, Hq, Hkv, S, W, D)
+        ws = _ws(nws, keys)
+        _check(lib().kvp_snapkv_score(_p(q_win), _st(q_win, 0), _st(q_win, 1), _st(q_win, 2),
+                                      _p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _DTYPES[keys.dtype],
+                                      B, Hq, Hkv, S, W, D, int(kernel_size), _p(scores), _p(ws), ws.numel(), _stream(keys)),
+               "kvp_snapkv_score")
+    return scores
+
+
+def snapkv_score_from_attn(attn_win: torch.Tensor, num_kv_heads: int, k_len: int, kernel_size: int) -> torch.Tensor:
+    """Same from given attention weights: attn_win = attentions[..., -W:, :-W]  [B,Hq,W,S-W]."""
+    attn_win = _rows_last_contig(_dev(attn_win))
+    B, Hq, W, Sm = attn_win.shape
+    S = int(k_len)
+    assert Sm == S - W, (attn_win.shape, S)
+    scores = torch.empty((B, num_kv_heads, S), dtype=torch.float32, device=attn_win.device)
+    with torch.cuda.device(attn_win.device):
+        nws = lib().kvp_snapkv_workspace_bytes(B, Hq, num_kv_heads, S, W, 1)
+        ws = _ws(nws, attn_win)
+        _check(lib().kvp_snapkv_score_from_attn(_p(attn_win), _st(attn_win, 0), _st(attn_win, 1), _st(attn_win, 2),
+                                                _DTYPES[attn_win.dtype], B, Hq, num_kv_heads, S, W, int(kernel_size),
+                                                _p(scores), _p(ws), ws.numel(), _stream(attn_win)),
+               "kvp_snapkv_score_from_attn")
+    return scores
+
+
+def ea_qstats(q: torch.Tensor, use_covariance: bool = True):
+    """mu [B,Hq,D], cov [B,Hq,D,D] (float32) of the queries q [B,Hq,Sq,D]."""
+    q = _rows_last_contig(_dev(q))
+    B, Hq, Sq, D = q.shape
+    mu = torch.empty((B, Hq, D), dtype=torch.float32, device=q.device)
+    cov = torch.empty((B, Hq, D, D), dtype=torch.float32, device=q.device) if use_covariance else None
+    with torch.cuda.device(q.device):
+        nws = lib().kvp_ea_qstats_workspace_bytes(B, Hq, Sq, D)
+        ws = _ws(nws, q)
+        _check(lib().kvp_ea_qstats(_p(q), _st(q, 0), _st(q, 1), _st(q, 2), _DTYPES[q.dtype], B, Hq, Sq, D,
+                                   _p(mu), _p(cov), _p(ws), ws.numel(), _stream(q)), "kvp_ea_qstats")
+    return mu, cov
+
+
+def ea_score(keys: torch.Tensor, values: torch.Tensor, mu: torch.Tensor, cov: Optional[torch.Tensor], n_sink: int,
+             use_vnorm: bool, epsilon: float) -> torch.Tensor:
+    """ExpectedAttention scores [B,Hkv,S] float32 (post-RoPE mu/cov float32 contiguous)."""
+    keys = _rows_last_contig(_dev(keys))
+    values = _rows_last_contig(_dev(values))
+    assert keys.dtype == values.dtype and keys.shape == values.shape
+    B, Hkv, S, D = keys.shape
+    mu = mu.to(torch.float32).contiguous()
+    cov = cov.to(torch.float32).contiguous() if cov is not None else None
+    Hq = mu.shape[1]
+    assert mu.shape == (B, Hq, D) and (cov is None or cov.shape == (B, Hq, D, D))
+    scores = torch.empty((B, Hkv, S), dtype=torch.float32, device=keys.device)
+    with torch.cuda.device(keys.device):
+        nws = lib().kvp_ea_score_workspace_bytes(B, Hq, Hkv, S, D)
+        ws = _ws(nws, keys)
+        _check(lib().kvp_ea_score(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2),
+                                  _p(values), _st(values, 0), _st(values, 1), _st(values, 2), _DTYPES[keys.dtype],
+                                  _p(mu), _p(cov), B, Hq, Hkv, S, D, int(n_sink), int(bool(use_vnorm)), float(epsilon),
+                                  _p(scores), _p(ws), ws.numel(), _stream(keys)), "kvp_ea_score")
+    return scores
+
+
+def topk_select(scores: torch.Tensor, k: int, order: int = ORDER_POSITION) -> torch.Tensor:
+    """Indices (int32 [..., k]) of the k largest scores per row of float32 scores[..., S]; ties -> lowest position."""
+    if not scores.is_cuda:
+        raise KvpressHipError(f"kvpress_amd kernels need tensors on a HIP device, got {scores.device}")
+    s = scores.to(torch.float32)
+    if s.stride(-1) != 1:
+        s = s.contiguous()
+    S = s.shape[-1]
+    lead = s.shape[:-1]
+    s2 = s.reshape(-1, S)  # a view whenever possible
+    if s2.stride(-1) != 1 or (s2.shape[0] > 1 and s2.stride(0) < S):
+        s2 = s2.contiguous()
+    R = s2.shape[0]
+    idx = torch.empty((R, k), dtype=torch.int32, device=s.device)
+    if R and k:
+        with torch.cuda.device(s.device):
+            nws = lib().kvp_topk_workspace_bytes(R, S, k)
+            ws = _ws(nws, s)
+            _check(lib().kvp_topk_select(_p(s2), R, S, s2.stride(0) if R > 1 else S, int(k), int(order), _p(idx), _p(ws),
+                                         ws.numel(), _stream(s)), "kvp_topk_select")
+    return idx.reshape(*lead, k)
+
+
+def gather_kv(keys: torch.Tensor, values: torch.Tensor, idx: torch.Tensor):
+    """K'[b,h,j] = K[b,h,idx[b,h,j]] (and V'), contiguous [B,H,n,D] in the input dtype."""
+    keys = _rows_last_contig(_dev(keys))
+    values = _rows_last_contig(_dev(values))
+    assert keys.dtype == values.dtype and keys.shape == values.shape
+    B, H, S, D = keys.shape
+    idx = idx.to(torch.int32).contiguous()
+    n = idx.shape[-1]
+    assert idx.shape == (B, H, n)
+    ko = torch.empty((B, H, n, D), dtype=keys.dtype, device=keys.device)
+    vo = torch.empty((B, H, n, D), dtype=values.dtype, device=values.device)
+    if B * H * n:
+        with torch.cuda.device(keys.device):
+            _check(lib().kvp_gather_kv(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2),
+                                       _p(values), _st(values, 0), _st(values, 1), _st(values, 2), _DTYPES[keys.dtype],
+                                       B, H, S, D, _p(idx), n, _p(ko), _p(vo), _stream(keys)), "kvp_gather_kv")
+    return ko, vo
+
+
+# ------------------------------------------------------------------------------------------------
+def prof_enable(on: bool) -> None:
+    """Turn the library's per-kernel HIP-event timing on/off (clears previous records)."""
+    _check(lib().kvp_prof_enable(int(bool(on))), "kvp_prof_enable")
+
+
+def prof_records():
+    """[(kernel name, milliseconds)] recorded since prof_enable(True); synchronises on each event."""
+    out = []
+    name, ms = c_char_p(), c_float()
+    for i in range(lib().kvp_prof_count()):
+        _check(lib().kvp_prof_get(i, ctypes.byref(name), ctypes.byref(ms)), "kvp_prof_get")
+        out.append((name.value.decode(), float(ms.value)))
+    return out

@@ -1,0 +1,376 @@
+// kvp_ea_qstats / kvp_ea_score -- ExpectedAttentionPress (kvpress/presses/expected_attention_press.py).
+//
+//   kvp_ea_qstats  (:74-80)   mu = mean_s q ; cov = (q-mu)^T (q-mu) / Sq      per (b, q-head)
+//   [host]         (:110-123) averaged RoPE applied to mu / cov (D x D math, stays in the host)
+//   kvp_ea_score   (:137-163) logits = k.mu/sqrt(D) + k^T cov k/(2D) per q-head  -> softmax over
+//                             the S-n_sink keys -> group mean -> (s+eps)*||v|| -> sinks = max+1
+//
+// Reference dataflow at S=128k: repeat_kv (1 GiB), a [B,32,128,S] einsum intermediate (>= 1 GiB),
+// softmax and norm temporaries.  Here: one pass over K writes the [B,Hq,S'] log2-logits (16 MiB)
+// together with per-block softmax partials; ||V|| comes from the rownorm kernel; the finalize
+// pass fuses softmax normalisation, group mean, the value-norm rescale and the device-side max.
+//
+// This file holds the host entry points and the generic VALU kernels (any D, dtype, stride).
+// The MFMA kernels for bf16/f16 D=128 live in ea_mfma.hip.
+#include "kvp_common.h"
+#include "softmax_stats.h"
+#include "ea_internal.h"
+
+int kvp_rownorm_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh,
+                       int64_t ss, float scale, float* out, hipStream_t stream);
+
+namespace {
+
+constexpr int EA_THREADS = 256;
+constexpr int EA_SUB = 64;
+
+// ------------------------------------------------------------------------------------------------
+// query statistics (generic)
+// ------------------------------------------------------------------------------------------------
+// partial column sums: psum[(b*Hq+h)][chunk][d] = sum over the chunk's rows of q[b,h,s,d]
+template <int DT>
+__global__ __launch_bounds__(EA_THREADS) void ea_colsum_partial(const typename Elem<DT>::T* __restrict__ q, int64_t sb,
+                                                                int64_t sh, int64_t ss, uint32_t Sq, uint32_t D,
+                                                                uint32_t rows_per_chunk, float* __restrict__ psum) {
+    const uint32_t chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const uint32_t Hq = gridDim.y, nchunk = gridDim.x;
+    const typename Elem<DT>::T* base = q + (int64_t)b * sb + (int64_t)h * sh;
+    const uint32_t s0 = chunk * rows_per_chunk, s1 = min(s0 + rows_per_chunk, Sq);
+    for (uint32_t d = threadIdx.x; d < D; d += EA_THREADS) {
+        float acc = 0.f;
+        for (uint32_t s = s0; s < s1; ++s) acc += Elem<DT>::ld(base + (int64_t)s * ss + d);
+        psum[((size_t)(b * Hq + h) * nchunk + chunk) * D + d] = acc;
+    }
+}
+
+// mu[bh][d] = sum_chunks psum / Sq
+__global__ void ea_mean_finalize(const float* __restrict__ psum, uint32_t nchunk, uint32_t D, float inv_n, uint32_t total,
+                                 float* __restrict__ mu) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t bh = i / D, d = i - bh * D;
+    float acc = 0.f;
+    for (uint32_t c = 0; c < nchunk; ++c) acc += psum[((size_t)bh * nchunk + c) * D + d];
+    mu[i] = acc * inv_n;
+}
+
+// partial centred outer products on 64x64 tiles of the D x D matrix:
+// pcov[bh][chunk][i][j] = sum over the chunk's rows of (q_i - mu_i)(q_j - mu_j)
+template <int DT>
+__global__ __launch_bounds__(EA_THREADS) void ea_cov_partial(const typename Elem<DT>::T* __restrict__ q, int64_t sb,
+                                                             int64_t sh, int64_t ss, uint32_t Sq, uint32_t D,
+                                                             uint32_t rows_per_chunk, uint32_t nchunk, uint32_t ntile,
+                                                             const float* __restrict__ mu, float* __restrict__ pcov) {
+    __shared__ float xi[32][64];
+    __shared__ float xj[32][64];
+    const uint32_t tile = blockIdx.x % (ntile * ntile), chunk = blockIdx.x / (ntile * ntile);
+    const uint32_t it = tile / ntile, jt = tile - it * ntile;
+    const uint32_t h = blockIdx.y, b = blockIdx.z, Hq = gridDim.y;
+    const uint32_t bh = b * Hq + h;
+    const typename Elem<DT>::T* base = q + (int64_t)b * sb + (int64_t)h * sh;
+    const float* mub = mu + (size_t)bh * D;
+    const uint32_t ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
+    const uint32_t s0 = chunk * rows_per_chunk, s1 = min(s0 + rows_per_chunk, Sq);
+    for (uint32_t sbeg = s0; sbeg < s1; sbeg += 32) {
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < 32 * 64; e += EA_THREADS) {
+            const uint32_t r = e >> 6, cc = e & 63;
+            const uint32_t s = sbeg + r;
+            const uint32_t di = it * 64 + cc, dj = jt * 64 + cc;
+            xi[r][cc] = (s < s1 && di < D) ? Elem<DT>::ld(base + (int64_t)s * ss + di) - mub[di] : 0.f;
+            xj[r][cc] = (s < s1 && dj < D) ? Elem<DT>::ld(base + (int64_t)s * ss + dj) - mub[dj] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < 32; ++r) {
+            float vi[4], vj[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { vi[a] = xi[r][ti + 16 * a]; vj[a] = xj[r][tj + 16 * a]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][c] = fmaf(vi[a], vj[c], acc[a][c]);
+        }
+    }
+    float* out = pcov + ((size_t)bh * nchunk + chunk) * D * D;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t i = it * 64 + ti + 16 * a, j = jt * 64 + tj + 16 * c;
+            if (i < D && j < D) out[(size_t)i * D + j] = acc[a][c];
+        }
+}
+
+// cov[bh][i][j] = sum_chunks pcov / Sq
+__global__ void ea_cov_finalize(const float* __restrict__ pcov, uint32_t nchunk, uint32_t DD, float inv_n, uint64_t total,
+                                float* __restrict__ cov) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint64_t bh = i / DD, e = i - bh * DD;
+    float acc = 0.f;
+    for (uint32_t c = 0; c < nchunk; ++c) acc += pcov[(bh * nchunk + c) * DD + e];
+    cov[i] = acc * inv_n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// score (generic logits)
+// ------------------------------------------------------------------------------------------------
+// log2-logits of 64 keys for one q-head + the block's softmax partial.
+template <int DT>
+__global__ __launch_bounds__(EA_THREADS) void ea_logits_generic(EaArgs a, float* __restrict__ logits, uint32_t nblk,
+                                                                float* __restrict__ part_m, float* __restrict__ part_z) {
+    using T = typename Elem<DT>::T;
+    extern __shared__ __attribute__((aligned(16))) float ea_lds[];
+    float* kt = ea_lds;                       // [64][D+1]
+    float* red = kt + EA_SUB * (a.D + 1);     // [2][4][64]
+    const uint32_t blk = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
+    const uint32_t h = hq / a.G;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const T* kb = static_cast<const T*>(a.k) + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh + (int64_t)a.n_sink * a.k_ss;
+    const uint32_t key0 = blk * EA_SUB;
+    for (uint32_t e = threadIdx.x; e < EA_SUB * a.D; e += EA_THREADS) {
+        const uint32_t r = e / a.D, d = e - r * a.D;
+        const uint32_t kk = key0 + r;
+        kt[r * (a.D + 1) + d] = kk < a.Sp ? Elem<DT>::ld(kb + (int64_t)kk * a.k_ss + d) : 0.f;
+    }
+    __syncthreads();
+    const float* krow = kt + lane * (a.D + 1);
+    const float* mu = a.mu + (size_t)(b * a.Hq + hq) * a.D;
+    const float* cov = a.cov ? a.cov + (size_t)(b * a.Hq + hq) * a.D * a.D : nullptr;
+    float lin = 0.f, quad = 0.f;
+    for (uint32_t i = wv; i < a.D; i += EA_THREADS / 64) {
+        const float ki = krow[i];
+        lin = fmaf(mu[i], ki, lin);
+        if (cov) {
+            const float* ci = cov + (size_t)i * a.D;
+            float inner = 0.f;
+            for (uint32_t j = 0; j < a.D; ++j) inner = fmaf(ci[j], krow[j], inner);
+            quad = fmaf(ki, inner, quad);
+        }
+    }
+    red[wv * 64 + lane] = lin;
+    red[256 + wv * 64 + lane] = quad;
+    __syncthreads();
+    if (wv == 0) {
+        const float l = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+        const float qd = red[256 + lane] + red[320 + lane] + red[384 + lane] + red[448 + lane];
+        const uint32_t kk = key0 + lane;
+        const bool valid = kk < a.Sp;
+        // scores = k.mu / sqrt(d) + k^T cov k / d / 2   (:149-151), in log2 units
+        const float l2 = valid ? (l * a.inv_sqrt_d + qd * a.inv_2d) * KVP_LOG2E : KVP_NEG_INF;
+        if (valid) logits[(size_t)(b * a.Hq + hq) * a.Sp + kk] = l2;
+        const float m = wave_max(l2);
+        const float z = wave_sum(valid ? exp2f(l2 - m) : 0.f);
+        if (lane == 0) {
+            part_m[(size_t)(b * a.Hq + hq) * nblk + blk] = m;
+            part_z[(size_t)(b * a.Hq + hq) * nblk + blk] = z;
+        }
+    }
+}
+
+// scores[b,h,n_sink+s] = (mean_g 2^(l2 - a_g) [+eps]) [* ||v||]  ; device-side global max
+__global__ __launch_bounds__(EA_THREADS) void ea_finalize_kernel(const float* __restrict__ logits, const float* __restrict__ rowstat,
+                                                                 const float* __restrict__ vnorm, uint32_t B, uint32_t Hq,
+                                                                 uint32_t Hkv, uint32_t S, uint32_t n_sink, int use_vnorm,
+                                                                 float epsilon, float* __restrict__ scores,
+                                                                 uint32_t* __restrict__ gmax_key) {
+    __shared__ uint32_t scr[4];
+    const uint32_t Sp = S - n_sink, G = Hq / Hkv;
+    const uint64_t total = (uint64_t)B * Hkv * Sp;
+    const float invG = 1.0f / (float)G;
+    float vmax = KVP_NEG_INF;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t bh = (uint32_t)(i / Sp);
+        const uint32_t s = (uint32_t)(i - (uint64_t)bh * Sp);
+        const uint32_t b = bh / Hkv, h = bh - b * Hkv;
+        float p = 0.f;
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint32_t row = b * Hq + h * G + g;
+            p += exp2f(logits[(size_t)row * Sp + s] - rowstat[row]);
+        }
+        p *= invG;
+        if (use_vnorm) p = (p + epsilon) * vnorm[i];
+        scores[(size_t)bh * S + n_sink + s] = p;
+        vmax = fmaxf(vmax, p);
+    }
+    block_atomic_max(vmax, scr, gmax_key);
+}
+
+struct EaScoreWs {
+    uint32_t* gmax;
+    float* logits;
+    float* part_m;
+    float* part_z;
+    float* rowstat;
+    float* vnorm;
+    void* scratch;
+    size_t total_bytes;
+};
+
+EaScoreWs carve_score_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t D) {
+    EaScoreWs w;
+    size_t off = 0;
+    char* base = static_cast<char*>(ws);
+    auto take = [&](size_t bytes) {
+        void* p = base ? base + off : nullptr;
+        off += kvp_align_up(bytes, 256);
+        return p;
+    };
+    const size_t nblk = (size_t)(S + EA_SUB - 1) / EA_SUB;
+    w.gmax = (uint32_t*)take(256);
+    w.logits = (float*)take((size_t)B * Hq * S * 4);
+    w.part_m = (float*)take((size_t)B * Hq * nblk * 4);
+    w.part_z = (float*)take((size_t)B * Hq * nblk * 4);
+    w.rowstat = (float*)take((size_t)B * Hq * 4);
+    w.vnorm = (float*)take((size_t)B * Hkv * S * 4);
+    w.scratch = take(ea_mfma_logits_scratch_bytes(B, Hq, D) + 256);
+    w.total_bytes = off;
+    return w;
+}
+
+struct EaStatWs {
+    float* psum;
+    float* pcov;
+    uint32_t rows_mean, nchunk_mean, rows_cov, nchunk_cov;
+    size_t total_bytes;
+};
+
+EaStatWs carve_stat_ws(void* ws, int64_t B, int64_t Hq, int64_t Sq, int64_t D) {
+    EaStatWs w;
+    size_t off = 0;
+    char* base = static_cast<char*>(ws);
+    auto take = [&](size_t bytes) {
+        void* p = base ? base + off : nullptr;
+        off += kvp_align_up(bytes, 256);
+        return p;
+    };
+    auto pick = [&](int64_t max_chunks, uint32_t& rows, uint32_t& nchunk) {
+        int64_t r = std::max<int64_t>(256, (Sq + max_chunks - 1) / max_chunks);
+        r = (r + 31) / 32 * 32;
+        rows = (uint32_t)r;
+        nchunk = (uint32_t)std::max<int64_t>(1, (Sq + r - 1) / r);
+    };
+    pick(64, w.rows_mean, w.nchunk_mean);
+    pick(16, w.rows_cov, w.nchunk_cov);
+    w.psum = (float*)take((size_t)B * Hq * w.nchunk_mean * D * 4);
+    w.pcov = (float*)take((size_t)B * Hq * w.nchunk_cov * D * D * 4);
+    w.total_bytes = off;
+    return w;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" size_t kvp_ea_qstats_workspace_bytes(int64_t B, int64_t Hq, int64_t Sq, int64_t D) {
+    if (B < 1 || Hq < 1 || Sq < 1 || D < 1) return 256;
+    return std::max(carve_stat_ws(nullptr, B, Hq, Sq, D).total_bytes, ea_mfma_qstats_ws_bytes(B, Hq, Sq, D));
+}
+
+extern "C" int kvp_ea_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int dtype, int64_t B, int64_t Hq,
+                             int64_t Sq, int64_t D, float* mu, float* cov, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "ea_qstats: bad dtype %d", dtype);
+    KVP_CHECK_ARG(B >= 1 && Hq >= 1 && Sq >= 1 && D >= 1 && D <= 1024, "ea_qstats: bad shape B=%ld Hq=%ld Sq=%ld D=%ld",
+                  (long)B, (long)Hq, (long)Sq, (long)D);
+    KVP_CHECK_ARG(B <= 65535 && Hq <= 65535 && Sq < ((int64_t)1 << 31), "ea_qstats: shape too large");
+    KVP_CHECK_ARG(q && mu, "ea_qstats: null pointer");
+    const size_t need = kvp_ea_qstats_workspace_bytes(B, Hq, Sq, D);
+    if (!ws || ws_bytes < need) {
+        kvp_set_error("ea_qstats: workspace too small (%zu < %zu)", ws_bytes, need);
+        return KVP_EWORKSPACE;
+    }
+    if (ea_mfma_qstats_eligible(q, q_sb, q_sh, q_ss, dtype, D))
+        return ea_mfma_qstats(q, q_sb, q_sh, q_ss, dtype, B, Hq, Sq, D, mu, cov, ws, stream);
+
+    EaStatWs w = carve_stat_ws(ws, B, Hq, Sq, D);
+    const float inv_n = (float)(1.0 / (double)Sq);
+    const uint32_t ntile = (uint32_t)((D + 63) / 64);
+    const uint32_t tot_mu = (uint32_t)(B * Hq * D);
+    const uint64_t tot_cov = (uint64_t)B * Hq * D * D;
+#define KVP_EA_STATS(DT)                                                                                              \
+    {                                                                                                                 \
+        const Elem<DT>::T* qp = static_cast<const Elem<DT>::T*>(q);                                                   \
+        KVP_LAUNCH("ea_colsum_partial", stream, ea_colsum_partial<DT><<<dim3(w.nchunk_mean, (uint32_t)Hq, (uint32_t)B), EA_THREADS, 0, stream>>>(             \
+            qp, q_sb, q_sh, q_ss, (uint32_t)Sq, (uint32_t)D, w.rows_mean, w.psum));                                    \
+        KVP_LAUNCH("ea_mean_finalize", stream, ea_mean_finalize<<<(tot_mu + 255) / 256, 256, 0, stream>>>(w.psum, w.nchunk_mean, (uint32_t)D, inv_n, tot_mu, mu)); \
+        if (cov) {                                                                                                    \
+            KVP_LAUNCH("ea_cov_partial", stream, ea_cov_partial<DT><<<dim3(ntile * ntile * w.nchunk_cov, (uint32_t)Hq, (uint32_t)B), EA_THREADS, 0, stream>>>( \
+                qp, q_sb, q_sh, q_ss, (uint32_t)Sq, (uint32_t)D, w.rows_cov, w.nchunk_cov, ntile, mu, w.pcov));        \
+            KVP_LAUNCH("ea_cov_finalize", stream, ea_cov_finalize<<<(uint32_t)((tot_cov + 255) / 256), 256, 0, stream>>>(w.pcov, w.nchunk_cov, (uint32_t)(D * D), inv_n, tot_cov, cov)); \
+        }                                                                                                             \
+    }
+    if (dtype == KVP_F32) KVP_EA_STATS(KVP_F32)
+    else if (dtype == KVP_F16) KVP_EA_STATS(KVP_F16)
+    else KVP_EA_STATS(KVP_BF16)
+#undef KVP_EA_STATS
+    KVP_CHECK_LAUNCH("ea_qstats");
+    return KVP_OK;
+}
+
+extern "C" size_t kvp_ea_score_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t D) {
+    if (B < 1 || Hq < 1 || Hkv < 1 || S < 1 || D < 1) return 256;
+    return carve_score_ws(nullptr, B, Hq, Hkv, S, D).total_bytes;
+}
+
+extern "C" int kvp_ea_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, const void* v, int64_t v_sb, int64_t v_sh,
+                            int64_t v_ss, int dtype, const float* mu, const float* cov, int64_t B, int64_t Hq, int64_t Hkv,
+                            int64_t S, int64_t D, int64_t n_sink, int use_vnorm, float epsilon, float* scores, void* ws,
+                            size_t ws_bytes, kvp_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "ea_score: bad dtype %d", dtype);
+    KVP_CHECK_ARG(B >= 1 && Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0 && D >= 1 && D <= 1024, "ea_score: bad shape");
+    KVP_CHECK_ARG(n_sink >= 0 && S > n_sink, "ea_score: Input should contain more tokens than n_sink=%ld", (long)n_sink);
+    KVP_CHECK_ARG(S < ((int64_t)1 << 31) && B <= 65535 && Hq <= 65535, "ea_score: shape too large");
+    KVP_CHECK_ARG(k && mu && scores && (v || !use_vnorm), "ea_score: null pointer");
+    EaScoreWs w = carve_score_ws(ws, B, Hq, Hkv, S, D);
+    if (!ws || ws_bytes < w.total_bytes) {
+        kvp_set_error("ea_score: workspace too small (%zu < %zu)", ws_bytes, w.total_bytes);
+        return KVP_EWORKSPACE;
+    }
+    if (hipMemsetAsync(w.gmax, 0, 256, stream) != hipSuccess) { kvp_set_error("ea_score: memset failed"); return KVP_EHIP; }
+    const int64_t Sp = S - n_sink;
+    EaArgs a;
+    a.k = k; a.k_sb = k_sb; a.k_sh = k_sh; a.k_ss = k_ss;
+    a.mu = mu; a.cov = cov;
+    a.B = (uint32_t)B; a.Hq = (uint32_t)Hq; a.Hkv = (uint32_t)Hkv; a.G = (uint32_t)(Hq / Hkv);
+    a.S = (uint32_t)S; a.Sp = (uint32_t)Sp; a.D = (uint32_t)D; a.n_sink = (uint32_t)n_sink;
+    a.inv_sqrt_d = (float)(1.0 / sqrt((double)D));
+    a.inv_2d = (float)(1.0 / (2.0 * (double)D));
+
+    uint32_t nblk;
+    if (ea_mfma_logits_eligible(a, dtype)) {
+        nblk = ea_mfma_logits_nblk(a);
+        if (int rc = ea_mfma_logits(a, dtype, w.logits, nblk, w.part_m, w.part_z, w.scratch, stream)) return rc;
+    } else {
+        nblk = (uint32_t)((Sp + EA_SUB - 1) / EA_SUB);
+        const size_t lds = ((size_t)EA_SUB * (D + 1) + 512) * 4;
+        KVP_CHECK_ARG(lds <= 64 * 1024, "ea_score: D=%ld exceeds the generic kernel's LDS budget", (long)D);
+        const dim3 grid(nblk, (uint32_t)Hq, (uint32_t)B);
+        if (dtype == KVP_F32) KVP_LAUNCH("ea_logits_generic", stream, ea_logits_generic<KVP_F32><<<grid, EA_THREADS, lds, stream>>>(a, w.logits, nblk, w.part_m, w.part_z));
+        else if (dtype == KVP_F16) KVP_LAUNCH("ea_logits_generic", stream, ea_logits_generic<KVP_F16><<<grid, EA_THREADS, lds, stream>>>(a, w.logits, nblk, w.part_m, w.part_z));
+        else KVP_LAUNCH("ea_logits_generic", stream, ea_logits_generic<KVP_BF16><<<grid, EA_THREADS, lds, stream>>>(a, w.logits, nblk, w.part_m, w.part_z));
+    }
+    const uint32_t nrows = (uint32_t)(B * Hq);
+    KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_kernel<<<(nrows + 3) / 4, 256, 0, stream>>>(w.part_m, w.part_z, nrows, nblk, w.rowstat));
+    KVP_CHECK_LAUNCH("ea_score(logits)");
+    if (use_vnorm) {
+        const char* vp = static_cast<const char*>(v) + n_sink * v_ss * kvp_elem_size(dtype);
+        if (int rc = kvp_rownorm_launch(vp, dtype, B, Hkv, Sp, D, v_sb, v_sh, v_ss, 1.0f, w.vnorm, stream)) return rc;
+    }
+    const uint64_t total = (uint64_t)B * Hkv * Sp;
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((total + EA_THREADS - 1) / EA_THREADS, 2048));
+    KVP_LAUNCH("ea_finalize_kernel", stream, ea_finalize_kernel<<<blocks, EA_THREADS, 0, stream>>>(w.logits, w.rowstat, w.vnorm, (uint32_t)B, (uint32_t)Hq, (uint32_t)Hkv,
+                                                          (uint32_t)S, (uint32_t)n_sink, use_vnorm, epsilon, scores, w.gmax));
+    if (n_sink > 0) {
+        const uint32_t BH = (uint32_t)(B * Hkv), nfill = BH * (uint32_t)n_sink;
+        KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, 0, (uint32_t)n_sink, w.gmax));
+    }
+    KVP_CHECK_LAUNCH("ea_score(finalize)");
+    return KVP_OK;
+}

@@ -1,0 +1,145 @@
+// kvp_gather_kv: K'[b,h,j,:] = K[b,h,idx[b*H+h,j],:], V' likewise.
+// Replaces `keys.gather(2, indices).contiguous()` / `values.gather(...)` (scorer_press.py:96-100),
+// where `indices` is an int64 [B,H,n,D] expanded view that torch re-reads for K and again for V.
+//
+// HBM-bound row copy: algorithmic bytes = 2 * n*B*H*D*esize read + the same written.
+// One output row = `chunks` 16-byte vectors handled by LPR adjacent lanes; K and V rows for the
+// same index are moved by the same lanes (one index load, two dwordx4 loads, two dwordx4 stores).
+// With position-ordered indices (the default of kvp_topk_select) the source addresses of a
+// (b,h) row are monotone, so consecutive lane groups stream forward through HBM pages.
+// The kernel is dtype-agnostic (bytes); four rows per lane group are in flight.
+#include "kvp_common.h"
+
+namespace {
+
+constexpr int GA_THREADS = 256;
+constexpr int GA_UNROLL = 4;
+
+struct GatherArgs {
+    const char* k;
+    const char* v;
+    char* ko;
+    char* vo;
+    const int32_t* idx;
+    int64_t k_sb, k_sh, k_ss;  // BYTE strides
+    int64_t v_sb, v_sh, v_ss;
+    uint32_t H, S, n;
+    uint32_t nrows;     // B*H*n output rows
+    uint32_t rowbytes;  // D*esize
+};
+
+template <int LPR>
+__global__ __launch_bounds__(GA_THREADS) void gather_vec_kernel(GatherArgs a) {
+    constexpr int GPB = GA_THREADS / LPR;
+    const uint32_t lir = threadIdx.x % LPR;
+    const uint32_t g = blockIdx.x * GPB + threadIdx.x / LPR;
+    const uint32_t TG = gridDim.x * GPB;
+    const uint32_t chunks = a.rowbytes / 16;
+
+    for (uint32_t r0 = g; r0 < a.nrows; r0 += TG * GA_UNROLL) {
+        uint4 kv[GA_UNROLL], vv[GA_UNROLL];
+        const char* ksrc[GA_UNROLL];
+        const char* vsrc[GA_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GA_UNROLL; ++u) {
+            const uint32_t r = r0 + u * TG;
+            ksrc[u] = nullptr;
+            vsrc[u] = nullptr;
+            if (r < a.nrows) {
+                const uint32_t bh = r / a.n;
+                const uint32_t b = bh / a.H, h = bh - b * a.H;
+                int32_t s = a.idx[r];
+                s = s < 0 ? 0 : (s >= (int32_t)a.S ? (int32_t)a.S - 1 : s);  // never fault on a bad index
+                ksrc[u] = a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh + (int64_t)s * a.k_ss;
+                vsrc[u] = a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh + (int64_t)s * a.v_ss;
+                if (lir < chunks) {
+                    kv[u] = *reinterpret_cast<const uint4*>(ksrc[u] + (size_t)lir * 16);
+                    vv[u] = *reinterpret_cast<const uint4*>(vsrc[u] + (size_t)lir * 16);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GA_UNROLL; ++u) {
+            const uint32_t r = r0 + u * TG;
+            if (r < a.nrows) {
+                char* kd = a.ko + (size_t)r * a.rowbytes;
+                char* vd = a.vo + (size_t)r * a.rowbytes;
+                if (lir < chunks) {
+                    *reinterpret_cast<uint4*>(kd + (size_t)lir * 16) = kv[u];
+                    *reinterpret_cast<uint4*>(vd + (size_t)lir * 16) = vv[u];
+                }
+                if (LPR == 64) {  // rows longer than 1 KiB
+                    for (uint32_t c = lir + LPR; c < chunks; c += LPR) {
+                        *reinterpret_cast<uint4*>(kd + (size_t)c * 16) = *reinterpret_cast<const uint4*>(ksrc[u] + (size_t)c * 16);
+                        *reinterpret_cast<uint4*>(vd + (size_t)c * 16) = *reinterpret_cast<const uint4*>(vsrc[u] + (size_t)c * 16);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Any row size / alignment: element-granular copy (ES = 2 or 4 bytes), one thread per element.
+template <typename E>
+__global__ __launch_bounds__(GA_THREADS) void gather_scalar_kernel(GatherArgs a, uint32_t D) {
+    const uint64_t total = (uint64_t)a.nrows * D;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(i / D), d = (uint32_t)(i - (uint64_t)r * D);
+        const uint32_t bh = r / a.n;
+        const uint32_t b = bh / a.H, h = bh - b * a.H;
+        int32_t s = a.idx[r];
+        s = s < 0 ? 0 : (s >= (int32_t)a.S ? (int32_t)a.S - 1 : s);
+        const E* ks = reinterpret_cast<const E*>(a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh + (int64_t)s * a.k_ss);
+        const E* vs = reinterpret_cast<const E*>(a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh + (int64_t)s * a.v_ss);
+        reinterpret_cast<E*>(a.ko)[i] = ks[d];
+        reinterpret_cast<E*>(a.vo)[i] = vs[d];
+    }
+}
+
+}  // namespace
+
+extern "C" int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, const void* v, int64_t v_sb,
+                             int64_t v_sh, int64_t v_ss, int dtype, int64_t B, int64_t H, int64_t S, int64_t D,
+                             const int32_t* idx, int64_t n, void* k_out, void* v_out, kvp_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "gather: bad dtype %d", dtype);
+    KVP_CHECK_ARG(B >= 0 && H >= 0 && S >= 0 && D >= 1 && n >= 0 && n <= S, "gather: bad shape B=%ld H=%ld S=%ld D=%ld n=%ld",
+                  (long)B, (long)H, (long)S, (long)D, (long)n);
+    const int64_t nrows64 = B * H * n;
+    if (nrows64 == 0) return KVP_OK;
+    KVP_CHECK_ARG(nrows64 < (int64_t)1 << 31 && S < (int64_t)1 << 31, "gather: too many rows");
+    KVP_CHECK_ARG(k && v && idx && k_out && v_out, "gather: null pointer");
+    const int64_t es = kvp_elem_size(dtype);
+    GatherArgs a;
+    a.k = static_cast<const char*>(k); a.v = static_cast<const char*>(v);
+    a.ko = static_cast<char*>(k_out); a.vo = static_cast<char*>(v_out);
+    a.idx = idx;
+    a.k_sb = k_sb * es; a.k_sh = k_sh * es; a.k_ss = k_ss * es;
+    a.v_sb = v_sb * es; a.v_sh = v_sh * es; a.v_ss = v_ss * es;
+    a.H = (uint32_t)H; a.S = (uint32_t)S; a.n = (uint32_t)n;
+    a.nrows = (uint32_t)nrows64;
+    a.rowbytes = (uint32_t)(D * es);
+    auto al16 = [](int64_t x) { return x % 16 == 0; };
+    const bool vec_ok = a.rowbytes % 16 == 0 && al16((int64_t)(uintptr_t)k) && al16((int64_t)(uintptr_t)v) &&
+                        al16((int64_t)(uintptr_t)k_out) && al16((int64_t)(uintptr_t)v_out) && al16(a.k_sb) &&
+                        al16(a.k_sh) && al16(a.k_ss) && al16(a.v_sb) && al16(a.v_sh) && al16(a.v_ss);
+    if (!vec_ok) {
+        const uint64_t total = (uint64_t)a.nrows * (uint64_t)D;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + GA_THREADS - 1) / GA_THREADS, 8192);
+        if (es == 4) KVP_LAUNCH("gather_scalar_kernel", stream, gather_scalar_kernel<uint32_t><<<blocks, GA_THREADS, 0, stream>>>(a, (uint32_t)D));
+        else KVP_LAUNCH("gather_scalar_kernel", stream, gather_scalar_kernel<uint16_t><<<blocks, GA_THREADS, 0, stream>>>(a, (uint32_t)D));
+        KVP_CHECK_LAUNCH("gather(scalar)");
+        return KVP_OK;
+    }
+    const uint32_t chunks = a.rowbytes / 16;
+    int lpr = 1;
+    while (lpr < 64 && (uint32_t)lpr < chunks) lpr <<= 1;
+    const uint32_t gpb = GA_THREADS / lpr;
+    const uint64_t groups_needed = ((uint64_t)a.nrows + GA_UNROLL - 1) / GA_UNROLL;
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((groups_needed + gpb - 1) / gpb, 256 * 8));
+#define KVP_GA_CASE(L) case L: KVP_LAUNCH("gather_vec_kernel", stream, gather_vec_kernel<L><<<blocks, GA_THREADS, 0, stream>>>(a)); break;
+    switch (lpr) { KVP_GA_CASE(1) KVP_GA_CASE(2) KVP_GA_CASE(4) KVP_GA_CASE(8) KVP_GA_CASE(16) KVP_GA_CASE(32) KVP_GA_CASE(64) }
+#undef KVP_GA_CASE
+    KVP_CHECK_LAUNCH("gather");
+    return KVP_OK;
+}

@@ -1,0 +1,149 @@
+// kvp_rownorm_score: out[b,h,s] = scale * ||x[b,h,s,:]||_2
+// Replaces `-keys.norm(dim=-1)` (kvpress/presses/knorm_press.py:38) and `values.norm(dim=-1)`
+// (expected_attention_press.py:160).
+//
+// HBM-bound streaming reduction (algorithmic bytes = B*H*S*D*esize read + 4*B*H*S written).
+// Fast path: a row is `chunks` 16-byte vectors; LPR (= next pow2 >= chunks, <= 64) adjacent lanes
+// own one row, so one wave-wide dwordx4 load covers 64/LPR consecutive rows = 1 KiB of contiguous
+// HBM when the tensor is contiguous (D=128 bf16: 16 lanes per 256-B row, 4 rows per instruction).
+// Four independent rows per lane are in flight before any reduction starts; the sum of squares
+// is accumulated in fp32 and reduced with xor-shuffles inside the LPR-lane group.
+#include "kvp_common.h"
+
+namespace {
+
+struct RowMap {
+    uint32_t S, H;
+    int64_t sb, sh, ss;  // element strides
+    __device__ __forceinline__ int64_t offset(uint32_t r) const {
+        const uint32_t bh = r / S, s = r - bh * S;
+        const uint32_t b = bh / H, h = bh - b * H;
+        return (int64_t)b * sb + (int64_t)h * sh + (int64_t)s * ss;
+    }
+};
+
+template <int DT>
+__device__ __forceinline__ float sumsq16(const uint4& v) {
+    float f[Elem<DT>::PER16];
+    unpack16<DT>(v, f);
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < Elem<DT>::PER16; ++i) a = fmaf(f[i], f[i], a);
+    return a;
+}
+
+constexpr int RN_THREADS = 256;
+constexpr int RN_UNROLL = 4;
+
+template <int DT, int LPR>
+__global__ __launch_bounds__(RN_THREADS) void rownorm_vec_kernel(
+    const typename Elem<DT>::T* __restrict__ x, RowMap map, uint32_t nrows, uint32_t chunks, float scale,
+    float* __restrict__ out) {
+    using T = typename Elem<DT>::T;
+    constexpr int PER16 = Elem<DT>::PER16;
+    constexpr int GPB = RN_THREADS / LPR;  // row groups per block
+    const uint32_t lir = threadIdx.x % LPR;
+    const uint32_t g = blockIdx.x * GPB + threadIdx.x / LPR;
+    const uint32_t TG = gridDim.x * GPB;
+
+    for (uint32_t r0 = g; r0 < nrows; r0 += TG * RN_UNROLL) {
+        uint4 v[RN_UNROLL];
+        const T* rowp[RN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RN_UNROLL; ++u) {
+            const uint32_t r = r0 + u * TG;
+            v[u] = make_uint4(0, 0, 0, 0);
+            rowp[u] = nullptr;
+            if (r < nrows) {
+                rowp[u] = x + map.offset(r);
+                if (lir < chunks) v[u] = *reinterpret_cast<const uint4*>(rowp[u] + (size_t)lir * PER16);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RN_UNROLL; ++u) {
+            const uint32_t r = r0 + u * TG;
+            float acc = sumsq16<DT>(v[u]);
+            if (LPR == 64 && r < nrows) {  // rows longer than 1 KiB: keep striding
+                for (uint32_t c = lir + LPR; c < chunks; c += LPR)
+                    acc += sumsq16<DT>(*reinterpret_cast<const uint4*>(rowp[u] + (size_t)c * PER16));
+            }
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lir == 0 && r < nrows) out[r] = scale * sqrtf(acc);
+        }
+    }
+}
+
+// Any D / alignment: one thread per row, scalar loads (tiny test shapes such as head_dim 6).
+template <int DT>
+__global__ __launch_bounds__(RN_THREADS) void rownorm_scalar_kernel(
+    const typename Elem<DT>::T* __restrict__ x, RowMap map, uint32_t nrows, uint32_t D, float scale,
+    float* __restrict__ out) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
+        const typename Elem<DT>::T* p = x + map.offset(r);
+        float acc = 0.f;
+        for (uint32_t d = 0; d < D; ++d) {
+            const float f = Elem<DT>::ld(p + d);
+            acc = fmaf(f, f, acc);
+        }
+        out[r] = scale * sqrtf(acc);
+    }
+}
+
+template <int DT>
+int launch_rownorm(const void* x, RowMap map, uint32_t nrows, uint32_t D, float scale, float* out,
+                   hipStream_t stream) {
+    using T = typename Elem<DT>::T;
+    const T* xp = static_cast<const T*>(x);
+    const size_t es = sizeof(T);
+    const size_t rowbytes = (size_t)D * es;
+    const bool vec_ok = rowbytes % 16 == 0 && ((uintptr_t)x % 16 == 0) && (map.sb * es) % 16 == 0 &&
+                        (map.sh * es) % 16 == 0 && (map.ss * es) % 16 == 0;
+    if (!vec_ok) {
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)nrows + RN_THREADS - 1) / RN_THREADS, 4096);
+        KVP_LAUNCH("rownorm_scalar_kernel", stream, rownorm_scalar_kernel<DT><<<blocks, RN_THREADS, 0, stream>>>(xp, map, nrows, D, scale, out));
+        return 0;
+    }
+    const uint32_t chunks = (uint32_t)(rowbytes / 16);
+    int lpr = 1;
+    while (lpr < 64 && (uint32_t)lpr < chunks) lpr <<= 1;
+    const uint32_t gpb = RN_THREADS / lpr;
+    const uint64_t groups_needed = ((uint64_t)nrows + RN_UNROLL - 1) / RN_UNROLL;
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((groups_needed + gpb - 1) / gpb, 256 * 8));
+#define KVP_RN_CASE(L)                                                                                     \
+    case L:                                                                                                \
+        KVP_LAUNCH("rownorm_vec_kernel", stream, rownorm_vec_kernel<DT, L><<<blocks, RN_THREADS, 0, stream>>>(xp, map, nrows, chunks, scale, out));   \
+        break;
+    switch (lpr) {
+        KVP_RN_CASE(1) KVP_RN_CASE(2) KVP_RN_CASE(4) KVP_RN_CASE(8) KVP_RN_CASE(16) KVP_RN_CASE(32) KVP_RN_CASE(64)
+    }
+#undef KVP_RN_CASE
+    return 0;
+}
+
+}  // namespace
+
+// Internal entry shared with the ExpectedAttention path (||V||).
+int kvp_rownorm_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh,
+                       int64_t ss, float scale, float* out, hipStream_t stream) {
+    KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "rownorm: bad dtype %d", dtype);
+    KVP_CHECK_ARG(B >= 0 && H >= 0 && S >= 0 && D >= 1, "rownorm: bad shape B=%ld H=%ld S=%ld D=%ld", (long)B, (long)H,
+                  (long)S, (long)D);
+    const int64_t nrows64 = B * H * S;
+    if (nrows64 == 0) return KVP_OK;
+    KVP_CHECK_ARG(nrows64 < (int64_t)1 << 31, "rownorm: B*H*S=%ld exceeds 2^31 rows", (long)nrows64);
+    KVP_CHECK_ARG(x && out, "rownorm: null pointer");
+    RowMap map{(uint32_t)S, (uint32_t)H, sb, sh, ss};
+    switch (dtype) {
+        case KVP_F32: launch_rownorm<KVP_F32>(x, map, (uint32_t)nrows64, (uint32_t)D, scale, out, stream); break;
+        case KVP_F16: launch_rownorm<KVP_F16>(x, map, (uint32_t)nrows64, (uint32_t)D, scale, out, stream); break;
+        default: launch_rownorm<KVP_BF16>(x, map, (uint32_t)nrows64, (uint32_t)D, scale, out, stream); break;
+    }
+    KVP_CHECK_LAUNCH("rownorm");
+    return KVP_OK;
+}
+
+extern "C" int kvp_rownorm_score(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb,
+                                 int64_t sh, int64_t ss, float scale, float* out, kvp_stream_t stream) {
+    return kvp_rownorm_launch(x, dtype, B, H, S, D, sb, sh, ss, scale, out, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,310 @@
+// kvp_snapkv_score / kvp_snapkv_score_from_attn -- SnapKVPress.score
+// (kvpress/presses/snapkv_press.py:60-105) from the RoPE'd window queries on.
+//
+// Reference dataflow at S=128k: repeat_kv (1 GiB) -> QK^T logits [32,64,S]
+// (512 MiB) -> 3 mask temporaries -> fp32 softmax (1 GiB) -> mean / avg_pool1d / group mean
+// -> F.pad with a host-synchronising .item().  Here nothing of size [Hq, W, S] ever exists:
+//
+//   pass 1  (p1)      per (kv-head, key chunk): logits tile -> per-row partial (max, sum-exp)
+//   combine           per row: a = M + log2 Z                      (softmax_stats.h)
+//   pass 2  (p2)      per (kv-head, key chunk): recompute the logits tile, P = 2^(L2 - a),
+//                     column sums over all G*W rows of the kv-head -> colsum[B,Hkv,S-W]
+//   pool              avg_pool1d(kernel) of colsum, scaled by 1/(G*W*kernel); device-side max
+//   fill              last W positions <- max + 1                   (no host sync)
+//
+// mean-over-window, pool and mean-over-group are all linear, so summing the G*W rows first
+// and pooling once is the same arithmetic up to fp32 rounding.  The causal mask
+// (triu(-inf, diagonal=S-W+1), snapkv_press.py:63-65) only touches the last W columns, which
+// are dropped from the result (:67): it matters for the normaliser (pass 1) only.
+//
+// Two implementations of p1/p2: the generic VALU kernels in this file (any W, D, dtype,
+// stride; used for small/odd shapes) and the MFMA kernels in snapkv_mfma.hip (bf16/f16,
+// D=128, W=64, G<=8: the Llama-3.1-8B hot path).
+#include "kvp_common.h"
+#include "softmax_stats.h"
+#include "snapkv_internal.h"
+
+namespace {
+
+constexpr int SK_THREADS = 256;
+constexpr int SK_SUB = 64;           // keys per sub-tile (= one wave wide)
+constexpr int SK_CHUNK_GENERIC = 512;  // keys per workgroup in the generic kernels
+
+template <int DT>
+__device__ __forceinline__ void load_k_subtile(const typename Elem<DT>::T* __restrict__ kbase, int64_t k_ss,
+                                               uint32_t key0, uint32_t S, uint32_t D, float* kt) {
+    for (uint32_t e = threadIdx.x; e < SK_SUB * D; e += SK_THREADS) {
+        const uint32_t r = e / D, d = e - r * D;
+        const uint32_t kk = key0 + r;
+        kt[r * (D + 1) + d] = kk < S ? Elem<DT>::ld(kbase + (int64_t)kk * k_ss + d) : 0.f;
+    }
+}
+
+// ---- generic pass 1: partial (max, sum-exp) per (b, hq, w, chunk) ------------------------------
+template <int DT>
+__global__ __launch_bounds__(SK_THREADS) void snapkv_p1_generic(SnapArgs a, uint32_t nchunk, float* __restrict__ part_m,
+                                                                float* __restrict__ part_z) {
+    using T = typename Elem<DT>::T;
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+    float* kt = sk_lds;                            // [64][D+1]
+    float* m_run = kt + SK_SUB * (a.D + 1);        // [W]
+    float* z_run = m_run + a.W;                    // [W]
+    const uint32_t chunk = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
+    const uint32_t h = hq / a.G;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const T* qb = static_cast<const T*>(a.q) + (int64_t)b * a.q_sb + (int64_t)hq * a.q_sh;
+    const T* kb = static_cast<const T*>(a.k) + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh;
+    for (uint32_t r = threadIdx.x; r < a.W; r += SK_THREADS) { m_run[r] = KVP_NEG_INF; z_run[r] = 0.f; }
+    const uint32_t kbeg = chunk * SK_CHUNK_GENERIC;
+    const uint32_t kend = min(kbeg + SK_CHUNK_GENERIC, a.S);
+    for (uint32_t key0 = kbeg; key0 < kend; key0 += SK_SUB) {
+        __syncthreads();
+        load_k_subtile<DT>(kb, a.k_ss, key0, a.S, a.D, kt);
+        __syncthreads();
+        const uint32_t kk = key0 + lane;
+        const float* krow = kt + lane * (a.D + 1);
+        for (uint32_t r = wv; r < a.W; r += SK_THREADS / 64) {
+            const T* qr = qb + (int64_t)r * a.q_sw;
+            float dot = 0.f;
+            for (uint32_t d = 0; d < a.D; ++d) dot = fmaf(Elem<DT>::ld(qr + d), krow[d], dot);
+            // window row r is token S-W+r and may attend keys <= S-W+r
+            const bool masked = kk >= a.S || kk > a.S - a.W + r;
+            const float l2 = masked ? KVP_NEG_INF : dot * a.c;
+            const float m = wave_max(l2);
+            if (m != KVP_NEG_INF) {
+                const float z = wave_sum(masked ? 0.f : exp2f(l2 - m));
+                if (lane == 0) {
+                    float mr = m_run[r], zr = z_run[r];
+                    softmax_merge(mr, zr, m, z);
+                    m_run[r] = mr; z_run[r] = zr;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < a.W; r += SK_THREADS) {
+        const size_t o = ((size_t)(b * a.Hq + hq) * a.W + r) * nchunk + chunk;
+        part_m[o] = m_run[r];
+        part_z[o] = z_run[r];
+    }
+}
+
+// ---- generic pass 2: colsum[b,h,c] = sum over the G*W rows of 2^(L2 - a_row) --------------------
+template <int DT>
+__global__ __launch_bounds__(SK_THREADS) void snapkv_p2_generic(SnapArgs a, const float* __restrict__ rowstat,
+                                                                float* __restrict__ colsum) {
+    using T = typename Elem<DT>::T;
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+    float* kt = sk_lds;                      // [64][D+1]
+    float* red = kt + SK_SUB * (a.D + 1);    // [4][64]
+    const uint32_t chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t Sm = a.S - a.W;
+    const T* kb = static_cast<const T*>(a.k) + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh;
+    const uint32_t kbeg = chunk * SK_CHUNK_GENERIC;
+    const uint32_t kend = min(kbeg + SK_CHUNK_GENERIC, Sm);
+    for (uint32_t key0 = kbeg; key0 < kend; key0 += SK_SUB) {
+        __syncthreads();
+        load_k_subtile<DT>(kb, a.k_ss, key0, a.S, a.D, kt);
+        __syncthreads();
+        const float* krow = kt + lane * (a.D + 1);
+        float acc = 0.f;
+        for (uint32_t g = 0; g < a.G; ++g) {
+            const uint32_t hq = h * a.G + g;
+            const T* qb = static_cast<const T*>(a.q) + (int64_t)b * a.q_sb + (int64_t)hq * a.q_sh;
+            const float* ar = rowstat + (size_t)(b * a.Hq + hq) * a.W;
+            for (uint32_t r = wv; r < a.W; r += SK_THREADS / 64) {
+                const T* qr = qb + (int64_t)r * a.q_sw;
+                float dot = 0.f;
+                for (uint32_t d = 0; d < a.D; ++d) dot = fmaf(Elem<DT>::ld(qr + d), krow[d], dot);
+                acc += exp2f(fmaf(dot, a.c, -ar[r]));
+            }
+        }
+        red[wv * 64 + lane] = acc;
+        __syncthreads();
+        if (wv == 0) {
+            const uint32_t kk = key0 + lane;
+            if (kk < Sm) colsum[(size_t)(b * a.Hkv + h) * Sm + kk] = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+        }
+    }
+}
+
+// ---- colsum from given attention weights: attn[..., -W:, :-W] (snapkv_press.py:88-89) ----------
+template <int DT>
+__global__ __launch_bounds__(SK_THREADS) void snapkv_colsum_from_attn(const typename Elem<DT>::T* __restrict__ attn,
+                                                                      int64_t sb, int64_t sh, int64_t sw, uint32_t B,
+                                                                      uint32_t Hq, uint32_t Hkv, uint32_t Sm, uint32_t W,
+                                                                      float* __restrict__ colsum) {
+    const uint32_t G = Hq / Hkv;
+    const uint64_t total = (uint64_t)B * Hkv * Sm;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)(i % Sm);
+        const uint32_t bh = (uint32_t)(i / Sm);
+        const uint32_t b = bh / Hkv, h = bh - b * Hkv;
+        float acc = 0.f;
+        for (uint32_t g = 0; g < G; ++g) {
+            const typename Elem<DT>::T* p = attn + (int64_t)b * sb + (int64_t)(h * G + g) * sh + c;
+            for (uint32_t w = 0; w < W; ++w) acc += Elem<DT>::ld(p + (int64_t)w * sw);
+        }
+        colsum[i] = acc;
+    }
+}
+
+// ---- avg_pool1d(kernel, pad=kernel/2, zero padded, divisor = kernel) + scaling + global max ----
+__global__ __launch_bounds__(SK_THREADS) void snapkv_pool_kernel(const float* __restrict__ colsum, uint32_t BH, uint32_t S,
+                                                                 uint32_t W, int pad, float inv, float* __restrict__ scores,
+                                                                 uint32_t* __restrict__ gmax_key) {
+    __shared__ uint32_t scr[4];
+    const uint32_t Sm = S - W;
+    const uint64_t total = (uint64_t)BH * Sm;
+    float vmax = KVP_NEG_INF;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t bh = (uint32_t)(i / Sm);
+        const int c = (int)(i - (uint64_t)bh * Sm);
+        const float* row = colsum + (size_t)bh * Sm;
+        float s = 0.f;
+        for (int j = -pad; j <= pad; ++j) {
+            const int cc = c + j;
+            if (cc >= 0 && cc < (int)Sm) s += row[cc];
+        }
+        s *= inv;
+        scores[(size_t)bh * S + c] = s;
+        vmax = fmaxf(vmax, s);
+    }
+    block_atomic_max(vmax, scr, gmax_key);
+}
+
+struct SnapWs {
+    float* part_m;
+    float* part_z;
+    float* rowstat;
+    float* colsum;
+    uint32_t* gmax;
+    size_t total_bytes;
+};
+
+SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W) {
+    SnapWs w;
+    size_t off = 0;
+    char* base = static_cast<char*>(ws);
+    auto take = [&](size_t bytes) {
+        void* p = base ? base + off : nullptr;
+        off += kvp_align_up(bytes, 256);
+        return p;
+    };
+    const int64_t nchunk_max = (S + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC;
+    const size_t rows = (size_t)B * Hq * W;
+    w.gmax = (uint32_t*)take(256);
+    w.part_m = (float*)take(rows * nchunk_max * 4);
+    w.part_z = (float*)take(rows * nchunk_max * 4);
+    w.rowstat = (float*)take(rows * 4);
+    w.colsum = (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4);
+    w.total_bytes = off;
+    return w;
+}
+
+int finish_scores(const SnapWs& w, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int kernel_size,
+                  float* scores, hipStream_t stream) {
+    const uint32_t BH = (uint32_t)(B * Hkv);
+    const uint64_t total = (uint64_t)BH * (uint64_t)(S - W);
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((total + SK_THREADS - 1) / SK_THREADS, 2048));
+    const int64_t G = Hq / Hkv;
+    const float inv = (float)(1.0 / ((double)G * (double)W * (double)kernel_size));
+    KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<<<blocks, SK_THREADS, 0, stream>>>(w.colsum, BH, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.gmax));
+    const uint32_t nfill = BH * (uint32_t)W;
+    KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, (uint32_t)(S - W), (uint32_t)W, w.gmax));
+    KVP_CHECK_LAUNCH("snapkv(pool/fill)");
+    return KVP_OK;
+}
+
+int check_common(int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int kernel_size) {
+    KVP_CHECK_ARG(B >= 1 && Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0, "snapkv: bad heads B=%ld Hq=%ld Hkv=%ld", (long)B, (long)Hq, (long)Hkv);
+    KVP_CHECK_ARG(W >= 1 && S > W, "snapkv: query length %ld should be greater than the window size %ld", (long)S, (long)W);
+    KVP_CHECK_ARG(kernel_size >= 1 && (kernel_size & 1), "snapkv: kernel_size must be odd (got %d)", kernel_size);
+    KVP_CHECK_ARG(S < ((int64_t)1 << 31) && B * Hq <= 65535 && B <= 65535, "snapkv: shape too large");
+    return KVP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t kvp_snapkv_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D) {
+    (void)D;
+    if (B < 1 || Hq < 1 || Hkv < 1 || S < 1 || W < 1) return 256;
+    return carve_snap_ws(nullptr, B, Hq, Hkv, S, W).total_bytes;
+}
+
+extern "C" int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* k, int64_t k_sb,
+                                int64_t k_sh, int64_t k_ss, int dtype, int64_t B, int64_t Hq, int64_t Hkv, int64_t S,
+                                int64_t W, int64_t D, int kernel_size, float* scores, void* ws, size_t ws_bytes,
+                                kvp_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "snapkv: bad dtype %d", dtype);
+    if (int rc = check_common(B, Hq, Hkv, S, W, kernel_size)) return rc;
+    KVP_CHECK_ARG(D >= 1 && D <= 1024, "snapkv: unsupported head_dim %ld", (long)D);
+    KVP_CHECK_ARG(q && k && scores, "snapkv: null pointer");
+    SnapWs w = carve_snap_ws(ws, B, Hq, Hkv, S, W);
+    if (!ws || ws_bytes < w.total_bytes) {
+        kvp_set_error("snapkv: workspace too small (%zu < %zu)", ws_bytes, w.total_bytes);
+        return KVP_EWORKSPACE;
+    }
+    if (hipMemsetAsync(w.gmax, 0, 256, stream) != hipSuccess) { kvp_set_error("snapkv: memset failed"); return KVP_EHIP; }
+
+    SnapArgs a;
+    a.q = q; a.k = k;
+    a.q_sb = q_sb; a.q_sh = q_sh; a.q_sw = q_sw;
+    a.k_sb = k_sb; a.k_sh = k_sh; a.k_ss = k_ss;
+    a.B = (uint32_t)B; a.Hq = (uint32_t)Hq; a.Hkv = (uint32_t)Hkv; a.G = (uint32_t)(Hq / Hkv);
+    a.S = (uint32_t)S; a.W = (uint32_t)W; a.D = (uint32_t)D;
+    a.c = (float)(1.4426950408889634 / sqrt((double)D));
+    const uint32_t nrows = (uint32_t)(B * Hq * W);
+
+    if (snapkv_mfma_eligible(a, dtype)) {
+        const uint32_t nchunk = snapkv_mfma_nchunk(a);
+        if (int rc = snapkv_mfma_p1(a, dtype, nchunk, w.part_m, w.part_z, stream)) return rc;
+        KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_kernel<<<(nrows + 3) / 4, 256, 0, stream>>>(w.part_m, w.part_z, nrows, nchunk, w.rowstat));
+        if (int rc = snapkv_mfma_p2(a, dtype, w.rowstat, w.colsum, stream)) return rc;
+    } else {
+        const uint32_t nchunk = (uint32_t)((S + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC);
+        const size_t lds1 = ((size_t)SK_SUB * (D + 1) + 2 * (size_t)W) * 4;
+        const size_t lds2 = ((size_t)SK_SUB * (D + 1) + 256) * 4;
+        KVP_CHECK_ARG(lds1 <= 64 * 1024 && lds2 <= 64 * 1024, "snapkv: W=%ld, D=%ld exceed the generic kernel's LDS budget", (long)W, (long)D);
+        const dim3 g1(nchunk, (uint32_t)Hq, (uint32_t)B);
+        const uint32_t nchunk2 = (uint32_t)((S - W + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC);
+        const dim3 g2(nchunk2, (uint32_t)Hkv, (uint32_t)B);
+#define KVP_SK_GENERIC(DT)                                                                                \
+    KVP_LAUNCH("snapkv_p1_generic", stream, snapkv_p1_generic<DT><<<g1, SK_THREADS, lds1, stream>>>(a, nchunk, w.part_m, w.part_z));               \
+    KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_kernel<<<(nrows + 3) / 4, 256, 0, stream>>>(w.part_m, w.part_z, nrows, nchunk, w.rowstat)); \
+    KVP_LAUNCH("snapkv_p2_generic", stream, snapkv_p2_generic<DT><<<g2, SK_THREADS, lds2, stream>>>(a, w.rowstat, w.colsum));
+        if (dtype == KVP_F32) { KVP_SK_GENERIC(KVP_F32) }
+        else if (dtype == KVP_F16) { KVP_SK_GENERIC(KVP_F16) }
+        else { KVP_SK_GENERIC(KVP_BF16) }
+#undef KVP_SK_GENERIC
+    }
+    KVP_CHECK_LAUNCH("snapkv(p1/p2)");
+    return finish_scores(w, B, Hq, Hkv, S, W, kernel_size, scores, stream);
+}
+
+extern "C" int kvp_snapkv_score_from_attn(const void* attn, int64_t a_sb, int64_t a_sh, int64_t a_sw, int dtype, int64_t B,
+                                          int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int kernel_size, float* scores,
+                                          void* ws, size_t ws_bytes, kvp_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "snapkv: bad dtype %d", dtype);
+    if (int rc = check_common(B, Hq, Hkv, S, W, kernel_size)) return rc;
+    KVP_CHECK_ARG(attn && scores, "snapkv: null pointer");
+    SnapWs w = carve_snap_ws(ws, B, Hq, Hkv, S, W);
+    if (!ws || ws_bytes < w.total_bytes) {
+        kvp_set_error("snapkv: workspace too small (%zu < %zu)", ws_bytes, w.total_bytes);
+        return KVP_EWORKSPACE;
+    }
+    if (hipMemsetAsync(w.gmax, 0, 256, stream) != hipSuccess) { kvp_set_error("snapkv: memset failed"); return KVP_EHIP; }
+    const uint64_t total = (uint64_t)B * Hkv * (S - W);
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((total + SK_THREADS - 1) / SK_THREADS, 4096));
+#define KVP_SK_ATTN(DT) \
+    KVP_LAUNCH("snapkv_colsum_from_attn", stream, snapkv_colsum_from_attn<DT><<<blocks, SK_THREADS, 0, stream>>>(static_cast<const Elem<DT>::T*>(attn), a_sb, a_sh, a_sw, (uint32_t)B, (uint32_t)Hq, (uint32_t)Hkv, (uint32_t)(S - W), (uint32_t)W, w.colsum));
+    if (dtype == KVP_F32) { KVP_SK_ATTN(KVP_F32) }
+    else if (dtype == KVP_F16) { KVP_SK_ATTN(KVP_F16) }
+    else { KVP_SK_ATTN(KVP_BF16) }
+#undef KVP_SK_ATTN
+    KVP_CHECK_LAUNCH("snapkv(from_attn)");
+    return finish_scores(w, B, Hq, Hkv, S, W, kernel_size, scores, stream);
+}

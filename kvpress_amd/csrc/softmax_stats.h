@@ -1,0 +1,65 @@
+// Shared pieces of the two-pass "softmax over all S keys" used by SnapKV and ExpectedAttention.
+//
+// Work in log2 units: L2 = logit * log2(e) so that exp() is a bare v_exp_f32 (exp2f).
+// Pass 1 produces per (row, key-chunk) partials (m = max L2, z = sum 2^(L2-m)); `combine` folds
+// them into one number per row, a = M + log2(Z), so that pass 2 evaluates the normalised
+// probability as 2^(L2 - a) with a single fma + exp2.
+#pragma once
+#include "kvp_common.h"
+
+constexpr float KVP_LOG2E = 1.4426950408889634f;
+constexpr float KVP_NEG_INF = -__builtin_huge_valf();
+
+// order-preserving key <-> float (for atomicMax over floats of any sign)
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+
+// fold (m2,z2) into (m,z); either side may be the empty partial (m = -inf, z = 0)
+__device__ __forceinline__ void softmax_merge(float& m, float& z, float m2, float z2) {
+    if (m2 == KVP_NEG_INF) return;
+    if (m == KVP_NEG_INF) { m = m2; z = z2; return; }
+    const float mn = fmaxf(m, m2);
+    z = z * exp2f(m - mn) + z2 * exp2f(m2 - mn);
+    m = mn;
+}
+
+// a[row] = M + log2(Z) from part_m/part_z [nrows][nchunk]; one wave per row.
+static __global__ __launch_bounds__(256) void softmax_combine_kernel(const float* __restrict__ part_m,
+                                                              const float* __restrict__ part_z, uint32_t nrows,
+                                                              uint32_t nchunk, float* __restrict__ a) {
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (row >= nrows) return;
+    float m = KVP_NEG_INF, z = 0.f;
+    for (uint32_t j = lane; j < nchunk; j += 64) softmax_merge(m, z, part_m[(size_t)row * nchunk + j], part_z[(size_t)row * nchunk + j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o), z2 = __shfl_xor(z, o);
+        softmax_merge(m, z, m2, z2);
+    }
+    if (lane == 0) a[row] = m + log2f(z);
+}
+
+// block max of a float -> atomicMax(order-preserving key) ; lds >= 4 words
+__device__ __forceinline__ void block_atomic_max(float v, uint32_t* lds, uint32_t* gmax_key) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = float_to_key(v);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t k = lds[0];
+        for (uint32_t i = 1; i < (blockDim.x >> 6); ++i) k = max(k, lds[i]);
+        atomicMax(gmax_key, k);
+    }
+}
+
+// scores[b,h, lo + j] = max + 1 for j < n  (F.pad(value=scores.max().item() + 1):
+// snapkv_press.py:103 pads the last W positions, expected_attention_press.py:163 the first n_sink)
+static __global__ void fill_pad_kernel(float* __restrict__ scores, uint32_t BH, uint32_t S, uint32_t lo, uint32_t n,
+                                const uint32_t* __restrict__ gmax_key) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BH * n) return;
+    const float fill = key_to_float(*gmax_key) + 1.0f;
+    scores[(size_t)(i / n) * S + lo + (i % n)] = fill;
+}

@@ -1,0 +1,303 @@
+// kvp_topk_select: indices of the k largest scores per row, ties -> lowest position, -0.0 == +0.0.
+// Replaces `scores.topk(n_kept, dim=-1).indices` (kvpress/presses/scorer_press.py:95).
+//
+// The score matrix is tiny (B*H_kv rows x S floats: 4 MiB at 8 x 131072) and L2-resident, but it
+// has FEW rows, so one-workgroup-per-row would leave 248 of 256 CUs idle.  Every pass is therefore
+// a (chunk, row) grid of 2048-element chunks and rows are combined through global histograms:
+//
+//   K1 hist<12 bits>  : histogram of key>>20 per row                    (key = order-preserving u32)
+//   K2 hist<12 bits>  : find digit b1 holding the k-th largest; histogram of (key>>8)&0xFFF among key>>20==b1
+//   K3 hist< 8 bits>  : find b2; per-CHUNK histogram of key&0xFF among key>>8==prefix24 (+ global one)
+//                       and per-chunk count of keys with a larger 24-bit prefix
+//   K4 write          : find b3 -> threshold T and tie quota q (= how many keys == T to keep, lowest
+//                       positions first); each chunk derives its output offset from the per-chunk
+//                       tables of the chunks before it, scans its keep flags and writes positions
+//                       in ascending order.
+//
+// Kernel boundaries order the passes (1.5-1.9 us each on MI355X, cheaper than a grid barrier);
+// the only inter-workgroup traffic inside a launch is atomicAdd into the row histograms.
+#include "kvp_common.h"
+
+namespace {
+
+constexpr int TK_THREADS = 256;
+constexpr int TK_PER = 8;
+constexpr int TK_CHUNK = TK_THREADS * TK_PER;  // 2048 scores per workgroup
+
+struct TopkWs {
+    uint32_t* hist1;       // [R][4096]
+    uint32_t* hist2;       // [R][4096]
+    uint32_t* hist3;       // [R][256]
+    uint32_t* sel;         // [R][4] : b1, k1, b2, k2
+    uint32_t* chunk_hist;  // [R][nchunks][256]
+    uint32_t* chunk_gt;    // [R][nchunks]
+    size_t zero_bytes;     // leading bytes that must be zeroed per call (hist1..hist3)
+    size_t total_bytes;
+};
+
+TopkWs carve_ws(void* ws, int64_t R, int64_t nchunks) {
+    TopkWs w;
+    size_t off = 0;
+    char* base = static_cast<char*>(ws);
+    auto take = [&](size_t bytes) {
+        void* p = base ? base + off : nullptr;
+        off += kvp_align_up(bytes, 256);
+        return p;
+    };
+    w.hist1 = (uint32_t*)take((size_t)R * 4096 * 4);
+    w.hist2 = (uint32_t*)take((size_t)R * 4096 * 4);
+    w.hist3 = (uint32_t*)take((size_t)R * 256 * 4);
+    w.zero_bytes = off;
+    w.sel = (uint32_t*)take((size_t)R * 4 * 4);
+    w.chunk_hist = (uint32_t*)take((size_t)R * nchunks * 256 * 4);
+    w.chunk_gt = (uint32_t*)take((size_t)R * nchunks * 4);
+    w.total_bytes = off;
+    return w;
+}
+
+// exclusive prefix sum over the 256 threads of the block (4 waves); lds: >= 4 words
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < TK_THREADS / 64; ++i) {
+        const uint32_t x = lds[i];
+        if (i < w) woff += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + inc - v;
+}
+
+// Find the digit bin that holds the k-th largest element (k >= 1) of a NB-bin histogram:
+// count(d > bin) < k <= count(d >= bin);  krem = k - count(d > bin).   lds: >= 8 words.
+template <int NB>
+__device__ __forceinline__ void find_bin(const uint32_t* __restrict__ hist, uint32_t k, uint32_t* lds, uint32_t& bin,
+                                         uint32_t& krem) {
+    constexpr int PER = NB / TK_THREADS;
+    const uint32_t rg = TK_THREADS - 1 - threadIdx.x;  // thread 0 owns the highest bins
+    uint32_t loc[PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        loc[i] = hist[rg * PER + i];
+        sum += loc[i];
+    }
+    uint32_t total;
+    const uint32_t excl = block_excl_scan(sum, lds, &total);  // # elements in bins above mine
+    if (excl < k && k <= excl + sum) {
+        uint32_t c = excl;
+#pragma unroll
+        for (int i = PER - 1; i >= 0; --i) {
+            if (k > c && k <= c + loc[i]) {
+                lds[4] = rg * PER + i;
+                lds[5] = k - c;
+            }
+            c += loc[i];
+        }
+    }
+    __syncthreads();
+    bin = lds[4];
+    krem = lds[5];
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t load_key(const float* __restrict__ row, uint32_t i, uint32_t S, bool& valid) {
+    valid = i < S;
+    return valid ? float_to_key(row[i]) : 0u;
+}
+
+// ---- K1 / K2: 12-bit histograms ---------------------------------------------------------------
+template <int PASS>
+__global__ __launch_bounds__(TK_THREADS) void topk_hist12_kernel(const float* __restrict__ scores, int64_t row_stride,
+                                                                 uint32_t S, uint32_t k, TopkWs w) {
+    __shared__ uint32_t lh[4096];
+    __shared__ uint32_t scr[8];
+    const uint32_t row = blockIdx.y, chunk = blockIdx.x;
+    const float* rp = scores + (int64_t)row * row_stride;
+    for (int i = threadIdx.x; i < 4096; i += TK_THREADS) lh[i] = 0;
+    uint32_t b1 = 0, k1 = 0;
+    if (PASS == 2) {
+        find_bin<4096>(w.hist1 + (size_t)row * 4096, k, scr, b1, k1);
+        if (chunk == 0 && threadIdx.x == 0) {
+            w.sel[row * 4 + 0] = b1;
+            w.sel[row * 4 + 1] = k1;
+        }
+    }
+    __syncthreads();
+    const uint32_t base = chunk * TK_CHUNK;
+#pragma unroll
+    for (int j = 0; j < TK_PER; ++j) {
+        bool valid;
+        const uint32_t key = load_key(rp, base + j * TK_THREADS + threadIdx.x, S, valid);
+        if (PASS == 1) {
+            if (valid) atomicAdd(&lh[key >> 20], 1u);
+        } else {
+            if (valid && (key >> 20) == b1) atomicAdd(&lh[(key >> 8) & 0xFFFu], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* gh = (PASS == 1 ? w.hist1 : w.hist2) + (size_t)row * 4096;
+    for (int i = threadIdx.x; i < 4096; i += TK_THREADS) {
+        const uint32_t c = lh[i];
+        if (c) atomicAdd(&gh[i], c);
+    }
+}
+
+// ---- K3: 8-bit histogram of the last digit, per chunk and per row ----------------------------
+__global__ __launch_bounds__(TK_THREADS) void topk_hist8_kernel(const float* __restrict__ scores, int64_t row_stride,
+                                                                uint32_t S, uint32_t nchunks, TopkWs w) {
+    __shared__ uint32_t lh[256];
+    __shared__ uint32_t scr[8];
+    const uint32_t row = blockIdx.y, chunk = blockIdx.x;
+    const float* rp = scores + (int64_t)row * row_stride;
+    lh[threadIdx.x] = 0;
+    const uint32_t b1 = w.sel[row * 4 + 0], k1 = w.sel[row * 4 + 1];
+    uint32_t b2, k2;
+    find_bin<4096>(w.hist2 + (size_t)row * 4096, k1, scr, b2, k2);
+    if (chunk == 0 && threadIdx.x == 0) {
+        w.sel[row * 4 + 2] = b2;
+        w.sel[row * 4 + 3] = k2;
+    }
+    const uint32_t prefix = (b1 << 12) | b2;
+    __syncthreads();
+    const uint32_t base = chunk * TK_CHUNK;
+    uint32_t ngt = 0;
+#pragma unroll
+    for (int j = 0; j < TK_PER; ++j) {
+        bool valid;
+        const uint32_t key = load_key(rp, base + j * TK_THREADS + threadIdx.x, S, valid);
+        const uint32_t p = key >> 8;
+        if (valid && p > prefix) ++ngt;
+        if (valid && p == prefix) atomicAdd(&lh[key & 0xFFu], 1u);
+    }
+    uint32_t tot;
+    block_excl_scan(ngt, scr, &tot);  // contains the barrier that also covers the LDS atomics
+    const uint32_t c = lh[threadIdx.x];
+    w.chunk_hist[((size_t)row * nchunks + chunk) * 256 + threadIdx.x] = c;
+    if (c) atomicAdd(&w.hist3[(size_t)row * 256 + threadIdx.x], c);
+    if (threadIdx.x == 0) w.chunk_gt[(size_t)row * nchunks + chunk] = tot;
+}
+
+// ---- K4: ordered compaction --------------------------------------------------------------------
+__global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __restrict__ scores, int64_t row_stride,
+                                                                uint32_t S, uint32_t k, uint32_t nchunks, TopkWs w,
+                                                                int32_t* __restrict__ idx) {
+    __shared__ uint32_t scr[8];
+    const uint32_t row = blockIdx.y, chunk = blockIdx.x;
+    const float* rp = scores + (int64_t)row * row_stride;
+    const uint32_t b1 = w.sel[row * 4 + 0], b2 = w.sel[row * 4 + 2], k2 = w.sel[row * 4 + 3];
+    uint32_t b3, quota;
+    find_bin<256>(w.hist3 + (size_t)row * 256, k2, scr, b3, quota);
+    const uint32_t T = (((b1 << 12) | b2) << 8) | b3;
+
+    // elements kept in the chunks before this one: thread t sums bin t of their last-digit histograms
+    uint32_t binsum = 0;
+    const uint32_t* ch = w.chunk_hist + (size_t)row * nchunks * 256 + threadIdx.x;
+    for (uint32_t j = 0; j < chunk; ++j) binsum += ch[(size_t)j * 256];
+    uint32_t gt_part = threadIdx.x > b3 ? binsum : 0u;
+    for (uint32_t j = threadIdx.x; j < chunk; j += TK_THREADS) gt_part += w.chunk_gt[(size_t)row * nchunks + j];
+    uint32_t gt_before, eq_before;
+    block_excl_scan(gt_part, scr, &gt_before);
+    block_excl_scan(threadIdx.x == b3 ? binsum : 0u, scr, &eq_before);
+
+    // this thread's 8 consecutive positions
+    const uint32_t p0 = chunk * TK_CHUNK + threadIdx.x * TK_PER;
+    uint32_t keys[TK_PER];
+    const bool fast = (p0 + TK_PER <= S) && ((((uintptr_t)(rp + p0)) & 15u) == 0);
+    if (fast) {
+        const float4 a = *reinterpret_cast<const float4*>(rp + p0);
+        const float4 b = *reinterpret_cast<const float4*>(rp + p0 + 4);
+        keys[0] = float_to_key(a.x); keys[1] = float_to_key(a.y); keys[2] = float_to_key(a.z); keys[3] = float_to_key(a.w);
+        keys[4] = float_to_key(b.x); keys[5] = float_to_key(b.y); keys[6] = float_to_key(b.z); keys[7] = float_to_key(b.w);
+    } else {
+#pragma unroll
+        for (int j = 0; j < TK_PER; ++j) keys[j] = (p0 + j < S) ? float_to_key(rp[p0 + j]) : 0u;
+    }
+    uint32_t cg = 0, ce = 0;
+#pragma unroll
+    for (int j = 0; j < TK_PER; ++j) {
+        const bool valid = p0 + j < S;
+        cg += (valid && keys[j] > T) ? 1u : 0u;
+        ce += (valid && keys[j] == T) ? 1u : 0u;
+    }
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(cg | (ce << 16), scr, &tot);  // chunk <= 2048: both fields < 65536
+    uint32_t g = gt_before + (ex & 0xFFFFu);
+    uint32_t e = eq_before + (ex >> 16);
+    int32_t* out = idx + (size_t)row * k;
+#pragma unroll
+    for (int j = 0; j < TK_PER; ++j) {
+        const bool valid = p0 + j < S;
+        const bool isg = valid && keys[j] > T;
+        const bool ise = valid && keys[j] == T;
+        if (isg || (ise && e < quota)) {
+            const uint32_t rank = g + (e < quota ? e : quota);
+            if (rank < k) out[rank] = (int32_t)(p0 + j);
+        }
+        g += isg ? 1u : 0u;
+        e += ise ? 1u : 0u;
+    }
+}
+
+// k == S: every position is kept (compression_ratio so small that int(S*(1-r)) == S)
+__global__ void topk_iota_kernel(int32_t* __restrict__ idx, uint32_t S, uint64_t total) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x)
+        idx[i] = (int32_t)(i % S);
+}
+
+}  // namespace
+
+extern "C" size_t kvp_topk_workspace_bytes(int64_t R, int64_t S, int64_t k) {
+    (void)k;
+    if (R <= 0 || S <= 0) return 256;
+    const int64_t nchunks = (S + TK_CHUNK - 1) / TK_CHUNK;
+    return carve_ws(nullptr, R, nchunks).total_bytes;
+}
+
+extern "C" int kvp_topk_select(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int order,
+                               int32_t* idx, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KVP_CHECK_ARG(R >= 0 && S >= 0 && k >= 0 && k <= S, "topk: bad shape R=%ld S=%ld k=%ld", (long)R, (long)S, (long)k);
+    KVP_CHECK_ARG(order == KVP_ORDER_POSITION || order == KVP_ORDER_SCORE, "topk: bad order %d", order);
+    if (order == KVP_ORDER_SCORE) {
+        kvp_set_error("topk: KVP_ORDER_SCORE is not implemented yet (use KVP_ORDER_POSITION)");
+        return KVP_EUNSUPPORTED;
+    }
+    if (R == 0 || k == 0) return KVP_OK;
+    KVP_CHECK_ARG(S < ((int64_t)1 << 31) && R <= 65535, "topk: S=%ld or R=%ld too large", (long)S, (long)R);
+    KVP_CHECK_ARG(scores && idx, "topk: null pointer");
+    KVP_CHECK_ARG(row_stride >= S, "topk: row_stride %ld < S %ld", (long)row_stride, (long)S);
+    if (k == S) {
+        const uint64_t total = (uint64_t)R * (uint64_t)S;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 2048);
+        KVP_LAUNCH("topk_iota_kernel", stream, topk_iota_kernel<<<blocks, 256, 0, stream>>>(idx, (uint32_t)S, total));
+        KVP_CHECK_LAUNCH("topk(iota)");
+        return KVP_OK;
+    }
+    const int64_t nchunks = (S + TK_CHUNK - 1) / TK_CHUNK;
+    TopkWs w = carve_ws(ws, R, nchunks);
+    if (!ws || ws_bytes < w.total_bytes) {
+        kvp_set_error("topk: workspace too small (%zu < %zu)", ws_bytes, w.total_bytes);
+        return KVP_EWORKSPACE;
+    }
+    if (hipMemsetAsync(ws, 0, w.zero_bytes, stream) != hipSuccess) {
+        kvp_set_error("topk: hipMemsetAsync failed");
+        return KVP_EHIP;
+    }
+    const dim3 grid((uint32_t)nchunks, (uint32_t)R);
+    KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<1><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
+    KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<2><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
+    KVP_LAUNCH("topk_hist8_kernel", stream, topk_hist8_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)nchunks, w));
+    KVP_LAUNCH("topk_write_kernel", stream, topk_write_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, (uint32_t)nchunks, w, idx));
+    KVP_CHECK_LAUNCH("topk");
+    return KVP_OK;
+}

@@ -1,0 +1,72 @@
+"""ExpectedAttentionPress (kvpress/presses/expected_attention_press.py:16-165) on
+kvp_ea_qstats / kvp_ea_score."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from kvpress_amd import _native
+from kvpress_amd.presses.scorer_press import ScorerPress
+from kvpress_amd.utils import get_prerope_query_states
+
+
+@dataclass
+class ExpectedAttentionPress(ScorerPress):
+    """Expected attention: E[exp(q.k/sqrt(d))] for future queries q ~ N(mu, cov) rotated by the
+    average RoPE of the next ``n_future_positions`` positions, rescaled by ||v||.
+
+    Parameters
+    ----------
+    compression_ratio : float, default=0.0
+    n_future_positions : int, default=512
+    n_sink : int, default=4
+        Initial tokens excluded from the statistics and never pruned.
+    use_covariance : bool, default=True
+    use_vnorm : bool, default=True
+        Rescale by ``(scores + epsilon) * ||V||_2``.
+    epsilon : float, default=0.0
+    """
+
+    compression_ratio: float = 0.0
+    n_future_positions: int = 512
+    n_sink: int = 4
+    use_covariance: bool = True
+    use_vnorm: bool = True
+    epsilon: float = 0.0
+
+    def get_query_statistics(self, module: nn.Module, hidden_states: torch.Tensor):
+        """Mean and covariance of the pre-RoPE queries (float32), then the averaged RoPE
+        (expected_attention_press.py:62-86).  The full-sequence q_proj is a model-owned GEMM."""
+        q_len = hidden_states.shape[1]
+        h = hidden_states[:, self.n_sink:]
+        query_states = get_prerope_query_states(module, h)
+        mu, cov = _native.ea_qstats(query_states, self.use_covariance)
+        return self.apply_avg_rope(module, mu, cov, q_len)
+
+    def apply_avg_rope(self, module: nn.Module, mu: torch.Tensor, cov: torch.Tensor, q_len: int):
+        """mu <- mu R^T, cov <- R cov R^T with R the RoPE matrix averaged over positions
+        q_len .. q_len + n_future_positions - 1 (expected_attention_press.py:88-124).
+        D x D host-side math in float32 on the device of mu."""
+        position_ids = torch.arange(q_len, q_len + self.n_future_positions, device=mu.device).unsqueeze(0)
+        head_dim = module.head_dim
+        cos, sin = module.rotary_emb(mu, position_ids)
+        cos, sin = cos[0].to(mu.dtype), sin[0].to(mu.dtype)
+        half = head_dim // 2
+        eye_h = torch.eye(half, device=mu.device, dtype=mu.dtype)
+        P = torch.zeros((head_dim, head_dim), device=mu.device, dtype=mu.dtype)
+        P[half:, :half] = eye_h
+        P[:half, half:] = -eye_h
+        # mean_p (diag(cos_p) + P * sin_p[:, None]) == diag(mean cos) + P * mean(sin)[:, None]
+        R = torch.diag(cos.mean(dim=0)) + sin.mean(dim=0).unsqueeze(1) * P
+        mu = torch.matmul(mu, R.T)
+        if cov is not None:
+            cov = torch.matmul(R, torch.matmul(cov, R.T))
+        return mu, cov
+
+    def score(self, module: nn.Module, hidden_states: torch.Tensor, keys: torch.Tensor, values: torch.Tensor,
+              attentions: torch.Tensor, kwargs) -> torch.Tensor:
+        assert keys.size(2) > self.n_sink, f"Input should contain more tokens than n_sink={self.n_sink}"
+        mean_query, cov_query = self.get_query_statistics(module, hidden_states)
+        return _native.ea_score(keys, values, mean_query, cov_query, self.n_sink, self.use_vnorm, self.epsilon)

@@ -1,0 +1,61 @@
+"""ScorerPress: score -> top-k -> gather, on the MI355X kernels.
+
+Mirror of kvpress/presses/scorer_press.py (ScorerPress :17-102).  ``compress`` keeps the
+reference semantics -- ratio 0 returns the inputs untouched (:86-87), ``n_kept =
+int(k_len * (1 - ratio))`` in Python double arithmetic (:93-94), new contiguous [B,H,n_kept,D]
+outputs in the input dtype, inputs never modified -- but top-k and gather are the HIP kernels
+``kvp_topk_select`` / ``kvp_gather_kv`` (include/kvpress_hip.h).
+
+Defined deviations (DESIGN.md "Parity contract"):
+  * scores are float32 (the reference keeps the model dtype; bf16 scores tie ~1000-fold at the
+    threshold and torch.topk's choice among ties is unspecified);
+  * among equal scores the lowest position is kept;
+  * the retained tokens are stored in ascending position order (``order = "position"``), the
+    reference stores them in descending score order, which no reference test observes.
+"""
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from kvpress_amd import _native
+from kvpress_amd.presses.base_press import BasePress
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass
+class ScorerPress(BasePress):
+    """Base class for score-based KV cache compression.
+
+    Parameters
+    ----------
+    compression_ratio : float, default=0.0
+        Fraction of key-value pairs to remove during compression.
+    """
+
+    compression_ratio: float = 0.0
+
+    def __post_init__(self):
+        assert 0 <= self.compression_ratio < 1, "Compression ratio must be between 0 and 1"
+
+    def score(self, module: nn.Module, hidden_states: torch.Tensor, keys: torch.Tensor, values: torch.Tensor,
+              attentions: torch.Tensor, kwargs) -> torch.Tensor:
+        """Importance score per KV pair, shape [B, num_kv_heads, seq_len]; higher = keep
+        (scorer_press.py:35-74)."""
+        raise NotImplementedError
+
+    def compress(self, module: nn.Module, hidden_states: torch.Tensor, keys: torch.Tensor, values: torch.Tensor,
+                 attentions: torch.Tensor, kwargs: dict) -> tuple[torch.Tensor, torch.Tensor]:
+        if self.compression_ratio == 0:
+            return keys, values
+
+        scores = self.score(module, hidden_states, keys, values, attentions, kwargs)
+
+        k_len = keys.shape[2]
+        n_kept = int(k_len * (1 - self.compression_ratio))
+        indices = _native.topk_select(scores, n_kept)        # int32 [B,H,n_kept], ascending position
+        return _native.gather_kv(keys, values, indices)      # contiguous [B,H,n_kept,D]

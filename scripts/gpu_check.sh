@@ -1,0 +1,32 @@
+#!/bin/bash
+# One GPU-box session: build check, parity tests by group, smoke, bench lines.  Logs -> gpurun_out/.
+# usage: scripts/gpu_check.sh [tests] [bench] [prof]
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
+WHAT="${*:-tests bench}"
+python __graft_entry__.py > gpurun_out/build.log 2>&1; echo "build rc=$?"
+rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
+if [[ "$WHAT" == *tests* ]]; then
+  for grp in rownorm topk gather snapkv_kernel snapkv_from ea_qstats ea_score press_fp32 press_native; do
+    timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --no-header -k "$grp" > gpurun_out/test_$grp.log 2>&1
+    echo "tests[$grp] rc=$? $(tail -1 gpurun_out/test_$grp.log)"
+  done
+  timeout 900 python -m pytest tests -m gpu -q --no-header --deselect tests/test_gpu_parity.py > gpurun_out/test_other.log 2>&1
+  echo "tests[other] rc=$? $(tail -1 gpurun_out/test_other.log)"
+  timeout 300 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$? $(tail -1 gpurun_out/smoke.log)"
+fi
+if [[ "$WHAT" == *bench* ]]; then
+  for wl in knorm32k knorm128k snapkv128k; do
+    timeout 600 python bench.py --workload $wl --steps 20 --warmup 3 --profile-json gpurun_out/kern_$wl.json > gpurun_out/bench_$wl.log 2>&1
+    echo "bench[$wl] rc=$? $(tail -1 gpurun_out/bench_$wl.log | cut -c1-600)"
+  done
+fi
+if [[ "$WHAT" == *prof* ]]; then
+  cd /tmp
+  for wl in snapkv128k knorm32k; do
+    timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -o $wl -- python "$GRAFT_REPO_ROOT/bench.py" --workload $wl --steps 20 --warmup 3 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" 2>&1
+    echo "prof[$wl] rc=$?"
+  done
+fi

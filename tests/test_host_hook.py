@@ -1,0 +1,166 @@
+"""Host logic of the boundary (BasePress hook / ScorerPress.compress) on CPU.
+
+The HIP kernels cannot run here, so the *test* swaps kvpress_amd._native's entry points for
+oracle-backed fakes (monkeypatch; test infrastructure only -- the product has no such switch).
+What is tested is the Python around the kernels: hook registration/removal, prefill detection
+without ``cache_position`` (transformers 5.x), cache write-back, n_kept arithmetic, and the
+golden lengths the reference's own tests pin."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kvpress_oracle as O
+
+
+@pytest.fixture
+def fake_native(monkeypatch):
+    from kvpress_amd import _native
+
+    def rownorm_score(x, scale):
+        return torch.from_numpy(-float(scale) * O.knorm_score(x.float().numpy()))  # scale * ||x||
+
+    def topk_select(scores, k, order=0):
+        return torch.from_numpy(O.topk_select(scores.float().numpy(), k))
+
+    def gather_kv(keys, values, idx):
+        ko, vo = O.gather_kv(keys.numpy(), values.numpy(), idx.numpy())
+        return torch.from_numpy(ko), torch.from_numpy(vo)
+
+    def snapkv_score(q_win, keys, kernel_size):
+        return torch.from_numpy(O.snapkv_score(q_win.float().numpy(), keys.float().numpy(), kernel_size))
+
+    def ea_qstats(q, use_cov=True):
+        mu, cov = O.ea_query_stats(q.float().numpy(), use_cov)
+        return torch.from_numpy(mu.astype(np.float32)), (torch.from_numpy(cov.astype(np.float32)) if cov is not None else None)
+
+    def ea_score(keys, values, mu, cov, n_sink, use_vnorm, eps):
+        return torch.from_numpy(O.ea_score(keys.float().numpy(), values.float().numpy(), mu.numpy(),
+                                           cov.numpy() if cov is not None else None, n_sink, use_vnorm, eps))
+
+    for name, fn in dict(rownorm_score=rownorm_score, topk_select=topk_select, gather_kv=gather_kv,
+                         snapkv_score=snapkv_score, ea_qstats=ea_qstats, ea_score=ea_score).items():
+        monkeypatch.setattr(_native, name, fn)
+    return _native
+
+
+@pytest.fixture(scope="module")
+def tiny_llama():
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    # the reference's unit-test model geometry: 2 layers, 2 KV heads, head_dim 6
+    cfg = LlamaConfig(hidden_size=24, num_attention_heads=4, num_key_value_heads=2, head_dim=6, num_hidden_layers=2,
+                      intermediate_size=32, vocab_size=64, max_position_embeddings=512)
+    torch.manual_seed(0)
+    return LlamaForCausalLM(cfg).eval()
+
+
+def test_context_manager_adds_and_removes_hook(tiny_llama, fake_native):
+    import kvpress_amd as P
+
+    with P.KnormPress(0.2)(tiny_llama):
+        for layer in tiny_llama.model.layers:
+            assert len(layer.self_attn._forward_hooks) == 1
+            assert layer.self_attn.rotary_emb is tiny_llama.model.rotary_emb
+    for layer in tiny_llama.model.layers:
+        assert len(layer.self_attn._forward_hooks) == 0
+
+
+def test_hooks_removed_on_exception(tiny_llama, fake_native):
+    import kvpress_amd as P
+
+    with pytest.raises(RuntimeError):
+        with P.KnormPress(0.2)(tiny_llama):
+            raise RuntimeError("boom")
+    assert all(len(layer.self_attn._forward_hooks) == 0 for layer in tiny_llama.model.layers)
+
+
+@pytest.mark.parametrize("ratio,seq_len", [(0.2, 256), (0.1, 256), (0.5, 23)])
+def test_context_manager_applies_compression(tiny_llama, fake_native, ratio, seq_len):
+    """tests/test_press_call.py:22-40 of the reference: keys.shape[2] == int(seq_len * (1 - ratio))."""
+    from transformers import DynamicCache
+
+    import kvpress_amd as P
+
+    ids = torch.randint(0, 64, (5, seq_len))
+    cache = DynamicCache()
+    with torch.no_grad(), P.KnormPress(ratio)(tiny_llama):
+        tiny_llama(ids, past_key_values=cache)
+    n = int(seq_len * (1 - ratio))
+    for layer in cache.layers:
+        assert layer.keys.shape == (5, 2, n, 6) and layer.values.shape == (5, 2, n, 6)
+    if (ratio, seq_len) == (0.1, 256):
+        assert n == 230  # tests/test_per_layer_compression_press.py:19 golden shape [5,2,230,6]
+
+
+def test_decode_steps_are_not_compressed(tiny_llama, fake_native):
+    from transformers import DynamicCache
+
+    import kvpress_amd as P
+
+    ids = torch.randint(0, 64, (1, 40))
+    cache = DynamicCache()
+    with torch.no_grad(), P.KnormPress(0.5)(tiny_llama):
+        tiny_llama(ids, past_key_values=cache)
+        assert cache.layers[0].keys.shape[2] == 20
+        for step in range(3):  # decoding inside the context: cache grows by one, no re-compression
+            tiny_llama(torch.randint(0, 64, (1, 1)), past_key_values=cache)
+            assert cache.layers[0].keys.shape[2] == 21 + step
+
+
+@pytest.mark.parametrize("press_name,seq_len,ratio,expect", [("ea", 23, 0.4, 13), ("ea", 28, 0.4, 16), ("snapkv", 100, 0.5, 50)])
+def test_pipeline_golden_lengths(tiny_llama, fake_native, press_name, seq_len, ratio, expect):
+    """tests/test_pipeline.py:31-32,105-106: Context Length 23 -> Compressed 13 (EA 0.4); 28 -> 16."""
+    from transformers import DynamicCache
+
+    import kvpress_amd as P
+
+    press = P.ExpectedAttentionPress(ratio) if press_name == "ea" else P.SnapKVPress(ratio, window_size=8)
+    cache = DynamicCache()
+    with torch.no_grad(), press(tiny_llama):
+        tiny_llama.model(input_ids=torch.randint(0, 64, (1, seq_len)), past_key_values=cache)
+    assert cache.get_seq_length() == expect
+
+
+def test_hook_matches_direct_compress(tiny_llama, fake_native):
+    """What the hook stores is exactly compress() of what the layer cached."""
+    from transformers import DynamicCache
+
+    import kvpress_amd as P
+
+    ids = torch.randint(0, 64, (2, 50))
+    ref = DynamicCache()
+    with torch.no_grad():
+        tiny_llama(ids, past_key_values=ref)
+    k_full, v_full = ref.layers[0].keys, ref.layers[0].values  # layer 0 sees the same inputs either way
+    cache = DynamicCache()
+    with torch.no_grad(), P.KnormPress(0.5)(tiny_llama):
+        tiny_llama(ids, past_key_values=cache)
+    sc = O.knorm_score(k_full.numpy())
+    ko, vo, idx = O.compress(sc, k_full.numpy(), v_full.numpy(), 0.5)
+    assert np.array_equal(cache.layers[0].keys.numpy(), ko) and np.array_equal(cache.layers[0].values.numpy(), vo)
+
+
+def test_opt_layer_locator(fake_native):
+    """BASELINE config 1 (OPT-125m plumbing): the reference's __call__ fails on OPT
+    ('OPTModel' object has no attribute 'layers'); ours finds model.model.decoder.layers."""
+    from transformers import OPTConfig, OPTForCausalLM
+
+    import kvpress_amd as P
+
+    cfg = OPTConfig(hidden_size=32, num_attention_heads=4, num_hidden_layers=2, ffn_dim=64, vocab_size=64,
+                    max_position_embeddings=128, word_embed_proj_dim=32)
+    torch.manual_seed(0)
+    model = OPTForCausalLM(cfg).eval()
+    with P.KnormPress(0.5)(model):
+        assert all(len(l.self_attn._forward_hooks) == 1 for l in model.model.decoder.layers)
+    assert all(len(l.self_attn._forward_hooks) == 0 for l in model.model.decoder.layers)
+
+
+def test_compression_ratio_is_a_plain_settable_attribute():
+    import kvpress_amd as P
+
+    p = P.SnapKVPress(0.3)
+    p.compression_ratio = 1.0  # wrappers bypass __post_init__ (per_layer_compression_press.py:56-61)
+    assert p.compression_ratio == 1.0 and (p.window_size, p.kernel_size) == (64, 5)
+    e = P.ExpectedAttentionPress()
+    assert (e.n_future_positions, e.n_sink, e.use_covariance, e.use_vnorm, e.epsilon) == (512, 4, True, True, 0.0)
