@@ -1,0 +1,178 @@
+"""Parity at BASELINE.json's full sizes (configs 1-4) through size-independent properties and a
+plain-PyTorch fp32 restatement evaluated on the GPU (the CPU oracle would need minutes at 128k):
+
+  * scores  : |kernel - torch fp32| <= 1e-3 relative (north_star tolerance);
+  * top-k   : indices ascending/unique/in range; partition property (every kept score >= every
+              dropped score); the multiset of kept score values equals torch.topk's on the same
+              scores; idempotence (selecting all kept again returns them all);
+  * gather  : K'/V' bit-identical to torch.gather with the kernel's indices; inputs untouched.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+H_Q, H_KV, D, HIDDEN = 32, 8, 128, 4096
+
+
+def _native():
+    from kvpress_amd import _native
+
+    return _native
+
+
+def check_topk_and_gather(scores, keys, values, n, ko, vo):
+    nat = _native()
+    B, H, S = scores.shape
+    idx = nat.topk_select(scores, n).long()
+    assert idx.shape == (B, H, n)
+    assert (idx[..., 1:] > idx[..., :-1]).all(), "indices must be strictly ascending"
+    assert idx.min() >= 0 and idx.max() < S
+    kept = torch.zeros((B, H, S), dtype=torch.bool, device=scores.device)
+    kept.scatter_(2, idx, True)
+    assert int(kept.sum()) == B * H * n
+    s_kept = scores.gather(2, idx)
+    dropped_max = scores.masked_fill(kept, float("-inf")).amax(-1)
+    assert (s_kept.amin(-1) >= dropped_max).all(), "a dropped score exceeds a kept one"
+    ref_vals = scores.topk(n, dim=-1).values.sort(-1).values
+    assert torch.equal(s_kept.sort(-1).values, ref_vals), "kept score multiset differs from torch.topk"
+    # tie rule: among scores equal to the threshold the lowest positions are kept
+    t = s_kept.amin(-1, keepdim=True)
+    eq = scores == t
+    eq_kept = (eq & kept).sum(-1)
+    first_eq = (eq.cumsum(-1) <= eq_kept.unsqueeze(-1)) & eq
+    assert torch.equal(first_eq, eq & kept), "ties at the threshold are not resolved lowest-position-first"
+    # idempotence
+    again = nat.topk_select(s_kept, n).long()
+    assert torch.equal(again, torch.arange(n, device=scores.device).expand(B, H, n))
+    # gather
+    e = idx.unsqueeze(-1).expand(-1, -1, -1, keys.shape[-1])
+    assert torch.equal(ko, keys.gather(2, e)) and torch.equal(vo, values.gather(2, e))
+    assert ko.is_contiguous() and vo.is_contiguous()
+
+
+def llama_module():
+    import bench
+
+    return bench.build_module(torch.device(DEV))
+
+
+def make_kv(S, seed, structured=False):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(seed)
+    k = torch.randn((1, H_KV, S, D), generator=g, device=DEV)
+    v = torch.randn((1, H_KV, S, D), generator=g, device=DEV)
+    if structured:
+        k = k * torch.exp(0.5 * torch.randn((1, H_KV, 1, D), generator=g, device=DEV))
+        k[:, :, :4] *= 8
+    return k.to(torch.bfloat16), v.to(torch.bfloat16)
+
+
+def test_config2_knorm_32k():
+    import kvpress_amd as P
+
+    S = 32768
+    keys, values = make_kv(S, 2)
+    kc, vc = keys.clone(), values.clone()
+    press = P.KnormPress(0.5)
+    sc = press.score(None, None, keys, values, None, {})
+    ref = -keys.float().norm(dim=-1)
+    assert ((sc - ref).abs() <= 1e-5 * ref.abs()).all()
+    ko, vo = press.compress(type("M", (), {"head_dim": D})(), None, keys, values, None, {})
+    assert ko.shape == (1, H_KV, 16384, D) and ko.dtype == torch.bfloat16
+    check_topk_and_gather(sc, keys, values, 16384, ko, vo)
+    assert torch.equal(keys, kc) and torch.equal(values, vc), "inputs must not be modified"
+
+
+def torch_snapkv_reference(q_win, keys, kernel_size):
+    """fp32 restatement of snapkv_press.py:60-105 with torch ops on the GPU (q_win already RoPE'd)."""
+    B, Hq, W, Dh = q_win.shape
+    H, S = keys.shape[1], keys.shape[2]
+    G = Hq // H
+    q = q_win.float()
+    k = keys.float().repeat_interleave(G, dim=1)
+    attn = torch.matmul(q, k.transpose(2, 3)) / (Dh ** 0.5)
+    mask = torch.triu(torch.full_like(attn, float("-inf")), diagonal=S - W + 1)
+    attn = torch.softmax(attn + mask, dim=-1)[..., :-W]
+    sc = attn.mean(dim=-2)
+    sc = torch.nn.functional.avg_pool1d(sc, kernel_size=kernel_size, padding=kernel_size // 2, stride=1)
+    sc = sc.view(B, H, G, S - W).mean(2)
+    return torch.nn.functional.pad(sc, (0, W), value=sc.max().item() + 1)
+
+
+@pytest.mark.parametrize("S,structured", [(131072, False), (131072 - 1000 + 37, True)])
+def test_config3_snapkv_128k(S, structured):
+    import kvpress_amd as P
+
+    keys, values = make_kv(S, 3, structured)
+    att, rot = llama_module()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(33)
+    hidden = torch.randn((1, S, HIDDEN), generator=g, device=DEV, dtype=torch.bfloat16)
+    with torch.no_grad():
+        pe = rot(hidden, torch.arange(S, device=DEV)[None])
+        press = P.SnapKVPress(0.5)
+        kwargs = {"position_embeddings": pe}
+        sc = press.score(att, hidden, keys, values, None, kwargs)
+        q_win = press.compute_window_queries(att, hidden, 64, pe)
+        ref = torch_snapkv_reference(q_win, keys, 5)
+        rel = ((sc - ref).abs() / ref.abs().clamp_min(1e-30))[..., :-64]
+        assert rel.max() <= 1e-3, f"max rel err {rel.max().item():.3e}"
+        assert (sc[..., -64:] == sc[..., :-64].max() + 1).all()
+        n = int(S * 0.5)
+        ko, vo = press.compress(att, hidden, keys, values, None, kwargs)
+        assert ko.shape == (1, H_KV, n, D)
+        check_topk_and_gather(sc, keys, values, n, ko, vo)
+        idx = _native().topk_select(sc, n)
+        assert (idx[..., -64:] == torch.arange(S - 64, S, device=DEV, dtype=torch.int32)).all(), "window must be kept"
+
+
+def test_config1_opt125m_plumbing():
+    """BASELINE config 1: OPT-125m geometry (12 heads, D=64, fp32, 2k tokens), KnormPress(0.5) under the
+    hook; [1,12,2048,64] -> [1,12,1024,64].  (The reference's __call__ cannot attach to OPT.)"""
+    from transformers import DynamicCache, OPTConfig, OPTForCausalLM
+
+    import kvpress_amd as P
+    from oracle import kvpress_oracle as O
+
+    torch.manual_seed(0)
+    model = OPTForCausalLM(OPTConfig()).eval().to(DEV)
+    ids = torch.randint(0, 1000, (1, 2048), generator=torch.Generator().manual_seed(0)).to(DEV)
+    full = DynamicCache()
+    with torch.no_grad():
+        model(ids, past_key_values=full)
+    k_full, v_full = full.layers[0].keys, full.layers[0].values
+    assert k_full.shape == (1, 12, 2048, 64) and k_full.dtype == torch.float32
+    cache = DynamicCache()
+    with torch.no_grad(), P.KnormPress(0.5)(model):
+        model(ids, past_key_values=cache)
+    for layer in cache.layers:
+        assert layer.keys.shape == (1, 12, 1024, 64)
+    sc = O.knorm_score(k_full.cpu().numpy())
+    got_sc = _native().rownorm_score(k_full, -1.0).cpu().numpy()
+    np.testing.assert_allclose(got_sc, sc, rtol=1e-5)
+    ko, vo, idx = O.compress(got_sc, k_full.cpu().numpy(), v_full.cpu().numpy(), 0.5)
+    assert np.array_equal(cache.layers[0].keys.cpu().numpy(), ko)
+    assert np.array_equal(cache.layers[0].values.cpu().numpy(), vo)
+
+
+def test_llama_hook_end_to_end_gpu():
+    """Hook path on the GPU with a small random Llama (bf16): every layer compressed to int(S*(1-r)),
+    decoding afterwards appends without re-compressing."""
+    from transformers import DynamicCache, LlamaConfig, LlamaForCausalLM
+
+    import kvpress_amd as P
+
+    cfg = LlamaConfig(hidden_size=512, num_attention_heads=4, num_key_value_heads=1, head_dim=128, num_hidden_layers=2,
+                      intermediate_size=256, vocab_size=128, max_position_embeddings=4096)
+    torch.manual_seed(0)
+    model = LlamaForCausalLM(cfg).eval().to(DEV, torch.bfloat16)
+    ids = torch.randint(0, 128, (2, 700), device=DEV)
+    for press, n in [(P.SnapKVPress(0.5), 350), (P.KnormPress(0.3), 489), (P.ExpectedAttentionPress(0.7), 210)]:
+        cache = DynamicCache()
+        with torch.no_grad(), press(model):
+            model(ids, past_key_values=cache)
+            assert all(l.keys.shape == (2, 1, n, 128) for l in cache.layers)
+            model(ids[:, :1], past_key_values=cache)
+            assert all(l.keys.shape == (2, 1, n + 1, 128) for l in cache.layers)
