@@ -1,5 +1,6 @@
 // Version / error plumbing of the C ABI (include/kvpress_hip.h).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "kvp_common.h"
@@ -13,6 +14,11 @@ void kvp_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int kvp_env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
 }
 
 extern "C" int kvp_version(void) { return KVP_VERSION; }

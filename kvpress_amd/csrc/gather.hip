@@ -24,54 +24,59 @@ struct GatherArgs {
     int64_t k_sb, k_sh, k_ss;  // BYTE strides
     int64_t v_sb, v_sh, v_ss;
     uint32_t H, S, n;
-    uint32_t nrows;     // B*H*n output rows
     uint32_t rowbytes;  // D*esize
 };
 
-template <int LPR>
+// grid = (row blocks, B*H): blockIdx.y selects the (b, h) plane -> no division per row.
+template <int LPR, bool NT>
 __global__ __launch_bounds__(GA_THREADS) void gather_vec_kernel(GatherArgs a) {
     constexpr int GPB = GA_THREADS / LPR;
+    const uint32_t bh = blockIdx.y;
+    const uint32_t b = bh / a.H, h = bh - b * a.H;
+    const char* __restrict__ kb = a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh;
+    const char* __restrict__ vb = a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh;
+    const int32_t* __restrict__ ib = a.idx + (size_t)bh * a.n;
+    char* __restrict__ kob = a.ko + (size_t)bh * a.n * a.rowbytes;
+    char* __restrict__ vob = a.vo + (size_t)bh * a.n * a.rowbytes;
     const uint32_t lir = threadIdx.x % LPR;
     const uint32_t g = blockIdx.x * GPB + threadIdx.x / LPR;
     const uint32_t TG = gridDim.x * GPB;
     const uint32_t chunks = a.rowbytes / 16;
+    const uint32_t n = a.n;
 
-    for (uint32_t r0 = g; r0 < a.nrows; r0 += TG * GA_UNROLL) {
-        uint4 kv[GA_UNROLL], vv[GA_UNROLL];
-        const char* ksrc[GA_UNROLL];
-        const char* vsrc[GA_UNROLL];
+    for (uint32_t j0 = g; j0 < n; j0 += TG * GA_UNROLL) {
+        int32_t src[GA_UNROLL];
 #pragma unroll
         for (int u = 0; u < GA_UNROLL; ++u) {
-            const uint32_t r = r0 + u * TG;
-            ksrc[u] = nullptr;
-            vsrc[u] = nullptr;
-            if (r < a.nrows) {
-                const uint32_t bh = r / a.n;
-                const uint32_t b = bh / a.H, h = bh - b * a.H;
-                int32_t s = a.idx[r];
-                s = s < 0 ? 0 : (s >= (int32_t)a.S ? (int32_t)a.S - 1 : s);  // never fault on a bad index
-                ksrc[u] = a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh + (int64_t)s * a.k_ss;
-                vsrc[u] = a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh + (int64_t)s * a.v_ss;
-                if (lir < chunks) {
-                    kv[u] = *reinterpret_cast<const uint4*>(ksrc[u] + (size_t)lir * 16);
-                    vv[u] = *reinterpret_cast<const uint4*>(vsrc[u] + (size_t)lir * 16);
-                }
+            const uint32_t j = j0 + u * TG;
+            int32_t s = j < n ? ib[j] : 0;
+            src[u] = s < 0 ? 0 : (s >= (int32_t)a.S ? (int32_t)a.S - 1 : s);  // never fault on a bad index
+        }
+        uint4 kv[GA_UNROLL], vv[GA_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GA_UNROLL; ++u) {
+            const uint32_t j = j0 + u * TG;
+            if (j < n && lir < chunks) {
+                kv[u] = ld16<NT>(kb + (int64_t)src[u] * a.k_ss + (size_t)lir * 16);
+                vv[u] = ld16<NT>(vb + (int64_t)src[u] * a.v_ss + (size_t)lir * 16);
             }
         }
 #pragma unroll
         for (int u = 0; u < GA_UNROLL; ++u) {
-            const uint32_t r = r0 + u * TG;
-            if (r < a.nrows) {
-                char* kd = a.ko + (size_t)r * a.rowbytes;
-                char* vd = a.vo + (size_t)r * a.rowbytes;
+            const uint32_t j = j0 + u * TG;
+            if (j < n) {
+                char* kd = kob + (size_t)j * a.rowbytes;
+                char* vd = vob + (size_t)j * a.rowbytes;
                 if (lir < chunks) {
-                    *reinterpret_cast<uint4*>(kd + (size_t)lir * 16) = kv[u];
-                    *reinterpret_cast<uint4*>(vd + (size_t)lir * 16) = vv[u];
+                    st16<NT>(kd + (size_t)lir * 16, kv[u]);
+                    st16<NT>(vd + (size_t)lir * 16, vv[u]);
                 }
                 if (LPR == 64) {  // rows longer than 1 KiB
+                    const char* ks = kb + (int64_t)src[u] * a.k_ss;
+                    const char* vs = vb + (int64_t)src[u] * a.v_ss;
                     for (uint32_t c = lir + LPR; c < chunks; c += LPR) {
-                        *reinterpret_cast<uint4*>(kd + (size_t)c * 16) = *reinterpret_cast<const uint4*>(ksrc[u] + (size_t)c * 16);
-                        *reinterpret_cast<uint4*>(vd + (size_t)c * 16) = *reinterpret_cast<const uint4*>(vsrc[u] + (size_t)c * 16);
+                        st16<NT>(kd + (size_t)c * 16, ld16<NT>(ks + (size_t)c * 16));
+                        st16<NT>(vd + (size_t)c * 16, ld16<NT>(vs + (size_t)c * 16));
                     }
                 }
             }
@@ -79,20 +84,20 @@ __global__ __launch_bounds__(GA_THREADS) void gather_vec_kernel(GatherArgs a) {
     }
 }
 
-// Any row size / alignment: element-granular copy (ES = 2 or 4 bytes), one thread per element.
+// Any row size / alignment: element-granular copy (2- or 4-byte elements), one thread per element.
 template <typename E>
 __global__ __launch_bounds__(GA_THREADS) void gather_scalar_kernel(GatherArgs a, uint32_t D) {
-    const uint64_t total = (uint64_t)a.nrows * D;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t r = (uint32_t)(i / D), d = (uint32_t)(i - (uint64_t)r * D);
-        const uint32_t bh = r / a.n;
-        const uint32_t b = bh / a.H, h = bh - b * a.H;
-        int32_t s = a.idx[r];
+    const uint32_t bh = blockIdx.y;
+    const uint32_t b = bh / a.H, h = bh - b * a.H;
+    const uint32_t total = a.n * D;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t j = i / D, d = i - j * D;
+        int32_t s = a.idx[(size_t)bh * a.n + j];
         s = s < 0 ? 0 : (s >= (int32_t)a.S ? (int32_t)a.S - 1 : s);
         const E* ks = reinterpret_cast<const E*>(a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh + (int64_t)s * a.k_ss);
         const E* vs = reinterpret_cast<const E*>(a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh + (int64_t)s * a.v_ss);
-        reinterpret_cast<E*>(a.ko)[i] = ks[d];
-        reinterpret_cast<E*>(a.vo)[i] = vs[d];
+        reinterpret_cast<E*>(a.ko)[(size_t)bh * total + i] = ks[d];
+        reinterpret_cast<E*>(a.vo)[(size_t)bh * total + i] = vs[d];
     }
 }
 
@@ -107,7 +112,7 @@ extern "C" int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t 
                   (long)B, (long)H, (long)S, (long)D, (long)n);
     const int64_t nrows64 = B * H * n;
     if (nrows64 == 0) return KVP_OK;
-    KVP_CHECK_ARG(nrows64 < (int64_t)1 << 31 && S < (int64_t)1 << 31, "gather: too many rows");
+    KVP_CHECK_ARG(n * D < ((int64_t)1 << 31) && S < ((int64_t)1 << 31) && B * H <= 65535, "gather: shape too large");
     KVP_CHECK_ARG(k && v && idx && k_out && v_out, "gather: null pointer");
     const int64_t es = kvp_elem_size(dtype);
     GatherArgs a;
@@ -117,17 +122,17 @@ extern "C" int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t 
     a.k_sb = k_sb * es; a.k_sh = k_sh * es; a.k_ss = k_ss * es;
     a.v_sb = v_sb * es; a.v_sh = v_sh * es; a.v_ss = v_ss * es;
     a.H = (uint32_t)H; a.S = (uint32_t)S; a.n = (uint32_t)n;
-    a.nrows = (uint32_t)nrows64;
     a.rowbytes = (uint32_t)(D * es);
+    const uint32_t BH = (uint32_t)(B * H);
     auto al16 = [](int64_t x) { return x % 16 == 0; };
     const bool vec_ok = a.rowbytes % 16 == 0 && al16((int64_t)(uintptr_t)k) && al16((int64_t)(uintptr_t)v) &&
                         al16((int64_t)(uintptr_t)k_out) && al16((int64_t)(uintptr_t)v_out) && al16(a.k_sb) &&
                         al16(a.k_sh) && al16(a.k_ss) && al16(a.v_sb) && al16(a.v_sh) && al16(a.v_ss);
     if (!vec_ok) {
-        const uint64_t total = (uint64_t)a.nrows * (uint64_t)D;
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + GA_THREADS - 1) / GA_THREADS, 8192);
-        if (es == 4) KVP_LAUNCH("gather_scalar_kernel", stream, gather_scalar_kernel<uint32_t><<<blocks, GA_THREADS, 0, stream>>>(a, (uint32_t)D));
-        else KVP_LAUNCH("gather_scalar_kernel", stream, gather_scalar_kernel<uint16_t><<<blocks, GA_THREADS, 0, stream>>>(a, (uint32_t)D));
+        const uint64_t total = (uint64_t)n * (uint64_t)D;
+        const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((total + GA_THREADS - 1) / GA_THREADS, 1024));
+        if (es == 4) KVP_LAUNCH("gather_scalar_kernel", stream, gather_scalar_kernel<uint32_t><<<dim3(bx, BH), GA_THREADS, 0, stream>>>(a, (uint32_t)D));
+        else KVP_LAUNCH("gather_scalar_kernel", stream, gather_scalar_kernel<uint16_t><<<dim3(bx, BH), GA_THREADS, 0, stream>>>(a, (uint32_t)D));
         KVP_CHECK_LAUNCH("gather(scalar)");
         return KVP_OK;
     }
@@ -135,9 +140,17 @@ extern "C" int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t 
     int lpr = 1;
     while (lpr < 64 && (uint32_t)lpr < chunks) lpr <<= 1;
     const uint32_t gpb = GA_THREADS / lpr;
-    const uint64_t groups_needed = ((uint64_t)a.nrows + GA_UNROLL - 1) / GA_UNROLL;
-    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((groups_needed + gpb - 1) / gpb, 256 * 8));
-#define KVP_GA_CASE(L) case L: KVP_LAUNCH("gather_vec_kernel", stream, gather_vec_kernel<L><<<blocks, GA_THREADS, 0, stream>>>(a)); break;
+    const uint64_t groups_needed = ((uint64_t)n + GA_UNROLL - 1) / GA_UNROLL;
+    const uint64_t bx_full = (groups_needed + gpb - 1) / gpb;
+    static const int wg_per_cu = kvp_env_int("KVP_GA_WG_PER_CU", 8);
+    const uint64_t bx_cap = std::max<uint64_t>(1, ((uint64_t)256 * wg_per_cu + BH - 1) / BH);
+    const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap));
+    static const bool nt = kvp_env_int("KVP_GA_NT", 0) != 0;
+#define KVP_GA_CASE(L)                                                                                                   \
+    case L:                                                                                                              \
+        if (nt) KVP_LAUNCH("gather_vec_kernel", stream, gather_vec_kernel<L, true><<<dim3(bx, BH), GA_THREADS, 0, stream>>>(a)); \
+        else KVP_LAUNCH("gather_vec_kernel", stream, gather_vec_kernel<L, false><<<dim3(bx, BH), GA_THREADS, 0, stream>>>(a));   \
+        break;
     switch (lpr) { KVP_GA_CASE(1) KVP_GA_CASE(2) KVP_GA_CASE(4) KVP_GA_CASE(8) KVP_GA_CASE(16) KVP_GA_CASE(32) KVP_GA_CASE(64) }
 #undef KVP_GA_CASE
     KVP_CHECK_LAUNCH("gather");

@@ -84,6 +84,27 @@ template <> __device__ __forceinline__ void unpack16<KVP_F16>(const uint4& v, fl
     }
 }
 
+// 16-byte loads/stores with an optional non-temporal (streaming, read/write-once) hint
+typedef uint32_t kvp_u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ uint4 ld16(const void* p) {
+    if (NT) {
+        const kvp_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const kvp_u32x4*>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const uint4*>(p);
+}
+template <bool NT> __device__ __forceinline__ void st16(void* p, const uint4& v) {
+    if (NT) {
+        kvp_u32x4 w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<kvp_u32x4*>(p));
+    } else {
+        *reinterpret_cast<uint4*>(p) = v;
+    }
+}
+
+// tuning knobs read from the environment once (KVP_* variables; used for A/B runs on hardware)
+int kvp_env_int(const char* name, int dflt);
+
 // ---- wave / block reductions -----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -12,16 +12,6 @@
 
 namespace {
 
-struct RowMap {
-    uint32_t S, H;
-    int64_t sb, sh, ss;  // element strides
-    __device__ __forceinline__ int64_t offset(uint32_t r) const {
-        const uint32_t bh = r / S, s = r - bh * S;
-        const uint32_t b = bh / H, h = bh - b * H;
-        return (int64_t)b * sb + (int64_t)h * sh + (int64_t)s * ss;
-    }
-};
-
 template <int DT>
 __device__ __forceinline__ float sumsq16(const uint4& v) {
     float f[Elem<DT>::PER16];
@@ -35,41 +25,49 @@ __device__ __forceinline__ float sumsq16(const uint4& v) {
 constexpr int RN_THREADS = 256;
 constexpr int RN_UNROLL = 4;
 
-template <int DT, int LPR>
+// grid = (row blocks, B*H): blockIdx.y selects the (b, h) plane, so the per-row address is one
+// multiply-add (no integer division in the streaming loop).
+struct PlaneMap {
+    uint32_t H, S;
+    int64_t sb, sh, ss;  // element strides
+};
+
+template <int DT, int LPR, bool NT>
 __global__ __launch_bounds__(RN_THREADS) void rownorm_vec_kernel(
-    const typename Elem<DT>::T* __restrict__ x, RowMap map, uint32_t nrows, uint32_t chunks, float scale,
-    float* __restrict__ out) {
+    const typename Elem<DT>::T* __restrict__ x, PlaneMap map, uint32_t chunks, float scale, float* __restrict__ out) {
     using T = typename Elem<DT>::T;
     constexpr int PER16 = Elem<DT>::PER16;
     constexpr int GPB = RN_THREADS / LPR;  // row groups per block
+    const uint32_t bh = blockIdx.y;
+    const uint32_t b = bh / map.H, h = bh - b * map.H;
+    const T* __restrict__ base = x + (int64_t)b * map.sb + (int64_t)h * map.sh;
+    float* __restrict__ ob = out + (size_t)bh * map.S;
     const uint32_t lir = threadIdx.x % LPR;
     const uint32_t g = blockIdx.x * GPB + threadIdx.x / LPR;
     const uint32_t TG = gridDim.x * GPB;
+    const uint32_t S = map.S;
 
-    for (uint32_t r0 = g; r0 < nrows; r0 += TG * RN_UNROLL) {
+    for (uint32_t s0 = g; s0 < S; s0 += TG * RN_UNROLL) {
         uint4 v[RN_UNROLL];
-        const T* rowp[RN_UNROLL];
 #pragma unroll
         for (int u = 0; u < RN_UNROLL; ++u) {
-            const uint32_t r = r0 + u * TG;
+            const uint32_t s = s0 + u * TG;
             v[u] = make_uint4(0, 0, 0, 0);
-            rowp[u] = nullptr;
-            if (r < nrows) {
-                rowp[u] = x + map.offset(r);
-                if (lir < chunks) v[u] = *reinterpret_cast<const uint4*>(rowp[u] + (size_t)lir * PER16);
-            }
+            if (s < S && lir < chunks)
+                v[u] = ld16<NT>(base + (int64_t)s * map.ss + (size_t)lir * PER16);
         }
 #pragma unroll
         for (int u = 0; u < RN_UNROLL; ++u) {
-            const uint32_t r = r0 + u * TG;
+            const uint32_t s = s0 + u * TG;
             float acc = sumsq16<DT>(v[u]);
-            if (LPR == 64 && r < nrows) {  // rows longer than 1 KiB: keep striding
+            if (LPR == 64 && s < S) {  // rows longer than 1 KiB: keep striding
+                const T* rowp = base + (int64_t)s * map.ss;
                 for (uint32_t c = lir + LPR; c < chunks; c += LPR)
-                    acc += sumsq16<DT>(*reinterpret_cast<const uint4*>(rowp[u] + (size_t)c * PER16));
+                    acc += sumsq16<DT>(*reinterpret_cast<const uint4*>(rowp + (size_t)c * PER16));
             }
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-            if (lir == 0 && r < nrows) out[r] = scale * sqrtf(acc);
+            if (lir == 0 && s < S) ob[s] = scale * sqrtf(acc);
         }
     }
 }
@@ -77,22 +75,23 @@ __global__ __launch_bounds__(RN_THREADS) void rownorm_vec_kernel(
 // Any D / alignment: one thread per row, scalar loads (tiny test shapes such as head_dim 6).
 template <int DT>
 __global__ __launch_bounds__(RN_THREADS) void rownorm_scalar_kernel(
-    const typename Elem<DT>::T* __restrict__ x, RowMap map, uint32_t nrows, uint32_t D, float scale,
-    float* __restrict__ out) {
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += gridDim.x * blockDim.x) {
-        const typename Elem<DT>::T* p = x + map.offset(r);
+    const typename Elem<DT>::T* __restrict__ x, PlaneMap map, uint32_t D, float scale, float* __restrict__ out) {
+    const uint32_t bh = blockIdx.y;
+    const uint32_t b = bh / map.H, h = bh - b * map.H;
+    const typename Elem<DT>::T* base = x + (int64_t)b * map.sb + (int64_t)h * map.sh;
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < map.S; s += gridDim.x * blockDim.x) {
+        const typename Elem<DT>::T* p = base + (int64_t)s * map.ss;
         float acc = 0.f;
         for (uint32_t d = 0; d < D; ++d) {
             const float f = Elem<DT>::ld(p + d);
             acc = fmaf(f, f, acc);
         }
-        out[r] = scale * sqrtf(acc);
+        out[(size_t)bh * map.S + s] = scale * sqrtf(acc);
     }
 }
 
 template <int DT>
-int launch_rownorm(const void* x, RowMap map, uint32_t nrows, uint32_t D, float scale, float* out,
-                   hipStream_t stream) {
+int launch_rownorm(const void* x, PlaneMap map, uint32_t BH, uint32_t D, float scale, float* out, hipStream_t stream) {
     using T = typename Elem<DT>::T;
     const T* xp = static_cast<const T*>(x);
     const size_t es = sizeof(T);
@@ -100,19 +99,23 @@ int launch_rownorm(const void* x, RowMap map, uint32_t nrows, uint32_t D, float 
     const bool vec_ok = rowbytes % 16 == 0 && ((uintptr_t)x % 16 == 0) && (map.sb * es) % 16 == 0 &&
                         (map.sh * es) % 16 == 0 && (map.ss * es) % 16 == 0;
     if (!vec_ok) {
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)nrows + RN_THREADS - 1) / RN_THREADS, 4096);
-        KVP_LAUNCH("rownorm_scalar_kernel", stream, rownorm_scalar_kernel<DT><<<blocks, RN_THREADS, 0, stream>>>(xp, map, nrows, D, scale, out));
+        const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)map.S + RN_THREADS - 1) / RN_THREADS, 1024));
+        KVP_LAUNCH("rownorm_scalar_kernel", stream, rownorm_scalar_kernel<DT><<<dim3(bx, BH), RN_THREADS, 0, stream>>>(xp, map, D, scale, out));
         return 0;
     }
     const uint32_t chunks = (uint32_t)(rowbytes / 16);
     int lpr = 1;
     while (lpr < 64 && (uint32_t)lpr < chunks) lpr <<= 1;
     const uint32_t gpb = RN_THREADS / lpr;
-    const uint64_t groups_needed = ((uint64_t)nrows + RN_UNROLL - 1) / RN_UNROLL;
-    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((groups_needed + gpb - 1) / gpb, 256 * 8));
+    const uint64_t groups_needed = ((uint64_t)map.S + RN_UNROLL - 1) / RN_UNROLL;
+    const uint64_t bx_full = (groups_needed + gpb - 1) / gpb;
+    const uint64_t bx_cap = std::max<uint64_t>(1, (256 * 8 + BH - 1) / BH);  // ~8 workgroups per CU in total
+    const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap));
+    static const bool nt = kvp_env_int("KVP_RN_NT", 0) != 0;
 #define KVP_RN_CASE(L)                                                                                     \
     case L:                                                                                                \
-        KVP_LAUNCH("rownorm_vec_kernel", stream, rownorm_vec_kernel<DT, L><<<blocks, RN_THREADS, 0, stream>>>(xp, map, nrows, chunks, scale, out));   \
+        if (nt) KVP_LAUNCH("rownorm_vec_kernel", stream, rownorm_vec_kernel<DT, L, true><<<dim3(bx, BH), RN_THREADS, 0, stream>>>(xp, map, chunks, scale, out)); \
+        else KVP_LAUNCH("rownorm_vec_kernel", stream, rownorm_vec_kernel<DT, L, false><<<dim3(bx, BH), RN_THREADS, 0, stream>>>(xp, map, chunks, scale, out)); \
         break;
     switch (lpr) {
         KVP_RN_CASE(1) KVP_RN_CASE(2) KVP_RN_CASE(4) KVP_RN_CASE(8) KVP_RN_CASE(16) KVP_RN_CASE(32) KVP_RN_CASE(64)
@@ -131,13 +134,17 @@ int kvp_rownorm_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S
                   (long)S, (long)D);
     const int64_t nrows64 = B * H * S;
     if (nrows64 == 0) return KVP_OK;
-    KVP_CHECK_ARG(nrows64 < (int64_t)1 << 31, "rownorm: B*H*S=%ld exceeds 2^31 rows", (long)nrows64);
     KVP_CHECK_ARG(x && out, "rownorm: null pointer");
-    RowMap map{(uint32_t)S, (uint32_t)H, sb, sh, ss};
+    // collapse (h, s) and (b, h) when the view is contiguous across them: fewer, longer planes
+    if (H > 1 && sh == S * ss) { S *= H; H = 1; sh = 0; }
+    if (H == 1 && B > 1 && sb == S * ss) { S *= B; B = 1; sb = 0; }
+    KVP_CHECK_ARG(S < ((int64_t)1 << 31) && B * H <= 65535, "rownorm: shape too large (S=%ld, B*H=%ld)", (long)S, (long)(B * H));
+    PlaneMap map{(uint32_t)H, (uint32_t)S, sb, sh, ss};
+    const uint32_t BH = (uint32_t)(B * H);
     switch (dtype) {
-        case KVP_F32: launch_rownorm<KVP_F32>(x, map, (uint32_t)nrows64, (uint32_t)D, scale, out, stream); break;
-        case KVP_F16: launch_rownorm<KVP_F16>(x, map, (uint32_t)nrows64, (uint32_t)D, scale, out, stream); break;
-        default: launch_rownorm<KVP_BF16>(x, map, (uint32_t)nrows64, (uint32_t)D, scale, out, stream); break;
+        case KVP_F32: launch_rownorm<KVP_F32>(x, map, BH, (uint32_t)D, scale, out, stream); break;
+        case KVP_F16: launch_rownorm<KVP_F16>(x, map, BH, (uint32_t)D, scale, out, stream); break;
+        default: launch_rownorm<KVP_BF16>(x, map, BH, (uint32_t)D, scale, out, stream); break;
     }
     KVP_CHECK_LAUNCH("rownorm");
     return KVP_OK;

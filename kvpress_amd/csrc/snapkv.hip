@@ -151,24 +151,22 @@ __global__ __launch_bounds__(SK_THREADS) void snapkv_colsum_from_attn(const type
 }
 
 // ---- avg_pool1d(kernel, pad=kernel/2, zero padded, divisor = kernel) + scaling + global max ----
-__global__ __launch_bounds__(SK_THREADS) void snapkv_pool_kernel(const float* __restrict__ colsum, uint32_t BH, uint32_t S,
-                                                                 uint32_t W, int pad, float inv, float* __restrict__ scores,
+__global__ __launch_bounds__(SK_THREADS) void snapkv_pool_kernel(const float* __restrict__ colsum, uint32_t S, uint32_t W,
+                                                                 int pad, float inv, float* __restrict__ scores,
                                                                  uint32_t* __restrict__ gmax_key) {
     __shared__ uint32_t scr[4];
-    const uint32_t Sm = S - W;
-    const uint64_t total = (uint64_t)BH * Sm;
+    const uint32_t Sm = S - W, bh = blockIdx.y;
+    const float* __restrict__ row = colsum + (size_t)bh * Sm;
+    float* __restrict__ out = scores + (size_t)bh * S;
     float vmax = KVP_NEG_INF;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t bh = (uint32_t)(i / Sm);
-        const int c = (int)(i - (uint64_t)bh * Sm);
-        const float* row = colsum + (size_t)bh * Sm;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < Sm; c += gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int j = -pad; j <= pad; ++j) {
-            const int cc = c + j;
+            const int cc = (int)c + j;
             if (cc >= 0 && cc < (int)Sm) s += row[cc];
         }
         s *= inv;
-        scores[(size_t)bh * S + c] = s;
+        out[c] = s;
         vmax = fmaxf(vmax, s);
     }
     block_atomic_max(vmax, scr, gmax_key);
@@ -206,11 +204,11 @@ SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, in
 int finish_scores(const SnapWs& w, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int kernel_size,
                   float* scores, hipStream_t stream) {
     const uint32_t BH = (uint32_t)(B * Hkv);
-    const uint64_t total = (uint64_t)BH * (uint64_t)(S - W);
-    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((total + SK_THREADS - 1) / SK_THREADS, 2048));
+    const uint64_t per_row = ((uint64_t)(S - W) + SK_THREADS - 1) / SK_THREADS;
+    const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per_row, std::max<uint64_t>(1, 2048 / BH)));
     const int64_t G = Hq / Hkv;
     const float inv = (float)(1.0 / ((double)G * (double)W * (double)kernel_size));
-    KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<<<blocks, SK_THREADS, 0, stream>>>(w.colsum, BH, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.gmax));
+    KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.gmax));
     const uint32_t nfill = BH * (uint32_t)W;
     KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, (uint32_t)(S - W), (uint32_t)W, w.gmax));
     KVP_CHECK_LAUNCH("snapkv(pool/fill)");

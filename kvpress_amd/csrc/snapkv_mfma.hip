@@ -50,15 +50,20 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 struct Stage {
     uint4 v[4];
 };
-__device__ __forceinline__ void stage_load(Stage& st, const char* __restrict__ kb, int64_t k_ssb, uint32_t key0, uint32_t S) {
+// Loads are UNCONDITIONAL (row index clamped to S-1): straight-line code lets hipcc emit counted
+// s_waitcnt vmcnt(N) instead of draining to 0 at every branch join.  Rows past S are duplicates of
+// the last row; they are masked (pass 1) or never stored (pass 2).
+__device__ __forceinline__ Stage stage_load(const char* __restrict__ kb, int64_t k_ssb, uint32_t key0, uint32_t S) {
     const uint32_t r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
+    Stage st;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const uint32_t kk = key0 + r0 + 16 * i;
-        st.v[i] = kk < S ? *reinterpret_cast<const uint4*>(kb + (int64_t)kk * k_ssb + ch * 16) : make_uint4(0, 0, 0, 0);
+        const uint32_t kk = min(key0 + r0 + 16 * i, S - 1);
+        st.v[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)kk * k_ssb + ch * 16);
     }
+    return st;
 }
-__device__ __forceinline__ void stage_store(const Stage& st, unsigned char* buf) {
+__device__ __forceinline__ void stage_store(const Stage st, unsigned char* buf) {
     const uint32_t r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -109,56 +114,72 @@ __global__ __launch_bounds__(MF_THREADS) void snapkv_p1_mfma(SnapArgs a, uint32_
     float z[2] = {0.f, 0.f};
     const float c = a.c;
 
-    Stage st;
-    stage_load(st, kb, k_ssb, kbeg, a.S);
-    stage_store(st, lds);
-    __syncthreads();
-
-    for (uint32_t t = 0; t < ntiles; ++t) {
-        const uint32_t key0 = kbeg + t * MF_TILE;
-        const unsigned char* buf = lds + (t & 1) * MF_TILEB;
-        if (t + 1 < ntiles) stage_load(st, kb, k_ssb, key0 + MF_TILE, a.S);
-        if (active) {
-            const bool need_mask = key0 + (MF_TILE - 1) > a.S - a.W;  // some (row, key) of this tile is masked / past S
+    // one 64-key tile: 32 MFMAs + the running (max, sum-exp) update of this lane's two q rows
+    auto compute = [&](uint32_t key0, const unsigned char* buf) {
+        const bool need_mask = key0 + (MF_TILE - 1) > a.S - a.W;  // some (row, key) of this tile is masked / past S
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                f32x16 acc[2];
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x16 acc[2];
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
+            for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[hf][i] = 0.f;
+                for (int i = 0; i < 16; ++i) acc[hf][i] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const uint4 kf = kfrag(buf, sub, ks, n, kg);
-                    acc[0] = mma32<DT>(kf, qf[0][ks], acc[0]);  // C[key][q row]
-                    acc[1] = mma32<DT>(kf, qf[1][ks], acc[1]);
+            for (int ks = 0; ks < 8; ++ks) {
+                const uint4 kf = kfrag(buf, sub, ks, n, kg);
+                acc[0] = mma32<DT>(kf, qf[0][ks], acc[0]);  // C[key][q row]
+                acc[1] = mma32<DT>(kf, qf[1][ks], acc[1]);
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                if (need_mask) {
+                    const uint32_t w = hf * 32 + n;  // window row: token S-W+w sees keys <= S-W+w
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t kk = key0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                        if (kk >= a.S || kk > a.S - a.W + w) acc[hf][r] = KVP_NEG_INF;
+                    }
                 }
+                float tm = acc[hf][0];
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    if (need_mask) {
-                        const uint32_t w = hf * 32 + n;  // window row: token S-W+w sees keys <= S-W+w
+                for (int r = 1; r < 16; ++r) tm = fmaxf(tm, acc[hf][r]);
+                const float mn = fmaxf(m[hf], tm);
+                if (!need_mask || mn != KVP_NEG_INF) {
+                    const float off = -mn * c;
+                    float s = 0.f;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const uint32_t kk = key0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                            if (kk >= a.S || kk > a.S - a.W + w) acc[hf][r] = KVP_NEG_INF;
-                        }
-                    }
-                    float tm = acc[hf][0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, acc[hf][r]);
-                    const float mn = fmaxf(m[hf], tm);
-                    if (!need_mask || mn != KVP_NEG_INF) {
-                        const float off = -mn * c;
-                        float s = 0.f;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) s += fast_exp2(fmaf(acc[hf][r], c, off));
-                        z[hf] = z[hf] * fast_exp2(fmaf(m[hf], c, off)) + s;
-                        m[hf] = mn;
-                    }
+                    for (int r = 0; r < 16; ++r) s += fast_exp2(fmaf(acc[hf][r], c, off));
+                    z[hf] = z[hf] * fast_exp2(fmaf(m[hf], c, off)) + s;
+                    m[hf] = mn;
                 }
             }
         }
-        if (t + 1 < ntiles) stage_store(st, lds + ((t + 1) & 1) * MF_TILEB);
+    };
+
+    // K streams HBM -> registers -> LDS with TWO tiles in flight behind the one being computed:
+    // stA / stB alternate; each tile's loads have two compute phases to land (issue-early, write-late).
+    Stage stA, stB;
+    unsigned char* buf0 = lds;
+    unsigned char* buf1 = lds + MF_TILEB;
+    stA = stage_load(kb, k_ssb, kbeg, a.S);
+    stage_store(stA, buf0);
+    const uint32_t klast = kbeg + (ntiles - 1) * MF_TILE;  // prefetches past the chunk re-read its last tile (L2 hits, never stored)
+    stA = stage_load(kb, k_ssb, min(kbeg + MF_TILE, klast), a.S);
+    __syncthreads();
+    for (uint32_t t = 0; t < ntiles; t += 2) {
+        const uint32_t key0 = kbeg + t * MF_TILE;
+        stB = stage_load(kb, k_ssb, min(key0 + 2 * MF_TILE, klast), a.S);
+        __builtin_amdgcn_sched_barrier(0);  // issue-early
+        if (active) compute(key0, buf0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the LDS write of the older stage BEHIND this tile's MFMAs (write-late)
+        if (t + 1 < ntiles) stage_store(stA, buf1);
+        __syncthreads();
+        if (t + 1 >= ntiles) break;
+        stA = stage_load(kb, k_ssb, min(key0 + 3 * MF_TILE, klast), a.S);
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) compute(key0 + MF_TILE, buf1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < ntiles) stage_store(stB, buf0);
         __syncthreads();
     }
 
@@ -213,49 +234,68 @@ __global__ __launch_bounds__(MF_THREADS) void snapkv_p2_mfma(SnapArgs a, uint32_
     float* cs = colsum + (size_t)(b * a.Hkv + h) * Sm;
     const uint32_t nact = min(4u, a.G - gb * 4);  // active waves in this workgroup
 
-    Stage st;
-    stage_load(st, kb, k_ssb, kbeg, a.S);
-    stage_store(st, lds);
-    __syncthreads();
-
-    for (uint32_t t = 0; t < ntiles; ++t) {
-        const uint32_t key0 = kbeg + t * MF_TILE;
-        const unsigned char* buf = lds + (t & 1) * MF_TILEB;
-        if (t + 1 < ntiles) stage_load(st, kb, k_ssb, key0 + MF_TILE, a.S);
-        if (active) {
+    // one 64-key tile: 32 MFMAs, P = 2^(L2 - a_row), column sums over this wave's 64 q rows -> red[par][wave][key]
+    auto compute = [&](const unsigned char* buf, int par) {
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                f32x16 acc[2];
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x16 acc[2];
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
+            for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[hf][i] = 0.f;
+                for (int i = 0; i < 16; ++i) acc[hf][i] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const uint4 kf = kfrag(buf, sub, ks, n, kg);
-                    acc[0] = mma32<DT>(qf[0][ks], kf, acc[0]);  // C[q row][key]
-                    acc[1] = mma32<DT>(qf[1][ks], kf, acc[1]);
-                }
-                float s = 0.f;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s += fast_exp2(fmaf(acc[hf][r], c, ar[hf][r]));
-                s += __shfl_xor(s, 32);
-                if (kg == 0) red[t & 1][wv][sub * 32 + n] = s;
+            for (int ks = 0; ks < 8; ++ks) {
+                const uint4 kf = kfrag(buf, sub, ks, n, kg);
+                acc[0] = mma32<DT>(qf[0][ks], kf, acc[0]);  // C[q row][key]
+                acc[1] = mma32<DT>(qf[1][ks], kf, acc[1]);
             }
+            float s = 0.f;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += fast_exp2(fmaf(acc[hf][r], c, ar[hf][r]));
+            s += __shfl_xor(s, 32);
+            if (kg == 0) red[par][wv][sub * 32 + n] = s;
         }
-        if (t + 1 < ntiles) stage_store(st, lds + ((t + 1) & 1) * MF_TILEB);
-        __syncthreads();
+    };
+    // after the tile's barrier: threads 0..63 add the active waves' partials and store 64 column sums
+    auto flush = [&](uint32_t key0, int par) {
         if (threadIdx.x < MF_TILE) {
             const uint32_t kk = key0 + threadIdx.x;
             if (kk < Sm) {
-                float s = red[t & 1][0][threadIdx.x];
-                for (uint32_t w = 1; w < nact; ++w) s += red[t & 1][w][threadIdx.x];
+                float s = red[par][0][threadIdx.x];
+                for (uint32_t w = 1; w < nact; ++w) s += red[par][w][threadIdx.x];
                 if (ngb == 1) cs[kk] = s;
                 else atomicAdd(&cs[kk], s);
             }
         }
+    };
+
+    Stage stA, stB;
+    unsigned char* buf0 = lds;
+    unsigned char* buf1 = lds + MF_TILEB;
+    stA = stage_load(kb, k_ssb, kbeg, a.S);
+    stage_store(stA, buf0);
+    const uint32_t klast = kbeg + (ntiles - 1) * MF_TILE;
+    stA = stage_load(kb, k_ssb, min(kbeg + MF_TILE, klast), a.S);
+    __syncthreads();
+    for (uint32_t t = 0; t < ntiles; t += 2) {
+        const uint32_t key0 = kbeg + t * MF_TILE;
+        stB = stage_load(kb, k_ssb, min(key0 + 2 * MF_TILE, klast), a.S);
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) compute(buf0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the LDS write of the older stage BEHIND this tile's MFMAs (write-late)
+        if (t + 1 < ntiles) stage_store(stA, buf1);
+        __syncthreads();
+        flush(key0, 0);
+        if (t + 1 >= ntiles) break;
+        stA = stage_load(kb, k_ssb, min(key0 + 3 * MF_TILE, klast), a.S);
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) compute(buf1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < ntiles) stage_store(stB, buf0);
+        __syncthreads();
+        flush(key0 + MF_TILE, 1);
     }
 }
 

@@ -13,14 +13,22 @@ if [[ "$WHAT" == *tests* ]]; then
     timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --no-header -k "$grp" > gpurun_out/test_$grp.log 2>&1
     echo "tests[$grp] rc=$? $(tail -1 gpurun_out/test_$grp.log)"
   done
-  timeout 900 python -m pytest tests -m gpu -q --no-header --deselect tests/test_gpu_parity.py > gpurun_out/test_other.log 2>&1
-  echo "tests[other] rc=$? $(tail -1 gpurun_out/test_other.log)"
+  timeout 1200 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --no-header > gpurun_out/test_fullsize.log 2>&1
+  echo "tests[fullsize] rc=$? $(tail -1 gpurun_out/test_fullsize.log)"
   timeout 300 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$? $(tail -1 gpurun_out/smoke.log)"
 fi
 if [[ "$WHAT" == *bench* ]]; then
   for wl in knorm32k knorm128k snapkv128k; do
     timeout 600 python bench.py --workload $wl --steps 20 --warmup 3 --profile-json gpurun_out/kern_$wl.json > gpurun_out/bench_$wl.log 2>&1
     echo "bench[$wl] rc=$? $(tail -1 gpurun_out/bench_$wl.log | cut -c1-600)"
+  done
+fi
+if [[ "$WHAT" == *ab* ]]; then
+  # A/B knobs: non-temporal loads/stores in the streaming kernels, workgroups per CU in the gather
+  for cfg in "KVP_GA_NT=0 KVP_RN_NT=0" "KVP_GA_NT=1 KVP_RN_NT=1" "KVP_GA_NT=0 KVP_GA_WG_PER_CU=4" "KVP_GA_NT=0 KVP_GA_WG_PER_CU=16" "KVP_GA_NT=1 KVP_GA_WG_PER_CU=16"; do
+    tag=$(echo "$cfg" | tr ' =' '__')
+    env $cfg timeout 300 python bench.py --workload knorm128k --steps 20 --warmup 3 --no-cpu-baseline --profile-json gpurun_out/ab_$tag.json > gpurun_out/ab_$tag.log 2>&1
+    echo "ab[$cfg] rc=$? $(python -c "import json;d=json.load(open('gpurun_out/ab_$tag.json'));print(round(d['ms_per_step']*1e3,1),'us/step', {k:round(v*1e3,1) for k,v in d['kernels_avg_ms'].items()})" 2>&1)"
   done
 fi
 if [[ "$WHAT" == *prof* ]]; then
