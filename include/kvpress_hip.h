@@ -67,6 +67,17 @@ int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw,
                      int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
                      float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream);
 
+/* Same, with the RoPE of the window queries (snapkv_press.py:56-58) done inside the library:
+ * q is the PRE-RoPE q_proj output viewed [B,Hq,W,D]; cos/sin are the last W rows of the layer's
+ * position embeddings, [Bc,W,D] with Bc = B or 1 (cs_sb = 0 broadcasts), same dtype as q.
+ * q_rot = q*cos + rotate_half(q)*sin is evaluated exactly as the reference's torch ops do in the
+ * model dtype (every product and the sum rounded to that dtype), so q_rot is bit-identical. */
+int kvp_snapkv_score_rope(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw,
+                          const void* cos, const void* sin, int64_t cs_sb, int64_t cs_sw,
+                          const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
+                          int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
+                          float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream);
+
 /* Same, when the attention layer returned its weights (snapkv_press.py:88-89):
  * attn is the [B,Hq,W,S-W] view attentions[..., -W:, :-W] (last dim contiguous). */
 int kvp_snapkv_score_from_attn(const void* attn, int64_t a_sb, int64_t a_sh, int64_t a_sw, int dtype,

@@ -29,6 +29,8 @@ SIGNATURES = {
     "kvp_snapkv_workspace_bytes": (c_size_t, [_I64] * 6),
     "kvp_snapkv_score": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int,
                                  _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "kvp_snapkv_score_rope": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, c_void_p, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int,
+                                      _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_snapkv_score_from_attn": (c_int, [c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, c_int,
                                            c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_ea_qstats_workspace_bytes": (c_size_t, [_I64] * 4),
@@ -135,6 +137,36 @@ def snapkv_score(q_win: torch.Tensor, keys: torch.Tensor, kernel_size: int) -> t
                                       _p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _DTYPES[keys.dtype],
                                       B, Hq, Hkv, S, W, D, int(kernel_size), _p(scores), _p(ws), ws.numel(), _stream(keys)),
                "kvp_snapkv_score")
+    return scores
+
+
+def snapkv_score_rope(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, keys: torch.Tensor,
+                      kernel_size: int) -> torch.Tensor:
+    """SnapKV scores from the PRE-RoPE window queries [B,Hq,W,D] and the window's cos/sin [1 or B, W, D]:
+    the RoPE (q*cos + rotate_half(q)*sin, rounded like torch does in the model dtype) runs in the library."""
+    keys = _rows_last_contig(_dev(keys))
+    q_pre = _rows_last_contig(_dev(q_pre))
+    dt = keys.dtype
+    if q_pre.dtype != dt:
+        q_pre = q_pre.to(dt)
+    cos = _rows_last_contig(_dev(cos.to(dt)))
+    sin = _rows_last_contig(_dev(sin.to(dt)))
+    B, Hq, W, D = q_pre.shape
+    Bk, Hkv, S, Dk = keys.shape
+    assert B == Bk and D == Dk and Hq % Hkv == 0, (q_pre.shape, keys.shape)
+    assert cos.shape == sin.shape and cos.shape[-2:] == (W, D) and cos.shape[0] in (1, B), (cos.shape, q_pre.shape)
+    assert cos.stride() == sin.stride() or cos.shape[0] == 1
+    if sin.stride() != cos.stride():
+        sin = sin.contiguous()
+        cos = cos.contiguous()
+    scores = torch.empty((B, Hkv, S), dtype=torch.float32, device=keys.device)
+    with torch.cuda.device(keys.device):
+        nws = lib().kvp_snapkv_workspace_bytes(B, Hq, Hkv, S, W, D)
+        ws = _ws(nws, keys)
+        _check(lib().kvp_snapkv_score_rope(_p(q_pre), _st(q_pre, 0), _st(q_pre, 1), _st(q_pre, 2), _p(cos), _p(sin),
+                                           _st(cos, 0), _st(cos, 1), _p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2),
+                                           _DTYPES[dt], B, Hq, Hkv, S, W, D, int(kernel_size), _p(scores), _p(ws), ws.numel(),
+                                           _stream(keys)), "kvp_snapkv_score_rope")
     return scores
 
 

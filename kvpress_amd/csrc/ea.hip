@@ -179,8 +179,8 @@ __global__ __launch_bounds__(EA_THREADS) void ea_finalize_kernel(const float* __
                                                                  const float* __restrict__ vnorm, uint32_t B, uint32_t Hq,
                                                                  uint32_t Hkv, uint32_t S, uint32_t n_sink, int use_vnorm,
                                                                  float epsilon, float* __restrict__ scores,
-                                                                 uint32_t* __restrict__ gmax_key) {
-    __shared__ uint32_t scr[4];
+                                                                 float* __restrict__ bmax) {
+    __shared__ float scr[4];
     const uint32_t Sp = S - n_sink, G = Hq / Hkv;
     const uint64_t total = (uint64_t)B * Hkv * Sp;
     const float invG = 1.0f / (float)G;
@@ -199,11 +199,11 @@ __global__ __launch_bounds__(EA_THREADS) void ea_finalize_kernel(const float* __
         scores[(size_t)bh * S + n_sink + s] = p;
         vmax = fmaxf(vmax, p);
     }
-    block_atomic_max(vmax, scr, gmax_key);
+    block_store_max(vmax, scr, bmax, blockIdx.x);
 }
 
 struct EaScoreWs {
-    uint32_t* gmax;
+    float* bmax;  // per-workgroup maxima of the finalize kernel (<= 2048)
     float* logits;
     float* part_m;
     float* part_z;
@@ -223,7 +223,7 @@ EaScoreWs carve_score_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S
         return p;
     };
     const size_t nblk = (size_t)(S + EA_SUB - 1) / EA_SUB;
-    w.gmax = (uint32_t*)take(256);
+    w.bmax = (float*)take(2048 * 4);
     w.logits = (float*)take((size_t)B * Hq * S * 4);
     w.part_m = (float*)take((size_t)B * Hq * nblk * 4);
     w.part_z = (float*)take((size_t)B * Hq * nblk * 4);
@@ -333,7 +333,6 @@ extern "C" int kvp_ea_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
         kvp_set_error("ea_score: workspace too small (%zu < %zu)", ws_bytes, w.total_bytes);
         return KVP_EWORKSPACE;
     }
-    if (hipMemsetAsync(w.gmax, 0, 256, stream) != hipSuccess) { kvp_set_error("ea_score: memset failed"); return KVP_EHIP; }
     const int64_t Sp = S - n_sink;
     EaArgs a;
     a.k = k; a.k_sb = k_sb; a.k_sh = k_sh; a.k_ss = k_ss;
@@ -366,10 +365,10 @@ extern "C" int kvp_ea_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
     const uint64_t total = (uint64_t)B * Hkv * Sp;
     const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((total + EA_THREADS - 1) / EA_THREADS, 2048));
     KVP_LAUNCH("ea_finalize_kernel", stream, ea_finalize_kernel<<<blocks, EA_THREADS, 0, stream>>>(w.logits, w.rowstat, w.vnorm, (uint32_t)B, (uint32_t)Hq, (uint32_t)Hkv,
-                                                          (uint32_t)S, (uint32_t)n_sink, use_vnorm, epsilon, scores, w.gmax));
+                                                          (uint32_t)S, (uint32_t)n_sink, use_vnorm, epsilon, scores, w.bmax));
     if (n_sink > 0) {
         const uint32_t BH = (uint32_t)(B * Hkv), nfill = BH * (uint32_t)n_sink;
-        KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, 0, (uint32_t)n_sink, w.gmax));
+        KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, 0, (uint32_t)n_sink, w.bmax, blocks));
     }
     KVP_CHECK_LAUNCH("ea_score(finalize)");
     return KVP_OK;

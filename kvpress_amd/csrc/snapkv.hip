@@ -150,11 +150,52 @@ __global__ __launch_bounds__(SK_THREADS) void snapkv_colsum_from_attn(const type
     }
 }
 
+// ---- RoPE of the window queries: q*cos + rotate_half(q)*sin, with torch's per-op rounding --------
+template <int DT> __device__ __forceinline__ float round_dt(float x);
+template <> __device__ __forceinline__ float round_dt<KVP_F32>(float x) { return x; }
+template <> __device__ __forceinline__ float round_dt<KVP_F16>(float x) { return (float)(_Float16)x; }
+template <> __device__ __forceinline__ float round_dt<KVP_BF16>(float x) {  // round-to-nearest-even to bf16
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7F800000u) == 0x7F800000u) return __uint_as_float(u & 0xFFFF0000u | ((u & 0xFFFFu) ? 0x00400000u : 0u));  // inf / nan
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xFFFF0000u);
+}
+template <int DT> __device__ __forceinline__ void st_dt(typename Elem<DT>::T* p, float x);
+template <> __device__ __forceinline__ void st_dt<KVP_F32>(float* p, float x) { *p = x; }
+template <> __device__ __forceinline__ void st_dt<KVP_F16>(_Float16* p, float x) { *p = (_Float16)x; }
+template <> __device__ __forceinline__ void st_dt<KVP_BF16>(uint16_t* p, float x) { *p = (uint16_t)(__float_as_uint(round_dt<KVP_BF16>(x)) >> 16); }
+
+// one thread per (row, d < D/2): out[d] = q[d]*cos[d] - q[d+h]*sin[d];  out[d+h] = q[d+h]*cos[d+h] + q[d]*sin[d+h]
+template <int DT>
+__global__ __launch_bounds__(SK_THREADS) void snapkv_rope_kernel(const typename Elem<DT>::T* __restrict__ q, int64_t q_sb,
+                                                                 int64_t q_sh, int64_t q_sw,
+                                                                 const typename Elem<DT>::T* __restrict__ cosp,
+                                                                 const typename Elem<DT>::T* __restrict__ sinp, int64_t cs_sb,
+                                                                 int64_t cs_sw, uint32_t B, uint32_t Hq, uint32_t W, uint32_t D,
+                                                                 typename Elem<DT>::T* __restrict__ out) {
+    const uint32_t half = D / 2;
+    const uint32_t total = B * Hq * W * half;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t d = i % half, row = i / half;
+        const uint32_t w = row % W, bh = row / W;
+        const uint32_t hq = bh % Hq, b = bh / Hq;
+        const typename Elem<DT>::T* qr = q + (int64_t)b * q_sb + (int64_t)hq * q_sh + (int64_t)w * q_sw;
+        const typename Elem<DT>::T* cr = cosp + (int64_t)b * cs_sb + (int64_t)w * cs_sw;
+        const typename Elem<DT>::T* sr = sinp + (int64_t)b * cs_sb + (int64_t)w * cs_sw;
+        const float q0 = Elem<DT>::ld(qr + d), q1 = Elem<DT>::ld(qr + d + half);
+        const float lo = round_dt<DT>(round_dt<DT>(q0 * Elem<DT>::ld(cr + d)) + round_dt<DT>(-q1 * Elem<DT>::ld(sr + d)));
+        const float hi = round_dt<DT>(round_dt<DT>(q1 * Elem<DT>::ld(cr + d + half)) + round_dt<DT>(q0 * Elem<DT>::ld(sr + d + half)));
+        typename Elem<DT>::T* o = out + (size_t)row * D;
+        st_dt<DT>(o + d, lo);
+        st_dt<DT>(o + d + half, hi);
+    }
+}
+
 // ---- avg_pool1d(kernel, pad=kernel/2, zero padded, divisor = kernel) + scaling + global max ----
 __global__ __launch_bounds__(SK_THREADS) void snapkv_pool_kernel(const float* __restrict__ colsum, uint32_t S, uint32_t W,
                                                                  int pad, float inv, float* __restrict__ scores,
-                                                                 uint32_t* __restrict__ gmax_key) {
-    __shared__ uint32_t scr[4];
+                                                                 float* __restrict__ bmax) {
+    __shared__ float scr[4];
     const uint32_t Sm = S - W, bh = blockIdx.y;
     const float* __restrict__ row = colsum + (size_t)bh * Sm;
     float* __restrict__ out = scores + (size_t)bh * S;
@@ -169,7 +210,7 @@ __global__ __launch_bounds__(SK_THREADS) void snapkv_pool_kernel(const float* __
         out[c] = s;
         vmax = fmaxf(vmax, s);
     }
-    block_atomic_max(vmax, scr, gmax_key);
+    block_store_max(vmax, scr, bmax, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 struct SnapWs {
@@ -177,11 +218,12 @@ struct SnapWs {
     float* part_z;
     float* rowstat;
     float* colsum;
-    uint32_t* gmax;
+    float* bmax;  // per-workgroup maxima of the pool kernel (<= 4096)
+    void* qrot;   // [B,Hq,W,D] RoPE'd window queries (kvp_snapkv_score_rope)
     size_t total_bytes;
 };
 
-SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W) {
+SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D) {
     SnapWs w;
     size_t off = 0;
     char* base = static_cast<char*>(ws);
@@ -192,11 +234,12 @@ SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, in
     };
     const int64_t nchunk_max = (S + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC;
     const size_t rows = (size_t)B * Hq * W;
-    w.gmax = (uint32_t*)take(256);
+    w.bmax = (float*)take((size_t)std::max<int64_t>(4096, B * Hkv) * 4);
     w.part_m = (float*)take(rows * nchunk_max * 4);
     w.part_z = (float*)take(rows * nchunk_max * 4);
     w.rowstat = (float*)take(rows * 4);
     w.colsum = (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4);
+    w.qrot = take((size_t)B * Hq * W * D * 4);
     w.total_bytes = off;
     return w;
 }
@@ -208,9 +251,9 @@ int finish_scores(const SnapWs& w, int64_t B, int64_t Hq, int64_t Hkv, int64_t S
     const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per_row, std::max<uint64_t>(1, 2048 / BH)));
     const int64_t G = Hq / Hkv;
     const float inv = (float)(1.0 / ((double)G * (double)W * (double)kernel_size));
-    KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.gmax));
+    KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.bmax));
     const uint32_t nfill = BH * (uint32_t)W;
-    KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, (uint32_t)(S - W), (uint32_t)W, w.gmax));
+    KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, (uint32_t)(S - W), (uint32_t)W, w.bmax, bx * BH));
     KVP_CHECK_LAUNCH("snapkv(pool/fill)");
     return KVP_OK;
 }
@@ -226,9 +269,8 @@ int check_common(int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int k
 }  // namespace
 
 extern "C" size_t kvp_snapkv_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D) {
-    (void)D;
-    if (B < 1 || Hq < 1 || Hkv < 1 || S < 1 || W < 1) return 256;
-    return carve_snap_ws(nullptr, B, Hq, Hkv, S, W).total_bytes;
+    if (B < 1 || Hq < 1 || Hkv < 1 || S < 1 || W < 1 || D < 1) return 256;
+    return carve_snap_ws(nullptr, B, Hq, Hkv, S, W, D).total_bytes;
 }
 
 extern "C" int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* k, int64_t k_sb,
@@ -240,12 +282,11 @@ extern "C" int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64
     if (int rc = check_common(B, Hq, Hkv, S, W, kernel_size)) return rc;
     KVP_CHECK_ARG(D >= 1 && D <= 1024, "snapkv: unsupported head_dim %ld", (long)D);
     KVP_CHECK_ARG(q && k && scores, "snapkv: null pointer");
-    SnapWs w = carve_snap_ws(ws, B, Hq, Hkv, S, W);
+    SnapWs w = carve_snap_ws(ws, B, Hq, Hkv, S, W, D);
     if (!ws || ws_bytes < w.total_bytes) {
         kvp_set_error("snapkv: workspace too small (%zu < %zu)", ws_bytes, w.total_bytes);
         return KVP_EWORKSPACE;
     }
-    if (hipMemsetAsync(w.gmax, 0, 256, stream) != hipSuccess) { kvp_set_error("snapkv: memset failed"); return KVP_EHIP; }
 
     SnapArgs a;
     a.q = q; a.k = k;
@@ -282,6 +323,37 @@ extern "C" int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64
     return finish_scores(w, B, Hq, Hkv, S, W, kernel_size, scores, stream);
 }
 
+extern "C" int kvp_snapkv_score_rope(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
+                                     int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
+                                     int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
+                                     float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "snapkv: bad dtype %d", dtype);
+    if (int rc = check_common(B, Hq, Hkv, S, W, kernel_size)) return rc;
+    KVP_CHECK_ARG(D >= 2 && D <= 1024 && D % 2 == 0, "snapkv: RoPE needs an even head_dim (got %ld)", (long)D);
+    KVP_CHECK_ARG(q && cosp && sinp && k && scores, "snapkv: null pointer");
+    KVP_CHECK_ARG(B * Hq * W * D < ((int64_t)1 << 31), "snapkv: window too large");
+    SnapWs w = carve_snap_ws(ws, B, Hq, Hkv, S, W, D);
+    if (!ws || ws_bytes < w.total_bytes) {
+        kvp_set_error("snapkv: workspace too small (%zu < %zu)", ws_bytes, w.total_bytes);
+        return KVP_EWORKSPACE;
+    }
+    const uint32_t total = (uint32_t)(B * Hq * W * (D / 2));
+    const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((total + SK_THREADS - 1) / SK_THREADS, 2048));
+#define KVP_SK_ROPE(DT)                                                                                                      \
+    KVP_LAUNCH("snapkv_rope_kernel", stream, snapkv_rope_kernel<DT><<<blocks, SK_THREADS, 0, stream>>>(                        \
+        static_cast<const Elem<DT>::T*>(q), q_sb, q_sh, q_sw, static_cast<const Elem<DT>::T*>(cosp),                          \
+        static_cast<const Elem<DT>::T*>(sinp), cs_sb, cs_sw, (uint32_t)B, (uint32_t)Hq, (uint32_t)W, (uint32_t)D,              \
+        static_cast<Elem<DT>::T*>(w.qrot)));
+    if (dtype == KVP_F32) { KVP_SK_ROPE(KVP_F32) }
+    else if (dtype == KVP_F16) { KVP_SK_ROPE(KVP_F16) }
+    else { KVP_SK_ROPE(KVP_BF16) }
+#undef KVP_SK_ROPE
+    KVP_CHECK_LAUNCH("snapkv(rope)");
+    return kvp_snapkv_score(w.qrot, Hq * W * D, W * D, D, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D, kernel_size, scores, ws,
+                            ws_bytes, stream_);
+}
+
 extern "C" int kvp_snapkv_score_from_attn(const void* attn, int64_t a_sb, int64_t a_sh, int64_t a_sw, int dtype, int64_t B,
                                           int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int kernel_size, float* scores,
                                           void* ws, size_t ws_bytes, kvp_stream_t stream_) {
@@ -289,12 +361,11 @@ extern "C" int kvp_snapkv_score_from_attn(const void* attn, int64_t a_sb, int64_
     KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "snapkv: bad dtype %d", dtype);
     if (int rc = check_common(B, Hq, Hkv, S, W, kernel_size)) return rc;
     KVP_CHECK_ARG(attn && scores, "snapkv: null pointer");
-    SnapWs w = carve_snap_ws(ws, B, Hq, Hkv, S, W);
+    SnapWs w = carve_snap_ws(ws, B, Hq, Hkv, S, W, 1);
     if (!ws || ws_bytes < w.total_bytes) {
         kvp_set_error("snapkv: workspace too small (%zu < %zu)", ws_bytes, w.total_bytes);
         return KVP_EWORKSPACE;
     }
-    if (hipMemsetAsync(w.gmax, 0, 256, stream) != hipSuccess) { kvp_set_error("snapkv: memset failed"); return KVP_EHIP; }
     const uint64_t total = (uint64_t)B * Hkv * (S - W);
     const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((total + SK_THREADS - 1) / SK_THREADS, 4096));
 #define KVP_SK_ATTN(DT) \

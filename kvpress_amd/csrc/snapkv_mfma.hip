@@ -114,22 +114,31 @@ __global__ __launch_bounds__(MF_THREADS) void snapkv_p1_mfma(SnapArgs a, uint32_
     float z[2] = {0.f, 0.f};
     const float c = a.c;
 
-    // one 64-key tile: 32 MFMAs + the running (max, sum-exp) update of this lane's two q rows
+    // one 64-key tile: 32 MFMAs + the running (max, sum-exp) update of this lane's two q rows.
+    // Schedule: all 8 K fragments of a 32-key sub-tile are read from LDS before its 16 MFMAs
+    // (counted lgkmcnt instead of read->wait->2 MFMAs), and BOTH sub-tiles' MFMAs are issued
+    // before any softmax VALU so the exp/max work of sub-tile 0 runs under sub-tile 1's MFMAs.
     auto compute = [&](uint32_t key0, const unsigned char* buf) {
         const bool need_mask = key0 + (MF_TILE - 1) > a.S - a.W;  // some (row, key) of this tile is masked / past S
+        f32x16 acc[2][2];  // [sub][hf]
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            f32x16 acc[2];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[hf][i] = 0.f;
+                for (int i = 0; i < 16; ++i) acc[sub][hf][i] = 0.f;
+            uint4 kf[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) kf[ks] = kfrag(buf, sub, ks, n, kg);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const uint4 kf = kfrag(buf, sub, ks, n, kg);
-                acc[0] = mma32<DT>(kf, qf[0][ks], acc[0]);  // C[key][q row]
-                acc[1] = mma32<DT>(kf, qf[1][ks], acc[1]);
+                acc[sub][0] = mma32<DT>(kf[ks], qf[0][ks], acc[sub][0]);  // C[key][q row]
+                acc[sub][1] = mma32<DT>(kf[ks], qf[1][ks], acc[sub][1]);
             }
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 if (need_mask) {
@@ -137,18 +146,18 @@ __global__ __launch_bounds__(MF_THREADS) void snapkv_p1_mfma(SnapArgs a, uint32_
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t kk = key0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                        if (kk >= a.S || kk > a.S - a.W + w) acc[hf][r] = KVP_NEG_INF;
+                        if (kk >= a.S || kk > a.S - a.W + w) acc[sub][hf][r] = KVP_NEG_INF;
                     }
                 }
-                float tm = acc[hf][0];
+                float tm = acc[sub][hf][0];
 #pragma unroll
-                for (int r = 1; r < 16; ++r) tm = fmaxf(tm, acc[hf][r]);
+                for (int r = 1; r < 16; ++r) tm = fmaxf(tm, acc[sub][hf][r]);
                 const float mn = fmaxf(m[hf], tm);
                 if (!need_mask || mn != KVP_NEG_INF) {
                     const float off = -mn * c;
                     float s = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s += fast_exp2(fmaf(acc[hf][r], c, off));
+                    for (int r = 0; r < 16; ++r) s += fast_exp2(fmaf(acc[sub][hf][r], c, off));
                     z[hf] = z[hf] * fast_exp2(fmaf(m[hf], c, off)) + s;
                     m[hf] = mn;
                 }
@@ -235,25 +244,32 @@ __global__ __launch_bounds__(MF_THREADS) void snapkv_p2_mfma(SnapArgs a, uint32_
     const uint32_t nact = min(4u, a.G - gb * 4);  // active waves in this workgroup
 
     // one 64-key tile: 32 MFMAs, P = 2^(L2 - a_row), column sums over this wave's 64 q rows -> red[par][wave][key]
+    // (same schedule as pass 1: fragment reads batched, both sub-tiles' MFMAs ahead of the exp work)
     auto compute = [&](const unsigned char* buf, int par) {
+        f32x16 acc[2][2];  // [sub][hf]
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            f32x16 acc[2];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[hf][i] = 0.f;
+                for (int i = 0; i < 16; ++i) acc[sub][hf][i] = 0.f;
+            uint4 kf[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) kf[ks] = kfrag(buf, sub, ks, n, kg);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const uint4 kf = kfrag(buf, sub, ks, n, kg);
-                acc[0] = mma32<DT>(qf[0][ks], kf, acc[0]);  // C[q row][key]
-                acc[1] = mma32<DT>(qf[1][ks], kf, acc[1]);
+                acc[sub][0] = mma32<DT>(qf[0][ks], kf[ks], acc[sub][0]);  // C[q row][key]
+                acc[sub][1] = mma32<DT>(qf[1][ks], kf[ks], acc[sub][1]);
             }
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
             float s = 0.f;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s += fast_exp2(fmaf(acc[hf][r], c, ar[hf][r]));
+                for (int r = 0; r < 16; ++r) s += fast_exp2(fmaf(acc[sub][hf][r], c, ar[hf][r]));
             s += __shfl_xor(s, 32);
             if (kg == 0) red[par][wv][sub * 32 + n] = s;
         }

@@ -42,24 +42,32 @@ static __global__ __launch_bounds__(256) void softmax_combine_kernel(const float
     if (lane == 0) a[row] = m + log2f(z);
 }
 
-// block max of a float -> atomicMax(order-preserving key) ; lds >= 4 words
-__device__ __forceinline__ void block_atomic_max(float v, uint32_t* lds, uint32_t* gmax_key) {
+// Global max without same-address atomics (2048 atomicMax on one word cost ~12 ns each = 25 us):
+// every workgroup stores its maximum to bmax[its linear id]; the (tiny) pad-fill kernel reduces them.
+// lds >= 4 words.
+__device__ __forceinline__ void block_store_max(float v, float* lds, float* __restrict__ bmax, uint32_t slot) {
     v = wave_max(v);
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = float_to_key(v);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t k = lds[0];
-        for (uint32_t i = 1; i < (blockDim.x >> 6); ++i) k = max(k, lds[i]);
-        atomicMax(gmax_key, k);
+        float m = lds[0];
+        for (uint32_t i = 1; i < (blockDim.x >> 6); ++i) m = fmaxf(m, lds[i]);
+        bmax[slot] = m;
     }
 }
 
 // scores[b,h, lo + j] = max + 1 for j < n  (F.pad(value=scores.max().item() + 1):
-// snapkv_press.py:103 pads the last W positions, expected_attention_press.py:163 the first n_sink)
-static __global__ void fill_pad_kernel(float* __restrict__ scores, uint32_t BH, uint32_t S, uint32_t lo, uint32_t n,
-                                const uint32_t* __restrict__ gmax_key) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= BH * n) return;
-    const float fill = key_to_float(*gmax_key) + 1.0f;
-    scores[(size_t)(i / n) * S + lo + (i % n)] = fill;
+// snapkv_press.py:103 pads the last W positions, expected_attention_press.py:163 the first n_sink).
+// max = max over bmax[0..nb) (per-workgroup maxima of the score-producing kernel).
+static __global__ __launch_bounds__(256) void fill_pad_kernel(float* __restrict__ scores, uint32_t BH, uint32_t S, uint32_t lo,
+                                                              uint32_t n, const float* __restrict__ bmax, uint32_t nb) {
+    __shared__ float red[4];
+    float m = KVP_NEG_INF;
+    for (uint32_t i = threadIdx.x; i < nb; i += 256) m = fmaxf(m, bmax[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const float fill = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) + 1.0f;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < BH * n) scores[(size_t)(i / n) * S + lo + (i % n)] = fill;
 }

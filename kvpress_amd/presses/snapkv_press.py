@@ -53,5 +53,8 @@ class SnapKVPress(ScorerPress):
         if attentions is not None:
             attn = attentions[..., -self.window_size:, : -self.window_size]  # snapkv_press.py:88-89
             return _native.snapkv_score_from_attn(attn, keys.shape[1], k_len, self.kernel_size)
-        q_win = self.compute_window_queries(module, hidden_states, self.window_size, kwargs["position_embeddings"])
-        return _native.snapkv_score(q_win, keys, self.kernel_size)
+        # q_proj of the last W tokens (model-owned GEMM); RoPE + everything after it runs in the library
+        q_pre = get_prerope_query_states(module, hidden_states[:, -self.window_size:])
+        cos, sin = kwargs["position_embeddings"]
+        return _native.snapkv_score_rope(q_pre, cos[:, -self.window_size:], sin[:, -self.window_size:], keys,
+                                         self.kernel_size)

@@ -304,3 +304,24 @@ def test_press_native_dtype_runs_and_overlaps_reference(name):
                 inter = np.mean([len(np.intersect1d(a, b)) / max(n, 1)
                                  for a, b in zip(idx.reshape(-1, n), ref_idx.reshape(-1, n))])
                 assert inter >= 0.85, f"{name} r={r}: overlap with the bf16 reference {inter:.3f}"
+
+
+@pytest.mark.parametrize("name", SK)
+def test_snapkv_fused_rope_is_bit_identical_to_torch_rope(name):
+    """kvp_snapkv_score_rope (RoPE inside the library, torch's per-op rounding reproduced) must give exactly
+    the scores of kvp_snapkv_score fed with torch's own q*cos + rotate_half(q)*sin (snapkv_press.py:56-58)."""
+    import kvpress_amd as P
+    from kvpress_amd.utils import get_prerope_query_states
+
+    s = _inputs.make_case(name)
+    dt = _inputs.torch_dtype(s["dtype"])
+    att, rot, hidden, pe = _inputs.build_llama_attention(s, dt, DEV)
+    keys = to_dev(s["keys"], s["dtype"])
+    W = s["W"]
+    with torch.no_grad():
+        q_win = P.SnapKVPress.compute_window_queries(att, hidden, W, pe)
+        a = native().snapkv_score(q_win, keys, s["ks"])
+        q_pre = get_prerope_query_states(att, hidden[:, -W:])
+        b = native().snapkv_score_rope(q_pre, pe[0][:, -W:], pe[1][:, -W:], keys, s["ks"])
+        c = P.SnapKVPress(0.5, window_size=W, kernel_size=s["ks"]).score(att, hidden, keys, None, None, {"position_embeddings": pe})
+    assert torch.equal(a, b) and torch.equal(b, c)
