@@ -183,8 +183,9 @@ __global__ __launch_bounds__(SK_THREADS) void snapkv_rope_kernel(const typename 
         const typename Elem<DT>::T* cr = cosp + (int64_t)b * cs_sb + (int64_t)w * cs_sw;
         const typename Elem<DT>::T* sr = sinp + (int64_t)b * cs_sb + (int64_t)w * cs_sw;
         const float q0 = Elem<DT>::ld(qr + d), q1 = Elem<DT>::ld(qr + d + half);
-        const float lo = round_dt<DT>(round_dt<DT>(q0 * Elem<DT>::ld(cr + d)) + round_dt<DT>(-q1 * Elem<DT>::ld(sr + d)));
-        const float hi = round_dt<DT>(round_dt<DT>(q1 * Elem<DT>::ld(cr + d + half)) + round_dt<DT>(q0 * Elem<DT>::ld(sr + d + half)));
+        // __fmul_rn / __fadd_rn: separately rounded ops as in torch's eager mul, mul, add (never contracted to an fma)
+        const float lo = round_dt<DT>(__fadd_rn(round_dt<DT>(__fmul_rn(q0, Elem<DT>::ld(cr + d))), round_dt<DT>(__fmul_rn(-q1, Elem<DT>::ld(sr + d)))));
+        const float hi = round_dt<DT>(__fadd_rn(round_dt<DT>(__fmul_rn(q1, Elem<DT>::ld(cr + d + half))), round_dt<DT>(__fmul_rn(q0, Elem<DT>::ld(sr + d + half)))));
         typename Elem<DT>::T* o = out + (size_t)row * D;
         st_dt<DT>(o + d, lo);
         st_dt<DT>(o + d + half, hi);

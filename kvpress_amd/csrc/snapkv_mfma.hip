@@ -106,9 +106,15 @@ __global__ __launch_bounds__(MF_THREADS) void snapkv_p1_mfma(SnapArgs a, uint32_
     uint4 qf[2][8];
     load_qfrags(qf, static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh) * 2, a.q_sw * 2, n, kg);
 
-    const uint32_t kbeg = chunk * MF_CHUNK;
-    const uint32_t kend = min(kbeg + MF_CHUNK, a.S);
-    const uint32_t ntiles = (kend - kbeg + MF_TILE - 1) / MF_TILE;
+    // Tile -> workgroup mapping is INTERLEAVED: workgroup `chunk` of the nchunk workgroups of this kv-head
+    // takes tiles chunk, chunk + nchunk, chunk + 2 nchunk, ...  The workgroups that run concurrently then read
+    // one contiguous, advancing region of K (nchunk x 16 KiB = 2 MiB per head) that covers every HBM
+    // channel evenly; giving each workgroup its own contiguous 256-KiB chunk instead puts all concurrent
+    // streams 256 KiB apart in lockstep (same low address bits -> same channels): measured 2.6 TB/s.
+    const uint32_t total_tiles = (a.S + MF_TILE - 1) / MF_TILE;
+    const uint32_t ntiles = chunk < total_tiles ? (total_tiles - chunk + nchunk - 1) / nchunk : 0;
+    const uint32_t tstride = nchunk * MF_TILE;           // keys between this workgroup's consecutive tiles
+    const uint32_t kbeg = chunk * MF_TILE;
 
     float m[2] = {KVP_NEG_INF, KVP_NEG_INF};  // raw-logit running max for q rows n and 32+n
     float z[2] = {0.f, 0.f};
@@ -170,26 +176,28 @@ __global__ __launch_bounds__(MF_THREADS) void snapkv_p1_mfma(SnapArgs a, uint32_
     Stage stA, stB;
     unsigned char* buf0 = lds;
     unsigned char* buf1 = lds + MF_TILEB;
-    stA = stage_load(kb, k_ssb, kbeg, a.S);
-    stage_store(stA, buf0);
-    const uint32_t klast = kbeg + (ntiles - 1) * MF_TILE;  // prefetches past the chunk re-read its last tile (L2 hits, never stored)
-    stA = stage_load(kb, k_ssb, min(kbeg + MF_TILE, klast), a.S);
-    __syncthreads();
-    for (uint32_t t = 0; t < ntiles; t += 2) {
-        const uint32_t key0 = kbeg + t * MF_TILE;
-        stB = stage_load(kb, k_ssb, min(key0 + 2 * MF_TILE, klast), a.S);
-        __builtin_amdgcn_sched_barrier(0);  // issue-early
-        if (active) compute(key0, buf0);
-        __builtin_amdgcn_sched_barrier(0);  // keep the LDS write of the older stage BEHIND this tile's MFMAs (write-late)
-        if (t + 1 < ntiles) stage_store(stA, buf1);
+    if (ntiles > 0) {
+        const uint32_t klast = kbeg + (ntiles - 1) * tstride;  // prefetches past the end re-read the last tile (L2 hits, never stored)
+        stA = stage_load(kb, k_ssb, kbeg, a.S);
+        stage_store(stA, buf0);
+        stA = stage_load(kb, k_ssb, min(kbeg + tstride, klast), a.S);
         __syncthreads();
-        if (t + 1 >= ntiles) break;
-        stA = stage_load(kb, k_ssb, min(key0 + 3 * MF_TILE, klast), a.S);
-        __builtin_amdgcn_sched_barrier(0);
-        if (active) compute(key0 + MF_TILE, buf1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < ntiles) stage_store(stB, buf0);
-        __syncthreads();
+        for (uint32_t t = 0; t < ntiles; t += 2) {
+            const uint32_t key0 = kbeg + t * tstride;
+            stB = stage_load(kb, k_ssb, min(key0 + 2 * tstride, klast), a.S);
+            __builtin_amdgcn_sched_barrier(0);  // issue-early
+            if (active) compute(key0, buf0);
+            __builtin_amdgcn_sched_barrier(0);  // keep the LDS write of the older stage BEHIND this tile's MFMAs (write-late)
+            if (t + 1 < ntiles) stage_store(stA, buf1);
+            __syncthreads();
+            if (t + 1 >= ntiles) break;
+            stA = stage_load(kb, k_ssb, min(key0 + 3 * tstride, klast), a.S);
+            __builtin_amdgcn_sched_barrier(0);
+            if (active) compute(key0 + tstride, buf1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < ntiles) stage_store(stB, buf0);
+            __syncthreads();
+        }
     }
 
     if (active) {
@@ -236,9 +244,12 @@ __global__ __launch_bounds__(MF_THREADS) void snapkv_p2_mfma(SnapArgs a, uint32_
 #pragma unroll
         for (int r = 0; r < 16; ++r) ar[hf][r] = -ars[hf * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg];
 
-    const uint32_t kbeg = chunk * MF_CHUNK;
-    const uint32_t kend = min(kbeg + MF_CHUNK, Sm);
-    const uint32_t ntiles = (kend - kbeg + MF_TILE - 1) / MF_TILE;
+    // interleaved tile -> workgroup mapping (see pass 1)
+    const uint32_t nchunk = gridDim.x;
+    const uint32_t total_tiles = (Sm + MF_TILE - 1) / MF_TILE;
+    const uint32_t ntiles = chunk < total_tiles ? (total_tiles - chunk + nchunk - 1) / nchunk : 0;
+    const uint32_t tstride = nchunk * MF_TILE;
+    const uint32_t kbeg = chunk * MF_TILE;
     const float c = a.c;
     float* cs = colsum + (size_t)(b * a.Hkv + h) * Sm;
     const uint32_t nact = min(4u, a.G - gb * 4);  // active waves in this workgroup
@@ -290,28 +301,29 @@ __global__ __launch_bounds__(MF_THREADS) void snapkv_p2_mfma(SnapArgs a, uint32_
     Stage stA, stB;
     unsigned char* buf0 = lds;
     unsigned char* buf1 = lds + MF_TILEB;
+    if (ntiles == 0) return;
+    const uint32_t klast = kbeg + (ntiles - 1) * tstride;
     stA = stage_load(kb, k_ssb, kbeg, a.S);
     stage_store(stA, buf0);
-    const uint32_t klast = kbeg + (ntiles - 1) * MF_TILE;
-    stA = stage_load(kb, k_ssb, min(kbeg + MF_TILE, klast), a.S);
+    stA = stage_load(kb, k_ssb, min(kbeg + tstride, klast), a.S);
     __syncthreads();
     for (uint32_t t = 0; t < ntiles; t += 2) {
-        const uint32_t key0 = kbeg + t * MF_TILE;
-        stB = stage_load(kb, k_ssb, min(key0 + 2 * MF_TILE, klast), a.S);
+        const uint32_t key0 = kbeg + t * tstride;
+        stB = stage_load(kb, k_ssb, min(key0 + 2 * tstride, klast), a.S);
         __builtin_amdgcn_sched_barrier(0);
         if (active) compute(buf0, 0);
-        __builtin_amdgcn_sched_barrier(0);  // keep the LDS write of the older stage BEHIND this tile's MFMAs (write-late)
+        __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntiles) stage_store(stA, buf1);
         __syncthreads();
         flush(key0, 0);
         if (t + 1 >= ntiles) break;
-        stA = stage_load(kb, k_ssb, min(key0 + 3 * MF_TILE, klast), a.S);
+        stA = stage_load(kb, k_ssb, min(key0 + 3 * tstride, klast), a.S);
         __builtin_amdgcn_sched_barrier(0);
         if (active) compute(buf1, 1);
         __builtin_amdgcn_sched_barrier(0);
         if (t + 2 < ntiles) stage_store(stB, buf0);
         __syncthreads();
-        flush(key0 + MF_TILE, 1);
+        flush(key0 + tstride, 1);
     }
 }
 

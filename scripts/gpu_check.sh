@@ -31,6 +31,19 @@ if [[ "$WHAT" == *ab* ]]; then
     echo "ab[$cfg] rc=$? $(python -c "import json;d=json.load(open('gpurun_out/ab_$tag.json'));print(round(d['ms_per_step']*1e3,1),'us/step', {k:round(v*1e3,1) for k,v in d['kernels_avg_ms'].items()})" 2>&1)"
   done
 fi
+if [[ "$WHAT" == *pmc* ]]; then
+  rocprofv3 -L > gpurun_out/counters_list.txt 2>&1
+  cd /tmp
+  i=0
+  for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE" \
+             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+             "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i+1))
+    timeout 600 rocprofv3 --kernel-trace --pmc $set -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$i" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --workload ${PMC_WL:-snapkv128k} --steps 3 --warmup 1 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$i.log" 2>&1
+    echo "pmc[$i: $set] rc=$?"
+  done
+  cd "$GRAFT_REPO_ROOT"
+fi
 if [[ "$WHAT" == *prof* ]]; then
   cd /tmp
   for wl in snapkv128k knorm32k; do
