@@ -20,6 +20,13 @@ LIB = os.path.join(LIBDIR, "libkvpress_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# MFMA results straight into VGPRs (gfx950 has a unified register file): the softmax epilogues read every
+# accumulator element with VALU ops, and v_accvgpr_read was 16 of their 73 instructions per 16 logits.
+FILE_FLAGS = {"snapkv_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "ea_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
+def flags_for(src: str):
+    return FLAGS + FILE_FLAGS.get(os.path.basename(src), [])
 
 
 def _hipcc() -> str:
@@ -58,7 +65,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
             return obj
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *flags_for(src), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -9,7 +9,7 @@ from kvpress_amd import build as B
 
 
 def _remarks(src):
-    cmd = [B._hipcc(), *B.FLAGS, "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
+    cmd = [B._hipcc(), *B.flags_for(src), "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     return r.stderr
