@@ -13,6 +13,7 @@ struct SnapArgs {
 
 // MFMA fast path (bf16/f16, D = 128, W = 64, G <= 8, 16-byte aligned rows)
 bool snapkv_mfma_eligible(const SnapArgs& a, int dtype);
-uint32_t snapkv_mfma_nchunk(const SnapArgs& a);
+uint32_t snapkv_mfma_nchunk(const SnapArgs& a);   // partials per row written by pass 1 (multiple of 8)
+uint32_t snapkv_mfma_nplanes(const SnapArgs& a);  // colsum planes written by pass 2 (summed by the pool kernel)
 int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m, float* part_z, hipStream_t stream);
 int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, hipStream_t stream);
