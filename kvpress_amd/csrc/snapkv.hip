@@ -193,9 +193,9 @@ __global__ __launch_bounds__(SK_THREADS) void snapkv_rope_kernel(const typename 
 }
 
 // ---- avg_pool1d(kernel, pad=kernel/2, zero padded, divisor = kernel) + scaling + global max ----
-__global__ __launch_bounds__(SK_THREADS) void snapkv_pool_kernel(const float* __restrict__ colsum, uint32_t nplanes,
-                                                                 size_t plane_stride, uint32_t S, uint32_t W, int pad, float inv,
-                                                                 float* __restrict__ scores, float* __restrict__ bmax) {
+__global__ __launch_bounds__(SK_THREADS) void snapkv_pool_kernel(const float* __restrict__ colsum, uint32_t S, uint32_t W,
+                                                                 int pad, float inv, float* __restrict__ scores,
+                                                                 float* __restrict__ bmax) {
     __shared__ float scr[4];
     const uint32_t Sm = S - W, bh = blockIdx.y;
     const float* __restrict__ row = colsum + (size_t)bh * Sm;
@@ -205,8 +205,7 @@ __global__ __launch_bounds__(SK_THREADS) void snapkv_pool_kernel(const float* __
         float s = 0.f;
         for (int j = -pad; j <= pad; ++j) {
             const int cc = (int)c + j;
-            if (cc >= 0 && cc < (int)Sm)
-                for (uint32_t p = 0; p < nplanes; ++p) s += row[p * plane_stride + cc];
+            if (cc >= 0 && cc < (int)Sm) s += row[cc];
         }
         s *= inv;
         out[c] = s;
@@ -234,27 +233,26 @@ SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, in
         off += kvp_align_up(bytes, 256);
         return p;
     };
-    const int64_t nchunk_max = std::max<int64_t>((S + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC, 8) + 8;  // MFMA path rounds up to 8
+    const int64_t nchunk_max = (S + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC;
     const size_t rows = (size_t)B * Hq * W;
     w.bmax = (float*)take((size_t)std::max<int64_t>(4096, B * Hkv) * 4);
     w.part_m = (float*)take(rows * nchunk_max * 4);
     w.part_z = (float*)take(rows * nchunk_max * 4);
     w.rowstat = (float*)take(rows * 4);
-    const int64_t nplanes_max = std::max<int64_t>(1, (Hq / std::max<int64_t>(Hkv, 1) + 1) / 2);
-    w.colsum = (float*)take((size_t)nplanes_max * B * Hkv * (S > W ? S - W : 0) * 4);
+    w.colsum = (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4);
     w.qrot = take((size_t)B * Hq * W * D * 4);
     w.total_bytes = off;
     return w;
 }
 
-int finish_scores(const SnapWs& w, uint32_t nplanes, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int kernel_size,
+int finish_scores(const SnapWs& w, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int kernel_size,
                   float* scores, hipStream_t stream) {
     const uint32_t BH = (uint32_t)(B * Hkv);
     const uint64_t per_row = ((uint64_t)(S - W) + SK_THREADS - 1) / SK_THREADS;
     const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per_row, std::max<uint64_t>(1, 2048 / BH)));
     const int64_t G = Hq / Hkv;
     const float inv = (float)(1.0 / ((double)G * (double)W * (double)kernel_size));
-    KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, nplanes, (size_t)BH * (size_t)(S - W), (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.bmax));
+    KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.bmax));
     const uint32_t nfill = BH * (uint32_t)W;
     KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, (uint32_t)(S - W), (uint32_t)W, w.bmax, bx * BH));
     KVP_CHECK_LAUNCH("snapkv(pool/fill)");
@@ -298,12 +296,12 @@ extern "C" int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64
     a.B = (uint32_t)B; a.Hq = (uint32_t)Hq; a.Hkv = (uint32_t)Hkv; a.G = (uint32_t)(Hq / Hkv);
     a.S = (uint32_t)S; a.W = (uint32_t)W; a.D = (uint32_t)D;
     a.c = (float)(1.4426950408889634 / sqrt((double)D));
+    static const int phase = kvp_env_int("KVP_SK_PHASE", 3);
+    a.phase = (uint32_t)phase;
     const uint32_t nrows = (uint32_t)(B * Hq * W);
 
-    uint32_t nplanes = 1;
     if (snapkv_mfma_eligible(a, dtype)) {
         const uint32_t nchunk = snapkv_mfma_nchunk(a);
-        nplanes = snapkv_mfma_nplanes(a);
         if (int rc = snapkv_mfma_p1(a, dtype, nchunk, w.part_m, w.part_z, stream)) return rc;
         KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_kernel<<<(nrows + 3) / 4, 256, 0, stream>>>(w.part_m, w.part_z, nrows, nchunk, w.rowstat));
         if (int rc = snapkv_mfma_p2(a, dtype, w.rowstat, w.colsum, stream)) return rc;
@@ -325,7 +323,7 @@ extern "C" int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64
 #undef KVP_SK_GENERIC
     }
     KVP_CHECK_LAUNCH("snapkv(p1/p2)");
-    return finish_scores(w, nplanes, B, Hq, Hkv, S, W, kernel_size, scores, stream);
+    return finish_scores(w, B, Hq, Hkv, S, W, kernel_size, scores, stream);
 }
 
 extern "C" int kvp_snapkv_score_rope(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
@@ -380,5 +378,5 @@ extern "C" int kvp_snapkv_score_from_attn(const void* attn, int64_t a_sb, int64_
     else { KVP_SK_ATTN(KVP_BF16) }
 #undef KVP_SK_ATTN
     KVP_CHECK_LAUNCH("snapkv(from_attn)");
-    return finish_scores(w, 1, B, Hq, Hkv, S, W, kernel_size, scores, stream);
+    return finish_scores(w, B, Hq, Hkv, S, W, kernel_size, scores, stream);
 }

@@ -9,11 +9,11 @@ struct SnapArgs {
     int64_t k_sb, k_sh, k_ss;
     uint32_t B, Hq, Hkv, G, S, W, D;
     float c;  // log2(e) / sqrt(D): logits in log2 units
+    uint32_t phase;  // MFMA path: start delay (x512 cycles) of every second co-resident workgroup
 };
 
 // MFMA fast path (bf16/f16, D = 128, W = 64, G <= 8, 16-byte aligned rows)
 bool snapkv_mfma_eligible(const SnapArgs& a, int dtype);
-uint32_t snapkv_mfma_nchunk(const SnapArgs& a);   // partials per row written by pass 1 (multiple of 8)
-uint32_t snapkv_mfma_nplanes(const SnapArgs& a);  // colsum planes written by pass 2 (summed by the pool kernel)
+uint32_t snapkv_mfma_nchunk(const SnapArgs& a);
 int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m, float* part_z, hipStream_t stream);
 int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, hipStream_t stream);

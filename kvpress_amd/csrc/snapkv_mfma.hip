@@ -26,23 +26,21 @@
 #include "softmax_stats.h"
 #include "snapkv_internal.h"
 
+#include <vector>
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int MF_THREADS = 256;      // 4 waves: 2 q-heads x 2 halves of the 64-row window
+constexpr int MF_THREADS = 512;      // 8 waves
 constexpr int MF_WAVES = MF_THREADS / 64;
-constexpr int MF_HPB = 2;            // q-heads per workgroup
-constexpr int MF_TILE = 64;          // keys per LDS tile
-constexpr int MF_CHUNK = 1024;       // keys per workgroup (16 tiles, interleaved across the workgroups of a head)
-constexpr int MF_ROWB = 256;         // bytes per key row in HBM (D = 128, 2-byte elements)
-// LDS rows are padded by 16 B: a ds_read_b128 service group (16 lanes = 16 distinct keys mod 16, same
-// k-chunk) then hits 16 distinct 16-byte slots of the 256-B bank row -> conflict-free, and every fragment
-// address is ONE per-lane base plus an immediate (an XOR swizzle needs 8 address registers + VALU).
-constexpr int MF_LROW = MF_ROWB + 16;
-constexpr int MF_TILEB = MF_TILE * MF_LROW;  // 17408 B
+constexpr int MF_TILE = 128;         // keys per LDS tile (one barrier per tile)
+constexpr int MF_SUBS = MF_TILE / 32;  // 32-key MFMA sub-tiles per tile
+constexpr int MF_CHUNK = 1024;       // minimum keys per workgroup
+constexpr int MF_ROWB = 256;         // bytes per key row (D = 128, 2-byte elements)
+constexpr int MF_TILEB = MF_TILE * MF_ROWB;
 
 template <int DT> __device__ __forceinline__ f32x16 mma32(const uint4& a, const uint4& b, f32x16 c);
 template <> __device__ __forceinline__ f32x16 mma32<KVP_BF16>(const uint4& a, const uint4& b, f32x16 c) {
@@ -55,9 +53,9 @@ template <> __device__ __forceinline__ f32x16 mma32<KVP_F16>(const uint4& a, con
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // --- K tile staging -------------------------------------------------------------------------------
-// thread t moves 4 x 16 B: rows (t >> 4) + 16 i, 16-byte column t & 15  (a wave = 4 full rows = 1 KiB)
+// thread t moves MF_SUBS x 16 B: rows (t >> 4) + 32 i, 16-byte column t & 15  (a wave = 4 full rows = 1 KiB)
 struct Stage {
-    uint4 v[4];
+    uint4 v[MF_SUBS];
 };
 // Loads are UNCONDITIONAL (row index clamped to S-1): straight-line code lets hipcc emit counted
 // s_waitcnt vmcnt(N) instead of draining to 0 at every branch join.  Rows past S are duplicates of
@@ -66,21 +64,24 @@ __device__ __forceinline__ Stage stage_load(const char* __restrict__ kb, int64_t
     const uint32_t r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
     Stage st;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t kk = min(key0 + r0 + 16 * i, S - 1);
+    for (int i = 0; i < MF_SUBS; ++i) {
+        const uint32_t kk = min(key0 + r0 + 32 * i, S - 1);
         st.v[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)kk * k_ssb + ch * 16);
     }
     return st;
 }
 __device__ __forceinline__ void stage_store(const Stage st, unsigned char* buf) {
-    unsigned char* p = buf + (threadIdx.x >> 4) * MF_LROW + (threadIdx.x & 15) * 16;
+    const uint32_t r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(p + i * 16 * MF_LROW) = st.v[i];
+    for (int i = 0; i < MF_SUBS; ++i) {
+        const uint32_t row = r0 + 32 * i;
+        *reinterpret_cast<uint4*>(buf + row * MF_ROWB + ((ch ^ (row & 15)) << 4)) = st.v[i];
+    }
 }
-// fragment of the 32-key sub-tile `sub` for k-step ks: lane (n = lane & 31, kg = lane >> 5);
-// fbase = n * MF_LROW + kg * 16 is computed once per kernel
-__device__ __forceinline__ uint4 kfrag(const unsigned char* buf, uint32_t fbase, int sub, int ks) {
-    return *reinterpret_cast<const uint4*>(buf + fbase + sub * 32 * MF_LROW + ks * 32);
+// fragment of the 32-key sub-tile `sub` for k-step ks: lane (n = lane & 31, kg = lane >> 5)
+__device__ __forceinline__ uint4 kfrag(const unsigned char* buf, uint32_t sub, uint32_t ks, uint32_t n, uint32_t kg) {
+    const uint32_t row = sub * 32 + n;
+    return *reinterpret_cast<const uint4*>(buf + row * MF_ROWB + (((ks * 2 + kg) ^ (row & 15)) << 4));
 }
 
 // Q fragments of 32 window rows of one q-head: lane (n, kg) holds row row0+n, dims ks*16+kg*8..+8
@@ -88,6 +89,17 @@ __device__ __forceinline__ void load_qfrags(uint4 (&qf)[8], const char* __restri
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
         qf[ks] = *reinterpret_cast<const uint4*>(qrow0 + (int64_t)n * q_swb + (ks * 16 + kg * 8) * 2);
+}
+
+// The two workgroups resident on a CU start together, do identical work and stay in lockstep: both are in
+// their MFMA phase (matrix pipe saturated) and then both in their store/barrier phase (pipe idle) -- measured
+// with s_memtime: ~2000 cycles compute + ~1500 cycles sync per tile.  Workgroup i and i + 256 share a CU
+// (i % 8 picks the XCD, then CUs round-robin), so every second group of 256 is delayed by about half a tile
+// period; from then on one workgroup's MFMAs run under the other's synchronisation phase.
+__device__ __forceinline__ void phase_shift(uint32_t units) {
+    const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if ((lin >> 8) & 1)
+        for (uint32_t i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(8);  // 8 * 64 = 512 cycles per unit
 }
 
 // Tile -> workgroup mapping is INTERLEAVED: workgroup `chunk` of the nchunk workgroups of a kv-head takes
@@ -105,108 +117,19 @@ struct TileWalk {
 };
 
 // =================================================================================================
-// Software pipeline shared by both passes.
-//
-// A wave's work per 32-key sub-tile is 8 dependent MFMAs (32 cycles apart on the matrix pipe) and
-// ~62 VALU instructions of softmax math on the 16 logits the MFMAs produce (exp = 8 cycles, the rest
-// 4).  Issued back to back (MFMA chain, then softmax) the two pipes never overlap inside a wave, and
-// the per-tile barrier puts all waves of a workgroup in the same phase (measured: VALU busy 47 %,
-// MFMA busy 32 %, sum ~ kernel time).  So every wave runs a two-stage pipeline instead:
-//
-//     step k:   MFMAs of sub-tile k+1  ||  softmax of sub-tile k     (one branch-free basic block:
-//               MFMA, 2 logits of softmax, MFMA, 2 logits, ...: ~32 VALU cycles per MFMA gap)
-//
-// with the two accumulators alternating.  The step that crosses a tile boundary sits right after
-// the tile's barrier (it needs the next LDS buffer but only REGISTERS of the previous tile), so two
-// LDS buffers still suffice.  Tiles that need the causal mask / sequence tail (the last tiles of a
-// head) are not pipelined: they run the simple path after the pipeline has drained.
-// =================================================================================================
-#define KVP_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-constexpr int SGB_VALU = 0x2, SGB_MFMA = 0x8, SGB_DSRD = 0x100;
-
-// ---- pass 1 pieces --------------------------------------------------------------------------------
-struct P1State {
-    float m, z;  // raw-logit running max / sum-exp (relative to m) of this lane's window row
-};
-
-// softmax-update of 16 finished logits `ap` interleaved with the 8 MFMAs producing `ac` from (buf, sub)
-template <int DT>
-__device__ __forceinline__ void p1_step(const unsigned char* buf, int sub, const uint4 (&qf)[8], uint32_t fbase,
-                                        const f32x16& ap, f32x16& ac, P1State& st, float c) {
-    uint4 kf[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) kf[ks] = kfrag(buf, fbase, sub, ks);
-    float tm = ap[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, ap[r]);
-    const float mn = fmaxf(st.m, tm);
-    const float off = -mn * c;
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) ac[i] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        ac = mma32<DT>(kf[ks], qf[ks], ac);  // C[key][q row]
-        s0 += fast_exp2(fmaf(ap[2 * ks], c, off));
-        s1 += fast_exp2(fmaf(ap[2 * ks + 1], c, off));
-    }
-    st.z = st.z * fast_exp2(fmaf(st.m, c, off)) + (s0 + s1);
-    st.m = mn;
-    // schedule: 4 fragment reads first, the max chain while they land, then per MFMA gap: 1 MFMA,
-    // 1 more fragment read (keeps only ~5 fragments live), 6 VALU (2 logits of fma/exp/add)
-    KVP_SGB(SGB_DSRD, 4);
-    KVP_SGB(SGB_VALU, 12);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        KVP_SGB(SGB_MFMA, 1);
-        if (ks < 4) KVP_SGB(SGB_DSRD, 1);
-        KVP_SGB(SGB_VALU, 6);
-    }
-}
-template <int DT>
-__device__ __forceinline__ void mma_only(const unsigned char* buf, int sub, const uint4 (&qf)[8], uint32_t fbase,
-                                         f32x16& ac, bool q_is_a) {
-    uint4 kf[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) kf[ks] = kfrag(buf, fbase, sub, ks);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) ac[i] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) ac = q_is_a ? mma32<DT>(qf[ks], kf[ks], ac) : mma32<DT>(kf[ks], qf[ks], ac);
-}
-__device__ __forceinline__ void p1_softmax_only(const f32x16& ap, P1State& st, float c) {
-    float tm = ap[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, ap[r]);
-    const float mn = fmaxf(st.m, tm);
-    const float off = -mn * c;
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        s0 += fast_exp2(fmaf(ap[r], c, off));
-        s1 += fast_exp2(fmaf(ap[r + 1], c, off));
-    }
-    st.z = st.z * fast_exp2(fmaf(st.m, c, off)) + (s0 + s1);
-    st.m = mn;
-}
-
-// =================================================================================================
 // pass 1: per (row, chunk) partial max / sum-exp (log2 units)
 // =================================================================================================
-template <int DT>
-__global__ __launch_bounds__(MF_THREADS, 3) void snapkv_p1_mfma(SnapArgs a, uint32_t ngb, uint32_t nchunk,
-                                                                float* __restrict__ part_m, float* __restrict__ part_z) {
+// TRACE (debug, KVP_SK_TRACE=1): wave-level s_memtime checkpoints of workgroup (5,0,0) -> trace[wave][tile][5]
+template <int DT, bool TRACE>
+__global__ __launch_bounds__(MF_THREADS, 4) void snapkv_p1_mfma(SnapArgs a, uint32_t ngb, uint32_t nchunk,
+                                                                float* __restrict__ part_m, float* __restrict__ part_z,
+                                                                unsigned long long* __restrict__ trace) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * MF_TILEB];
-    // blockIdx.x enumerates (chunk, group-block) so that the ngb workgroups that read the SAME K tiles sit on
-    // the same XCD (workgroup i runs on XCD i % 8; slots i/8 of one XCD are dispatched back to back) and
-    // share its L2: K crosses HBM once per pass although it is staged into LDS ngb times.
-    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const uint32_t gb = slot % ngb, chunk = (slot / ngb) * 8 + xcd;
-    const uint32_t h = blockIdx.y, b = blockIdx.z;
+    const uint32_t chunk = blockIdx.x, b = blockIdx.z;
+    const uint32_t h = blockIdx.y / ngb, gb = blockIdx.y - h * ngb;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t n = lane & 31, kg = lane >> 5;
-    const uint32_t fbase = n * MF_LROW + kg * 16;
-    const uint32_t rg = gb * MF_HPB + (wv >> 1);  // q-head inside the GQA group
+    const uint32_t rg = gb * 4 + (wv >> 1);  // q-head inside the GQA group
     const uint32_t row0 = (wv & 1) * 32;     // first of this wave's 32 window rows
     const bool active = rg < a.G;
     const uint32_t hq = h * a.G + (active ? rg : 0);
@@ -218,81 +141,94 @@ __global__ __launch_bounds__(MF_THREADS, 3) void snapkv_p1_mfma(SnapArgs a, uint
                 a.q_sw * 2, n, kg);
 
     const TileWalk tw(chunk, nchunk, a.S);
-    // tiles entirely below the causal-mask region (and the sequence end) take the pipelined path
-    uint32_t ntf = 0;
-    if (a.S - a.W >= (uint32_t)(MF_TILE - 1)) {
-        const uint32_t last_fast_key0 = a.S - a.W - (MF_TILE - 1);  // key0 + 63 <= S - W
-        if (tw.kbeg <= last_fast_key0) ntf = min(tw.ntiles, (last_fast_key0 - tw.kbeg) / tw.tstride + 1);
-    }
-    P1State st{KVP_NEG_INF, 0.f};
+    const bool tr = TRACE && blockIdx.x == 5 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0;
+    auto stamp = [&](uint32_t tile, int cp) {
+        if (TRACE && tr && tile < 20) trace[(wv * 20 + tile) * 6 + cp] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0, 5);
+    float m = KVP_NEG_INF, z = 0.f;  // raw-logit running max / sum-exp of window row row0 + n over this lane's keys
     const float c = a.c;
-    const uint32_t w = row0 + n;  // window row: token S-W+w sees keys <= S-W+w
-    unsigned char* buf0 = lds;
-    unsigned char* buf1 = lds + MF_TILEB;
+    const uint32_t w = row0 + n;     // window row: token S-W+w sees keys <= S-W+w
 
-    if (ntf > 0) {
-        // K streams HBM -> registers -> LDS with two tiles in flight behind the one being computed
-        // (issue-early, write-late; counted vmcnt, loads unconditional).
-        Stage st1, st2;  // st1: tile t+1 (in flight / landed), st2: tile t+2 (just issued)
-        f32x16 accA, accB;
-        unsigned char* bufc = lds;             // tile t
-        unsigned char* bufn = lds + MF_TILEB;  // tile t+1
-        stage_store(stage_load(kb, k_ssb, tw.kbeg, a.S), bufc);
-        st1 = stage_load(kb, k_ssb, min(tw.kbeg + tw.tstride, tw.klast), a.S);
-        __syncthreads();
-        if (active) mma_only<DT>(bufc, 0, qf, fbase, accA, false);  // pipeline fill: sub-tile 0 of tile 0
-        for (uint32_t t = 0; t < ntf; ++t) {
-            const uint32_t key0 = tw.kbeg + t * tw.tstride;
-            st2 = stage_load(kb, k_ssb, min(key0 + 2 * tw.tstride, tw.klast), a.S);
-            __builtin_amdgcn_sched_barrier(0);  // issue-early
-            if (active) p1_step<DT>(bufc, 1, qf, fbase, accA, accB, st, c);  // MFMA sub 1 of t || softmax sub 0 of t
-            __builtin_amdgcn_sched_barrier(0);  // write-late: the LDS store of tile t+1 stays behind the MFMAs
-            stage_store(st1, bufn);
-            __syncthreads();
-            if (t + 1 >= ntf) {
-                if (active) p1_softmax_only(accB, st, c);  // drain
-                break;
-            }
-            if (active) p1_step<DT>(bufn, 0, qf, fbase, accB, accA, st, c);  // MFMA sub 0 of t+1 || softmax sub 1 of t
-            unsigned char* tmp = bufc; bufc = bufn; bufn = tmp;
-            st1 = st2;
-        }
-    }
-
-    // ---- masked / tail tiles (at most the last few of a head): simple, synchronous path ---------------
-    for (uint32_t t = ntf; t < tw.ntiles; ++t) {
-        const uint32_t key0 = tw.kbeg + t * tw.tstride;
-        __syncthreads();
-        stage_store(stage_load(kb, k_ssb, key0, a.S), buf0);
-        __syncthreads();
-        if (active) {
+    // one 64-key tile = 2 sub-tiles of 32 keys: 8 batched LDS fragment reads, 8 MFMAs, softmax update
+    auto compute = [&](uint32_t key0, const unsigned char* buf) {
+        const bool need_mask = key0 + (MF_TILE - 1) > a.S - a.W;  // some (row, key) of this tile is masked / past S
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                f32x16 acc;
-                mma_only<DT>(buf0, sub, qf, fbase, acc, false);
+        for (int sub = 0; sub < MF_SUBS; ++sub) {
+            uint4 kf[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) kf[ks] = kfrag(buf, sub, ks, n, kg);
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc = mma32<DT>(kf[ks], qf[ks], acc);  // C[key][q row]
+            if (need_mask) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t kk = key0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
                     if (kk >= a.S || kk > a.S - a.W + w) acc[r] = KVP_NEG_INF;
                 }
-                float tm = acc[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) tm = fmaxf(tm, acc[r]);
-                const float mn = fmaxf(st.m, tm);
-                if (mn != KVP_NEG_INF) {
-                    const float off = -mn * c;
-                    float s = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s += fast_exp2(fmaf(acc[r], c, off));
-                    st.z = st.z * fast_exp2(fmaf(st.m, c, off)) + s;
-                    st.m = mn;
-                }
             }
+            float tm = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tm = fmaxf(tm, acc[r]);
+            const float mn = fmaxf(m, tm);
+            if (!need_mask || mn != KVP_NEG_INF) {
+                const float off = -mn * c;
+                float s0 = 0.f, s1 = 0.f;  // two chains: the 16 adds are otherwise one dependent sequence
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    s0 += fast_exp2(fmaf(acc[r], c, off));
+                    s1 += fast_exp2(fmaf(acc[r + 1], c, off));
+                }
+                z = z * fast_exp2(fmaf(m, c, off)) + (s0 + s1);
+                m = mn;
+            }
+        }
+    };
+
+    // K streams HBM -> registers -> LDS with TWO tiles in flight behind the one being computed:
+    // stA / stB alternate; each tile's loads have two compute phases to land (issue-early, write-late).
+    Stage stA, stB;
+    unsigned char* buf0 = lds;
+    unsigned char* buf1 = lds + MF_TILEB;
+    if (tw.ntiles > 0) {
+        stA = stage_load(kb, k_ssb, tw.kbeg, a.S);
+        stage_store(stA, buf0);
+        stA = stage_load(kb, k_ssb, min(tw.kbeg + tw.tstride, tw.klast), a.S);
+        __syncthreads();
+        phase_shift(a.phase);
+        for (uint32_t t = 0; t < tw.ntiles; t += 2) {
+            const uint32_t key0 = tw.kbeg + t * tw.tstride;
+            stamp(t, 0);
+            stB = stage_load(kb, k_ssb, min(key0 + 2 * tw.tstride, tw.klast), a.S);
+            __builtin_amdgcn_sched_barrier(0);  // issue-early
+            stamp(t, 1);
+            if (active) compute(key0, buf0);
+            __builtin_amdgcn_sched_barrier(0);  // keep the LDS write of the older stage BEHIND this tile's MFMAs (write-late)
+            stamp(t, 2);
+            if (t + 1 < tw.ntiles) stage_store(stA, buf1);
+            stamp(t, 3);
+            __syncthreads();
+            stamp(t, 4);
+            if (t + 1 >= tw.ntiles) break;
+            stamp(t + 1, 0);
+            stA = stage_load(kb, k_ssb, min(key0 + 3 * tw.tstride, tw.klast), a.S);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(t + 1, 1);
+            if (active) compute(key0 + tw.tstride, buf1);
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(t + 1, 2);
+            if (t + 2 < tw.ntiles) stage_store(stB, buf0);
+            stamp(t + 1, 3);
+            __syncthreads();
+            stamp(t + 1, 4);
         }
     }
 
     if (active) {
-        float mm = st.m == KVP_NEG_INF ? KVP_NEG_INF : st.m * c, zz = st.z;
+        float mm = m == KVP_NEG_INF ? KVP_NEG_INF : m * c, zz = z;
         const float m2 = __shfl_xor(mm, 32), z2 = __shfl_xor(zz, 32);
         softmax_merge(mm, zz, m2, z2);
         if (kg == 0) {
@@ -305,64 +241,17 @@ __global__ __launch_bounds__(MF_THREADS, 3) void snapkv_p1_mfma(SnapArgs a, uint
 
 // =================================================================================================
 // pass 2: colsum[b,h,key] = sum over the group's G*64 rows of 2^(L2 - a_row), keys < S - W
-// (no mask needed: every window row sees every key < S - W; keys >= S - W are simply not stored)
 // =================================================================================================
-// column sums of P = 2^(L2 - a_row) over the 16 finished logits `ap` (32 keys x this wave's 32 q rows)
-// -> red[key], interleaved with the 8 MFMAs producing `ac` from (buf, sub)
 template <int DT>
-__device__ __forceinline__ void p2_step(const unsigned char* buf, int sub, const uint4 (&qf)[8], uint32_t fbase, uint32_t n,
-                                        uint32_t kg, const f32x16& ap, f32x16& ac, const float (&ar)[16], float c, float* red_dst) {
-    uint4 kf[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) kf[ks] = kfrag(buf, fbase, sub, ks);
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) ac[i] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        ac = mma32<DT>(qf[ks], kf[ks], ac);  // C[q row][key]
-        s0 += fast_exp2(fmaf(ap[2 * ks], c, ar[2 * ks]));
-        s1 += fast_exp2(fmaf(ap[2 * ks + 1], c, ar[2 * ks + 1]));
-    }
-    float s = s0 + s1;
-    s += __shfl_xor(s, 32);
-    if (kg == 0) red_dst[n] = s;
-    KVP_SGB(SGB_DSRD, 4);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        KVP_SGB(SGB_MFMA, 1);
-        if (ks < 4) KVP_SGB(SGB_DSRD, 1);
-        KVP_SGB(SGB_VALU, 6);
-    }
-}
-__device__ __forceinline__ void p2_colsum_only(const f32x16& ap, const float (&ar)[16], float c, uint32_t n, uint32_t kg,
-                                               float* red_dst) {
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        s0 += fast_exp2(fmaf(ap[r], c, ar[r]));
-        s1 += fast_exp2(fmaf(ap[r + 1], c, ar[r + 1]));
-    }
-    float s = s0 + s1;
-    s += __shfl_xor(s, 32);
-    if (kg == 0) red_dst[n] = s;
-}
-
-template <int DT>
-__global__ __launch_bounds__(MF_THREADS, 3) void snapkv_p2_mfma(SnapArgs a, uint32_t ngb, uint32_t nchunk,
-                                                                const float* __restrict__ rowstat, float* __restrict__ colsum) {
+__global__ __launch_bounds__(MF_THREADS, 4) void snapkv_p2_mfma(SnapArgs a, uint32_t ngb, const float* __restrict__ rowstat,
+                                                                float* __restrict__ colsum) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * MF_TILEB];
-    __shared__ float red[3][MF_WAVES][MF_TILE];  // by tile % 3: a tile is flushed one barrier after it completes
-    // blockIdx.x enumerates (chunk, group-block) so that the ngb workgroups that read the SAME K tiles sit on
-    // the same XCD (workgroup i runs on XCD i % 8; slots i/8 of one XCD are dispatched back to back) and
-    // share its L2: K crosses HBM once per pass although it is staged into LDS ngb times.
-    const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const uint32_t gb = slot % ngb, chunk = (slot / ngb) * 8 + xcd;
-    const uint32_t h = blockIdx.y, b = blockIdx.z;
+    __shared__ float red[2][MF_WAVES][MF_TILE];
+    const uint32_t chunk = blockIdx.x, b = blockIdx.z;
+    const uint32_t h = blockIdx.y / ngb, gb = blockIdx.y - h * ngb;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t n = lane & 31, kg = lane >> 5;
-    const uint32_t fbase = n * MF_LROW + kg * 16;
-    const uint32_t rg = gb * MF_HPB + (wv >> 1);
+    const uint32_t rg = gb * 4 + (wv >> 1);
     const uint32_t row0 = (wv & 1) * 32;
     const bool active = rg < a.G;
     const uint32_t hq = h * a.G + (active ? rg : 0);
@@ -379,54 +268,63 @@ __global__ __launch_bounds__(MF_THREADS, 3) void snapkv_p2_mfma(SnapArgs a, uint
 #pragma unroll
     for (int r = 0; r < 16; ++r) ar[r] = -ars[(r & 3) + 8 * (r >> 2) + 4 * kg];
 
-    const TileWalk tw(chunk, nchunk, Sm);
+    const TileWalk tw(chunk, gridDim.x, Sm);
     const float c = a.c;
-    float* cs = colsum + ((size_t)gb * a.B * a.Hkv + (size_t)(b * a.Hkv + h)) * Sm;  // plane gb: summed by the pool kernel
-    const uint32_t nact = 2 * min((uint32_t)MF_HPB, a.G - gb * MF_HPB);  // active waves in this workgroup
-    if (tw.ntiles == 0) return;
+    float* cs = colsum + (size_t)(b * a.Hkv + h) * Sm;
+    const uint32_t nact = 2 * min(4u, a.G - gb * 4);  // active waves in this workgroup
 
-    // threads 0..63 add the active waves' partials of one finished tile and store 64 column sums
+    // one 64-key tile: P = 2^(L2 - a_row), column sums over this wave's 32 q rows -> red[par][wave][key]
+    auto compute = [&](const unsigned char* buf, int par) {
+#pragma unroll
+        for (int sub = 0; sub < MF_SUBS; ++sub) {
+            uint4 kf[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) kf[ks] = kfrag(buf, sub, ks, n, kg);
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc = mma32<DT>(qf[ks], kf[ks], acc);  // C[q row][key]
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                s0 += fast_exp2(fmaf(acc[r], c, ar[r]));
+                s1 += fast_exp2(fmaf(acc[r + 1], c, ar[r + 1]));
+            }
+            float s = s0 + s1;
+            s += __shfl_xor(s, 32);
+            if (kg == 0) red[par][wv][sub * 32 + n] = s;
+        }
+    };
+    // after the tile's barrier: threads 0..63 add the active waves' partials and store 64 column sums
     auto flush = [&](uint32_t key0, int par) {
         if (threadIdx.x < MF_TILE) {
             const uint32_t kk = key0 + threadIdx.x;
             if (kk < Sm) {
                 float s = red[par][0][threadIdx.x];
                 for (uint32_t w = 1; w < nact; ++w) s += red[par][w][threadIdx.x];
-                cs[kk] = s;
+                if (ngb == 1) cs[kk] = s;
+                else atomicAdd(&cs[kk], s);
             }
         }
     };
 
-    // Pipeline as in pass 1.  The column sums of tile t are complete after the step that follows tile t's
-    // barrier (sub-tile 1 rides with the next tile's first MFMAs), so tile t is flushed after the NEXT
-    // barrier.  One K tile is in flight behind the one being computed (register budget: 168 for 3 waves/SIMD).
-    Stage st1;
-    f32x16 accA, accB;
+    Stage st;
     unsigned char* bufc = lds;
     unsigned char* bufn = lds + MF_TILEB;
-    const uint32_t nt = tw.ntiles;
+    if (tw.ntiles == 0) return;
     stage_store(stage_load(kb, k_ssb, tw.kbeg, a.S), bufc);
     __syncthreads();
-    if (active) mma_only<DT>(bufc, 0, qf, fbase, accA, true);
-    uint32_t par = 0;  // t % 3
-    for (uint32_t t = 0; t < nt; ++t) {
+    for (uint32_t t = 0; t < tw.ntiles; ++t) {
         const uint32_t key0 = tw.kbeg + t * tw.tstride;
-        st1 = stage_load(kb, k_ssb, min(key0 + tw.tstride, tw.klast), a.S);
+        st = stage_load(kb, k_ssb, min(key0 + tw.tstride, tw.klast), a.S);  // next tile: in flight under this tile's math
         __builtin_amdgcn_sched_barrier(0);
-        if (active) p2_step<DT>(bufc, 1, qf, fbase, n, kg, accA, accB, ar, c, &red[par][wv][0]);   // colsum sub 0 of t
+        if (active) compute(bufc, t & 1);
         __builtin_amdgcn_sched_barrier(0);
-        stage_store(st1, bufn);
-        __syncthreads();  // tile t+1 visible; tile t-1's column sums complete
-        if (t > 0) flush(key0 - tw.tstride, par == 0 ? 2 : par - 1);
-        if (t + 1 >= nt) {
-            if (active) p2_colsum_only(accB, ar, c, n, kg, &red[par][wv][32]);
-            __syncthreads();
-            flush(key0, par);
-            break;
-        }
-        if (active) p2_step<DT>(bufn, 0, qf, fbase, n, kg, accB, accA, ar, c, &red[par][wv][32]);  // colsum sub 1 of t
+        if (t + 1 < tw.ntiles) stage_store(st, bufn);
+        __syncthreads();
+        flush(key0, t & 1);
         unsigned char* tmp = bufc; bufc = bufn; bufn = tmp;
-        par = par == 2 ? 0 : par + 1;
     }
 }
 
@@ -440,28 +338,62 @@ bool snapkv_mfma_eligible(const SnapArgs& a, int dtype) {
     return al8(a.q_sb) && al8(a.q_sh) && al8(a.q_sw) && al8(a.k_sb) && al8(a.k_sh) && al8(a.k_ss);
 }
 
-static uint32_t round8(uint32_t x) { return (x + 7) / 8 * 8; }
-// workgroups per (kv-head, group-block): a multiple of 8 (the XCD-paired mapping enumerates chunk = 8*j + xcd)
-uint32_t snapkv_mfma_nchunk(const SnapArgs& a) { return round8((a.S + MF_CHUNK - 1) / MF_CHUNK); }
-uint32_t snapkv_mfma_nplanes(const SnapArgs& a) { return (a.G + MF_HPB - 1) / MF_HPB; }
+// Workgroups per (batch, kv-head, group-block).  The grid is sized to ONE resident round (2 workgroups of 8 waves
+// per CU x 256 CUs): every workgroup pays its ~3.5 us start-up (Q fragments, first K tile) once and there is
+// no second dispatch round; each workgroup then walks its interleaved tile list (TileWalk).
+static uint32_t mfma_nchunk_for(const SnapArgs& a, uint32_t nkeys) {
+    const uint32_t ngb = (a.G + 3) / 4;
+    const uint32_t planes = std::max<uint32_t>(1, a.B * a.Hkv * ngb);
+    const uint32_t by_keys = (nkeys + MF_CHUNK - 1) / MF_CHUNK;   // >= 1024 keys per workgroup
+    const uint32_t by_cus = std::max<uint32_t>(1, 512 / planes);  // 2 x 256 workgroup slots
+    return std::max<uint32_t>(1, std::min(by_keys, by_cus));
+}
+uint32_t snapkv_mfma_nchunk(const SnapArgs& a) { return mfma_nchunk_for(a, a.S); }
 
 int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m, float* part_z, hipStream_t stream) {
-    const uint32_t ngb = snapkv_mfma_nplanes(a);
-    const dim3 grid(nchunk * ngb, a.Hkv, a.B);
-    if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
-    else KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
+    const uint32_t ngb = (a.G + 3) / 4;
+    const dim3 grid(nchunk, a.Hkv * ngb, a.B);
+    static const int trace_on = kvp_env_int("KVP_SK_TRACE", 0);
+    if (trace_on && dtype == KVP_BF16) {  // debug: one traced launch, dump, then fall through to the normal launch
+        static int dumped = 0;
+        if (dumped++ == 3) {
+            unsigned long long* d = nullptr;
+            const size_t nb = MF_WAVES * 20 * 6 * sizeof(unsigned long long);
+            if (hipMalloc(&d, nb) == hipSuccess) {
+                hipMemsetAsync(d, 0, nb, stream);
+                snapkv_p1_mfma<KVP_BF16, true><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, d);
+                hipStreamSynchronize(stream);
+                std::vector<unsigned long long> h(MF_WAVES * 20 * 6);
+                hipMemcpy(h.data(), d, nb, hipMemcpyDeviceToHost);
+                hipFree(d);
+                const unsigned long long t0 = h[5];
+                for (int w = 0; w < MF_WAVES; ++w)
+                    for (int tl = 0; tl < 17; ++tl) {
+                        fprintf(stderr, "TRACE w%d t%02d:", w, tl);
+                        for (int c = 0; c < 5; ++c) fprintf(stderr, " %8lld", (long long)(h[(w * 20 + tl) * 6 + c] - t0));
+                        fprintf(stderr, "\n");
+                    }
+            }
+        }
+    }
+    if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_BF16, false><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, nullptr));
+    else KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_F16, false><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, nullptr));
     KVP_CHECK_LAUNCH("snapkv_p1_mfma");
     return KVP_OK;
 }
 
-// colsum: [nplanes][B][Hkv][S-W]; plane gb holds the column sums of q-heads gb*2, gb*2+1 of every group
 int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, hipStream_t stream) {
-    const uint32_t ngb = snapkv_mfma_nplanes(a);
+    const uint32_t ngb = (a.G + 3) / 4;
     const uint32_t Sm = a.S - a.W;
-    const uint32_t nchunk = round8((Sm + MF_CHUNK - 1) / MF_CHUNK);
-    const dim3 grid(nchunk * ngb, a.Hkv, a.B);
-    if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, rowstat, colsum));
-    else KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, rowstat, colsum));
+    if (ngb > 1) {
+        if (hipMemsetAsync(colsum, 0, (size_t)a.B * a.Hkv * Sm * 4, stream) != hipSuccess) {
+            kvp_set_error("snapkv_p2_mfma: memset failed");
+            return KVP_EHIP;
+        }
+    }
+    const dim3 grid(mfma_nchunk_for(a, Sm), a.Hkv * ngb, a.B);
+    if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum));
+    else KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum));
     KVP_CHECK_LAUNCH("snapkv_p2_mfma");
     return KVP_OK;
 }

@@ -31,6 +31,12 @@ if [[ "$WHAT" == *ab* ]]; then
     echo "ab[$cfg] rc=$? $(python -c "import json;d=json.load(open('gpurun_out/ab_$tag.json'));print(round(d['ms_per_step']*1e3,1),'us/step', {k:round(v*1e3,1) for k,v in d['kernels_avg_ms'].items()})" 2>&1)"
   done
 fi
+if [[ "$WHAT" == *phase* ]]; then
+  for ph in 0 2 3 4 6; do
+    KVP_SK_PHASE=$ph timeout 300 python bench.py --workload snapkv128k --steps 10 --warmup 2 --no-cpu-baseline --profile-json gpurun_out/ph_$ph.json > gpurun_out/ph_$ph.log 2>&1
+    echo "phase[$ph] rc=$? $(python -c "import json;d=json.load(open('gpurun_out/ph_$ph.json'));print(round(d['ms_per_step']*1e3,1), {k:round(v*1e3,1) for k,v in d['kernels_avg_ms'].items() if 'snapkv_p' in k})" 2>&1)"
+  done
+fi
 if [[ "$WHAT" == *abl* ]]; then
   # timing-only ablations of snapkv_p1_mfma (results are wrong by design)
   for a in 0 1 2 3 4 5; do
