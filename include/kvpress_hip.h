@@ -42,6 +42,10 @@ enum kvp_status { KVP_OK = 0, KVP_EINVAL = -1, KVP_EUNSUPPORTED = -2, KVP_EWORKS
  * monotone stream).  SCORE: descending score, ties by ascending position -- the element order
  * torch.topk(sorted=True) produces at scorer_press.py:95, for tensor-exact comparisons. */
 enum kvp_order { KVP_ORDER_POSITION = 0, KVP_ORDER_SCORE = 1 };
+/* OR-ed into `order`: the workspace was zero-filled once (its first kvp_topk_workspace_bytes() bytes) and has
+ * only been used by kvp_topk_select on ONE stream since.  The call then skips its memset: the histograms in
+ * the workspace are self-cleaning (left zero on completion). */
+#define KVP_TOPK_WS_CLEAN 0x100
 
 int kvp_version(void);
 const char* kvp_last_error(void);

@@ -18,6 +18,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libkvpress_hip.so")
 
 KVP_F32, KVP_F16, KVP_BF16 = 0, 1, 2
 ORDER_POSITION, ORDER_SCORE = 0, 1
+TOPK_WS_CLEAN = 0x100
+_TOPK_WS: dict = {}  # (device index, stream, R, S) -> zero-initialised, self-cleaning workspace
 _DTYPES = {torch.float32: KVP_F32, torch.float16: KVP_F16, torch.bfloat16: KVP_BF16}
 
 # name -> (restype, argtypes); mirrors include/kvpress_hip.h line by line
@@ -240,9 +242,17 @@ def topk_select(scores: torch.Tensor, k: int, order: int = ORDER_POSITION) -> to
     if R and k:
         with torch.cuda.device(s.device):
             nws = lib().kvp_topk_workspace_bytes(R, S, k)
-            ws = _ws(nws, s)
-            _check(lib().kvp_topk_select(_p(s2), R, S, s2.stride(0) if R > 1 else S, int(k), int(order), _p(idx), _p(ws),
-                                         ws.numel(), _stream(s)), "kvp_topk_select")
+            # self-cleaning workspace: zeroed once per (device, stream, size), reused with KVP_TOPK_WS_CLEAN
+            stream = torch.cuda.current_stream(s.device)
+            key = (s.device.index, stream.cuda_stream, R, S)  # the layout (hence the clean region) depends on R and S
+            ws = _TOPK_WS.get(key)
+            if ws is None:
+                if len(_TOPK_WS) > 64:
+                    _TOPK_WS.clear()
+                ws = torch.zeros(max(int(nws), 256), dtype=torch.uint8, device=s.device)
+                _TOPK_WS[key] = ws
+            _check(lib().kvp_topk_select(_p(s2), R, S, s2.stride(0) if R > 1 else S, int(k), int(order) | TOPK_WS_CLEAN, _p(idx),
+                                         _p(ws), ws.numel(), _stream(s)), "kvp_topk_select")
     return idx.reshape(*lead, k)
 
 

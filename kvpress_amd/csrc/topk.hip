@@ -14,6 +14,11 @@
 //                       tables of the chunks before it, scans its keep flags and writes positions
 //                       in ascending order.
 //
+// The row histograms are SELF-CLEANING: K4 zeroes hist1/hist2 (nobody reads them after K3) and K1 zeroes
+// hist3 (next read two launches later), so a workspace that was zero once stays valid call after call and
+// no per-call memset is needed (kvp_topk_select takes a `ws_is_clean` flag; the binding caches a zeroed
+// workspace per device and stream).
+//
 // Kernel boundaries order the passes (1.5-1.9 us each on MI355X, cheaper than a grid barrier);
 // the only inter-workgroup traffic inside a launch is atomicAdd into the row histograms.
 #include "kvp_common.h"
@@ -29,7 +34,7 @@ struct TopkWs {
     uint32_t* hist2;       // [R][4096]
     uint32_t* hist3;       // [R][256]
     uint32_t* sel;         // [R][4] : b1, k1, b2, k2
-    uint32_t* chunk_hist;  // [R][nchunks][256]
+    uint32_t* chunk_hist;  // [R][nchunks][257] suffix counts of the last digit: [d] = #(digit >= d), [256] = 0
     uint32_t* chunk_gt;    // [R][nchunks]
     size_t zero_bytes;     // leading bytes that must be zeroed per call (hist1..hist3)
     size_t total_bytes;
@@ -49,7 +54,7 @@ TopkWs carve_ws(void* ws, int64_t R, int64_t nchunks) {
     w.hist3 = (uint32_t*)take((size_t)R * 256 * 4);
     w.zero_bytes = off;
     w.sel = (uint32_t*)take((size_t)R * 4 * 4);
-    w.chunk_hist = (uint32_t*)take((size_t)R * nchunks * 256 * 4);
+    w.chunk_hist = (uint32_t*)take((size_t)R * nchunks * 257 * 4);
     w.chunk_gt = (uint32_t*)take((size_t)R * nchunks * 4);
     w.total_bytes = off;
     return w;
@@ -123,9 +128,19 @@ __global__ __launch_bounds__(TK_THREADS) void topk_hist12_kernel(const float* __
     __shared__ uint32_t scr[8];
     const uint32_t row = blockIdx.y, chunk = blockIdx.x;
     const float* rp = scores + (int64_t)row * row_stride;
+    // the scores are requested first so that their latency overlaps the histogram scan below
+    const uint32_t base = chunk * TK_CHUNK;
+    uint32_t keys[TK_PER];
+#pragma unroll
+    for (int j = 0; j < TK_PER; ++j) {
+        const uint32_t i = base + j * TK_THREADS + threadIdx.x;
+        keys[j] = i < S ? float_to_key(rp[i]) : 0u;
+    }
     for (int i = threadIdx.x; i < 4096; i += TK_THREADS) lh[i] = 0;
     uint32_t b1 = 0, k1 = 0;
-    if (PASS == 2) {
+    if (PASS == 1) {
+        if (chunk == 0) w.hist3[(size_t)row * 256 + threadIdx.x] = 0;  // self-cleaning: read again only in K4
+    } else {
         find_bin<4096>(w.hist1 + (size_t)row * 4096, k, scr, b1, k1);
         if (chunk == 0 && threadIdx.x == 0) {
             w.sel[row * 4 + 0] = b1;
@@ -133,15 +148,13 @@ __global__ __launch_bounds__(TK_THREADS) void topk_hist12_kernel(const float* __
         }
     }
     __syncthreads();
-    const uint32_t base = chunk * TK_CHUNK;
 #pragma unroll
     for (int j = 0; j < TK_PER; ++j) {
-        bool valid;
-        const uint32_t key = load_key(rp, base + j * TK_THREADS + threadIdx.x, S, valid);
+        const bool valid = base + j * TK_THREADS + threadIdx.x < S;
         if (PASS == 1) {
-            if (valid) atomicAdd(&lh[key >> 20], 1u);
+            if (valid) atomicAdd(&lh[keys[j] >> 20], 1u);
         } else {
-            if (valid && (key >> 20) == b1) atomicAdd(&lh[(key >> 8) & 0xFFFu], 1u);
+            if (valid && (keys[j] >> 20) == b1) atomicAdd(&lh[(keys[j] >> 8) & 0xFFFu], 1u);
         }
     }
     __syncthreads();
@@ -159,6 +172,13 @@ __global__ __launch_bounds__(TK_THREADS) void topk_hist8_kernel(const float* __r
     __shared__ uint32_t scr[8];
     const uint32_t row = blockIdx.y, chunk = blockIdx.x;
     const float* rp = scores + (int64_t)row * row_stride;
+    const uint32_t base = chunk * TK_CHUNK;
+    uint32_t keys[TK_PER];
+#pragma unroll
+    for (int j = 0; j < TK_PER; ++j) {
+        const uint32_t i = base + j * TK_THREADS + threadIdx.x;
+        keys[j] = i < S ? float_to_key(rp[i]) : 0u;
+    }
     lh[threadIdx.x] = 0;
     const uint32_t b1 = w.sel[row * 4 + 0], k1 = w.sel[row * 4 + 1];
     uint32_t b2, k2;
@@ -169,22 +189,28 @@ __global__ __launch_bounds__(TK_THREADS) void topk_hist8_kernel(const float* __r
     }
     const uint32_t prefix = (b1 << 12) | b2;
     __syncthreads();
-    const uint32_t base = chunk * TK_CHUNK;
     uint32_t ngt = 0;
 #pragma unroll
     for (int j = 0; j < TK_PER; ++j) {
-        bool valid;
-        const uint32_t key = load_key(rp, base + j * TK_THREADS + threadIdx.x, S, valid);
-        const uint32_t p = key >> 8;
+        const bool valid = base + j * TK_THREADS + threadIdx.x < S;
+        const uint32_t p = keys[j] >> 8;
         if (valid && p > prefix) ++ngt;
-        if (valid && p == prefix) atomicAdd(&lh[key & 0xFFu], 1u);
+        if (valid && p == prefix) atomicAdd(&lh[keys[j] & 0xFFu], 1u);
     }
     uint32_t tot;
     block_excl_scan(ngt, scr, &tot);  // contains the barrier that also covers the LDS atomics
-    const uint32_t c = lh[threadIdx.x];
-    w.chunk_hist[((size_t)row * nchunks + chunk) * 256 + threadIdx.x] = c;
-    if (c) atomicAdd(&w.hist3[(size_t)row * 256 + threadIdx.x], c);
-    if (threadIdx.x == 0) w.chunk_gt[(size_t)row * nchunks + chunk] = tot;
+    // thread t owns bin 255 - t: the exclusive scan over threads counts the keys in HIGHER bins, so
+    // suffix[d] = #(last digit >= d) among this chunk's prefix-matching keys
+    const uint32_t d = 255u - threadIdx.x;
+    const uint32_t c = lh[d];
+    uint32_t tot2;
+    const uint32_t above = block_excl_scan(c, scr, &tot2);
+    w.chunk_hist[((size_t)row * nchunks + chunk) * 257 + d] = above + c;
+    if (threadIdx.x == 0) {
+        w.chunk_hist[((size_t)row * nchunks + chunk) * 257 + 256] = 0;  // suffix[256]
+        w.chunk_gt[(size_t)row * nchunks + chunk] = tot;
+    }
+    if (c) atomicAdd(&w.hist3[(size_t)row * 256 + d], c);
 }
 
 // ---- K4: ordered compaction --------------------------------------------------------------------
@@ -194,22 +220,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __r
     __shared__ uint32_t scr[8];
     const uint32_t row = blockIdx.y, chunk = blockIdx.x;
     const float* rp = scores + (int64_t)row * row_stride;
-    const uint32_t b1 = w.sel[row * 4 + 0], b2 = w.sel[row * 4 + 2], k2 = w.sel[row * 4 + 3];
-    uint32_t b3, quota;
-    find_bin<256>(w.hist3 + (size_t)row * 256, k2, scr, b3, quota);
-    const uint32_t T = (((b1 << 12) | b2) << 8) | b3;
-
-    // elements kept in the chunks before this one: thread t sums bin t of their last-digit histograms
-    uint32_t binsum = 0;
-    const uint32_t* ch = w.chunk_hist + (size_t)row * nchunks * 256 + threadIdx.x;
-    for (uint32_t j = 0; j < chunk; ++j) binsum += ch[(size_t)j * 256];
-    uint32_t gt_part = threadIdx.x > b3 ? binsum : 0u;
-    for (uint32_t j = threadIdx.x; j < chunk; j += TK_THREADS) gt_part += w.chunk_gt[(size_t)row * nchunks + j];
-    uint32_t gt_before, eq_before;
-    block_excl_scan(gt_part, scr, &gt_before);
-    block_excl_scan(threadIdx.x == b3 ? binsum : 0u, scr, &eq_before);
-
-    // this thread's 8 consecutive positions
+    // this thread's 8 consecutive positions (requested before the threshold is resolved)
     const uint32_t p0 = chunk * TK_CHUNK + threadIdx.x * TK_PER;
     uint32_t keys[TK_PER];
     const bool fast = (p0 + TK_PER <= S) && ((((uintptr_t)(rp + p0)) & 15u) == 0);
@@ -222,6 +233,29 @@ __global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < TK_PER; ++j) keys[j] = (p0 + j < S) ? float_to_key(rp[p0 + j]) : 0u;
     }
+    const uint32_t b1 = w.sel[row * 4 + 0], b2 = w.sel[row * 4 + 2], k2 = w.sel[row * 4 + 3];
+    uint32_t b3, quota;
+    find_bin<256>(w.hist3 + (size_t)row * 256, k2, scr, b3, quota);
+    const uint32_t T = (((b1 << 12) | b2) << 8) | b3;
+
+    // kept elements in the chunks before this one, from their suffix tables: thread j handles chunk j
+    uint32_t gt_part = 0, eq_part = 0;
+    for (uint32_t j = threadIdx.x; j < chunk; j += TK_THREADS) {
+        const uint32_t* sf = w.chunk_hist + ((size_t)row * nchunks + j) * 257;
+        const uint32_t ge = sf[b3], gt = sf[b3 + 1];
+        gt_part += w.chunk_gt[(size_t)row * nchunks + j] + gt;
+        eq_part += ge - gt;
+    }
+    uint32_t gt_before, eq_before;
+    block_excl_scan(gt_part, scr, &gt_before);
+    block_excl_scan(eq_part, scr, &eq_before);
+
+    // self-cleaning: hist1 / hist2 of this row are dead now (hist3 is zeroed by the next call's K1)
+    for (uint32_t i = chunk * TK_THREADS + threadIdx.x; i < 4096; i += nchunks * TK_THREADS) {
+        w.hist1[(size_t)row * 4096 + i] = 0;
+        w.hist2[(size_t)row * 4096 + i] = 0;
+    }
+
     uint32_t cg = 0, ce = 0;
 #pragma unroll
     for (int j = 0; j < TK_PER; ++j) {
@@ -267,8 +301,9 @@ extern "C" int kvp_topk_select(const float* scores, int64_t R, int64_t S, int64_
                                int32_t* idx, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     KVP_CHECK_ARG(R >= 0 && S >= 0 && k >= 0 && k <= S, "topk: bad shape R=%ld S=%ld k=%ld", (long)R, (long)S, (long)k);
-    KVP_CHECK_ARG(order == KVP_ORDER_POSITION || order == KVP_ORDER_SCORE, "topk: bad order %d", order);
-    if (order == KVP_ORDER_SCORE) {
+    const int ord = order & ~KVP_TOPK_WS_CLEAN;
+    KVP_CHECK_ARG(ord == KVP_ORDER_POSITION || ord == KVP_ORDER_SCORE, "topk: bad order %d", order);
+    if (ord == KVP_ORDER_SCORE) {
         kvp_set_error("topk: KVP_ORDER_SCORE is not implemented yet (use KVP_ORDER_POSITION)");
         return KVP_EUNSUPPORTED;
     }
@@ -289,7 +324,7 @@ extern "C" int kvp_topk_select(const float* scores, int64_t R, int64_t S, int64_
         kvp_set_error("topk: workspace too small (%zu < %zu)", ws_bytes, w.total_bytes);
         return KVP_EWORKSPACE;
     }
-    if (hipMemsetAsync(ws, 0, w.zero_bytes, stream) != hipSuccess) {
+    if (!(order & KVP_TOPK_WS_CLEAN) && hipMemsetAsync(ws, 0, w.zero_bytes, stream) != hipSuccess) {
         kvp_set_error("topk: hipMemsetAsync failed");
         return KVP_EHIP;
     }
