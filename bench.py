@@ -85,6 +85,29 @@ def kernel_bytes(name: str, kind: str, S: int, ratio: float) -> float:
     return 0.0
 
 
+def pmc_traffic(kernel_name: str, workload: str):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary of this same command
+    (profiles/r01_pmc_summary_<workload>.txt; separate --pmc passes).  MI355X_MICROARCH.md §HBM: FETCH_SIZE and
+    WRITE_SIZE are in KiB and on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads -> doubled."""
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_summary_{workload}.txt")
+    if not os.path.exists(path):
+        return None
+    fetch = write = None
+    inside = False
+    for line in open(path):
+        if line.startswith("=="):
+            inside = kernel_name in line
+        elif inside:
+            f = line.split()
+            if len(f) == 2 and f[0] == "FETCH_SIZE":
+                fetch = float(f[1])
+            if len(f) == 2 and f[0] == "WRITE_SIZE":
+                write = float(f[1])
+    if fetch is None or write is None:
+        return None
+    return int((2.0 * fetch + write) * 1024)
+
+
 def build_module(device):
     import torch
     from transformers import LlamaConfig
@@ -201,7 +224,7 @@ def main():
             ach = kb / (cand[dom] * 1e-3) / 1e9
             roofline = {
                 "kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.workload),
                 "algorithmic_bytes_per_launch": kb, "avg_launch_us": round(cand[dom] * 1e3, 2),
                 "path": {
                     "algorithmic_bytes_per_layer": ab["total"] * B,

@@ -56,11 +56,16 @@ if [[ "$WHAT" == *pmc* ]]; then
     echo "pmc[$i: $set] rc=$?"
   done
   cd "$GRAFT_REPO_ROOT"
+  python scripts/rocpd_pmc.py gpurun_out/pmc_*/pmc_results.db > gpurun_out/pmc_summary_${PMC_WL:-snapkv128k}.txt 2>&1
+  rm -rf gpurun_out/pmc_[0-9]*
 fi
 if [[ "$WHAT" == *prof* ]]; then
   cd /tmp
   for wl in snapkv128k knorm32k; do
-    timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -o $wl -- python "$GRAFT_REPO_ROOT/bench.py" --workload $wl --steps 20 --warmup 3 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -o $wl -- python "$GRAFT_REPO_ROOT/bench.py" --workload $wl --steps 20 --warmup 3 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" 2>&1
     echo "prof[$wl] rc=$?"
+    find "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -name "*kernel_trace.csv" -delete 2>/dev/null
+    find "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -name "*.db" -delete 2>/dev/null
   done
+  cd "$GRAFT_REPO_ROOT"
 fi
