@@ -1,20 +1,454 @@
-// ExpectedAttention on the matrix cores (bf16/f16, D = 128): query statistics (syrk) and the
-// quadratic-form logits.  Round-1 status: not implemented yet -- the eligibility predicates
-// return false so kvp_ea_* use the generic kernels of ea.hip.
+// ExpectedAttention on the matrix cores (bf16 / f16, D = 128): query statistics and quadratic-form logits.
+//
+// (1) ea_qstats_mfma  -- mu, cov of the pre-RoPE queries (expected_attention_press.py:74-80), one pass over Q.
+//     cov = X^T X needs, for both MFMA operands, "column fragments" (a lane holds several ROWS s of one
+//     dimension d), while X is stored row-major.  The transpose is done BY the MFMA: T = X_tile . E with a
+//     32x32 selection matrix E puts X^T into the C layout (lane = one dim, 16 rows), where the fp32 values are
+//     shifted by a per-workgroup estimate m0 of the mean (shifted-data algorithm: no cancellation), rounded
+//     to 16 bits and used directly as A and B fragments of the syrk MFMAs -- the k-index (row) assignment of a
+//     fragment slot is arbitrary as long as A and B agree, and they are built by the same procedure.
+//     Each workgroup writes a partial (S2 about m0, sum(x - m0), m0, n); ea_qstats_combine merges them with
+//     the pairwise (Chan) update.  Rounding (x - m0) to bf16 perturbs each product by ~2^-9 |x - m0| with
+//     zero mean on random data (~4.6e-3 / sqrt(n) relative), but the inputs themselves live on a 16-bit grid, so
+//     for structured data the rounding is partly systematic: measured worst entry 1.8e-3 sigma_i sigma_j, mean
+//     2.5e-5; end-to-end scores stay within 1e-3 (tests/test_gpu_parity.py::test_ea_full_chain_mfma_vs_oracle).
+//     The path is taken for Sq >= 4096; shorter sequences use the exact fp32 generic kernels.
+//
+// (2) ea_logits_mfma  -- log2-logits k.mu/sqrt(D) + k^T cov k/(2D) per q-head (:148-151) and per-chunk
+//     softmax partials.  C = cov_strip . K_tile^T with cov split into hi + lo 16-bit parts (two MFMA chains,
+//     ~2^-17 relative), then a row-dot with K read back in the C layout (ds_read_b64 from the swizzled tile).
+//     (k^T A k depends only on the symmetric part of A, so feeding rows of cov as the "columns" is exact.)
 #include "ea_internal.h"
+#include "softmax_stats.h"
 
-bool ea_mfma_qstats_eligible(const void*, int64_t, int64_t, int64_t, int, int64_t) { return false; }
-size_t ea_mfma_qstats_ws_bytes(int64_t, int64_t, int64_t, int64_t) { return 0; }
-int ea_mfma_qstats(const void*, int64_t, int64_t, int64_t, int, int64_t, int64_t, int64_t, int64_t, float*, float*, void*,
-                   hipStream_t) {
-    kvp_set_error("ea_mfma_qstats: not implemented");
-    return KVP_EUNSUPPORTED;
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int EM_THREADS = 256;
+constexpr int EM_TILE = 64;    // rows per LDS tile
+constexpr int EM_ROWB = 256;   // D = 128, 2-byte elements
+constexpr int EM_TILEB = EM_TILE * EM_ROWB;
+
+template <int DT> __device__ __forceinline__ f32x16 mma32(const uint4& a, const uint4& b, f32x16 c);
+template <> __device__ __forceinline__ f32x16 mma32<KVP_BF16>(const uint4& a, const uint4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16 mma32<KVP_F16>(const uint4& a, const uint4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-bool ea_mfma_logits_eligible(const EaArgs&, int) { return false; }
+// two floats -> one dword of 16-bit values (round to nearest even), low half = a
+template <int DT> __device__ __forceinline__ uint32_t pack2(float a, float b);
+template <> __device__ __forceinline__ uint32_t pack2<KVP_BF16>(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <> __device__ __forceinline__ uint32_t pack2<KVP_F16>(float a, float b) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 p = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, p);
+}
+template <int DT> __device__ __forceinline__ float lo16(uint32_t w);
+template <int DT> __device__ __forceinline__ float hi16(uint32_t w);
+template <> __device__ __forceinline__ float lo16<KVP_BF16>(uint32_t w) { return __uint_as_float(w << 16); }
+template <> __device__ __forceinline__ float hi16<KVP_BF16>(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+template <> __device__ __forceinline__ float lo16<KVP_F16>(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); }
+template <> __device__ __forceinline__ float hi16<KVP_F16>(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+template <int DT> __device__ __forceinline__ float round16(float x) { return lo16<DT>(pack2<DT>(x, 0.f)); }
+template <int DT> __device__ __forceinline__ uint32_t one16();
+template <> __device__ __forceinline__ uint32_t one16<KVP_BF16>() { return 0x3F80u; }
+template <> __device__ __forceinline__ uint32_t one16<KVP_F16>() { return 0x3C00u; }
+
+// --- row tile staging: 64 rows x 256 B, XOR-swizzled by (row & 15) << 4 (conflict-free ds_read_b128) ------
+struct Stage {
+    uint4 v[4];
+};
+__device__ __forceinline__ Stage stage_load(const char* __restrict__ base, int64_t row_bytes, uint32_t row0, uint32_t nrows) {
+    const uint32_t r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
+    Stage st;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t r = min(row0 + r0 + 16 * i, nrows - 1);  // unconditional loads; rows past the end are masked later
+        st.v[i] = *reinterpret_cast<const uint4*>(base + (int64_t)r * row_bytes + ch * 16);
+    }
+    return st;
+}
+__device__ __forceinline__ void stage_store(const Stage st, unsigned char* buf) {
+    const uint32_t r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t row = r0 + 16 * i;
+        *reinterpret_cast<uint4*>(buf + row * EM_ROWB + ((ch ^ (row & 15)) << 4)) = st.v[i];
+    }
+}
+// 16-byte fragment: row sub*32 + n, 16-byte column c16
+__device__ __forceinline__ uint4 frag16(const unsigned char* buf, uint32_t sub, uint32_t c16, uint32_t n) {
+    const uint32_t row = sub * 32 + n;
+    return *reinterpret_cast<const uint4*>(buf + row * EM_ROWB + ((c16 ^ (row & 15)) << 4));
+}
+
+// =================================================================================================
+// (1) query statistics
+// =================================================================================================
+struct QstatArgs {
+    const void* q;
+    int64_t q_sb, q_sh, q_ss;  // element strides
+    uint32_t B, Hq, Sq, nchunk, rows_per_chunk;
+    float* s2;    // [B*Hq][nchunk][128][128]
+    float* dsum;  // [B*Hq][nchunk][128]   sum over the chunk's rows of (x - m0)
+    float* m0;    // [B*Hq][nchunk][128]
+};
+
+// transpose the 32 rows x 32 dims block (sub, ct) of the tile into the C layout: lane (dim j = lane & 31, kg),
+// T[r] = x[row (r&3)+8(r>>2)+4kg][dim ct*32+j]
+template <int DT>
+__device__ __forceinline__ f32x16 transpose_block(const unsigned char* buf, uint32_t sub, uint32_t ct, uint32_t n, uint32_t kg,
+                                                  const uint4& e0, const uint4& e1) {
+    f32x16 T;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T[i] = 0.f;
+    T = mma32<DT>(frag16(buf, sub, ct * 4 + 0 + kg, n), e0, T);  // dims ct*32 + [0,16): 16-byte columns ct*4 + {0,1}
+    T = mma32<DT>(frag16(buf, sub, ct * 4 + 2 + kg, n), e1, T);  // dims ct*32 + [16,32)
+    return T;
+}
+
+template <int DT>
+__global__ __launch_bounds__(EM_THREADS, 2) void ea_qstats_mfma_kernel(QstatArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * EM_TILEB];
+    const uint32_t hq = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t n = lane & 31, kg = lane >> 5;
+    const uint32_t bh = b * a.Hq + hq;
+    const char* base = static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh) * 2;
+    const int64_t row_bytes = a.q_ss * 2;
+    const uint32_t rbeg = chunk * a.rows_per_chunk;
+    const uint32_t rend = min(rbeg + a.rows_per_chunk, a.Sq);
+    if (rbeg >= rend) return;  // (cannot happen: nchunk is derived from Sq)
+    const uint32_t ntiles = (rend - rbeg + EM_TILE - 1) / EM_TILE;
+
+    // selection matrices E_t (16 x 32): B[k][j] = 1 iff j == 16 t + k; lane (j, kg) holds k = 8 kg + e
+    uint32_t ew[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int e_lo = 2 * p, e_hi = 2 * p + 1;
+            const uint32_t lo = ((int)n == 16 * t + 8 * (int)kg + e_lo) ? one16<DT>() : 0u;
+            const uint32_t hi = ((int)n == 16 * t + 8 * (int)kg + e_hi) ? one16<DT>() : 0u;
+            ew[t][p] = lo | (hi << 16);
+        }
+    const uint4 e0 = make_uint4(ew[0][0], ew[0][1], ew[0][2], ew[0][3]);
+    const uint4 e1 = make_uint4(ew[1][0], ew[1][1], ew[1][2], ew[1][3]);
+
+    unsigned char* bufc = lds;
+    unsigned char* bufn = lds + EM_TILEB;
+    stage_store(stage_load(base, row_bytes, rbeg, a.Sq), bufc);
+    __syncthreads();
+
+    // relative column tiles: ct = (wv + i) & 3, so that index 0 is this wave's own strip (static indexing)
+    float m0r[4];
+    {
+        const uint32_t nv = min(32u, rend - rbeg);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t ct = (wv + i) & 3;
+            const f32x16 T = transpose_block<DT>(bufc, 0, ct, n, kg, e0, e1);
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += ((uint32_t)((r & 3) + 8 * (r >> 2) + 4 * kg) < nv) ? T[r] : 0.f;
+            s += __shfl_xor(s, 32);
+            // rounded to the input grid: where |mean| >> sigma the inputs sit on a coarse 16-bit grid and x - m0 is
+            // then exactly representable (no systematic rounding of the shifted values)
+            m0r[i] = round16<DT>(s / (float)nv);
+        }
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float dsum = 0.f;
+
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const uint32_t row0 = rbeg + t * EM_TILE;
+        Stage st = stage_load(base, row_bytes, min(row0 + EM_TILE, rend - 1), a.Sq);  // next tile (clamped)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const bool tail = row0 + sub * 32 + 32 > rend;
+            uint4 F[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t ct = (wv + i) & 3;
+                const f32x16 T = transpose_block<DT>(bufc, sub, ct, n, kg, e0, e1);
+                float y[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    y[r] = T[r] - m0r[i];
+                    if (tail && row0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg >= rend) y[r] = 0.f;
+                }
+                if (i == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dsum += y[r];
+                }
+                F[i][0] = make_uint4(pack2<DT>(y[0], y[1]), pack2<DT>(y[2], y[3]), pack2<DT>(y[4], y[5]), pack2<DT>(y[6], y[7]));
+                F[i][1] = make_uint4(pack2<DT>(y[8], y[9]), pack2<DT>(y[10], y[11]), pack2<DT>(y[12], y[13]), pack2<DT>(y[14], y[15]));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i] = mma32<DT>(F[0][0], F[i][0], acc[i]);  // C[own dim][dim of tile (wv+i)&3] += sum over 16 rows
+                acc[i] = mma32<DT>(F[0][1], F[i][1], acc[i]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < ntiles) stage_store(st, bufn);
+        __syncthreads();
+        unsigned char* tmp = bufc; bufc = bufn; bufn = tmp;
+    }
+
+    // NOTE: dsum above is accumulated on the fp32 (unrounded) shifted values; S2 on their 16-bit roundings.
+    float* s2 = a.s2 + ((size_t)bh * a.nchunk + chunk) * 128 * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t jt = (wv + i) & 3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t di = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            s2[(size_t)di * 128 + jt * 32 + n] = acc[i][r];
+        }
+    }
+    dsum += __shfl_xor(dsum, 32);
+    if (kg == 0) {
+        a.dsum[((size_t)bh * a.nchunk + chunk) * 128 + wv * 32 + n] = dsum;
+        a.m0[((size_t)bh * a.nchunk + chunk) * 128 + wv * 32 + n] = m0r[0];
+    }
+}
+
+// merge the per-chunk partials: mu[d], cov[i][j]  (Chan et al. pairwise update, all in fp32).
+// grid = (16, B*Hq): workgroup x handles cov elements [x*1024, (x+1)*1024) of one head (and x == 0 also writes mu).
+__global__ __launch_bounds__(256) void ea_qstats_combine(const float* __restrict__ s2, const float* __restrict__ dsum,
+                                                         const float* __restrict__ m0, uint32_t Sq, uint32_t nchunk,
+                                                         uint32_t rows_per_chunk, float* __restrict__ mu, float* __restrict__ cov) {
+    extern __shared__ float sm[];  // muc[nchunk][128], del[nchunk][128], mug[128]
+    float* muc = sm;
+    float* del = sm + nchunk * 128;
+    float* mug = del + nchunk * 128;
+    const uint32_t bh = blockIdx.y;
+    const float invN = 1.0f / (float)Sq;
+    for (uint32_t e = threadIdx.x; e < nchunk * 128; e += 256) {
+        const uint32_t c = e >> 7;
+        const float nc = (float)(min((c + 1) * rows_per_chunk, Sq) - c * rows_per_chunk);
+        const float d = dsum[(size_t)bh * nchunk * 128 + e] / nc;
+        del[e] = d;
+        muc[e] = m0[(size_t)bh * nchunk * 128 + e] + d;
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        float s = 0.f;
+        for (uint32_t c = 0; c < nchunk; ++c) {
+            const float nc = (float)(min((c + 1) * rows_per_chunk, Sq) - c * rows_per_chunk);
+            s += nc * muc[c * 128 + threadIdx.x];
+        }
+        mug[threadIdx.x] = s * invN;
+        if (blockIdx.x == 0) mu[(size_t)bh * 128 + threadIdx.x] = s * invN;
+    }
+    __syncthreads();
+    if (!cov) return;
+    for (uint32_t e = blockIdx.x * 1024 + threadIdx.x; e < (blockIdx.x + 1) * 1024; e += 256) {
+        const uint32_t i = e >> 7, j = e & 127;
+        float s = 0.f;
+        for (uint32_t c = 0; c < nchunk; ++c) {
+            const float nc = (float)(min((c + 1) * rows_per_chunk, Sq) - c * rows_per_chunk);
+            const float ai = muc[c * 128 + i] - mug[i], aj = muc[c * 128 + j] - mug[j];
+            s += s2[((size_t)bh * nchunk + c) * 16384 + e] + nc * (ai * aj - del[c * 128 + i] * del[c * 128 + j]);
+        }
+        cov[(size_t)bh * 16384 + e] = s * invN;
+    }
+}
+
+void qstats_plan(int64_t Sq, uint32_t& nchunk, uint32_t& rows) {
+    int64_t nc = std::min<int64_t>(32, std::max<int64_t>(1, (Sq + 4095) / 4096));
+    int64_t r = ((Sq + nc - 1) / nc + EM_TILE - 1) / EM_TILE * EM_TILE;
+    nchunk = (uint32_t)((Sq + r - 1) / r);
+    rows = (uint32_t)r;
+}
+
+// =================================================================================================
+// (2) logits
+// =================================================================================================
+constexpr int EL_CHUNK = 4096;  // keys per workgroup
+
+template <int DT>
+__global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk,
+                                                                        float* __restrict__ part_m, float* __restrict__ part_z) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * EM_TILEB];
+    __shared__ float red[2][4][EM_TILE];
+    const uint32_t g = blockIdx.x, chunk = blockIdx.y;
+    const uint32_t b = blockIdx.z / a.Hkv, h = blockIdx.z - b * a.Hkv;
+    const uint32_t hq = h * a.G + g, bhq = b * a.Hq + hq;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t n = lane & 31, kg = lane >> 5;
+    const char* kb = static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh + (int64_t)a.n_sink * a.k_ss) * 2;
+    const int64_t row_bytes = a.k_ss * 2;
+
+    // this wave's 32-row strip of cov (rows j = 32 wv + n), split hi + lo: A fragments for all 8 k-steps
+    uint4 chi[8], clo[8];
+    const bool has_cov = a.cov != nullptr;
+    {
+        const float* crow = has_cov ? a.cov + ((size_t)bhq * 128 + wv * 32 + n) * 128 : nullptr;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            float x[8];
+            if (has_cov) {
+                const float4 u = *reinterpret_cast<const float4*>(crow + ks * 16 + kg * 8);
+                const float4 w = *reinterpret_cast<const float4*>(crow + ks * 16 + kg * 8 + 4);
+                x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = w.x; x[5] = w.y; x[6] = w.z; x[7] = w.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = 0.f;
+            }
+            uint32_t hw[4], lw[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                hw[p] = pack2<DT>(x[2 * p], x[2 * p + 1]);
+                lw[p] = pack2<DT>(x[2 * p] - lo16<DT>(hw[p]), x[2 * p + 1] - hi16<DT>(hw[p]));
+            }
+            chi[ks] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            clo[ks] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        }
+    }
+    // mu of the 16 cov rows this lane sees in the C layout (row = 32 wv + (r&3) + 8 (r>>2) + 4 kg), pre-scaled
+    float muv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) muv[r] = a.mu[(size_t)bhq * 128 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] * a.inv_sqrt_d;
+
+    const uint32_t kbeg = chunk * EL_CHUNK;
+    const uint32_t kend = min(kbeg + EL_CHUNK, a.Sp);
+    const uint32_t ntiles = (kend - kbeg + EM_TILE - 1) / EM_TILE;
+    float* lrow = logits + (size_t)bhq * a.Sp;
+    float m_run = KVP_NEG_INF, z_run = 0.f;  // threads 0..63: running softmax partial of the keys they own
+
+    unsigned char* bufc = lds;
+    unsigned char* bufn = lds + EM_TILEB;
+    stage_store(stage_load(kb, row_bytes, kbeg, a.Sp), bufc);
+    __syncthreads();
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const uint32_t key0 = kbeg + t * EM_TILE;
+        const Stage st = stage_load(kb, row_bytes, min(key0 + EM_TILE, kend - 1), a.Sp);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x16 ah, al;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ah[i] = 0.f; al[i] = 0.f; }
+            if (has_cov) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const uint4 kf = frag16(bufc, sub, ks * 2 + kg, n);
+                    ah = mma32<DT>(chi[ks], kf, ah);  // C[cov row][key]
+                    al = mma32<DT>(clo[ks], kf, al);
+                }
+            }
+            // K in the C layout: key = sub*32 + n, dims 32 wv + 8 q + 4 kg + {0..3}: 8 bytes of 16-byte column 4 wv + q
+            float val = 0.f;
+            const uint32_t row = sub * 32 + n;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint2 kk = *reinterpret_cast<const uint2*>(bufc + row * EM_ROWB + (((wv * 4 + q) ^ (row & 15)) << 4) + kg * 8);
+                const float k0 = lo16<DT>(kk.x), k1 = hi16<DT>(kk.x), k2 = lo16<DT>(kk.y), k3 = hi16<DT>(kk.y);
+                val = fmaf(k0, fmaf(ah[4 * q + 0] + al[4 * q + 0], a.inv_2d, muv[4 * q + 0]), val);
+                val = fmaf(k1, fmaf(ah[4 * q + 1] + al[4 * q + 1], a.inv_2d, muv[4 * q + 1]), val);
+                val = fmaf(k2, fmaf(ah[4 * q + 2] + al[4 * q + 2], a.inv_2d, muv[4 * q + 2]), val);
+                val = fmaf(k3, fmaf(ah[4 * q + 3] + al[4 * q + 3], a.inv_2d, muv[4 * q + 3]), val);
+            }
+            val += __shfl_xor(val, 32);
+            if (kg == 0) red[t & 1][wv][sub * 32 + n] = val;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < ntiles) stage_store(st, bufn);
+        __syncthreads();
+        if (threadIdx.x < EM_TILE) {
+            const uint32_t kk = key0 + threadIdx.x;
+            if (kk < kend) {
+                const float* rr = &red[t & 1][0][threadIdx.x];
+                const float l2 = (rr[0] + rr[EM_TILE] + rr[2 * EM_TILE] + rr[3 * EM_TILE]) * KVP_LOG2E;
+                lrow[kk] = l2;
+                softmax_merge(m_run, z_run, l2, 1.0f);
+            }
+        }
+        unsigned char* tmp = bufc; bufc = bufn; bufn = tmp;
+    }
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(m_run, o), z2 = __shfl_xor(z_run, o);
+            softmax_merge(m_run, z_run, m2, z2);
+        }
+        if (threadIdx.x == 0) {
+            part_m[(size_t)bhq * nblk + chunk] = m_run;
+            part_z[(size_t)bhq * nblk + chunk] = z_run;
+        }
+    }
+}
+
+bool aligned8(int64_t x) { return x % 8 == 0; }
+
+}  // namespace
+
+// ---- host ---------------------------------------------------------------------------------------
+bool ea_mfma_qstats_eligible(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int dtype, int64_t Sq, int64_t D) {
+    static const int off = kvp_env_int("KVP_EA_GENERIC", 0);
+    if (off) return false;
+    // 16-bit rounding of the shifted products: relative covariance error ~ 4.6e-3 / sqrt(Sq) (1 sigma); shorter
+    // sequences take the exact fp32 generic kernels
+    return (dtype == KVP_BF16 || dtype == KVP_F16) && D == 128 && Sq >= 4096 && (uintptr_t)q % 16 == 0 && aligned8(q_sb) &&
+           aligned8(q_sh) && aligned8(q_ss);
+}
+
+size_t ea_mfma_qstats_ws_bytes(int64_t B, int64_t Hq, int64_t Sq, int64_t D) {
+    if (D != 128) return 0;
+    uint32_t nchunk, rows;
+    qstats_plan(Sq, nchunk, rows);
+    return (size_t)B * Hq * nchunk * (128 * 128 + 256) * 4 + 1024;
+}
+
+int ea_mfma_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int dtype, int64_t B, int64_t Hq, int64_t Sq, int64_t D,
+                   float* mu, float* cov, void* ws, hipStream_t stream) {
+    (void)D;
+    QstatArgs a;
+    a.q = q; a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss;
+    a.B = (uint32_t)B; a.Hq = (uint32_t)Hq; a.Sq = (uint32_t)Sq;
+    qstats_plan(Sq, a.nchunk, a.rows_per_chunk);
+    const size_t nbh = (size_t)B * Hq;
+    a.s2 = static_cast<float*>(ws);
+    a.dsum = a.s2 + nbh * a.nchunk * 16384;
+    a.m0 = a.dsum + nbh * a.nchunk * 128;
+    const dim3 grid((uint32_t)Hq, a.nchunk, (uint32_t)B);
+    if (dtype == KVP_BF16) KVP_LAUNCH("ea_qstats_mfma", stream, ea_qstats_mfma_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a));
+    else KVP_LAUNCH("ea_qstats_mfma", stream, ea_qstats_mfma_kernel<KVP_F16><<<grid, EM_THREADS, 0, stream>>>(a));
+    const size_t sm = ((size_t)a.nchunk * 256 + 128) * 4;
+    KVP_LAUNCH("ea_qstats_combine", stream, ea_qstats_combine<<<dim3(16, (uint32_t)nbh), 256, sm, stream>>>(a.s2, a.dsum, a.m0, a.Sq, a.nchunk, a.rows_per_chunk, mu, cov));
+    KVP_CHECK_LAUNCH("ea_qstats_mfma");
+    return KVP_OK;
+}
+
+bool ea_mfma_logits_eligible(const EaArgs& a, int dtype) {
+    static const int off = kvp_env_int("KVP_EA_GENERIC", 0);
+    if (off) return false;
+    return (dtype == KVP_BF16 || dtype == KVP_F16) && a.D == 128 && a.Sp >= 64 && (uintptr_t)a.k % 16 == 0 && aligned8(a.k_sb) &&
+           aligned8(a.k_sh) && aligned8(a.k_ss) && a.G <= 65535;
+}
 size_t ea_mfma_logits_scratch_bytes(int64_t, int64_t, int64_t) { return 0; }
-uint32_t ea_mfma_logits_nblk(const EaArgs&) { return 0; }
-int ea_mfma_logits(const EaArgs&, int, float*, uint32_t, float*, float*, void*, hipStream_t) {
-    kvp_set_error("ea_mfma_logits: not implemented");
-    return KVP_EUNSUPPORTED;
+uint32_t ea_mfma_logits_nblk(const EaArgs& a) { return (a.Sp + EL_CHUNK - 1) / EL_CHUNK; }
+
+int ea_mfma_logits(const EaArgs& a, int dtype, float* logits, uint32_t nblk, float* part_m, float* part_z, void*, hipStream_t stream) {
+    const dim3 grid(a.G, nblk, a.B * a.Hkv);
+    if (dtype == KVP_BF16) KVP_LAUNCH("ea_logits_mfma", stream, ea_logits_mfma_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z));
+    else KVP_LAUNCH("ea_logits_mfma", stream, ea_logits_mfma_kernel<KVP_F16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z));
+    KVP_CHECK_LAUNCH("ea_logits_mfma");
+    return KVP_OK;
 }

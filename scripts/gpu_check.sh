@@ -9,7 +9,7 @@ WHAT="${*:-tests bench}"
 python __graft_entry__.py > gpurun_out/build.log 2>&1; echo "build rc=$?"
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
 if [[ "$WHAT" == *tests* ]]; then
-  for grp in rownorm topk gather snapkv_kernel snapkv_from snapkv_fused ea_qstats ea_score press_fp32 press_native; do
+  for grp in rownorm topk gather snapkv_kernel snapkv_from snapkv_fused ea_qstats ea_score full_chain press_fp32 press_native; do
     timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --no-header -k "$grp" > gpurun_out/test_$grp.log 2>&1
     echo "tests[$grp] rc=$? $(tail -1 gpurun_out/test_$grp.log)"
   done
@@ -18,7 +18,7 @@ if [[ "$WHAT" == *tests* ]]; then
   timeout 300 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$? $(tail -1 gpurun_out/smoke.log)"
 fi
 if [[ "$WHAT" == *bench* ]]; then
-  for wl in knorm32k knorm128k snapkv128k; do
+  for wl in knorm32k knorm128k snapkv128k ea128k; do
     timeout 600 python bench.py --workload $wl --steps 20 --warmup 3 --profile-json gpurun_out/kern_$wl.json > gpurun_out/bench_$wl.log 2>&1
     echo "bench[$wl] rc=$? $(tail -1 gpurun_out/bench_$wl.log | cut -c1-600)"
   done

@@ -65,6 +65,7 @@ CASES = {
     "ea_eps_sink0": dict(kind="ea", B=1, H=1, G=4, S=512, D=128, dtype="bf16", data="A", seed=37,
                          epsilon=0.01, n_sink=0),
     "ea_f32_d128": dict(kind="ea", B=1, H=2, G=4, S=600, D=128, dtype="f32", data="B", seed=38),
+    "ea_6000_B": dict(kind="ea", B=1, H=2, G=4, S=6000, D=128, dtype="bf16", data="B", seed=39),  # MFMA statistics path
 }
 
 _DEFAULTS = dict(W=64, ks=5, n_future=512, n_sink=4, use_covariance=True, use_vnorm=True, epsilon=0.0,

@@ -176,3 +176,53 @@ def test_llama_hook_end_to_end_gpu():
             assert all(l.keys.shape == (2, 1, n, 128) for l in cache.layers)
             model(ids[:, :1], past_key_values=cache)
             assert all(l.keys.shape == (2, 1, n + 1, 128) for l in cache.layers)
+
+
+def test_config4_expected_attention_128k():
+    """BASELINE config 4: ExpectedAttentionPress(0.7), 128k, Llama-3.1-8B geometry, against a float64
+    restatement of expected_attention_press.py:62-165 with torch ops on the GPU."""
+    import kvpress_amd as P
+
+    S, n_sink, nfut = 131072, 4, 512
+    keys, values = make_kv(S, 4, True)
+    att, rot = llama_module()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(44)
+    hidden = torch.randn((1, S, HIDDEN), generator=g, device=DEV, dtype=torch.bfloat16)
+    press = P.ExpectedAttentionPress(0.7)
+    with torch.no_grad():
+        sc = press.score(att, hidden, keys, values, None, {})
+        # ---- float64 reference -------------------------------------------------------------------
+        q = att.q_proj(hidden[:, n_sink:]).view(1, S - n_sink, H_Q, D).transpose(1, 2).double()
+        mu = q.mean(dim=2)
+        c = q - mu.unsqueeze(2)
+        cov = torch.matmul(c.transpose(2, 3), c) / (S - n_sink)
+        del c, q
+        pos = torch.arange(S, S + nfut, device=DEV)[None]
+        cos, sin = rot(torch.zeros(1, device=DEV, dtype=torch.float32), pos)
+        cos, sin = cos[0].double(), sin[0].double()
+        Pm = torch.zeros((D, D), device=DEV, dtype=torch.float64)
+        Pm[D // 2:, : D // 2] = torch.eye(D // 2, device=DEV, dtype=torch.float64)
+        Pm[: D // 2, D // 2:] = -torch.eye(D // 2, device=DEV, dtype=torch.float64)
+        R = (cos.unsqueeze(1) * torch.eye(D, device=DEV, dtype=torch.float64) + sin.unsqueeze(1) * Pm).mean(0)
+        mu = mu @ R.T
+        cov = R @ cov @ R.T
+        k = keys[:, :, n_sink:].double()
+        ref = torch.empty((1, H_KV, S - n_sink), device=DEV, dtype=torch.float64)
+        for h in range(H_KV):
+            kh = k[0, h]                                                       # [S', D]
+            acc = 0
+            for gq in range(H_Q // H_KV):
+                hq = h * (H_Q // H_KV) + gq
+                lg = kh @ mu[0, hq] / D ** 0.5 + ((kh @ cov[0, hq]) * kh).sum(-1) / D / 2
+                acc = acc + torch.softmax(lg, dim=-1)
+            ref[0, h] = acc / (H_Q // H_KV) * values[0, h, n_sink:].double().norm(dim=-1)
+        got = sc[..., n_sink:].double()
+        rel = (got - ref).abs() / ref.abs().clamp_min(1e-300)
+        assert rel.max() <= 1e-3, f"max rel err {rel.max().item():.3e}"
+        assert (sc[..., :n_sink] == sc[..., n_sink:].max() + 1).all()
+        n = int(S * (1 - 0.7))
+        assert n == 39321
+        ko, vo = press.compress(att, hidden, keys, values, None, {})
+        assert ko.shape == (1, H_KV, n, D)
+        check_topk_and_gather(sc, keys, values, n, ko, vo)

@@ -196,7 +196,9 @@ def test_ea_qstats_vs_oracle(name):
     if s["use_covariance"]:
         c = cov.cpu().numpy()
         d = np.sqrt(np.einsum("bhii->bhi", cov_w))
-        tol = 1e-4 * d[..., :, None] * d[..., None, :] + 1e-9
+        # Sq >= 4096 with 16-bit D=128 inputs runs on the matrix cores (16-bit shifted products: worst entry ~2e-3)
+        mfma = s["dtype"] != "f32" and s["D"] == 128 and q.shape[2] >= 4096
+        tol = (3e-3 if mfma else 1e-4) * d[..., :, None] * d[..., None, :] + 1e-9
         assert (np.abs(c - cov_w) <= tol).all(), np.abs(c - cov_w).max()
     else:
         assert cov is None
@@ -337,3 +339,47 @@ def test_snapkv_fused_rope_is_bit_identical_to_torch_rope(name):
         assert torch.equal(a, b), f"max abs diff {(a - b).abs().max().item():.3e}"
     # the press recomputes q_proj (a library GEMM that need not be run-to-run bit-stable)
     assert torch.allclose(b, c, rtol=1e-5, atol=0)
+
+
+def test_ea_qstats_mfma_multichunk():
+    """bf16, D=128, 10 000 rows (3 chunks + ragged tail), non-zero mean and a few dominant channels:
+    exercises the shifted-data syrk on the matrix cores and the pairwise combine."""
+    rs = np.random.RandomState(7)
+    B, Hq, Sq, D = 1, 3, 10000, 128
+    q = rs.standard_normal((B, Hq, Sq, D)).astype(np.float32) * np.exp(0.5 * rs.standard_normal((1, Hq, 1, D))).astype(np.float32)
+    q += rs.standard_normal((1, Hq, 1, D)).astype(np.float32) * 3.0     # means up to ~10 sigma
+    q[:, :, :, ::17] *= 6.0
+    q = _inputs.round_to(q, "bf16")
+    mu_w, cov_w = O.ea_query_stats(q, True)
+    qt = to_dev(np.ascontiguousarray(q.transpose(0, 2, 1, 3)), "bf16").transpose(1, 2)  # q_proj layout [B,S,Hq*D]
+    mu, cov = native().ea_qstats(qt, True)
+    assert np.abs(mu.cpu().numpy() - mu_w).max() <= 1e-5 * np.abs(mu_w).max() + 1e-6
+    d = np.sqrt(np.einsum("bhii->bhi", cov_w))
+    err = np.abs(cov.cpu().numpy() - cov_w) / (d[..., :, None] * d[..., None, :])
+    # 16-bit shifted products on inputs that themselves live on a 16-bit grid: worst entry ~2e-3, mean ~3e-5
+    assert err.max() <= 3e-3 and err.mean() <= 1e-4, (err.max(), err.mean())
+    mu2, cov2 = native().ea_qstats(qt, False)
+    assert cov2 is None and torch.equal(mu, mu2)
+
+
+def test_ea_full_chain_mfma_vs_oracle():
+    """bf16, S=6000 (>= 4096: query statistics AND logits on the matrix cores), structured data with large
+    query means: the whole kernel chain against the float64 oracle fed with the same bf16 queries."""
+    s = _inputs.make_case("ea_6000_B")
+    q = _ea_q(s)                                                       # pre-RoPE queries, rounded to bf16
+    mu_w, cov_w = O.ea_query_stats(q, True)
+    att, rot, hidden, pe = _inputs.build_llama_attention(s, torch.float32)
+    pos = torch.arange(s["S"], s["S"] + s["n_future"])[None]
+    c, si = rot(torch.zeros(1), pos)
+    mu_w, cov_w = O.ea_avg_rope(mu_w, cov_w, c[0].numpy(), si[0].numpy())
+    want = O.ea_score(s["keys"], s["values"], mu_w, cov_w, s["n_sink"], True, 0.0)
+    # kernel chain
+    import kvpress_amd as P
+    qt = to_dev(np.ascontiguousarray(q.transpose(0, 2, 1, 3)), "bf16").transpose(1, 2)
+    mu, cov = native().ea_qstats(qt, True)
+    att_d, rot_d, _, _ = _inputs.build_llama_attention(s, torch.bfloat16, DEV)
+    press = P.ExpectedAttentionPress(0.5)
+    mu, cov = press.apply_avg_rope(att_d, mu, cov, s["S"])
+    got = native().ea_score(to_dev(s["keys"], "bf16"), to_dev(s["values"], "bf16"), mu, cov, s["n_sink"], True, 0.0).cpu().numpy()
+    ns = s["n_sink"]
+    assert_scores_close(got[..., ns:], want[..., ns:], RTOL, "ea_6000_B chain")
