@@ -36,7 +36,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int MF_THREADS = 512;      // 8 waves
 constexpr int MF_WAVES = MF_THREADS / 64;
-constexpr int MF_TILE = 128;         // keys per LDS tile (one barrier per tile)
+constexpr int MF_TILE = 256;         // keys per LDS tile (one barrier per tile; 2 x 64 KiB of the CU's 160 KiB LDS)
 constexpr int MF_SUBS = MF_TILE / 32;  // 32-key MFMA sub-tiles per tile
 constexpr int MF_CHUNK = 1024;       // minimum keys per workgroup
 constexpr int MF_ROWB = 256;         // bytes per key row (D = 128, 2-byte elements)
@@ -121,7 +121,7 @@ struct TileWalk {
 // =================================================================================================
 // TRACE (debug, KVP_SK_TRACE=1): wave-level s_memtime checkpoints of workgroup (5,0,0) -> trace[wave][tile][5]
 template <int DT, bool TRACE>
-__global__ __launch_bounds__(MF_THREADS, 4) void snapkv_p1_mfma(SnapArgs a, uint32_t ngb, uint32_t nchunk,
+__global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint32_t ngb, uint32_t nchunk,
                                                                 float* __restrict__ part_m, float* __restrict__ part_z,
                                                                 unsigned long long* __restrict__ trace) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * MF_TILEB];
@@ -150,80 +150,109 @@ __global__ __launch_bounds__(MF_THREADS, 4) void snapkv_p1_mfma(SnapArgs a, uint
     const float c = a.c;
     const uint32_t w = row0 + n;     // window row: token S-W+w sees keys <= S-W+w
 
-    // one 64-key tile = 2 sub-tiles of 32 keys: 8 batched LDS fragment reads, 8 MFMAs, softmax update
+    // softmax-update of the 16 finished logits of one sub-tile (lane's q row: running max m, sum-exp z);
+    // MASKED: causal mask / sequence tail handled per element (only the last tiles of a head)
+    auto softmax16 = [&](f32x16& acc, uint32_t key0, int sub, bool masked) {
+        if (masked) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t kk = key0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (kk >= a.S || kk > a.S - a.W + w) acc[r] = KVP_NEG_INF;
+            }
+        }
+        float tm = acc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, acc[r]);
+        const float mn = fmaxf(m, tm);
+        if (!masked || mn != KVP_NEG_INF) {
+            const float off = -mn * c;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                s0 += fast_exp2(fmaf(acc[r], c, off));
+                s1 += fast_exp2(fmaf(acc[r + 1], c, off));
+            }
+            z = z * fast_exp2(fmaf(m, c, off)) + (s0 + s1);
+            m = mn;
+        }
+    };
+
+    // One 128-key tile = 4 sub-tiles of 32 keys.  Per wave the work of a sub-tile is a chain of 8 MFMAs and
+    // ~62 VALU instructions of softmax that DEPEND on it; issued back to back they serialise, and the two waves a
+    // SIMD hosts run in lockstep (same code, per-tile barrier), so nothing overlaps: measured ~5700 cycles per
+    // tile for a lone workgroup vs 2048 cycles of matrix-pipe time.  Hence a two-stage software pipeline inside
+    // the tile: the MFMA chain of sub-tile s is interleaved (1 MFMA : 6 VALU) with the softmax of sub-tile s-1,
+    // with double-buffered accumulators and fragment registers (LDS reads of s+1 are in flight during s).
     auto compute = [&](uint32_t key0, const unsigned char* buf) {
         const bool need_mask = key0 + (MF_TILE - 1) > a.S - a.W;  // some (row, key) of this tile is masked / past S
+        uint4 kf[2][8];
+        f32x16 acc[2];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) kf[0][ks] = kfrag(buf, 0, ks, n, kg);
 #pragma unroll
         for (int sub = 0; sub < MF_SUBS; ++sub) {
-            uint4 kf[8];
+            if (sub + 1 < MF_SUBS) {
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) kf[ks] = kfrag(buf, sub, ks, n, kg);
-            f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) acc = mma32<DT>(kf[ks], qf[ks], acc);  // C[key][q row]
-            if (need_mask) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t kk = key0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                    if (kk >= a.S || kk > a.S - a.W + w) acc[r] = KVP_NEG_INF;
-                }
+                for (int ks = 0; ks < 8; ++ks) kf[(sub + 1) & 1][ks] = kfrag(buf, sub + 1, ks, n, kg);
             }
-            float tm = acc[0];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 1; r < 16; ++r) tm = fmaxf(tm, acc[r]);
-            const float mn = fmaxf(m, tm);
-            if (!need_mask || mn != KVP_NEG_INF) {
+            for (int i = 0; i < 16; ++i) acc[sub & 1][i] = 0.f;
+            if (sub == 0 || need_mask) {
+                if (sub > 0) softmax16(acc[(sub - 1) & 1], key0, sub - 1, true);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc[sub & 1] = mma32<DT>(kf[sub & 1][ks], qf[ks], acc[sub & 1]);  // C[key][q row]
+            } else {
+                // branch-free: MFMA chain of this sub-tile || softmax of the previous one
+                f32x16& ap = acc[(sub - 1) & 1];
+                float tm = ap[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tm = fmaxf(tm, ap[r]);
+                const float mn = fmaxf(m, tm);
                 const float off = -mn * c;
-                float s0 = 0.f, s1 = 0.f;  // two chains: the 16 adds are otherwise one dependent sequence
+                float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    s0 += fast_exp2(fmaf(acc[r], c, off));
-                    s1 += fast_exp2(fmaf(acc[r + 1], c, off));
+                for (int ks = 0; ks < 8; ++ks) {
+                    acc[sub & 1] = mma32<DT>(kf[sub & 1][ks], qf[ks], acc[sub & 1]);
+                    s0 += fast_exp2(fmaf(ap[2 * ks], c, off));
+                    s1 += fast_exp2(fmaf(ap[2 * ks + 1], c, off));
                 }
                 z = z * fast_exp2(fmaf(m, c, off)) + (s0 + s1);
                 m = mn;
+                __builtin_amdgcn_sched_group_barrier(0x2, 12, 0);   // max chain + offsets while the fragments land
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);  // 6 VALU: 2 x (fma, exp, add)
+                }
             }
         }
+        softmax16(acc[(MF_SUBS - 1) & 1], key0, MF_SUBS - 1, need_mask);
     };
 
     // K streams HBM -> registers -> LDS with TWO tiles in flight behind the one being computed:
     // stA / stB alternate; each tile's loads have two compute phases to land (issue-early, write-late).
-    Stage stA, stB;
-    unsigned char* buf0 = lds;
-    unsigned char* buf1 = lds + MF_TILEB;
+    // K streams HBM -> registers -> LDS one 256-key tile (64 KiB) ahead of the tile being computed
+    // (issue-early / write-late, loads unconditional so that hipcc emits counted vmcnt waits).
+    unsigned char* bufc = lds;
+    unsigned char* bufn = lds + MF_TILEB;
     if (tw.ntiles > 0) {
-        stA = stage_load(kb, k_ssb, tw.kbeg, a.S);
-        stage_store(stA, buf0);
-        stA = stage_load(kb, k_ssb, min(tw.kbeg + tw.tstride, tw.klast), a.S);
+        stage_store(stage_load(kb, k_ssb, tw.kbeg, a.S), bufc);
         __syncthreads();
-        phase_shift(a.phase);
-        for (uint32_t t = 0; t < tw.ntiles; t += 2) {
+        for (uint32_t t = 0; t < tw.ntiles; ++t) {
             const uint32_t key0 = tw.kbeg + t * tw.tstride;
             stamp(t, 0);
-            stB = stage_load(kb, k_ssb, min(key0 + 2 * tw.tstride, tw.klast), a.S);
+            const Stage st = stage_load(kb, k_ssb, min(key0 + tw.tstride, tw.klast), a.S);
             __builtin_amdgcn_sched_barrier(0);  // issue-early
             stamp(t, 1);
-            if (active) compute(key0, buf0);
-            __builtin_amdgcn_sched_barrier(0);  // keep the LDS write of the older stage BEHIND this tile's MFMAs (write-late)
+            if (active) compute(key0, bufc);
+            __builtin_amdgcn_sched_barrier(0);  // write-late
             stamp(t, 2);
-            if (t + 1 < tw.ntiles) stage_store(stA, buf1);
+            if (t + 1 < tw.ntiles) stage_store(st, bufn);
             stamp(t, 3);
             __syncthreads();
             stamp(t, 4);
-            if (t + 1 >= tw.ntiles) break;
-            stamp(t + 1, 0);
-            stA = stage_load(kb, k_ssb, min(key0 + 3 * tw.tstride, tw.klast), a.S);
-            __builtin_amdgcn_sched_barrier(0);
-            stamp(t + 1, 1);
-            if (active) compute(key0 + tw.tstride, buf1);
-            __builtin_amdgcn_sched_barrier(0);
-            stamp(t + 1, 2);
-            if (t + 2 < tw.ntiles) stage_store(stB, buf0);
-            stamp(t + 1, 3);
-            __syncthreads();
-            stamp(t + 1, 4);
+            unsigned char* tmp = bufc; bufc = bufn; bufn = tmp;
         }
     }
 
@@ -243,7 +272,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void snapkv_p1_mfma(SnapArgs a, uint
 // pass 2: colsum[b,h,key] = sum over the group's G*64 rows of 2^(L2 - a_row), keys < S - W
 // =================================================================================================
 template <int DT>
-__global__ __launch_bounds__(MF_THREADS, 4) void snapkv_p2_mfma(SnapArgs a, uint32_t ngb, const float* __restrict__ rowstat,
+__global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint32_t ngb, const float* __restrict__ rowstat,
                                                                 float* __restrict__ colsum) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * MF_TILEB];
     __shared__ float red[2][MF_WAVES][MF_TILE];
@@ -273,28 +302,56 @@ __global__ __launch_bounds__(MF_THREADS, 4) void snapkv_p2_mfma(SnapArgs a, uint
     float* cs = colsum + (size_t)(b * a.Hkv + h) * Sm;
     const uint32_t nact = 2 * min(4u, a.G - gb * 4);  // active waves in this workgroup
 
-    // one 64-key tile: P = 2^(L2 - a_row), column sums over this wave's 32 q rows -> red[par][wave][key]
+    // column sums of P = 2^(L2 - a_row) over this wave's 32 q rows for the 32 keys of one finished sub-tile
+    auto colsum16 = [&](const f32x16 acc, int par, int sub) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            s0 += fast_exp2(fmaf(acc[r], c, ar[r]));
+            s1 += fast_exp2(fmaf(acc[r + 1], c, ar[r + 1]));
+        }
+        float s = s0 + s1;
+        s += __shfl_xor(s, 32);
+        if (kg == 0) red[par][wv][sub * 32 + n] = s;
+    };
+    // one 128-key tile, software-pipelined like pass 1: MFMA chain of sub-tile s || exp/add stream of sub-tile s-1
     auto compute = [&](const unsigned char* buf, int par) {
+        uint4 kf[2][8];
+        f32x16 acc[2];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) kf[0][ks] = kfrag(buf, 0, ks, n, kg);
 #pragma unroll
         for (int sub = 0; sub < MF_SUBS; ++sub) {
-            uint4 kf[8];
+            if (sub + 1 < MF_SUBS) {
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) kf[ks] = kfrag(buf, sub, ks, n, kg);
-            f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) acc = mma32<DT>(qf[ks], kf[ks], acc);  // C[q row][key]
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                s0 += fast_exp2(fmaf(acc[r], c, ar[r]));
-                s1 += fast_exp2(fmaf(acc[r + 1], c, ar[r + 1]));
+                for (int ks = 0; ks < 8; ++ks) kf[(sub + 1) & 1][ks] = kfrag(buf, sub + 1, ks, n, kg);
             }
-            float s = s0 + s1;
-            s += __shfl_xor(s, 32);
-            if (kg == 0) red[par][wv][sub * 32 + n] = s;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[sub & 1][i] = 0.f;
+            if (sub == 0) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc[0] = mma32<DT>(qf[ks], kf[0][ks], acc[0]);  // C[q row][key]
+            } else {
+                const f32x16& ap = acc[(sub - 1) & 1];
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    acc[sub & 1] = mma32<DT>(qf[ks], kf[sub & 1][ks], acc[sub & 1]);
+                    s0 += fast_exp2(fmaf(ap[2 * ks], c, ar[2 * ks]));
+                    s1 += fast_exp2(fmaf(ap[2 * ks + 1], c, ar[2 * ks + 1]));
+                }
+                float s = s0 + s1;
+                s += __shfl_xor(s, 32);
+                if (kg == 0) red[par][wv][(sub - 1) * 32 + n] = s;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
+                }
+            }
         }
+        colsum16(acc[(MF_SUBS - 1) & 1], par, MF_SUBS - 1);
     };
     // after the tile's barrier: threads 0..63 add the active waves' partials and store 64 column sums
     auto flush = [&](uint32_t key0, int par) {
@@ -309,7 +366,6 @@ __global__ __launch_bounds__(MF_THREADS, 4) void snapkv_p2_mfma(SnapArgs a, uint
         }
     };
 
-    Stage st;
     unsigned char* bufc = lds;
     unsigned char* bufn = lds + MF_TILEB;
     if (tw.ntiles == 0) return;
@@ -317,7 +373,7 @@ __global__ __launch_bounds__(MF_THREADS, 4) void snapkv_p2_mfma(SnapArgs a, uint
     __syncthreads();
     for (uint32_t t = 0; t < tw.ntiles; ++t) {
         const uint32_t key0 = tw.kbeg + t * tw.tstride;
-        st = stage_load(kb, k_ssb, min(key0 + tw.tstride, tw.klast), a.S);  // next tile: in flight under this tile's math
+        const Stage st = stage_load(kb, k_ssb, min(key0 + tw.tstride, tw.klast), a.S);  // next tile: in flight under this tile's math
         __builtin_amdgcn_sched_barrier(0);
         if (active) compute(bufc, t & 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -338,14 +394,15 @@ bool snapkv_mfma_eligible(const SnapArgs& a, int dtype) {
     return al8(a.q_sb) && al8(a.q_sh) && al8(a.q_sw) && al8(a.k_sb) && al8(a.k_sh) && al8(a.k_ss);
 }
 
-// Workgroups per (batch, kv-head, group-block).  The grid is sized to ONE resident round (2 workgroups of 8 waves
-// per CU x 256 CUs): every workgroup pays its ~3.5 us start-up (Q fragments, first K tile) once and there is
+// Workgroups per (batch, kv-head, group-block).  The grid is sized to ONE resident round (1 workgroup of 8 waves
+// per CU x 256 CUs; co-resident workgroups only add latency to each other): every workgroup pays its ~3.5 us start-up (Q fragments, first K tile) once and there is
 // no second dispatch round; each workgroup then walks its interleaved tile list (TileWalk).
 static uint32_t mfma_nchunk_for(const SnapArgs& a, uint32_t nkeys) {
     const uint32_t ngb = (a.G + 3) / 4;
     const uint32_t planes = std::max<uint32_t>(1, a.B * a.Hkv * ngb);
     const uint32_t by_keys = (nkeys + MF_CHUNK - 1) / MF_CHUNK;   // >= 1024 keys per workgroup
-    const uint32_t by_cus = std::max<uint32_t>(1, 512 / planes);  // 2 x 256 workgroup slots
+    static const int slots = kvp_env_int("KVP_SK_SLOTS", 256);   // one 8-wave workgroup per CU
+    const uint32_t by_cus = std::max<uint32_t>(1, (uint32_t)slots / planes);
     return std::max<uint32_t>(1, std::min(by_keys, by_cus));
 }
 uint32_t snapkv_mfma_nchunk(const SnapArgs& a) { return mfma_nchunk_for(a, a.S); }

@@ -53,9 +53,10 @@ __global__ void k(float* out, const uint4* in) {
                 __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
             }
         }
-        // keep the VALU inputs changing so nothing is hoisted
+        // ALL VALU inputs change every iteration (with only a few changing, the compiler hoists the invariant
+        // fma/exp work out of the loop and the benchmark under-counts VALU time -- that happened in round 1)
 #pragma unroll
-        for (int j = 0; j < 32; j += 8) v[j] += 1e-6f;
+        for (int j = 0; j < 32; ++j) v[j] += 1e-6f;
     }
     float r = s0 + s1;
     for (int i = 0; i < 16; ++i) r += acc0[i] + acc1[i];
