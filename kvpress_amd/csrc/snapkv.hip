@@ -296,8 +296,6 @@ extern "C" int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64
     a.B = (uint32_t)B; a.Hq = (uint32_t)Hq; a.Hkv = (uint32_t)Hkv; a.G = (uint32_t)(Hq / Hkv);
     a.S = (uint32_t)S; a.W = (uint32_t)W; a.D = (uint32_t)D;
     a.c = (float)(1.4426950408889634 / sqrt((double)D));
-    static const int phase = kvp_env_int("KVP_SK_PHASE", 3);
-    a.phase = (uint32_t)phase;
     const uint32_t nrows = (uint32_t)(B * Hq * W);
 
     if (snapkv_mfma_eligible(a, dtype)) {

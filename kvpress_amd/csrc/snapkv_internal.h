@@ -9,7 +9,6 @@ struct SnapArgs {
     int64_t k_sb, k_sh, k_ss;
     uint32_t B, Hq, Hkv, G, S, W, D;
     float c;  // log2(e) / sqrt(D): logits in log2 units
-    uint32_t phase;  // MFMA path: start delay (x512 cycles) of every second co-resident workgroup
 };
 
 // MFMA fast path (bf16/f16, D = 128, W = 64, G <= 8, 16-byte aligned rows)

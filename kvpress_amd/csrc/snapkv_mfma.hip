@@ -1,17 +1,20 @@
 // SnapKV window-attention passes on the gfx950 matrix cores (bf16 / f16, D = 128, W = 64).
 //
-// Work decomposition (per launch): workgroup = (tile set, kv-head [x group-block], batch), 8 waves;
-// wave w owns HALF a q-head of the GQA group (q-head w/2, window rows 32*(w&1) .. +32), whose Q
-// fragments (32 rows x 128 dims = 8 x dwordx4 per lane) stay in registers for the whole launch.
-// The kernels are VALU-bound (softmax math: ~3.6 VALU per logit vs 1 MFMA per 512 logits), so the
-// design goal is occupancy: <= 128 VGPRs -> 4 waves per SIMD, MFMA results written straight to
-// VGPRs (-mllvm -amdgpu-mfma-vgpr-form: no v_accvgpr_read), so that one wave's exp/max/add stream
-// runs under another wave's MFMAs.  K streams HBM -> registers -> LDS in 64-key tiles (16 KiB, full 256-B rows, coalesced
-// dwordx4), double buffered, ONE barrier per tile; the next tile's global loads are issued
-// before the current tile's MFMAs (issue-early / write-late).  All four waves read the same
-// K tile from LDS (ds_read_b128, rows XOR-swizzled by (row & 15) << 4 so every 16-lane service
-// group of the read hits 16 distinct 16-byte slots -> conflict-free), so K crosses HBM once
-// per pass and the LDS read traffic is 4x the HBM rate (40 of 256 B/clk/CU).
+// Work decomposition (per launch): workgroup = (tile set, kv-head [x group-block], batch), 8 waves, ONE workgroup
+// per CU; wave w owns half a q-head of the GQA group (q-head w/2, window rows 32*(w&1) .. +32), whose Q fragments
+// (32 rows x 128 dims = 8 x dwordx4 per lane) stay in registers for the whole launch.
+//
+// K stream: 128-key tiles (32 KiB) travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: every lane names a
+// 16-byte global chunk, the wave's 64 chunks land contiguously at an LDS address taken from M0) into a ring of
+// three buffers; tile t+2 is requested while tile t is computed, ONE request per thread per 32-key sub-tile step,
+// so the requests trickle through the address path instead of arriving as a burst, no VGPRs hold K in transit and
+// there is no ds_write phase.  (The earlier global -> VGPR -> ds_write staging cost as much as all the math:
+// tools/ubench_steps.hip, 894 vs 530 ns per sub-tile and wave.)  vmcnt is managed by hand (the requests are inline
+// asm: with the builtin hipcc makes every ds_read wait for vmcnt(0)): at the end of tile t `s_waitcnt vmcnt(4)`
+// leaves only tile t+2's four requests pending, then one barrier publishes tile t+1.
+// Rows are XOR-swizzled in LDS (16-byte slot p of row r holds chunk p ^ (r & 15)); the swizzle is applied on the
+// GLOBAL side of the DMA (lane (r, p) fetches chunk p ^ (r & 15)), which keeps the 256-byte row fully coalesced,
+// and makes every ds_read_b128 of the fragment reads conflict-free.
 //
 // v_mfma_f32_32x32x16 with operands swapped between the passes so that each pass's reduction
 // axis is lane-local (C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)):
@@ -19,9 +22,11 @@
 //           (max, sum-exp) per lane, 2 states per wave-lane, no cross-lane traffic in the loop;
 //   pass 2  C   = Q . K_tile^T   -> a lane holds ONE key and 16 q rows per MFMA: the column sum
 //           over rows is an in-lane add chain + one xor-32 shuffle; the per-row normalisers
-//           a_r = M + log2 Z are 32 registers loaded once.
-// Both passes read identical fragments (same registers / same LDS addresses); only the operand
-// order changes.  The causal mask exists only in pass 1 and only in the last tiles of a row.
+//           a_r = M + log2 Z are 16 registers loaded once.
+// Inside a tile the MFMA chain of sub-tile s is interleaved with the softmax update of sub-tile s-1 (double-buffered
+// accumulators and fragment registers).  On a gfx950 SIMD MFMAs and VALU instructions do not overlap
+// (tools/ubench_valu.hip, ubench_overlap.hip), so the per-sub-tile cost is ~272 cycles of MFMA + ~290 of VALU.
+// The causal mask exists only in pass 1 and only in the last tiles of a row.
 #include "kvp_common.h"
 #include "softmax_stats.h"
 #include "snapkv_internal.h"
@@ -36,11 +41,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int MF_THREADS = 512;      // 8 waves
 constexpr int MF_WAVES = MF_THREADS / 64;
-constexpr int MF_TILE = 256;         // keys per LDS tile (one barrier per tile; 2 x 64 KiB of the CU's 160 KiB LDS)
-constexpr int MF_SUBS = MF_TILE / 32;  // 32-key MFMA sub-tiles per tile
+constexpr int MF_TILE = 128;         // keys per LDS tile
+constexpr int MF_SUBS = MF_TILE / 32;  // 32-key MFMA sub-tiles per tile == DMA requests per thread per tile
+constexpr int MF_NBUF = 3;           // LDS ring: computing t, landed/landing t+1, landing t+2
 constexpr int MF_CHUNK = 1024;       // minimum keys per workgroup
 constexpr int MF_ROWB = 256;         // bytes per key row (D = 128, 2-byte elements)
 constexpr int MF_TILEB = MF_TILE * MF_ROWB;
+static_assert(MF_TILEB / 16 / MF_THREADS == MF_SUBS, "one DMA request per thread per sub-tile step");
 
 template <int DT> __device__ __forceinline__ f32x16 mma32(const uint4& a, const uint4& b, f32x16 c);
 template <> __device__ __forceinline__ f32x16 mma32<KVP_BF16>(const uint4& a, const uint4& b, f32x16 c) {
@@ -52,32 +59,43 @@ template <> __device__ __forceinline__ f32x16 mma32<KVP_F16>(const uint4& a, con
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// --- K tile staging -------------------------------------------------------------------------------
-// thread t moves MF_SUBS x 16 B: rows (t >> 4) + 32 i, 16-byte column t & 15  (a wave = 4 full rows = 1 KiB)
-struct Stage {
-    uint4 v[MF_SUBS];
+// --- K tile stream (LDS-DMA) ----------------------------------------------------------------------
+// Request i (0..MF_SUBS-1) of a tile: wave w moves rows 32 i + 4 w .. +4 (1 KiB); lane (lr = lane >> 4, p = lane & 15)
+// fetches chunk p ^ (row & 15) of row 32 i + 4 w + lr, which the DMA drops into LDS slot p of that row.
+// Row indices are clamped to S-1 (unconditional requests): rows past S are copies of the last row; they are masked
+// (pass 1) or never stored (pass 2).
+struct KStream {
+    const char* kb;     // K[b, h, 0, 0]
+    int64_t k_ssb;      // bytes between keys
+    uint32_t S;
+    uint32_t lrow;      // 4 w + lr
+    uint32_t choff;     // byte offset of this lane's chunk inside a row: (p ^ (lrow & 15)) << 4  (32 i is a multiple of 16)
+    uint32_t ldsrow;    // 4 w: first row of this wave's 1 KiB block inside a sub-tile
+    __device__ KStream(const char* kb_, int64_t k_ssb_, uint32_t S_) : kb(kb_), k_ssb(k_ssb_), S(S_) {
+        const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        lrow = wv * 4 + (lane >> 4);
+        choff = ((lane & 15) ^ (lrow & 15)) << 4;
+        ldsrow = wv * 4;
+    }
+    __device__ __forceinline__ void request(unsigned char* buf, uint32_t key0, int i) const {
+        const uint32_t kk = min(key0 + i * 32 + lrow, S - 1);
+        const char* g = kb + (int64_t)kk * k_ssb + choff;
+        const uint32_t la = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(buf + (i * 32 + ldsrow) * MF_ROWB));
+        // M0 is a reserved register that hipcc never keeps values in (nothing else in these kernels uses it)
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(g) : "memory");
+    }
+    __device__ __forceinline__ void request_tile(unsigned char* buf, uint32_t key0) const {
+#pragma unroll
+        for (int i = 0; i < MF_SUBS; ++i) request(buf, key0, i);
+    }
 };
-// Loads are UNCONDITIONAL (row index clamped to S-1): straight-line code lets hipcc emit counted
-// s_waitcnt vmcnt(N) instead of draining to 0 at every branch join.  Rows past S are duplicates of
-// the last row; they are masked (pass 1) or never stored (pass 2).
-__device__ __forceinline__ Stage stage_load(const char* __restrict__ kb, int64_t k_ssb, uint32_t key0, uint32_t S) {
-    const uint32_t r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
-    Stage st;
-#pragma unroll
-    for (int i = 0; i < MF_SUBS; ++i) {
-        const uint32_t kk = min(key0 + r0 + 32 * i, S - 1);
-        st.v[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)kk * k_ssb + ch * 16);
-    }
-    return st;
-}
-__device__ __forceinline__ void stage_store(const Stage st, unsigned char* buf) {
-    const uint32_t r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
-#pragma unroll
-    for (int i = 0; i < MF_SUBS; ++i) {
-        const uint32_t row = r0 + 32 * i;
-        *reinterpret_cast<uint4*>(buf + row * MF_ROWB + ((ch ^ (row & 15)) << 4)) = st.v[i];
-    }
-}
+// s_waitcnt through the builtin (simm16: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8): unlike an asm string, hipcc's own
+// wait-count bookkeeping sees it, so it stops re-waiting for the Q-fragment loads inside the tile loop.
+// only the newest tile's MF_SUBS requests of this wave may still be in flight
+__device__ __forceinline__ void wait_tile_landed() { __builtin_amdgcn_s_waitcnt(0x0F70 | MF_SUBS); }
+__device__ __forceinline__ void wait_all_landed() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // fragment of the 32-key sub-tile `sub` for k-step ks: lane (n = lane & 31, kg = lane >> 5)
 __device__ __forceinline__ uint4 kfrag(const unsigned char* buf, uint32_t sub, uint32_t ks, uint32_t n, uint32_t kg) {
     const uint32_t row = sub * 32 + n;
@@ -91,20 +109,9 @@ __device__ __forceinline__ void load_qfrags(uint4 (&qf)[8], const char* __restri
         qf[ks] = *reinterpret_cast<const uint4*>(qrow0 + (int64_t)n * q_swb + (ks * 16 + kg * 8) * 2);
 }
 
-// The two workgroups resident on a CU start together, do identical work and stay in lockstep: both are in
-// their MFMA phase (matrix pipe saturated) and then both in their store/barrier phase (pipe idle) -- measured
-// with s_memtime: ~2000 cycles compute + ~1500 cycles sync per tile.  Workgroup i and i + 256 share a CU
-// (i % 8 picks the XCD, then CUs round-robin), so every second group of 256 is delayed by about half a tile
-// period; from then on one workgroup's MFMAs run under the other's synchronisation phase.
-__device__ __forceinline__ void phase_shift(uint32_t units) {
-    const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if ((lin >> 8) & 1)
-        for (uint32_t i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(8);  // 8 * 64 = 512 cycles per unit
-}
-
 // Tile -> workgroup mapping is INTERLEAVED: workgroup `chunk` of the nchunk workgroups of a kv-head takes
 // tiles chunk, chunk + nchunk, ...: the workgroups running concurrently read one contiguous, advancing
-// region of K (nchunk x 16 KiB) instead of nchunk streams 256 KiB apart.
+// region of K (nchunk x 32 KiB) instead of nchunk streams far apart.
 struct TileWalk {
     uint32_t ntiles, tstride, kbeg, klast;
     __device__ TileWalk(uint32_t chunk, uint32_t nchunk, uint32_t nkeys) {
@@ -112,19 +119,20 @@ struct TileWalk {
         ntiles = chunk < total ? (total - chunk + nchunk - 1) / nchunk : 0;
         tstride = nchunk * MF_TILE;
         kbeg = chunk * MF_TILE;
-        klast = kbeg + (ntiles ? ntiles - 1 : 0) * tstride;  // prefetches past the end re-read the last tile (L2 hits, never stored)
+        klast = kbeg + (ntiles ? ntiles - 1 : 0) * tstride;  // requests past the end re-fetch the last tile (L2 hits, never read)
     }
+    __device__ __forceinline__ uint32_t key0(uint32_t t) const { return min(kbeg + t * tstride, klast); }
 };
+__device__ __forceinline__ int ring_next(int b) { return b + 1 == MF_NBUF ? 0 : b + 1; }
+__device__ __forceinline__ int ring_prev(int b) { return b == 0 ? MF_NBUF - 1 : b - 1; }
 
 // =================================================================================================
 // pass 1: per (row, chunk) partial max / sum-exp (log2 units)
 // =================================================================================================
-// TRACE (debug, KVP_SK_TRACE=1): wave-level s_memtime checkpoints of workgroup (5,0,0) -> trace[wave][tile][5]
-template <int DT, bool TRACE>
+template <int DT>
 __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint32_t ngb, uint32_t nchunk,
-                                                                float* __restrict__ part_m, float* __restrict__ part_z,
-                                                                unsigned long long* __restrict__ trace) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * MF_TILEB];
+                                                                float* __restrict__ part_m, float* __restrict__ part_z) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[MF_NBUF * MF_TILEB];
     const uint32_t chunk = blockIdx.x, b = blockIdx.z;
     const uint32_t h = blockIdx.y / ngb, gb = blockIdx.y - h * ngb;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -134,18 +142,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
     const bool active = rg < a.G;
     const uint32_t hq = h * a.G + (active ? rg : 0);
 
-    const char* kb = static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2;
-    const int64_t k_ssb = a.k_ss * 2;
+    const KStream ks_(static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2, a.k_ss * 2, a.S);
     uint4 qf[8];
     load_qfrags(qf, static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)row0 * a.q_sw) * 2,
                 a.q_sw * 2, n, kg);
+    wait_all_landed();  // Q fragments are in; from here on vmcnt only counts the K stream
 
     const TileWalk tw(chunk, nchunk, a.S);
-    const bool tr = TRACE && blockIdx.x == 5 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0;
-    auto stamp = [&](uint32_t tile, int cp) {
-        if (TRACE && tr && tile < 20) trace[(wv * 20 + tile) * 6 + cp] = __builtin_amdgcn_s_memtime();
-    };
-    stamp(0, 5);
     float m = KVP_NEG_INF, z = 0.f;  // raw-logit running max / sum-exp of window row row0 + n over this lane's keys
     const float c = a.c;
     const uint32_t w = row0 + n;     // window row: token S-W+w sees keys <= S-W+w
@@ -177,13 +180,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
         }
     };
 
-    // One 128-key tile = 4 sub-tiles of 32 keys.  Per wave the work of a sub-tile is a chain of 8 MFMAs and
-    // ~62 VALU instructions of softmax that DEPEND on it; issued back to back they serialise, and the two waves a
-    // SIMD hosts run in lockstep (same code, per-tile barrier), so nothing overlaps: measured ~5700 cycles per
-    // tile for a lone workgroup vs 2048 cycles of matrix-pipe time.  Hence a two-stage software pipeline inside
-    // the tile: the MFMA chain of sub-tile s is interleaved (1 MFMA : 6 VALU) with the softmax of sub-tile s-1,
-    // with double-buffered accumulators and fragment registers (LDS reads of s+1 are in flight during s).
-    auto compute = [&](uint32_t key0, const unsigned char* buf) {
+    // One tile = MF_SUBS sub-tiles of 32 keys; per sub-tile step: one DMA request for the tile two ahead, the LDS
+    // fragment reads of the next sub-tile, and the MFMA chain of this sub-tile interleaved (1 MFMA : 6 VALU) with
+    // the softmax of the previous one.
+    auto compute = [&](uint32_t key0, const unsigned char* buf, unsigned char* bufr, uint32_t keyr) {
         const bool need_mask = key0 + (MF_TILE - 1) > a.S - a.W;  // some (row, key) of this tile is masked / past S
         uint4 kf[2][8];
         f32x16 acc[2];
@@ -195,6 +195,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) kf[(sub + 1) & 1][ks] = kfrag(buf, sub + 1, ks, n, kg);
             }
+            ks_.request(bufr, keyr, sub);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[sub & 1][i] = 0.f;
@@ -230,30 +231,22 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
         softmax16(acc[(MF_SUBS - 1) & 1], key0, MF_SUBS - 1, need_mask);
     };
 
-    // K streams HBM -> registers -> LDS with TWO tiles in flight behind the one being computed:
-    // stA / stB alternate; each tile's loads have two compute phases to land (issue-early, write-late).
-    // K streams HBM -> registers -> LDS one 256-key tile (64 KiB) ahead of the tile being computed
-    // (issue-early / write-late, loads unconditional so that hipcc emits counted vmcnt waits).
-    unsigned char* bufc = lds;
-    unsigned char* bufn = lds + MF_TILEB;
     if (tw.ntiles > 0) {
-        stage_store(stage_load(kb, k_ssb, tw.kbeg, a.S), bufc);
+        ks_.request_tile(lds, tw.key0(0));
+        ks_.request_tile(lds + MF_TILEB, tw.key0(1));
+        wait_tile_landed();
         __syncthreads();
+        int bc = 0;
         for (uint32_t t = 0; t < tw.ntiles; ++t) {
-            const uint32_t key0 = tw.kbeg + t * tw.tstride;
-            stamp(t, 0);
-            const Stage st = stage_load(kb, k_ssb, min(key0 + tw.tstride, tw.klast), a.S);
-            __builtin_amdgcn_sched_barrier(0);  // issue-early
-            stamp(t, 1);
-            if (active) compute(key0, bufc);
-            __builtin_amdgcn_sched_barrier(0);  // write-late
-            stamp(t, 2);
-            if (t + 1 < tw.ntiles) stage_store(st, bufn);
-            stamp(t, 3);
-            __syncthreads();
-            stamp(t, 4);
-            unsigned char* tmp = bufc; bufc = bufn; bufn = tmp;
+            unsigned char* bufr = lds + ring_prev(bc) * MF_TILEB;  // tile t-1's buffer: everybody left it at the last barrier
+            if (active) compute(tw.key0(t), lds + bc * MF_TILEB, bufr, tw.key0(t + 2));
+            else ks_.request_tile(bufr, tw.key0(t + 2));
+            __builtin_amdgcn_sched_barrier(0);
+            wait_tile_landed();  // this wave's part of tile t+1 is in LDS ...
+            __syncthreads();     // ... and so is everybody else's; all fragment reads of tile t are done
+            bc = ring_next(bc);
         }
+        wait_all_landed();
     }
 
     if (active) {
@@ -274,7 +267,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
 template <int DT>
 __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint32_t ngb, const float* __restrict__ rowstat,
                                                                 float* __restrict__ colsum) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * MF_TILEB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[MF_NBUF * MF_TILEB];
     __shared__ float red[2][MF_WAVES][MF_TILE];
     const uint32_t chunk = blockIdx.x, b = blockIdx.z;
     const uint32_t h = blockIdx.y / ngb, gb = blockIdx.y - h * ngb;
@@ -286,8 +279,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
     const uint32_t hq = h * a.G + (active ? rg : 0);
     const uint32_t Sm = a.S - a.W;
 
-    const char* kb = static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2;
-    const int64_t k_ssb = a.k_ss * 2;
+    const KStream ks_(static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2, a.k_ss * 2, a.S);
     uint4 qf[8];
     load_qfrags(qf, static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)row0 * a.q_sw) * 2,
                 a.q_sw * 2, n, kg);
@@ -296,6 +288,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
     const float* ars = rowstat + (size_t)(b * a.Hq + hq) * a.W + row0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ar[r] = -ars[(r & 3) + 8 * (r >> 2) + 4 * kg];
+    wait_all_landed();  // Q fragments and normalisers are in; from here on vmcnt only counts the K stream (+ the flush stores)
 
     const TileWalk tw(chunk, gridDim.x, Sm);
     const float c = a.c;
@@ -314,8 +307,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
         s += __shfl_xor(s, 32);
         if (kg == 0) red[par][wv][sub * 32 + n] = s;
     };
-    // one 128-key tile, software-pipelined like pass 1: MFMA chain of sub-tile s || exp/add stream of sub-tile s-1
-    auto compute = [&](const unsigned char* buf, int par) {
+    // one tile, software-pipelined like pass 1: MFMA chain of sub-tile s || exp/add stream of sub-tile s-1
+    auto compute = [&](const unsigned char* buf, int par, unsigned char* bufr, uint32_t keyr) {
         uint4 kf[2][8];
         f32x16 acc[2];
 #pragma unroll
@@ -326,6 +319,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) kf[(sub + 1) & 1][ks] = kfrag(buf, sub + 1, ks, n, kg);
             }
+            ks_.request(bufr, keyr, sub);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[sub & 1][i] = 0.f;
@@ -353,7 +347,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
         }
         colsum16(acc[(MF_SUBS - 1) & 1], par, MF_SUBS - 1);
     };
-    // after the tile's barrier: threads 0..63 add the active waves' partials and store 64 column sums
+    // after the tile's barrier: threads 0..127 add the active waves' partials and store the tile's column sums
     auto flush = [&](uint32_t key0, int par) {
         if (threadIdx.x < MF_TILE) {
             const uint32_t kk = key0 + threadIdx.x;
@@ -366,22 +360,23 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
         }
     };
 
-    unsigned char* bufc = lds;
-    unsigned char* bufn = lds + MF_TILEB;
     if (tw.ntiles == 0) return;
-    stage_store(stage_load(kb, k_ssb, tw.kbeg, a.S), bufc);
+    ks_.request_tile(lds, tw.key0(0));
+    ks_.request_tile(lds + MF_TILEB, tw.key0(1));
+    wait_tile_landed();
     __syncthreads();
+    int bc = 0;
     for (uint32_t t = 0; t < tw.ntiles; ++t) {
-        const uint32_t key0 = tw.kbeg + t * tw.tstride;
-        const Stage st = stage_load(kb, k_ssb, min(key0 + tw.tstride, tw.klast), a.S);  // next tile: in flight under this tile's math
+        unsigned char* bufr = lds + ring_prev(bc) * MF_TILEB;
+        if (active) compute(lds + bc * MF_TILEB, t & 1, bufr, tw.key0(t + 2));
+        else ks_.request_tile(bufr, tw.key0(t + 2));
         __builtin_amdgcn_sched_barrier(0);
-        if (active) compute(bufc, t & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < tw.ntiles) stage_store(st, bufn);
+        wait_tile_landed();
         __syncthreads();
-        flush(key0, t & 1);
-        unsigned char* tmp = bufc; bufc = bufn; bufn = tmp;
+        flush(tw.key0(t), t & 1);
+        bc = ring_next(bc);
     }
+    wait_all_landed();
 }
 
 }  // namespace
@@ -395,7 +390,7 @@ bool snapkv_mfma_eligible(const SnapArgs& a, int dtype) {
 }
 
 // Workgroups per (batch, kv-head, group-block).  The grid is sized to ONE resident round (1 workgroup of 8 waves
-// per CU x 256 CUs; co-resident workgroups only add latency to each other): every workgroup pays its ~3.5 us start-up (Q fragments, first K tile) once and there is
+// per CU x 256 CUs): every workgroup pays its start-up (Q fragments, first two K tiles) once and there is
 // no second dispatch round; each workgroup then walks its interleaved tile list (TileWalk).
 static uint32_t mfma_nchunk_for(const SnapArgs& a, uint32_t nkeys) {
     const uint32_t ngb = (a.G + 3) / 4;
@@ -410,31 +405,8 @@ uint32_t snapkv_mfma_nchunk(const SnapArgs& a) { return mfma_nchunk_for(a, a.S);
 int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m, float* part_z, hipStream_t stream) {
     const uint32_t ngb = (a.G + 3) / 4;
     const dim3 grid(nchunk, a.Hkv * ngb, a.B);
-    static const int trace_on = kvp_env_int("KVP_SK_TRACE", 0);
-    if (trace_on && dtype == KVP_BF16) {  // debug: one traced launch, dump, then fall through to the normal launch
-        static int dumped = 0;
-        if (dumped++ == 3) {
-            unsigned long long* d = nullptr;
-            const size_t nb = MF_WAVES * 20 * 6 * sizeof(unsigned long long);
-            if (hipMalloc(&d, nb) == hipSuccess) {
-                hipMemsetAsync(d, 0, nb, stream);
-                snapkv_p1_mfma<KVP_BF16, true><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, d);
-                hipStreamSynchronize(stream);
-                std::vector<unsigned long long> h(MF_WAVES * 20 * 6);
-                hipMemcpy(h.data(), d, nb, hipMemcpyDeviceToHost);
-                hipFree(d);
-                const unsigned long long t0 = h[5];
-                for (int w = 0; w < MF_WAVES; ++w)
-                    for (int tl = 0; tl < 17; ++tl) {
-                        fprintf(stderr, "TRACE w%d t%02d:", w, tl);
-                        for (int c = 0; c < 5; ++c) fprintf(stderr, " %8lld", (long long)(h[(w * 20 + tl) * 6 + c] - t0));
-                        fprintf(stderr, "\n");
-                    }
-            }
-        }
-    }
-    if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_BF16, false><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, nullptr));
-    else KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_F16, false><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, nullptr));
+    if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
+    else KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
     KVP_CHECK_LAUNCH("snapkv_p1_mfma");
     return KVP_OK;
 }

@@ -1,25 +1,31 @@
-// Micro-benchmark: grow a synthetic loop step by step toward snapkv_p1's inner loop and watch where the
-// MFMA / VALU overlap is lost.  One 512-thread workgroup per CU (8 waves, 2 per SIMD), ITER "sub-tiles" each:
-//   V0  8 dependent MFMAs (32x32x16 bf16)                                   -> matrix-pipe floor
-//   V1  V0 + softmax-like VALU on the PREVIOUS sub-tile's accumulators (software pipelined, 2 acc sets)
-//   V2  V1 with the MFMA A operands read from LDS (ds_read_b128, prefetched one sub-tile ahead)
-//   V3  V2 + __syncthreads() every 4 sub-tiles
-//   V4  V3 + global->register->LDS staging of a fresh 32 KiB tile every 4 sub-tiles (one tile in flight)
-//   V5  V0 + the softmax VALU on the SAME sub-tile's accumulators right after the chain (no pipelining)
-// Reported: ns per sub-tile per wave (8 MFMAs = 8 * 32 cycles = 116 ns at 2.2 GHz when a wave has the pipe alone,
-// 233 ns when two waves share it).
+// Micro-benchmark: snapkv_p1's tile loop rebuilt with its ingredients switchable, to see which one costs what.
+//   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form tools/ubench_steps.hip -o tools/ubench_steps
+// One 512-thread workgroup per CU (8 waves, 2 per SIMD) unless noted; a tile = 256 keys = 8 sub-tiles of 32 keys,
+// per sub-tile and wave 8 x v_mfma_f32_32x32x16_bf16 + the 16-logit online-softmax update (~62 VALU).
+// Flags: LDSF  K fragments come from LDS (8 x ds_read_b128 per sub-tile, prefetched one sub-tile ahead)
+//        BAR   __syncthreads() per tile
+//        STG   the next tile streams global -> registers -> LDS (8 x dwordx4 per thread per tile, issue-early/write-late)
+//        PIPE  softmax of sub-tile s-1 interleaved into the MFMA chain of sub-tile s (else: chain, then its softmax)
+//        PRIO  s_setprio 1 around the MFMA chain of the non-pipelined variant
+// Reported: ns per sub-tile per wave; instruction-cost floor ~ (8 x 34 + ~290) cycles x 2 waves per SIMD = 470 ns.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define ITER 1024
+#define TILES 128
+#define SUBS 8
+#define TILEB (SUBS * 32 * 256)
 
 __device__ __forceinline__ f32x16 mma(const uint4& a, const uint4& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-__device__ __forceinline__ void softmax16(const f32x16& ap, float& m, float& z, float c) {
+__device__ __forceinline__ uint4 kfrag(const unsigned char* buf, uint32_t sub, uint32_t ks, uint32_t n, uint32_t kg) {
+    const uint32_t row = sub * 32 + n;
+    return *reinterpret_cast<const uint4*>(buf + row * 256 + (((ks * 2 + kg) ^ (row & 15)) << 4));
+}
+__device__ __forceinline__ void softmax16(const f32x16 ap, float& m, float& z, float c) {
     float tm = ap[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) tm = fmaxf(tm, ap[r]);
@@ -34,95 +40,272 @@ __device__ __forceinline__ void softmax16(const f32x16& ap, float& m, float& z, 
     m = mn;
 }
 
-template <int V>
-__global__ __launch_bounds__(512, 2) void k(float* out, const uint4* in, const char* kglob, size_t kbytes) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 32768];
+template <bool LDSF, bool BAR, int STG, bool PIPE, bool PRIO, int THREADS>
+__global__ __launch_bounds__(THREADS, 1) void k(float* out, const uint4* in, const char* kglob) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const uint32_t lane = threadIdx.x & 63, n = lane & 31, kg = lane >> 5;
     uint4 qf[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) qf[i] = in[(lane + i * 7) & 127];
-    for (int i = threadIdx.x; i < 4096; i += 512) reinterpret_cast<uint4*>(lds)[i] = in[i & 127];
+    for (int i = threadIdx.x; i < 2 * TILEB / 16; i += THREADS) reinterpret_cast<uint4*>(lds)[i] = in[i & 127];
     __syncthreads();
-    f32x16 accA, accB;
-    for (int i = 0; i < 16; ++i) { accA[i] = 0.f; accB[i] = 0.f; }
     float m = -1e30f, z = 0.f;
     const float c = 0.1275f;
-    const char* src = kglob + (size_t)blockIdx.x * 65536;
-    uint4 st[4];
-    auto frag = [&](const unsigned char* buf, int sub, int ks) {
-        const uint32_t row = sub * 32 + n;
-        return *reinterpret_cast<const uint4*>(buf + row * 256 + (((ks * 2 + kg) ^ (row & 15)) << 4));
-    };
-    for (int it = 0; it < ITER; ++it) {
-        const unsigned char* buf = lds + ((it >> 2) & 1) * 32768;
-        const int sub = it & 3;
-        if (V == 4 && sub == 0) {
-            const size_t off = ((size_t)(it >> 2) * 32768 + threadIdx.x * 16) % (kbytes - 65536);
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    const char* src = kglob + (size_t)blockIdx.x * TILEB;
+    const size_t tstride = (size_t)gridDim.x * TILEB;
+    constexpr int NST = TILEB / 16 / THREADS;  // dwordx4 per thread per tile
+    unsigned char* bufc = lds;
+    unsigned char* bufn = lds + TILEB;
+    uint4 st[NST];
+    if (STG == 5) {  // rolling staging: st[] holds tile t+1 while tile t is computed
 #pragma unroll
-            for (int i = 0; i < 4; ++i) st[i] = *reinterpret_cast<const uint4*>(src + off + i * 8192);
-        }
-        uint4 kf[8];
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) kf[ks] = (V >= 2 && V != 5) ? frag(buf, sub, ks) : qf[(ks + 3) & 7];
-        f32x16& ac = (it & 1) ? accB : accA;
-        f32x16& ap = (it & 1) ? accA : accB;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) ac[i] = 0.f;
-        if (V == 0) {
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) ac = mma(kf[ks], qf[ks], ac);
-            m += ac[0];
-        } else if (V == 5) {
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) ac = mma(kf[ks], qf[ks], ac);
-            softmax16(ac, m, z, c);
-        } else {
-            float tm = ap[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) tm = fmaxf(tm, ap[r]);
-            const float mn = fmaxf(m, tm), off = -mn * c;
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                ac = mma(kf[ks], qf[ks], ac);
-                s0 += __builtin_amdgcn_exp2f(fmaf(ap[2 * ks], c, off));
-                s1 += __builtin_amdgcn_exp2f(fmaf(ap[2 * ks + 1], c, off));
-            }
-            z = z * __builtin_amdgcn_exp2f(fmaf(m, c, off)) + s0 + s1;
-            m = mn;
-        }
-        if (V >= 3 && V != 5 && sub == 3) {
-            if (V == 4) {
-                unsigned char* nb = lds + (((it >> 2) + 1) & 1) * 32768;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(nb + threadIdx.x * 16 + i * 8192) = st[i];
-            }
-            __syncthreads();
-        }
+        for (int i = 0; i < NST; ++i) st[i] = *reinterpret_cast<const uint4*>(src + tstride + (size_t)(threadIdx.x + i * THREADS) * 16);
     }
-    float r = m + z;
-    for (int i = 0; i < 16; ++i) r += accA[i] + accB[i];
-    out[blockIdx.x * 512 + threadIdx.x] = r;
+    for (int t = 0; t < TILES; ++t) {
+        // STG: 0 none, 1 full, 2 global loads only (consumed by an xor), 3 LDS stores only, 4 full from an L2-resident source
+        if (STG == 1 || STG == 2 || STG == 4) {
+#pragma unroll
+            for (int i = 0; i < NST; ++i)
+                st[i] = *reinterpret_cast<const uint4*>(src + (STG == 4 ? 0 : (size_t)(t + 1) * tstride) + (size_t)(threadIdx.x + i * THREADS) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (STG == 3) {
+#pragma unroll
+            for (int i = 0; i < NST; ++i) st[i] = qf[i & 7];
+        }
+        uint4 kf[2][8];
+        f32x16 acc[2];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) kf[0][ks] = LDSF ? kfrag(bufc, 0, ks, n, kg) : qf[(ks + 3) & 7];
+#pragma unroll
+        for (int sub = 0; sub < SUBS; ++sub) {
+            if (sub + 1 < SUBS) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) kf[(sub + 1) & 1][ks] = LDSF ? kfrag(bufc, sub + 1, ks, n, kg) : qf[(ks + sub) & 7];
+            }
+            if (STG == 5) {
+                // piece `sub` of tile t+1 (loaded one tile ago) -> LDS, then its register is refilled from tile t+2
+                static_assert(NST == SUBS || STG != 5, "one piece per sub-tile step");
+                const uint32_t e = threadIdx.x + sub * THREADS, row = e >> 4, ch = e & 15;
+                *reinterpret_cast<uint4*>(bufn + row * 256 + ((ch ^ (row & 15)) << 4)) = st[sub];
+                st[sub] = *reinterpret_cast<const uint4*>(src + (size_t)(t + 2) * tstride + (size_t)e * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[sub & 1][i] = 0.f;
+            if (!PIPE) {
+                if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc[sub & 1] = mma(kf[sub & 1][ks], qf[ks], acc[sub & 1]);
+                if (PRIO) __builtin_amdgcn_s_setprio(0);
+                softmax16(acc[sub & 1], m, z, c);
+            } else if (sub == 0) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc[0] = mma(kf[0][ks], qf[ks], acc[0]);
+            } else {
+                const f32x16& ap = acc[(sub - 1) & 1];
+                float tm = ap[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tm = fmaxf(tm, ap[r]);
+                const float mn = fmaxf(m, tm), off = -mn * c;
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    acc[sub & 1] = mma(kf[sub & 1][ks], qf[ks], acc[sub & 1]);
+                    s0 += __builtin_amdgcn_exp2f(fmaf(ap[2 * ks], c, off));
+                    s1 += __builtin_amdgcn_exp2f(fmaf(ap[2 * ks + 1], c, off));
+                }
+                z = z * __builtin_amdgcn_exp2f(fmaf(m, c, off)) + (s0 + s1);
+                m = mn;
+                __builtin_amdgcn_sched_group_barrier(0x2, 12, 0);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
+                }
+            }
+        }
+        if (PIPE) softmax16(acc[(SUBS - 1) & 1], m, z, c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (STG == 1 || STG == 3 || STG == 4) {
+#pragma unroll
+            for (int i = 0; i < NST; ++i) {
+                const uint32_t e = threadIdx.x + i * THREADS, row = e >> 4, ch = e & 15;
+                *reinterpret_cast<uint4*>(bufn + row * 256 + ((ch ^ (row & 15)) << 4)) = st[i];
+            }
+        }
+        if (STG == 2) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int i = 0; i < NST; ++i) x ^= st[i].x ^ st[i].y ^ st[i].z ^ st[i].w;
+            if (x == 0x12345u) m += 1.f;  // consume the loads (never true)
+        }
+        if (BAR) __syncthreads();
+        if (STG) { unsigned char* tmp = bufc; bufc = bufn; bufn = tmp; }
+    }
+    out[blockIdx.x * THREADS + threadIdx.x] = m + z;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // shader-clock ticks vs 100 MHz real-time ticks -> effective core clock
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        reinterpret_cast<unsigned long long*>(out + 256 * 512)[0] = c1 - c0;
+        reinterpret_cast<unsigned long long*>(out + 256 * 512)[1] = r1 - r0;
+    }
 }
 
-template <int V> float run(float* out, const uint4* in, const char* kg, size_t kb) {
+// ---- LDS-DMA variant: K tiles of DSUBS x 32 keys land in LDS by global_load_lds_dwordx4 (no staging VGPRs, no ds_write),
+// NBUF buffers, tile t+NBUF-1 is requested during tile t, one request per thread per sub-tile step.
+// PAT: 0 = all workgroups walk one contiguous window; 1 = the kernel's layout: 8 kv-heads 32 MiB apart, 32 workgroups per head,
+// tile t of workgroup c at head*32 MiB + (t*32 + c) * tile bytes; 2 = like 1 with head h starting a fraction h/8 into its walk
+template <int DSUBS, int NBUF, bool PIPE, int PAT>
+__global__ __launch_bounds__(512, 1) void kd(float* out, const uint4* in, const char* kglob, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int DTILEB = DSUBS * 32 * 256;
+    constexpr int NLD = DTILEB / 16 / 512;   // requests per thread per tile
+    static_assert(NLD == DSUBS, "one request per sub-tile step");
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = lane & 31, kg = lane >> 5;
+    uint4 qf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qf[i] = in[(lane + i * 7) & 127];
+    float m = -1e30f, z = 0.f;
+    const float c = 0.1275f;
+    const uint32_t head = blockIdx.x >> 5, chunk = blockIdx.x & 31;
+    const char* src = PAT == 0 ? kglob + (size_t)blockIdx.x * DTILEB : kglob + ((size_t)head << 25) + (size_t)chunk * DTILEB;
+    const size_t tstride = (PAT == 0 ? (size_t)gridDim.x : (size_t)32) * DTILEB;
+    const int rot = PAT == 2 ? (int)(head * tiles / 8) : 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q fragments are in; from here on vmcnt is managed by hand
+    // request i of a tile: this wave's lanes cover rows i*32 + wv*4 .. +4; lane -> (row, LDS slot p), fetches chunk p ^ (row & 15)
+    const uint32_t lrow = wv * 4 + (lane >> 4), p = lane & 15;
+    auto request = [&](int tile, int i, int buf) {
+        const uint32_t row = i * 32 + lrow;
+        if (PAT != 0) { tile += rot; tile = tile >= tiles ? tile - tiles : tile; tile = tile >= tiles ? tile - tiles : tile; }
+        const char* g = src + (size_t)tile * tstride + row * 256 + ((p ^ (row & 15)) << 4);
+        unsigned char* l = lds + buf * DTILEB + (i * 32 + wv * 4) * 256;
+        // inline asm: with the builtin, hipcc makes every later ds_read wait for vmcnt(0) (LDS may-alias), serialising the stream
+        const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)l);
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(g) : "memory", "m0");
+    };
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) request(b, i, b);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((NBUF - 2) * NLD));  // vmcnt: only the newest NBUF-2 tiles may be pending
+    __builtin_amdgcn_s_barrier();
+    int bc = 0;
+    for (int t = 0; t < tiles; ++t) {
+        const unsigned char* bufc = lds + bc * DTILEB;
+        const int bn = bc == 0 ? NBUF - 1 : bc - 1;  // buffer of tile t-1 == buffer of tile t+NBUF-1
+        uint4 kf[2][8];
+        f32x16 acc[2];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) kf[0][ks] = kfrag(bufc, 0, ks, n, kg);
+#pragma unroll
+        for (int sub = 0; sub < DSUBS; ++sub) {
+            if (sub + 1 < DSUBS) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) kf[(sub + 1) & 1][ks] = kfrag(bufc, sub + 1, ks, n, kg);
+            }
+            request(t + NBUF - 1, sub, bn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[sub & 1][i] = 0.f;
+            if (!PIPE) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc[sub & 1] = mma(kf[sub & 1][ks], qf[ks], acc[sub & 1]);
+                softmax16(acc[sub & 1], m, z, c);
+            } else if (sub == 0) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc[0] = mma(kf[0][ks], qf[ks], acc[0]);
+            } else {
+                const f32x16& ap = acc[(sub - 1) & 1];
+                float tm = ap[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tm = fmaxf(tm, ap[r]);
+                const float mn = fmaxf(m, tm), off = -mn * c;
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    acc[sub & 1] = mma(kf[sub & 1][ks], qf[ks], acc[sub & 1]);
+                    s0 += __builtin_amdgcn_exp2f(fmaf(ap[2 * ks], c, off));
+                    s1 += __builtin_amdgcn_exp2f(fmaf(ap[2 * ks + 1], c, off));
+                }
+                z = z * __builtin_amdgcn_exp2f(fmaf(m, c, off)) + (s0 + s1);
+                m = mn;
+                __builtin_amdgcn_sched_group_barrier(0x2, 12, 0);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
+                }
+            }
+        }
+        if (PIPE) softmax16(acc[(DSUBS - 1) & 1], m, z, c);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070 | ((NBUF - 2) * NLD));  // lgkmcnt(0) (our LDS reads) + tile t+1 landed
+        __builtin_amdgcn_s_barrier();
+        bc = bc + 1 == NBUF ? 0 : bc + 1;
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = m + z;
+}
+template <int DSUBS, int NBUF, bool PIPE, int PAT = 0>
+float rund(float* out, const uint4* in, const char* kg, int tiles_override = 0) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    k<V><<<256, 512>>>(out, in, kg, kb); (void)hipDeviceSynchronize();
-    (void)hipEventRecord(e0); k<V><<<256, 512>>>(out, in, kg, kb); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    auto kern = kd<DSUBS, NBUF, PIPE, PAT>;
+    const int ldsb = NBUF * DSUBS * 32 * 256, tiles = tiles_override ? tiles_override : TILES * SUBS / DSUBS;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+    kern<<<256, 512, ldsb>>>(out, in, kg, tiles); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0); kern<<<256, 512, ldsb>>>(out, in, kg, tiles); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-    return ms * 1e6f / ITER;
+    return ms * 1e6f / (tiles * DSUBS);
+}
+
+static double g_mhz = 0.0;
+template <bool LDSF, bool BAR, int STG, bool PIPE, bool PRIO, int THREADS>
+float run(float* out, const uint4* in, const char* kg, int blocks) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    auto kern = k<LDSF, BAR, STG, PIPE, PRIO, THREADS>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILEB);
+    kern<<<blocks, THREADS, 2 * TILEB>>>(out, in, kg); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0); kern<<<blocks, THREADS, 2 * TILEB>>>(out, in, kg); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long ck[2]; (void)hipMemcpy(ck, out + 256 * 512, 16, hipMemcpyDeviceToHost);
+    g_mhz = ck[1] ? (double)ck[0] / (double)ck[1] * 100.0 : 0.0;
+    return ms * 1e6f / (TILES * SUBS);
 }
 int main() {
-    float* out; uint4* in; char* kg; const size_t kb = (size_t)512 << 20;
-    (void)hipMalloc(&out, 256 * 512 * 4); (void)hipMalloc(&in, 128 * sizeof(uint4)); (void)hipMalloc(&kg, kb);
+    float* out; uint4* in; char* kg; const size_t kb = (size_t)(TILES + 4) * 256 * TILEB;
+    (void)hipMalloc(&out, 256 * 512 * 4 + 64); (void)hipMalloc(&in, 128 * sizeof(uint4)); (void)hipMalloc(&kg, kb);
     std::vector<uint32_t> h(512, 0x3c003c00u); (void)hipMemcpy(in, h.data(), 2048, hipMemcpyHostToDevice);
     (void)hipMemset(kg, 0x3c, kb);
-    printf("ns per 32-key sub-tile per wave (8 waves per CU, 2 per SIMD); matrix-pipe floor = 233 ns\n");
-    printf("V0 mfma only                  %.0f\n", run<0>(out, in, kg, kb));
-    printf("V5 mfma then dependent softmax %.0f\n", run<5>(out, in, kg, kb));
-    printf("V1 pipelined softmax           %.0f\n", run<1>(out, in, kg, kb));
-    printf("V2 + operands from LDS         %.0f\n", run<2>(out, in, kg, kb));
-    printf("V3 + barrier per 4 sub-tiles   %.0f\n", run<3>(out, in, kg, kb));
-    printf("V4 + global->LDS staging       %.0f\n", run<4>(out, in, kg, kb));
+    printf("ns per 32-key sub-tile per wave; 256 workgroups\n");
+#define R(name, ...) { const float t_ = run<__VA_ARGS__>(out, in, kg, 256); printf("%-58s %6.0f   (s_memtime/s_memrealtime -> %.0f MHz)\n", name, t_, g_mhz); }
+    //                                   LDSF   BAR  STG PIPE   PRIO  THREADS
+    R("regs only, sequential", false, false, 0, false, false, 512)
+    R("regs only, pipelined", false, false, 0, true, false, 512)
+    R("+ LDS fragments + barrier, pipelined", true, true, 0, true, false, 512)
+    R("+ staging (= kernel)", true, true, 1, true, false, 512)
+    R("+ global loads only", true, true, 2, true, false, 512)
+    R("+ LDS stores only", true, true, 3, true, false, 512)
+    R("+ staging from an L2-resident source", true, true, 4, true, false, 512)
+    R("rolling staging (1 ds_write + 1 global load per sub-tile)", true, true, 5, true, false, 512)
+    R("rolling staging, sequential softmax", true, true, 5, false, false, 512)
+    R("global loads only, regs-only compute, no barrier", false, false, 2, true, false, 512)
+    printf("%-58s %6.0f\n", "LDS-DMA, 128-key tiles, 3 buffers, pipelined", rund<4, 3, true>(out, in, kg));
+    printf("%-58s %6.0f\n", "LDS-DMA, 128-key tiles, 4 buffers, pipelined", rund<4, 4, true>(out, in, kg));
+    printf("%-58s %6.0f\n", "LDS-DMA, 128-key tiles, 3 buffers, sequential", rund<4, 3, false>(out, in, kg));
+    printf("%-58s %6.0f\n", "LDS-DMA, 64-key tiles, 4 buffers, pipelined", rund<2, 4, true>(out, in, kg));
+    printf("%-58s %6.0f\n", "LDS-DMA 128/3, kernel's 8 x 32 MiB head layout", rund<4, 3, true, 1>(out, in, kg));
+    printf("%-58s %6.0f\n", "LDS-DMA 128/3, head layout + per-head rotation", rund<4, 3, true, 2>(out, in, kg));
+    printf("%-58s %6.0f\n", "LDS-DMA 128/3, head layout, only 32 tiles per workgroup", rund<4, 3, true, 1>(out, in, kg, 32));
+    {   // random bf16 data in K and Q (values ~N(0,1)): does the data-dependent power draw change the clocks?
+        std::vector<uint16_t> hk((size_t)64 << 20);
+        uint32_t x = 12345u;
+        for (auto& v : hk) { x = x * 1664525u + 1013904223u; v = (uint16_t)(0x3c00u + ((x >> 9) & 0x7ffu) - 0x400u) | (uint16_t)((x >> 16) & 0x8000u); }
+        for (size_t off = 0; off + hk.size() * 2 <= kb; off += hk.size() * 2) (void)hipMemcpy(kg + off, hk.data(), hk.size() * 2, hipMemcpyHostToDevice);
+        (void)hipMemcpy(in, hk.data() + 4096, 2048, hipMemcpyHostToDevice);
+        printf("%-58s %6.0f\n", "LDS-DMA 128/3, head layout, RANDOM data", rund<4, 3, true, 1>(out, in, kg));
+        printf("%-58s %6.0f\n", "LDS-DMA 128/3, head layout, RANDOM data, 32 tiles", rund<4, 3, true, 1>(out, in, kg, 32));
+        R("regs only, pipelined, RANDOM Q", false, false, 0, true, false, 512)
+        R("regs only, sequential, RANDOM Q", false, false, 0, false, false, 512)
+    }
     return 0;
 }
