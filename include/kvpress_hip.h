@@ -126,6 +126,20 @@ int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
                   int64_t B, int64_t H, int64_t S, int64_t D,
                   const int32_t* idx, int64_t n, void* k_out, void* v_out, kvp_stream_t stream);
 
+/* ---- KeyDiffPress.score (kvpress/presses/keydiff_press.py:45-46) ----------------------------------
+ * anchor[b,h,:] = mean_s k[b,h,s,:] / max(||k[b,h,s,:]||, 1e-12)   (F.normalize(keys).mean(dim=2))
+ * scores[b,h,s] = -cosine_similarity(k[b,h,s,:], anchor[b,h,:])     (eps 1e-8), contiguous [B,H,S] float32. */
+size_t kvp_keydiff_workspace_bytes(int64_t B, int64_t H, int64_t S, int64_t D);
+int kvp_keydiff_score(const void* k, int dtype, int64_t B, int64_t H, int64_t S, int64_t D,
+                      int64_t sb, int64_t sh, int64_t ss, float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream);
+
+/* ---- TOVAPress.score tail (kvpress/presses/tova_press.py:52-53) -----------------------------------
+ * scores[b,h,s] <- mean over h' of scores[b,h',s] for every h, in place (`attn_weights.mean(1)` followed by
+ * `.repeat(1, num_kv_heads, 1)`, applied to the per-kv-group means kvp_snapkv_score* produce with W = 1, kernel 1).
+ * Strides in elements. */
+int kvp_scores_head_mean(float* scores, int64_t B, int64_t H, int64_t S, int64_t stride_b, int64_t stride_h,
+                         kvp_stream_t stream);
+
 /* ---- measurement aid (not part of the reference boundary) ------------------------------------
  * kvp_prof_enable(1) makes every kernel launch of the calling thread record a HIP event pair on
  * its launch stream; after synchronising, kvp_prof_get(i) returns kernel i's name and duration.

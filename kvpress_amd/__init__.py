@@ -1,15 +1,32 @@
 """kvpress_amd: MI355X-native score -> top-k -> gather hot path of NVIDIA/kvpress.
 
 Public API mirrors the reference for this path (same class names, dataclass fields and
-method signatures): BasePress, ScorerPress, KnormPress, SnapKVPress, ExpectedAttentionPress.
+method signatures): BasePress, ScorerPress, KnormPress, SnapKVPress, ExpectedAttentionPress, the scorers that reuse
+the path's kernels (PyramidKVPress, TOVAPress, KeyDiffPress, StreamingLLMPress, RandomPress) and the
+"kv-press-text-generation" pipeline (kvpress_amd.pipeline, imported on first use).
 Everything below ``ScorerPress.compress`` runs in hand-written HIP kernels (gfx950) reached
 through the C ABI of include/kvpress_hip.h; there is no CPU or pure-PyTorch fallback.
 """
 from kvpress_amd.presses.base_press import BasePress
 from kvpress_amd.presses.expected_attention_press import ExpectedAttentionPress
+from kvpress_amd.presses.keydiff_press import KeyDiffPress
 from kvpress_amd.presses.knorm_press import KnormPress
+from kvpress_amd.presses.pyramidkv_press import PyramidKVPress
+from kvpress_amd.presses.random_press import RandomPress
 from kvpress_amd.presses.scorer_press import ScorerPress
 from kvpress_amd.presses.snapkv_press import SnapKVPress
+from kvpress_amd.presses.streaming_llm_press import StreamingLLMPress
+from kvpress_amd.presses.tova_press import TOVAPress
 
 __version__ = "0.1.0"
-__all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress"]
+__all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
+           "KeyDiffPress", "StreamingLLMPress", "RandomPress", "KVPressTextGenerationPipeline"]
+
+
+def __getattr__(name):
+    # the pipeline pulls in transformers.pipelines (slow import): load it on first use
+    if name == "KVPressTextGenerationPipeline":
+        from kvpress_amd.pipeline import KVPressTextGenerationPipeline
+
+        return KVPressTextGenerationPipeline
+    raise AttributeError(f"module 'kvpress_amd' has no attribute {name!r}")

@@ -28,6 +28,9 @@ SIGNATURES = {
     "kvp_version": (c_int, []),
     "kvp_last_error": (c_char_p, []),
     "kvp_rownorm_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_float, c_void_p, c_void_p]),
+    "kvp_keydiff_workspace_bytes": (c_size_t, [_I64] * 4),
+    "kvp_keydiff_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "kvp_scores_head_mean": (c_int, [c_void_p, _I64, _I64, _I64, _I64, _I64, c_void_p]),
     "kvp_snapkv_workspace_bytes": (c_size_t, [_I64] * 6),
     "kvp_snapkv_score": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int,
                                  _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -120,6 +123,30 @@ def rownorm_score(x: torch.Tensor, scale: float) -> torch.Tensor:
         _check(lib().kvp_rownorm_score(_p(x), _DTYPES[x.dtype], B, H, S, D, _st(x, 0), _st(x, 1), _st(x, 2),
                                        float(scale), _p(out), _stream(x)), "kvp_rownorm_score")
     return out
+
+
+def keydiff_score(keys: torch.Tensor) -> torch.Tensor:
+    """KeyDiff scores [B,H,S] float32: -cos(k, mean of the normalised keys of the head)."""
+    keys = _rows_last_contig(_dev(keys))
+    B, H, S, D = keys.shape
+    scores = torch.empty((B, H, S), dtype=torch.float32, device=keys.device)
+    with torch.cuda.device(keys.device):
+        nws = lib().kvp_keydiff_workspace_bytes(B, H, S, D)
+        ws = _ws(nws, keys)
+        _check(lib().kvp_keydiff_score(_p(keys), _DTYPES[keys.dtype], B, H, S, D, _st(keys, 0), _st(keys, 1), _st(keys, 2),
+                                       _p(scores), _p(ws), ws.numel(), _stream(keys)), "kvp_keydiff_score")
+    return scores
+
+
+def scores_head_mean_(scores: torch.Tensor) -> torch.Tensor:
+    """In place: every head's scores <- the mean over heads (scores float32 [B,H,S], last dim contiguous)."""
+    assert scores.dtype == torch.float32 and scores.dim() == 3 and scores.stride(2) == 1
+    _dev(scores)
+    B, H, S = scores.shape
+    with torch.cuda.device(scores.device):
+        _check(lib().kvp_scores_head_mean(_p(scores), B, H, S, _st(scores, 0), _st(scores, 1), _stream(scores)),
+               "kvp_scores_head_mean")
+    return scores
 
 
 def snapkv_score(q_win: torch.Tensor, keys: torch.Tensor, kernel_size: int) -> torch.Tensor:

@@ -1,0 +1,59 @@
+"""PyramidKVPress (kvpress/presses/pyramidkv_press.py:16-112): SnapKV scores, per-layer budgets.
+
+Scores are SnapKVPress's (kvp_snapkv_score*); what changes is how many tokens a layer keeps: a linear ramp from
+many (first layer) to few (last layer) whose mean is ``q_len * (1 - compression_ratio)``.  Top-k and gather are the
+same HIP kernels as everywhere else (kvp_topk_select, kvp_gather_kv)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from kvpress_amd import _native
+from kvpress_amd.presses.snapkv_press import SnapKVPress
+
+
+@dataclass
+class PyramidKVPress(SnapKVPress):
+    """PyramidKV (https://arxiv.org/abs/2406.02069).
+
+    Parameters
+    ----------
+    compression_ratio : float, default=0.0
+    window_size : int, default=64
+    kernel_size : int, default=5
+    beta : int, default=20
+        Shape of the pyramid: the last layer keeps 1/beta of the mean non-window budget.
+    """
+
+    compression_ratio: float = 0.0
+    window_size: int = 64
+    kernel_size: int = 5
+    beta: int = 20
+
+    def get_layer_budget(self, module: nn.Module, q_len: int) -> int:
+        """Tokens this layer keeps (pyramidkv_press.py:47-81).  With n = q_len * (1 - ratio) non-window tokens on
+        average, budgets run linearly from hi (layer 0) to lo = n / beta (last layer), hi + lo = 2 n; hi is capped
+        at q_len - window_size.  If the ramp leaves [window_size, q_len] the SnapKV budget round(n) is used."""
+        assert self.beta >= 1, "Beta should >= 1"
+        w = self.window_size
+        mean_budget = q_len * (1 - self.compression_ratio)   # = max_capacity_prompt - window_size of the paper's code
+        lo = mean_budget / self.beta
+        hi = 2 * mean_budget - lo
+        if hi >= q_len - w:
+            hi = q_len - w
+            lo = 2 * mean_budget - hi
+        if not (q_len >= hi >= lo >= w):
+            return round(q_len * (1 - self.compression_ratio))
+        step = (hi - lo) / (module.config.num_hidden_layers - 1)
+        return round(hi - module.layer_idx * step)
+
+    def compress(self, module: nn.Module, hidden_states: torch.Tensor, keys: torch.Tensor, values: torch.Tensor,
+                 attentions: torch.Tensor, kwargs: dict) -> tuple[torch.Tensor, torch.Tensor]:
+        if self.compression_ratio == 0:
+            return keys, values
+        scores = self.score(module, hidden_states, keys, values, attentions, kwargs)
+        n_kept = self.get_layer_budget(module, keys.shape[2])      # pyramidkv_press.py:100-101
+        indices = _native.topk_select(scores, n_kept)
+        return _native.gather_kv(keys, values, indices)

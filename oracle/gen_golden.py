@@ -51,7 +51,8 @@ def main(argv):
     _install_shims()
     import numpy as np
     import torch
-    from kvpress import ExpectedAttentionPress, KnormPress, SnapKVPress  # the reference
+    from kvpress import (ExpectedAttentionPress, KeyDiffPress, KnormPress, PyramidKVPress, SnapKVPress,  # the reference
+                         StreamingLLMPress, TOVAPress)
 
     import _inputs
 
@@ -67,6 +68,14 @@ def main(argv):
                 return KnormPress(compression_ratio=ratio)
             if s["kind"] == "snapkv":
                 return SnapKVPress(compression_ratio=ratio, window_size=s["W"], kernel_size=s["ks"])
+            if s["kind"] == "keydiff":
+                return KeyDiffPress(compression_ratio=ratio)
+            if s["kind"] == "tova":
+                return TOVAPress(compression_ratio=ratio)
+            if s["kind"] == "pyramid":
+                return PyramidKVPress(compression_ratio=ratio, window_size=s["W"], kernel_size=s["ks"], beta=s["beta"])
+            if s["kind"] == "streaming":
+                return StreamingLLMPress(compression_ratio=ratio, n_sink=s["n_sink"])
             return ExpectedAttentionPress(
                 compression_ratio=ratio, n_future_positions=s["n_future"], n_sink=s["n_sink"],
                 use_covariance=s["use_covariance"], use_vnorm=s["use_vnorm"], epsilon=s["epsilon"])
@@ -75,6 +84,9 @@ def main(argv):
         captured = {}
         for mode, dt in (("f32", torch.float32), ("nat", _inputs.torch_dtype(s["dtype"]))):
             att, rot, hidden, pe = _inputs.build_llama_attention(s, dt)
+            if s["kind"] == "pyramid":  # the budget reads the layer's position in the stack (pyramidkv_press.py:80-81)
+                att.config.num_hidden_layers = s["n_layers"]
+                att.layer_idx = s["layer_idx"]
             keys = torch.from_numpy(s["keys"]).to(dt)
             values = torch.from_numpy(s["values"]).to(dt)
             kwargs = {"position_embeddings": pe}
@@ -85,7 +97,7 @@ def main(argv):
                     captured["mu_f32"] = mu.numpy().astype(np.float32)
                     if s["D"] <= 64:
                         captured["cov_f32"] = cov.numpy().astype(np.float32) if cov is not None else np.zeros(0, np.float32)
-                if mode == "f32" and s["kind"] == "snapkv":
+                if mode == "f32" and s["kind"] in ("snapkv", "tova", "pyramid"):
                     from kvpress.utils import get_prerope_query_states
                     from transformers.models.llama.modeling_llama import rotate_half
 
@@ -100,8 +112,9 @@ def main(argv):
                         ko, vo = p.compress(att, hidden, keys, values, None, kwargs)
                         assert ko.shape == vo.shape and ko.is_contiguous()
                         out[f"nkept_{i}"] = np.int64(ko.shape[2])
-                        n = int(s["S"] * (1 - r))
-                        idx = sc.topk(n, dim=-1).indices.sort(dim=-1).values
+                        n = ko.shape[2]  # int(S * (1 - r)) except for per-layer budgets (PyramidKV)
+                        sc_r = p.score(att, hidden, keys, values, None, kwargs) if s["kind"] == "streaming" else sc
+                        idx = sc_r.topk(n, dim=-1).indices.sort(dim=-1).values
                         out[f"idx_f32_{i}"] = idx.numpy().astype(np.int32)
         out.update(captured)
         path = os.path.join(outdir, f"{name}.npz")

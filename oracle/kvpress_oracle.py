@@ -35,6 +35,10 @@ __all__ = [
     "snapkv_window_attention",
     "snapkv_score",
     "snapkv_score_from_attentions",
+    "keydiff_score",
+    "tova_score",
+    "pyramidkv_budget",
+    "streaming_llm_score",
     "ea_query_stats",
     "ea_avg_rope",
     "ea_score",
@@ -306,3 +310,55 @@ def ea_score(keys, values, mu, cov, n_sink=4, use_vnorm=True, epsilon=0.0, ctype
     fill = float(np.float32(sc.max())) + 1.0
     out = np.concatenate([np.full((B, H, n_sink), fill, dtype=ctype), sc], axis=-1)
     return out.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# scorers that reuse the path's kernels
+# ----------------------------------------------------------------------------------------------
+def keydiff_score(keys: np.ndarray, ctype=np.float64) -> np.ndarray:
+    """KeyDiffPress.score (keydiff_press.py:45-46): ``anchor = F.normalize(keys, p=2, dim=-1).mean(dim=2, keepdim=True)``,
+    ``-F.cosine_similarity(keys, anchor, dim=-1)``.  F.normalize: x / max(||x||, 1e-12); cosine_similarity (ATen
+    Distance.cpp, torch >= 1.12): sum (x / max(||x||, 1e-8)) * (y / max(||y||, 1e-8))."""
+    k = keys.astype(ctype)
+    nk = np.sqrt((k * k).sum(-1, keepdims=True))
+    anchor = (k / np.maximum(nk, 1e-12)).mean(axis=2, keepdims=True)
+    na = np.sqrt((anchor * anchor).sum(-1, keepdims=True))
+    cos = ((k / np.maximum(nk, 1e-8)) * (anchor / np.maximum(na, 1e-8))).sum(-1)
+    return (-cos).astype(np.float32)
+
+
+def tova_score(q_last, keys, ctype=np.float64) -> np.ndarray:
+    """TOVAPress.score with ``attentions=None`` (tova_press.py:45-59) from the RoPE'd query of the LAST token
+    ``q_last [B,Hq,1,D]``: window attention with window 1 (SnapKVPress.compute_window_attention, snapkv_press.py:41-69),
+    mean over ALL heads (:52), repeated for every kv-head (:53), right-padded with max + 1 (:58)."""
+    attn = snapkv_window_attention(q_last, keys, ctype)          # [B,Hq,1,S-1]
+    s = attn.mean(axis=1)                                        # [B,1,S-1]
+    s = np.repeat(s, keys.shape[1], axis=1)
+    pad = np.full(s.shape[:-1] + (1,), s.max() + 1.0, dtype=s.dtype)
+    return np.concatenate([s, pad], axis=-1).astype(np.float32)
+
+
+def pyramidkv_budget(q_len: int, compression_ratio: float, window_size: int, beta: int, num_layers: int, layer_idx: int) -> int:
+    """PyramidKVPress.get_layer_budget (pyramidkv_press.py:47-81): a linear ramp of per-layer budgets from max_num
+    (layer 0) to min_num (last layer) whose mean keeps q_len * (1 - ratio) tokens; falls back to the SnapKV budget
+    ``round(q_len * (1 - ratio))`` when the ramp would leave [window_size, q_len]."""
+    assert beta >= 1
+    cap = window_size + q_len * (1 - compression_ratio)
+    lo = (cap - window_size) / beta
+    hi = (cap - window_size) * 2 - lo
+    if hi >= q_len - window_size:
+        hi = q_len - window_size
+        lo = (cap - window_size) * 2 - hi
+    if not (q_len >= hi >= lo >= window_size):
+        return round(q_len * (1 - compression_ratio))
+    step = (hi - lo) / (num_layers - 1)
+    return round(hi - layer_idx * step)
+
+
+def streaming_llm_score(B: int, H: int, k_len: int, compression_ratio: float, n_sink: int = 4) -> np.ndarray:
+    """StreamingLLMPress.score (streaming_llm_press.py:47-52): ones, zeros on the n_pruned positions after the sinks."""
+    assert k_len > n_sink
+    n_pruned = k_len - int(k_len * (1 - compression_ratio))
+    s = np.ones((B, H, k_len), dtype=np.float32)
+    s[:, :, n_sink:n_sink + n_pruned] = 0
+    return s

@@ -9,10 +9,12 @@ WHAT="${*:-tests bench}"
 python __graft_entry__.py > gpurun_out/build.log 2>&1; echo "build rc=$?"
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
 if [[ "$WHAT" == *tests* ]]; then
-  for grp in rownorm topk gather snapkv_kernel snapkv_from snapkv_fused ea_qstats ea_score full_chain press_fp32 press_native; do
+  for grp in rownorm topk gather snapkv_kernel snapkv_from snapkv_fused ea_qstats ea_score full_chain keydiff head_mean tova_from random_press press_fp32 press_native; do
     timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --no-header -k "$grp" > gpurun_out/test_$grp.log 2>&1
     echo "tests[$grp] rc=$? $(tail -1 gpurun_out/test_$grp.log)"
   done
+  timeout 600 python -m pytest tests/test_pipeline.py -m gpu -q --no-header > gpurun_out/test_pipeline.log 2>&1
+  echo "tests[pipeline] rc=$? $(tail -1 gpurun_out/test_pipeline.log)"
   timeout 1200 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --no-header > gpurun_out/test_fullsize.log 2>&1
   echo "tests[fullsize] rc=$? $(tail -1 gpurun_out/test_fullsize.log)"
   timeout 300 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$? $(tail -1 gpurun_out/smoke.log)"
@@ -29,19 +31,6 @@ if [[ "$WHAT" == *ab* ]]; then
     tag=$(echo "$cfg" | tr ' =' '__')
     env $cfg timeout 300 python bench.py --workload knorm128k --steps 20 --warmup 3 --no-cpu-baseline --profile-json gpurun_out/ab_$tag.json > gpurun_out/ab_$tag.log 2>&1
     echo "ab[$cfg] rc=$? $(python -c "import json;d=json.load(open('gpurun_out/ab_$tag.json'));print(round(d['ms_per_step']*1e3,1),'us/step', {k:round(v*1e3,1) for k,v in d['kernels_avg_ms'].items()})" 2>&1)"
-  done
-fi
-if [[ "$WHAT" == *phase* ]]; then
-  for ph in 0 2 3 4 6; do
-    KVP_SK_PHASE=$ph timeout 300 python bench.py --workload snapkv128k --steps 10 --warmup 2 --no-cpu-baseline --profile-json gpurun_out/ph_$ph.json > gpurun_out/ph_$ph.log 2>&1
-    echo "phase[$ph] rc=$? $(python -c "import json;d=json.load(open('gpurun_out/ph_$ph.json'));print(round(d['ms_per_step']*1e3,1), {k:round(v*1e3,1) for k,v in d['kernels_avg_ms'].items() if 'snapkv_p' in k})" 2>&1)"
-  done
-fi
-if [[ "$WHAT" == *abl* ]]; then
-  # timing-only ablations of snapkv_p1_mfma (results are wrong by design)
-  for a in 0 1 2 3 4 5; do
-    KVP_SK_ABL=$a timeout 300 python bench.py --workload snapkv128k --steps 10 --warmup 2 --no-cpu-baseline --profile-json gpurun_out/abl_$a.json > gpurun_out/abl_$a.log 2>&1
-    echo "abl[$a] rc=$? $(python -c "import json;d=json.load(open('gpurun_out/abl_$a.json'));print({k:round(v*1e3,1) for k,v in d['kernels_avg_ms'].items() if 'snapkv_p' in k})" 2>&1)"
   done
 fi
 if [[ "$WHAT" == *pmc* ]]; then

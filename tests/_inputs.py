@@ -66,6 +66,23 @@ CASES = {
                          epsilon=0.01, n_sink=0),
     "ea_f32_d128": dict(kind="ea", B=1, H=2, G=4, S=600, D=128, dtype="f32", data="B", seed=38),
     "ea_6000_B": dict(kind="ea", B=1, H=2, G=4, S=6000, D=128, dtype="bf16", data="B", seed=39),  # MFMA statistics path
+    # ---- KeyDiff / TOVA / PyramidKV / StreamingLLM -------------------------
+    "kd_tiny_d6": dict(kind="keydiff", B=2, H=2, G=1, S=100, D=6, dtype="f32", data="A", seed=41),
+    "kd_bf16_A": dict(kind="keydiff", B=2, H=8, G=1, S=4096, D=128, dtype="bf16", data="A", seed=42),
+    "kd_bf16_B": dict(kind="keydiff", B=1, H=8, G=1, S=3001, D=128, dtype="bf16", data="B", seed=43),
+    "kd_f16_d64": dict(kind="keydiff", B=1, H=4, G=1, S=1000, D=64, dtype="f16", data="A", seed=44),
+    "kd_d96_bf16": dict(kind="keydiff", B=2, H=3, G=1, S=515, D=96, dtype="bf16", data="B", seed=45),
+    "tv_tiny": dict(kind="tova", B=2, H=2, G=2, S=100, D=16, dtype="f32", data="A", seed=51, W=1, ks=1),
+    "tv_257": dict(kind="tova", B=2, H=2, G=4, S=257, D=128, dtype="bf16", data="A", seed=52, W=1, ks=1),
+    "tv_4096_B": dict(kind="tova", B=1, H=2, G=4, S=4096, D=128, dtype="bf16", data="B", seed=53, W=1, ks=1),
+    "py_l0": dict(kind="pyramid", B=1, H=2, G=2, S=400, D=16, dtype="f32", data="A", seed=61, W=8, ks=5,
+                  n_layers=8, layer_idx=0, beta=20, ratios=(0.3, 0.5, 0.8)),
+    "py_l5": dict(kind="pyramid", B=1, H=2, G=2, S=400, D=16, dtype="f32", data="B", seed=62, W=8, ks=5,
+                  n_layers=8, layer_idx=5, beta=20, ratios=(0.3, 0.5, 0.8)),
+    "py_bf16_l7": dict(kind="pyramid", B=1, H=2, G=4, S=1000, D=128, dtype="bf16", data="A", seed=63, W=64, ks=5,
+                       n_layers=8, layer_idx=7, beta=5, ratios=(0.5, 0.9)),
+    "st_tiny": dict(kind="streaming", B=1, H=2, G=1, S=100, D=8, dtype="f32", data="A", seed=71),
+    "st_sink0": dict(kind="streaming", B=2, H=2, G=1, S=257, D=8, dtype="f32", data="A", seed=72, n_sink=0),
 }
 
 _DEFAULTS = dict(W=64, ks=5, n_future=512, n_sink=4, use_covariance=True, use_vnorm=True, epsilon=0.0,
@@ -140,4 +157,54 @@ def build_llama_attention(s: dict, dtype, device="cpu"):
     hidden = torch.from_numpy(s["hidden"]).to(device=device, dtype=dtype)
     pos = torch.arange(s["S"], device=device)[None]
     cos, sin = rot(hidden, pos)
+    if "n_layers" in s:  # PyramidKV's budget reads the layer's place in the stack (pyramidkv_press.py:80-81)
+        att.config.num_hidden_layers = s["n_layers"]
+        att.layer_idx = s["layer_idx"]
     return att, rot, hidden, (cos, sin)
+
+
+# ---- tiny end-to-end fixtures (pipeline tests) -----------------------------------------------------
+TINY_WORDS = [f"w{i}" for i in range(56)]
+
+
+def make_tiny_llama(seed: int = 0, dtype=None, device="cpu"):
+    """The reference's unit-test geometry (2 layers, 2 KV heads, head_dim 6), random-init, eos = 2."""
+    import torch
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    cfg = LlamaConfig(hidden_size=24, num_attention_heads=4, num_key_value_heads=2, head_dim=6, num_hidden_layers=2,
+                      intermediate_size=32, vocab_size=64, max_position_embeddings=512, bos_token_id=1, eos_token_id=2,
+                      pad_token_id=0)
+    torch.manual_seed(seed)
+    model = LlamaForCausalLM(cfg).eval()
+    if dtype is not None:
+        model = model.to(dtype)
+    return model.to(device)
+
+
+def make_tiny_tokenizer():
+    """Word-level tokenizer built in memory (no download): <unk>=0 <s>=1 </s>=2, then w0..w55; no chat template."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+
+    vocab = {"<unk>": 0, "<s>": 1, "</s>": 2}
+    for w in TINY_WORDS:
+        vocab[w] = len(vocab)
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    return PreTrainedTokenizerFast(tokenizer_object=tk, bos_token="<s>", eos_token="</s>", unk_token="<unk>",
+                                   model_max_length=512)
+
+
+def tiny_context(n_words: int, seed: int = 0) -> str:
+    rng = np.random.default_rng(seed)
+    return " ".join(TINY_WORDS[i] for i in rng.integers(0, len(TINY_WORDS), n_words))
+
+
+PIPELINE_CASES = {
+    # name: (press kind, press kwargs, context words, questions, max_new_tokens)
+    "pipe_knorm": ("knorm", dict(compression_ratio=0.5), 120, ["w1 w2 w3", "w7"], 8),
+    "pipe_snapkv": ("snapkv", dict(compression_ratio=0.5, window_size=16, kernel_size=5), 150, ["w4 w5"], 8),
+    "pipe_ea": ("ea", dict(compression_ratio=0.4), 23, ["w9 w10 w11 w12 w13"], 6),
+    "pipe_none": (None, {}, 40, ["w3"], 6),
+}

@@ -29,3 +29,64 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# ---- CPU stand-in for the HIP entry points (tests of the HOST logic only) ---------------------------------------
+# The HIP kernels cannot run in the build container, so host-logic tests swap kvpress_amd._native's entry points for
+# oracle-backed fakes.  Test infrastructure only: the product has no such switch and fails loudly without the library.
+@pytest.fixture
+def fake_native(monkeypatch):
+    import numpy as np
+    import torch
+
+    from kvpress_amd import _native
+    from oracle import kvpress_oracle as O
+
+    def rownorm_score(x, scale):
+        return torch.from_numpy(-float(scale) * O.knorm_score(x.float().numpy()))  # scale * ||x||
+
+    def topk_select(scores, k, order=0):
+        return torch.from_numpy(O.topk_select(scores.float().numpy(), k))
+
+    def gather_kv(keys, values, idx):
+        ko, vo = O.gather_kv(keys.numpy(), values.numpy(), idx.numpy())
+        return torch.from_numpy(ko), torch.from_numpy(vo)
+
+    def snapkv_score(q_win, keys, kernel_size):
+        return torch.from_numpy(O.snapkv_score(q_win.float().numpy(), keys.float().numpy(), kernel_size))
+
+    def snapkv_score_rope(q_pre, cos, sin, keys, kernel_size):
+        q = q_pre.double().numpy()
+        c, s = cos.double().numpy()[:, None], sin.double().numpy()[:, None]
+        q_rot = q * c + O.rotate_half(q) * s  # snapkv_press.py:56-58
+        return torch.from_numpy(O.snapkv_score(q_rot, keys.float().numpy(), kernel_size))
+
+    def snapkv_score_from_attn(attn_win, num_kv_heads, k_len, kernel_size):
+        a = attn_win.double().numpy()
+        B, Hq, W, Sm = a.shape
+        full = np.zeros((B, Hq, W, k_len))
+        full[..., :Sm] = a
+        return torch.from_numpy(O.snapkv_score_from_attentions(full, num_kv_heads, W, kernel_size))
+
+    def keydiff_score(keys):
+        return torch.from_numpy(O.keydiff_score(keys.float().numpy()))
+
+    def scores_head_mean_(scores):
+        scores.copy_(scores.mean(dim=1, keepdim=True).expand_as(scores).clone())
+        return scores
+
+    def ea_qstats(q, use_cov=True):
+        mu, cov = O.ea_query_stats(q.float().numpy(), use_cov)
+        return torch.from_numpy(mu.astype(np.float32)), (torch.from_numpy(cov.astype(np.float32)) if cov is not None else None)
+
+    def ea_score(keys, values, mu, cov, n_sink, use_vnorm, eps):
+        return torch.from_numpy(O.ea_score(keys.float().numpy(), values.float().numpy(), mu.numpy(),
+                                           cov.numpy() if cov is not None else None, n_sink, use_vnorm, eps))
+
+    for name, fn in dict(rownorm_score=rownorm_score, topk_select=topk_select, gather_kv=gather_kv,
+                         snapkv_score=snapkv_score, snapkv_score_rope=snapkv_score_rope, snapkv_score_from_attn=snapkv_score_from_attn,
+                         keydiff_score=keydiff_score, scores_head_mean_=scores_head_mean_, ea_qstats=ea_qstats, ea_score=ea_score).items():
+        monkeypatch.setattr(_native, name, fn)
+    return _native
+
+

@@ -226,6 +226,83 @@ def test_ea_score_kernel_vs_oracle(name):
         assert np.all(got[..., :ns] == np.float32(got[..., ns:].max()) + np.float32(1.0))
 
 
+KD = [n for n, c in _inputs.CASES.items() if c["kind"] == "keydiff"]
+
+
+@pytest.mark.parametrize("name", KD)
+def test_keydiff_kernel_vs_oracle(name):
+    """kvp_keydiff_score in the case's dtype against the float64 restatement on the same (dtype-exact) keys."""
+    s = _inputs.make_case(name)
+    k = to_dev(s["keys"], s["dtype"])
+    got = native().keydiff_score(k).cpu().numpy()
+    np.testing.assert_allclose(got, O.keydiff_score(s["keys"]), rtol=0, atol=2e-6, err_msg=name)
+    # strided view (every second token), the way wrapper presses hand over slices
+    got2 = native().keydiff_score(k[:, :, ::2]).cpu().numpy()
+    np.testing.assert_allclose(got2, O.keydiff_score(s["keys"][:, :, ::2]), rtol=0, atol=2e-6, err_msg=name)
+
+
+def test_keydiff_is_deterministic_and_handles_zero_rows():
+    rs = np.random.RandomState(3)
+    k = rs.standard_normal((1, 2, 5000, 128)).astype(np.float32)
+    k[0, 0, 17] = 0.0   # an all-zero key: normalize -> 0, cosine -> 0
+    kd = to_dev(_inputs.round_to(k, "bf16"), "bf16")
+    a = native().keydiff_score(kd)
+    b = native().keydiff_score(kd)
+    assert torch.equal(a, b)
+    assert a[0, 0, 17].item() == 0.0
+    np.testing.assert_allclose(a.cpu().numpy(), O.keydiff_score(_inputs.round_to(k, "bf16")), rtol=0, atol=2e-6)
+
+
+def test_scores_head_mean():
+    rs = np.random.RandomState(4)
+    x = rs.standard_normal((3, 8, 1001)).astype(np.float32)
+    t = torch.from_numpy(x).to(DEV)
+    out = native().scores_head_mean_(t)
+    assert out.data_ptr() == t.data_ptr()
+    want = np.repeat(x.astype(np.float64).mean(1, keepdims=True), 8, axis=1)
+    np.testing.assert_allclose(t.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+    # a strided view: heads 1::2 of a larger tensor
+    big = torch.from_numpy(rs.standard_normal((2, 6, 500)).astype(np.float32)).to(DEV)
+    ref = big.clone()
+    native().scores_head_mean_(big[:, 1::2])
+    assert torch.equal(big[:, 0::2], ref[:, 0::2])
+    np.testing.assert_allclose(big[:, 1::2].cpu().numpy(), np.repeat(ref[:, 1::2].cpu().numpy().mean(1, keepdims=True), 3, 1),
+                               rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", [n for n, c in _inputs.CASES.items() if c["kind"] == "tova"])
+def test_tova_from_attentions(name):
+    """TOVA when the layer returns attention weights (tova_press.py:45-46): last row, all but the last column."""
+    import kvpress_amd as P
+
+    s = _inputs.make_case(name)
+    att, rot, hidden, (cos, sin) = _inputs.build_llama_attention(s, torch.float32)
+    q = O.snapkv_window_queries(s["hidden"], s["wq"], None, cos.numpy(), sin.numpy(), s["Hq"], s["D"], 1)
+    wa = O.snapkv_window_attention(q, s["keys"])                       # [B,Hq,1,S-1]
+    full = np.zeros((s["B"], s["Hq"], 3, s["S"]), dtype=np.float32)    # a 3-row stand-in for [.., S, S]
+    full[:, :, -1:, :-1] = wa
+    keys = to_dev(s["keys"], "f32")
+    sc = P.TOVAPress(0.5).score(None, None, keys, keys, torch.from_numpy(full).to(DEV), {})
+    want = O.tova_score(q, s["keys"])
+    assert_scores_close(sc.cpu().numpy()[..., :-1], want[..., :-1], RTOL, name)
+    assert (sc[..., -1:] > sc[..., :-1].amax()).all()
+
+
+def test_random_press_properties():
+    import kvpress_amd as P
+
+    k = torch.randn(2, 4, 300, 64, device=DEV, dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    p = P.RandomPress(compression_ratio=0.5, seed=7)
+    s1, s2 = p.score(None, None, k, v, None, {}), p.score(None, None, k, v, None, {})
+    assert torch.equal(s1, s2) and s1.dtype == torch.float32 and tuple(s1.shape) == (2, 4, 300)
+    ko, vo = p.compress(None, None, k, v, None, {})
+    assert tuple(ko.shape) == (2, 4, 150, 64)
+    idx = native().topk_select(s1, 150).cpu().numpy()
+    wk, wv = O.gather_kv(k.float().cpu().numpy(), v.float().cpu().numpy(), idx)
+    assert np.array_equal(ko.float().cpu().numpy(), wk) and np.array_equal(vo.float().cpu().numpy(), wv)
+
+
 # ---------------------------------------------------------------------------------------------
 # press level: the public classes against the committed outputs of the real reference
 # ---------------------------------------------------------------------------------------------
@@ -236,6 +313,14 @@ def make_press(s, ratio):
         return P.KnormPress(compression_ratio=ratio)
     if s["kind"] == "snapkv":
         return P.SnapKVPress(compression_ratio=ratio, window_size=s["W"], kernel_size=s["ks"])
+    if s["kind"] == "pyramid":
+        return P.PyramidKVPress(compression_ratio=ratio, window_size=s["W"], kernel_size=s["ks"], beta=s["beta"])
+    if s["kind"] == "tova":
+        return P.TOVAPress(compression_ratio=ratio)
+    if s["kind"] == "keydiff":
+        return P.KeyDiffPress(compression_ratio=ratio)
+    if s["kind"] == "streaming":
+        return P.StreamingLLMPress(compression_ratio=ratio, n_sink=s["n_sink"])
     return P.ExpectedAttentionPress(compression_ratio=ratio, n_future_positions=s["n_future"], n_sink=s["n_sink"],
                                     use_covariance=s["use_covariance"], use_vnorm=s["use_vnorm"], epsilon=s["epsilon"])
 
@@ -255,9 +340,13 @@ def test_press_fp32_vs_reference(name):
         got = sc.cpu().numpy()
         ref = g["scores_f32"]
         pad = slice(None)
-        if s["kind"] == "snapkv":
+        if s["kind"] in ("snapkv", "pyramid", "tova"):
             assert_scores_close(got[..., :-s["W"]], ref[..., :-s["W"]], RTOL, name)
             assert (got[..., -s["W"]:] > got[..., :-s["W"]].max()).all()
+        elif s["kind"] == "keydiff":  # a cosine in [-1, 1] crossing zero: absolute tolerance
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5, err_msg=name)
+        elif s["kind"] == "streaming":
+            assert np.array_equal(got, ref)
         elif s["kind"] == "ea":
             assert_scores_close(got[..., s["n_sink"]:], ref[..., s["n_sink"]:], RTOL, name)
             if s["n_sink"]:
@@ -269,6 +358,10 @@ def test_press_fp32_vs_reference(name):
             n = int(g[f"nkept_{i}"])
             assert tuple(ko.shape) == tuple(vo.shape) == (s["B"], s["H"], n, s["D"])
             assert ko.is_contiguous() and vo.is_contiguous() and ko.dtype == keys.dtype
+            if s["kind"] == "streaming":  # the 0/1 scores depend on the ratio; the kept set is pinned exactly
+                sc = make_press(s, r).score(att, hidden, keys, values, None, kwargs)
+                ref = O.streaming_llm_score(s["B"], s["H"], s["S"], r, s["n_sink"])
+                assert np.array_equal(native().topk_select(sc, n).cpu().numpy(), g[f"idx_f32_{i}"])
             idx = native().topk_select(sc, n).cpu().numpy()
             ok, msg = O.topk_is_valid(ref, idx, n, rel_band=1e-4)
             assert ok, f"{name} r={r}: {msg}"

@@ -12,43 +12,6 @@ import torch
 from oracle import kvpress_oracle as O
 
 
-@pytest.fixture
-def fake_native(monkeypatch):
-    from kvpress_amd import _native
-
-    def rownorm_score(x, scale):
-        return torch.from_numpy(-float(scale) * O.knorm_score(x.float().numpy()))  # scale * ||x||
-
-    def topk_select(scores, k, order=0):
-        return torch.from_numpy(O.topk_select(scores.float().numpy(), k))
-
-    def gather_kv(keys, values, idx):
-        ko, vo = O.gather_kv(keys.numpy(), values.numpy(), idx.numpy())
-        return torch.from_numpy(ko), torch.from_numpy(vo)
-
-    def snapkv_score(q_win, keys, kernel_size):
-        return torch.from_numpy(O.snapkv_score(q_win.float().numpy(), keys.float().numpy(), kernel_size))
-
-    def snapkv_score_rope(q_pre, cos, sin, keys, kernel_size):
-        q = q_pre.double().numpy()
-        c, s = cos.double().numpy()[:, None], sin.double().numpy()[:, None]
-        q_rot = q * c + O.rotate_half(q) * s  # snapkv_press.py:56-58
-        return torch.from_numpy(O.snapkv_score(q_rot, keys.float().numpy(), kernel_size))
-
-    def ea_qstats(q, use_cov=True):
-        mu, cov = O.ea_query_stats(q.float().numpy(), use_cov)
-        return torch.from_numpy(mu.astype(np.float32)), (torch.from_numpy(cov.astype(np.float32)) if cov is not None else None)
-
-    def ea_score(keys, values, mu, cov, n_sink, use_vnorm, eps):
-        return torch.from_numpy(O.ea_score(keys.float().numpy(), values.float().numpy(), mu.numpy(),
-                                           cov.numpy() if cov is not None else None, n_sink, use_vnorm, eps))
-
-    for name, fn in dict(rownorm_score=rownorm_score, topk_select=topk_select, gather_kv=gather_kv,
-                         snapkv_score=snapkv_score, snapkv_score_rope=snapkv_score_rope, ea_qstats=ea_qstats, ea_score=ea_score).items():
-        monkeypatch.setattr(_native, name, fn)
-    return _native
-
-
 @pytest.fixture(scope="module")
 def tiny_llama():
     from transformers import LlamaConfig, LlamaForCausalLM

@@ -20,13 +20,20 @@ def oracle_scores(s, cos=None, sin=None):
     """Oracle chain for a case, from the same seeded inputs the reference saw."""
     if s["kind"] == "knorm":
         return O.knorm_score(s["keys"])
+    if s["kind"] == "keydiff":
+        return O.keydiff_score(s["keys"])
+    if s["kind"] == "streaming":
+        return O.streaming_llm_score(s["B"], s["H"], s["S"], 0.5, s["n_sink"])  # the fixture's scores are those of ratio 0.5
     import torch
 
     att, rot, hidden, (cos, sin) = _inputs.build_llama_attention(s, torch.float32)
     cos, sin = cos.numpy(), sin.numpy()
-    if s["kind"] == "snapkv":
+    if s["kind"] in ("snapkv", "pyramid"):  # PyramidKV scores are SnapKV's; only the budget differs
         q = O.snapkv_window_queries(s["hidden"], s["wq"], None, cos, sin, s["Hq"], s["D"], s["W"])
         return O.snapkv_score(q, s["keys"], s["ks"])
+    if s["kind"] == "tova":
+        q = O.snapkv_window_queries(s["hidden"], s["wq"], None, cos, sin, s["Hq"], s["D"], 1)
+        return O.tova_score(q, s["keys"])
     # ea: q = q_proj(hidden[:, n_sink:])  (expected_attention_press.py:70-71, utils.py:43-46)
     h = s["hidden"][:, s["n_sink"]:].astype(np.float64)
     q = (h @ s["wq"].astype(np.float64).T).reshape(s["B"], -1, s["Hq"], s["D"]).transpose(0, 2, 1, 3)
@@ -45,7 +52,8 @@ def test_oracle_scores_match_reference(name):
     ref = g["scores_f32"]
     assert sc.shape == ref.shape == (s["B"], s["H"], s["S"])
     # float32 reference vs float64 oracle: both approximate the same math
-    np.testing.assert_allclose(sc, ref, rtol=2e-4, atol=1e-30)
+    # (KeyDiff: a cosine in [-1, 1] that crosses zero -> absolute tolerance)
+    np.testing.assert_allclose(sc, ref, rtol=2e-4, atol=2e-6 if s["kind"] == "keydiff" else 1e-30)
 
 
 @pytest.mark.parametrize("name", ALL)
@@ -54,8 +62,14 @@ def test_oracle_topk_matches_reference(name):
     g = load(name)
     ref = g["scores_f32"]
     for i, r in enumerate(s["ratios"]):
-        n = O.n_kept(s["S"], r)
-        assert n == int(g[f"nkept_{i}"]), "n_kept = int(S*(1-r)) (scorer_press.py:94)"
+        if s["kind"] == "pyramid":
+            n = O.pyramidkv_budget(s["S"], r, s["W"], s["beta"], s["n_layers"], s["layer_idx"])
+            assert n == int(g[f"nkept_{i}"]), "per-layer budget (pyramidkv_press.py:47-81)"
+        else:
+            n = O.n_kept(s["S"], r)
+            assert n == int(g[f"nkept_{i}"]), "n_kept = int(S*(1-r)) (scorer_press.py:94)"
+        if s["kind"] == "streaming":
+            ref = O.streaming_llm_score(s["B"], s["H"], s["S"], r, s["n_sink"])
         idx = O.topk_select(ref, n)
         gold = g[f"idx_f32_{i}"]
         assert idx.shape == gold.shape
