@@ -126,6 +126,28 @@ int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
                   int64_t B, int64_t H, int64_t S, int64_t D,
                   const int32_t* idx, int64_t n, void* k_out, void* v_out, kvp_stream_t stream);
 
+/* ---- fused ScorerPress.compress (scorer_press.py:76-102 with the scorer inlined) ---------------------------------
+ * One call = score -> select n_kept -> gather into caller-allocated contiguous k_out / v_out [B,H,n_kept,D].  Same
+ * kernels and results as the modular sequence kvp_*_score + kvp_topk_select + kvp_gather_kv; the score-writing kernel
+ * also accumulates the select's first histogram, and SnapKV's window columns are appended to the selection instead of
+ * being scored with max + 1 (snapkv_press.py:103), which removes the global max and the pad fill.
+ * flags: KVP_TOPK_WS_CLEAN if the first kvp_topk_workspace_bytes(R, S, n_kept) bytes of ws were zero-filled once and
+ * the workspace has only been used by these calls on ONE stream since (they leave it clean), else 0. */
+size_t kvp_knorm_compress_workspace_bytes(int64_t B, int64_t H, int64_t S, int64_t n_kept);
+int kvp_knorm_compress(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
+                       const void* v, int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype,
+                       int64_t B, int64_t H, int64_t S, int64_t D, int64_t n_kept,
+                       void* k_out, void* v_out, void* ws, size_t ws_bytes, int flags, kvp_stream_t stream);
+size_t kvp_snapkv_compress_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int64_t n_kept);
+/* arguments as kvp_snapkv_score_rope (pre-RoPE window queries + the window's cos/sin) plus V and the outputs */
+int kvp_snapkv_compress_rope(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw,
+                             const void* cos, const void* sin, int64_t cs_sb, int64_t cs_sw,
+                             const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
+                             const void* v, int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype,
+                             int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
+                             int64_t n_kept, void* k_out, void* v_out, void* ws, size_t ws_bytes, int flags,
+                             kvp_stream_t stream);
+
 /* ---- KeyDiffPress.score (kvpress/presses/keydiff_press.py:45-46) ----------------------------------
  * anchor[b,h,:] = mean_s k[b,h,s,:] / max(||k[b,h,s,:]||, 1e-12)   (F.normalize(keys).mean(dim=2))
  * scores[b,h,s] = -cosine_similarity(k[b,h,s,:], anchor[b,h,:])     (eps 1e-8), contiguous [B,H,S] float32. */

@@ -28,6 +28,13 @@ SIGNATURES = {
     "kvp_version": (c_int, []),
     "kvp_last_error": (c_char_p, []),
     "kvp_rownorm_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_float, c_void_p, c_void_p]),
+    "kvp_knorm_compress_workspace_bytes": (c_size_t, [_I64] * 4),
+    "kvp_knorm_compress": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64,
+                                   c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "kvp_snapkv_compress_workspace_bytes": (c_size_t, [_I64] * 7),
+    "kvp_snapkv_compress_rope": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, c_void_p, _I64, _I64, c_void_p, _I64, _I64, _I64,
+                                         c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _I64,
+                                         c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "kvp_keydiff_workspace_bytes": (c_size_t, [_I64] * 4),
     "kvp_keydiff_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_scores_head_mean": (c_int, [c_void_p, _I64, _I64, _I64, _I64, _I64, c_void_p]),
@@ -281,6 +288,80 @@ def topk_select(scores: torch.Tensor, k: int, order: int = ORDER_POSITION) -> to
             _check(lib().kvp_topk_select(_p(s2), R, S, s2.stride(0) if R > 1 else S, int(k), int(order) | TOPK_WS_CLEAN, _p(idx),
                                          _p(ws), ws.numel(), _stream(s)), "kvp_topk_select")
     return idx.reshape(*lead, k)
+
+
+def _clean_ws(kind: str, shape: tuple, nbytes: int, like: torch.Tensor) -> torch.Tensor:
+    """Zero-filled-once workspace of a fused compress call, one per (device, stream, call shape): the calls leave its
+    histogram region clean, so it is passed with KVP_TOPK_WS_CLEAN from then on."""
+    stream = torch.cuda.current_stream(like.device)
+    key = (kind, like.device.index, stream.cuda_stream) + tuple(shape)
+    ws = _TOPK_WS.get(key)
+    if ws is None:
+        if len(_TOPK_WS) > 64:
+            _TOPK_WS.clear()
+        ws = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
+        _TOPK_WS[key] = ws
+    return ws
+
+
+def _drop_ws(ws: torch.Tensor):
+    for key in [k for k, v in _TOPK_WS.items() if v is ws]:
+        del _TOPK_WS[key]
+
+
+def knorm_compress(keys: torch.Tensor, values: torch.Tensor, n_kept: int):
+    """KnormPress.compress in one library call: (K', V') contiguous [B,H,n_kept,D]."""
+    keys = _rows_last_contig(_dev(keys))
+    values = _rows_last_contig(_dev(values))
+    assert keys.dtype == values.dtype and keys.shape == values.shape
+    B, H, S, D = keys.shape
+    n = int(n_kept)
+    ko = torch.empty((B, H, n, D), dtype=keys.dtype, device=keys.device)
+    vo = torch.empty_like(ko)
+    if n and B and H:
+        with torch.cuda.device(keys.device):
+            ws = _clean_ws("knorm", (B, H, S, n), lib().kvp_knorm_compress_workspace_bytes(B, H, S, n), keys)
+            rc = lib().kvp_knorm_compress(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _p(values), _st(values, 0), _st(values, 1),
+                                          _st(values, 2), _DTYPES[keys.dtype], B, H, S, D, n, _p(ko), _p(vo), _p(ws), ws.numel(),
+                                          TOPK_WS_CLEAN, _stream(keys))
+            if rc != 0:
+                _drop_ws(ws)
+            _check(rc, "kvp_knorm_compress")
+    return ko, vo
+
+
+def snapkv_compress_rope(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, keys: torch.Tensor, values: torch.Tensor,
+                         kernel_size: int, n_kept: int):
+    """SnapKVPress.compress (attentions=None) in one library call from the pre-RoPE window queries."""
+    keys = _rows_last_contig(_dev(keys))
+    values = _rows_last_contig(_dev(values))
+    q_pre = _rows_last_contig(_dev(q_pre))
+    dt = keys.dtype
+    assert values.dtype == dt and keys.shape == values.shape
+    if q_pre.dtype != dt:
+        q_pre = q_pre.to(dt)
+    cos = _rows_last_contig(_dev(cos.to(dt)))
+    sin = _rows_last_contig(_dev(sin.to(dt)))
+    B, Hq, W, D = q_pre.shape
+    Bk, Hkv, S, Dk = keys.shape
+    assert B == Bk and D == Dk and Hq % Hkv == 0, (q_pre.shape, keys.shape)
+    assert cos.shape == sin.shape and cos.shape[-2:] == (W, D) and cos.shape[0] in (1, B), (cos.shape, q_pre.shape)
+    if sin.stride() != cos.stride():
+        sin, cos = sin.contiguous(), cos.contiguous()
+    n = int(n_kept)
+    ko = torch.empty((B, Hkv, n, D), dtype=dt, device=keys.device)
+    vo = torch.empty_like(ko)
+    if n:
+        with torch.cuda.device(keys.device):
+            ws = _clean_ws("snapkv", (B, Hq, Hkv, S, W, D, n), lib().kvp_snapkv_compress_workspace_bytes(B, Hq, Hkv, S, W, D, n), keys)
+            rc = lib().kvp_snapkv_compress_rope(_p(q_pre), _st(q_pre, 0), _st(q_pre, 1), _st(q_pre, 2), _p(cos), _p(sin), _st(cos, 0),
+                                                _st(cos, 1), _p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _p(values),
+                                                _st(values, 0), _st(values, 1), _st(values, 2), _DTYPES[dt], B, Hq, Hkv, S, W, D,
+                                                int(kernel_size), n, _p(ko), _p(vo), _p(ws), ws.numel(), TOPK_WS_CLEAN, _stream(keys))
+            if rc != 0:
+                _drop_ws(ws)
+            _check(rc, "kvp_snapkv_compress_rope")
+    return ko, vo
 
 
 def gather_kv(keys: torch.Tensor, values: torch.Tensor, idx: torch.Tensor):

@@ -9,6 +9,7 @@
 // Four independent rows per lane are in flight before any reduction starts; the sum of squares
 // is accumulated in fp32 and reduced with xor-shuffles inside the LPR-lane group.
 #include "kvp_common.h"
+#include "topk_internal.h"
 
 namespace {
 
@@ -32,10 +33,17 @@ struct PlaneMap {
     int64_t sb, sh, ss;  // element strides
 };
 
-template <int DT, int LPR, bool NT>
+// HIST: the kernel also accumulates the top-k's first radix histogram of the scores it writes (hist1[bh][4096]).
+template <int DT, int LPR, bool NT, bool HIST>
 __global__ __launch_bounds__(RN_THREADS) void rownorm_vec_kernel(
-    const typename Elem<DT>::T* __restrict__ x, PlaneMap map, uint32_t chunks, float scale, float* __restrict__ out) {
+    const typename Elem<DT>::T* __restrict__ x, PlaneMap map, uint32_t chunks, float scale, float* __restrict__ out,
+    uint32_t* __restrict__ hist1) {
     using T = typename Elem<DT>::T;
+    __shared__ uint32_t lh[HIST ? 4096 : 1];
+    if (HIST) {
+        for (uint32_t i = threadIdx.x; i < 4096; i += RN_THREADS) lh[i] = 0;
+        __syncthreads();
+    }
     constexpr int PER16 = Elem<DT>::PER16;
     constexpr int GPB = RN_THREADS / LPR;  // row groups per block
     const uint32_t bh = blockIdx.y;
@@ -67,8 +75,15 @@ __global__ __launch_bounds__(RN_THREADS) void rownorm_vec_kernel(
             }
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-            if (lir == 0 && s < S) ob[s] = scale * sqrtf(acc);
+            const float sc = scale * sqrtf(acc);
+            if (lir == 0 && s < S) ob[s] = sc;
+            // 64 / LPR scores per wave: plain LDS atomics (the wave-aggregated topk_hist1_add costs more than it saves here)
+            if (HIST && lir == 0 && s < S) atomicAdd(&lh[float_to_key(sc) >> 20], 1u);
         }
+    }
+    if (HIST) {
+        __syncthreads();
+        topk_hist1_flush(lh, hist1 + (size_t)bh * 4096);
     }
 }
 
@@ -90,8 +105,9 @@ __global__ __launch_bounds__(RN_THREADS) void rownorm_scalar_kernel(
     }
 }
 
+// returns 1 if hist1 was requested and produced (vector path only), else 0
 template <int DT>
-int launch_rownorm(const void* x, PlaneMap map, uint32_t BH, uint32_t D, float scale, float* out, hipStream_t stream) {
+int launch_rownorm(const void* x, PlaneMap map, uint32_t BH, uint32_t D, float scale, float* out, uint32_t* hist1, hipStream_t stream) {
     using T = typename Elem<DT>::T;
     const T* xp = static_cast<const T*>(x);
     const size_t es = sizeof(T);
@@ -114,21 +130,25 @@ int launch_rownorm(const void* x, PlaneMap map, uint32_t BH, uint32_t D, float s
     static const bool nt = kvp_env_int("KVP_RN_NT", 0) != 0;
 #define KVP_RN_CASE(L)                                                                                     \
     case L:                                                                                                \
-        if (nt) KVP_LAUNCH("rownorm_vec_kernel", stream, rownorm_vec_kernel<DT, L, true><<<dim3(bx, BH), RN_THREADS, 0, stream>>>(xp, map, chunks, scale, out)); \
-        else KVP_LAUNCH("rownorm_vec_kernel", stream, rownorm_vec_kernel<DT, L, false><<<dim3(bx, BH), RN_THREADS, 0, stream>>>(xp, map, chunks, scale, out)); \
+        if (hist1) KVP_LAUNCH("rownorm_vec_kernel", stream, rownorm_vec_kernel<DT, L, false, true><<<dim3(bx, BH), RN_THREADS, 0, stream>>>(xp, map, chunks, scale, out, hist1)); \
+        else if (nt) KVP_LAUNCH("rownorm_vec_kernel", stream, rownorm_vec_kernel<DT, L, true, false><<<dim3(bx, BH), RN_THREADS, 0, stream>>>(xp, map, chunks, scale, out, nullptr)); \
+        else KVP_LAUNCH("rownorm_vec_kernel", stream, rownorm_vec_kernel<DT, L, false, false><<<dim3(bx, BH), RN_THREADS, 0, stream>>>(xp, map, chunks, scale, out, nullptr)); \
         break;
     switch (lpr) {
         KVP_RN_CASE(1) KVP_RN_CASE(2) KVP_RN_CASE(4) KVP_RN_CASE(8) KVP_RN_CASE(16) KVP_RN_CASE(32) KVP_RN_CASE(64)
     }
 #undef KVP_RN_CASE
-    return 0;
+    return hist1 ? 1 : 0;
 }
 
 }  // namespace
 
-// Internal entry shared with the ExpectedAttention path (||V||).
+// Internal entry shared with the ExpectedAttention path (||V||) and the fused Knorm compress.
+// hist1 (nullable): [B*H][4096] first-pass radix histogram of the top-k over the rows (b, h); *hist1_done tells whether it
+// was produced (only the vector path does; the caller runs the separate pass otherwise).
 int kvp_rownorm_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh,
-                       int64_t ss, float scale, float* out, hipStream_t stream) {
+                       int64_t ss, float scale, float* out, hipStream_t stream, uint32_t* hist1, bool* hist1_done) {
+    if (hist1_done) *hist1_done = false;
     KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "rownorm: bad dtype %d", dtype);
     KVP_CHECK_ARG(B >= 0 && H >= 0 && S >= 0 && D >= 1, "rownorm: bad shape B=%ld H=%ld S=%ld D=%ld", (long)B, (long)H,
                   (long)S, (long)D);
@@ -136,21 +156,24 @@ int kvp_rownorm_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S
     if (nrows64 == 0) return KVP_OK;
     KVP_CHECK_ARG(x && out, "rownorm: null pointer");
     // collapse (h, s) and (b, h) when the view is contiguous across them: fewer, longer planes
-    if (H > 1 && sh == S * ss) { S *= H; H = 1; sh = 0; }
-    if (H == 1 && B > 1 && sb == S * ss) { S *= B; B = 1; sb = 0; }
+    // (not with a fused histogram: its rows are the (b, h) planes)
+    if (!hist1 && H > 1 && sh == S * ss) { S *= H; H = 1; sh = 0; }
+    if (!hist1 && H == 1 && B > 1 && sb == S * ss) { S *= B; B = 1; sb = 0; }
     KVP_CHECK_ARG(S < ((int64_t)1 << 31) && B * H <= 65535, "rownorm: shape too large (S=%ld, B*H=%ld)", (long)S, (long)(B * H));
     PlaneMap map{(uint32_t)H, (uint32_t)S, sb, sh, ss};
     const uint32_t BH = (uint32_t)(B * H);
+    int done = 0;
     switch (dtype) {
-        case KVP_F32: launch_rownorm<KVP_F32>(x, map, BH, (uint32_t)D, scale, out, stream); break;
-        case KVP_F16: launch_rownorm<KVP_F16>(x, map, BH, (uint32_t)D, scale, out, stream); break;
-        default: launch_rownorm<KVP_BF16>(x, map, BH, (uint32_t)D, scale, out, stream); break;
+        case KVP_F32: done = launch_rownorm<KVP_F32>(x, map, BH, (uint32_t)D, scale, out, hist1, stream); break;
+        case KVP_F16: done = launch_rownorm<KVP_F16>(x, map, BH, (uint32_t)D, scale, out, hist1, stream); break;
+        default: done = launch_rownorm<KVP_BF16>(x, map, BH, (uint32_t)D, scale, out, hist1, stream); break;
     }
+    if (hist1_done) *hist1_done = done != 0;
     KVP_CHECK_LAUNCH("rownorm");
     return KVP_OK;
 }
 
 extern "C" int kvp_rownorm_score(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb,
                                  int64_t sh, int64_t ss, float scale, float* out, kvp_stream_t stream) {
-    return kvp_rownorm_launch(x, dtype, B, H, S, D, sb, sh, ss, scale, out, static_cast<hipStream_t>(stream));
+    return kvp_rownorm_launch(x, dtype, B, H, S, D, sb, sh, ss, scale, out, static_cast<hipStream_t>(stream), nullptr, nullptr);
 }

@@ -23,6 +23,7 @@
 #include "kvp_common.h"
 #include "softmax_stats.h"
 #include "snapkv_internal.h"
+#include "topk_internal.h"
 
 namespace {
 
@@ -193,25 +194,43 @@ __global__ __launch_bounds__(SK_THREADS) void snapkv_rope_kernel(const typename 
 }
 
 // ---- avg_pool1d(kernel, pad=kernel/2, zero padded, divisor = kernel) + scaling + global max ----
+// HIST (fused compress): instead of the block maximum for the pad value, the kernel accumulates the top-k's first radix
+// histogram of the S - W scores it writes; the pad columns are appended to the selection by construction.
+template <bool HIST>
 __global__ __launch_bounds__(SK_THREADS) void snapkv_pool_kernel(const float* __restrict__ colsum, uint32_t S, uint32_t W,
                                                                  int pad, float inv, float* __restrict__ scores,
-                                                                 float* __restrict__ bmax) {
+                                                                 float* __restrict__ bmax, uint32_t* __restrict__ hist1) {
     __shared__ float scr[4];
+    __shared__ uint32_t lh[HIST ? 4096 : 1];
+    if (HIST) {
+        for (uint32_t i = threadIdx.x; i < 4096; i += SK_THREADS) lh[i] = 0;
+        __syncthreads();
+    }
     const uint32_t Sm = S - W, bh = blockIdx.y;
     const float* __restrict__ row = colsum + (size_t)bh * Sm;
     float* __restrict__ out = scores + (size_t)bh * S;
     float vmax = KVP_NEG_INF;
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < Sm; c += gridDim.x * blockDim.x) {
+    // (loop bound rounded up to whole waves: the histogram's wave-level aggregation wants converged lanes)
+    const uint32_t Smw = (Sm + 63) & ~63u;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < Smw; c += gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int j = -pad; j <= pad; ++j) {
-            const int cc = (int)c + j;
-            if (cc >= 0 && cc < (int)Sm) s += row[cc];
+        if (c < Sm) {
+            for (int j = -pad; j <= pad; ++j) {
+                const int cc = (int)c + j;
+                if (cc >= 0 && cc < (int)Sm) s += row[cc];
+            }
+            s *= inv;
+            out[c] = s;
+            vmax = fmaxf(vmax, s);
         }
-        s *= inv;
-        out[c] = s;
-        vmax = fmaxf(vmax, s);
+        if (HIST) topk_hist1_add(lh, s, c < Sm);
     }
-    block_store_max(vmax, scr, bmax, blockIdx.y * gridDim.x + blockIdx.x);
+    if (HIST) {
+        __syncthreads();
+        topk_hist1_flush(lh, hist1 + (size_t)bh * 4096);
+    } else {
+        block_store_max(vmax, scr, bmax, blockIdx.y * gridDim.x + blockIdx.x);
+    }
 }
 
 struct SnapWs {
@@ -245,14 +264,20 @@ SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, in
     return w;
 }
 
+// hist1 != nullptr (fused compress): scores[.., :S-W] are written and histogrammed, the pad columns are NOT filled
 int finish_scores(const SnapWs& w, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int kernel_size,
-                  float* scores, hipStream_t stream) {
+                  float* scores, hipStream_t stream, uint32_t* hist1 = nullptr) {
     const uint32_t BH = (uint32_t)(B * Hkv);
     const uint64_t per_row = ((uint64_t)(S - W) + SK_THREADS - 1) / SK_THREADS;
     const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per_row, std::max<uint64_t>(1, 2048 / BH)));
     const int64_t G = Hq / Hkv;
     const float inv = (float)(1.0 / ((double)G * (double)W * (double)kernel_size));
-    KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.bmax));
+    if (hist1) {
+        KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<true><<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.bmax, hist1));
+        KVP_CHECK_LAUNCH("snapkv(pool+hist)");
+        return KVP_OK;
+    }
+    KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<false><<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.bmax, nullptr));
     const uint32_t nfill = BH * (uint32_t)W;
     KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, (uint32_t)(S - W), (uint32_t)W, w.bmax, bx * BH));
     KVP_CHECK_LAUNCH("snapkv(pool/fill)");
@@ -274,11 +299,10 @@ extern "C" size_t kvp_snapkv_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv,
     return carve_snap_ws(nullptr, B, Hq, Hkv, S, W, D).total_bytes;
 }
 
-extern "C" int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* k, int64_t k_sb,
-                                int64_t k_sh, int64_t k_ss, int dtype, int64_t B, int64_t Hq, int64_t Hkv, int64_t S,
-                                int64_t W, int64_t D, int kernel_size, float* scores, void* ws, size_t ws_bytes,
-                                kvp_stream_t stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+int snapkv_score_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* k, int64_t k_sb,
+                      int64_t k_sh, int64_t k_ss, int dtype, int64_t B, int64_t Hq, int64_t Hkv, int64_t S,
+                      int64_t W, int64_t D, int kernel_size, float* scores, void* ws, size_t ws_bytes,
+                      hipStream_t stream, uint32_t* hist1) {
     KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "snapkv: bad dtype %d", dtype);
     if (int rc = check_common(B, Hq, Hkv, S, W, kernel_size)) return rc;
     KVP_CHECK_ARG(D >= 1 && D <= 1024, "snapkv: unsupported head_dim %ld", (long)D);
@@ -321,14 +345,21 @@ extern "C" int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64
 #undef KVP_SK_GENERIC
     }
     KVP_CHECK_LAUNCH("snapkv(p1/p2)");
-    return finish_scores(w, B, Hq, Hkv, S, W, kernel_size, scores, stream);
+    return finish_scores(w, B, Hq, Hkv, S, W, kernel_size, scores, stream, hist1);
 }
 
-extern "C" int kvp_snapkv_score_rope(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
-                                     int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
-                                     int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
-                                     float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
+extern "C" int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* k, int64_t k_sb,
+                                int64_t k_sh, int64_t k_ss, int dtype, int64_t B, int64_t Hq, int64_t Hkv, int64_t S,
+                                int64_t W, int64_t D, int kernel_size, float* scores, void* ws, size_t ws_bytes,
+                                kvp_stream_t stream_) {
+    return snapkv_score_impl(q, q_sb, q_sh, q_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D, kernel_size, scores, ws, ws_bytes,
+                             static_cast<hipStream_t>(stream_), nullptr);
+}
+
+int snapkv_score_rope_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
+                           int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
+                           int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
+                           float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1) {
     KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "snapkv: bad dtype %d", dtype);
     if (int rc = check_common(B, Hq, Hkv, S, W, kernel_size)) return rc;
     KVP_CHECK_ARG(D >= 2 && D <= 1024 && D % 2 == 0, "snapkv: RoPE needs an even head_dim (got %ld)", (long)D);
@@ -351,8 +382,16 @@ extern "C" int kvp_snapkv_score_rope(const void* q, int64_t q_sb, int64_t q_sh, 
     else { KVP_SK_ROPE(KVP_BF16) }
 #undef KVP_SK_ROPE
     KVP_CHECK_LAUNCH("snapkv(rope)");
-    return kvp_snapkv_score(w.qrot, Hq * W * D, W * D, D, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D, kernel_size, scores, ws,
-                            ws_bytes, stream_);
+    return snapkv_score_impl(w.qrot, Hq * W * D, W * D, D, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D, kernel_size, scores, ws,
+                             ws_bytes, stream, hist1);
+}
+
+extern "C" int kvp_snapkv_score_rope(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
+                                     int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
+                                     int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
+                                     float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
+    return snapkv_score_rope_impl(q, q_sb, q_sh, q_sw, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D,
+                                  kernel_size, scores, ws, ws_bytes, static_cast<hipStream_t>(stream_), nullptr);
 }
 
 extern "C" int kvp_snapkv_score_from_attn(const void* attn, int64_t a_sb, int64_t a_sh, int64_t a_sw, int dtype, int64_t B,

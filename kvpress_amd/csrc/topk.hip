@@ -14,51 +14,18 @@
 //                       tables of the chunks before it, scans its keep flags and writes positions
 //                       in ascending order.
 //
-// The row histograms are SELF-CLEANING: K4 zeroes hist1/hist2 (nobody reads them after K3) and K1 zeroes
-// hist3 (next read two launches later), so a workspace that was zero once stays valid call after call and
+// The row histograms are SELF-CLEANING: K4 zeroes hist1/hist2 (nobody reads them after K3) and K2 zeroes
+// hist3 (filled by K3, read by K4), so a workspace that was zero once stays valid call after call and
 // no per-call memset is needed (kvp_topk_select takes a `ws_is_clean` flag; the binding caches a zeroed
-// workspace per device and stream).
+// workspace per device and stream).  K1 can be skipped altogether when the kernel that WROTE the scores already
+// accumulated hist1 (topk_internal.h: topk_hist1_add / topk_hist1_flush; used by the fused compress entry points).
 //
 // Kernel boundaries order the passes (1.5-1.9 us each on MI355X, cheaper than a grid barrier);
 // the only inter-workgroup traffic inside a launch is atomicAdd into the row histograms.
 #include "kvp_common.h"
+#include "topk_internal.h"
 
 namespace {
-
-constexpr int TK_THREADS = 256;
-constexpr int TK_PER = 8;
-constexpr int TK_CHUNK = TK_THREADS * TK_PER;  // 2048 scores per workgroup
-
-struct TopkWs {
-    uint32_t* hist1;       // [R][4096]
-    uint32_t* hist2;       // [R][4096]
-    uint32_t* hist3;       // [R][256]
-    uint32_t* sel;         // [R][4] : b1, k1, b2, k2
-    uint32_t* chunk_hist;  // [R][nchunks][257] suffix counts of the last digit: [d] = #(digit >= d), [256] = 0
-    uint32_t* chunk_gt;    // [R][nchunks]
-    size_t zero_bytes;     // leading bytes that must be zeroed per call (hist1..hist3)
-    size_t total_bytes;
-};
-
-TopkWs carve_ws(void* ws, int64_t R, int64_t nchunks) {
-    TopkWs w;
-    size_t off = 0;
-    char* base = static_cast<char*>(ws);
-    auto take = [&](size_t bytes) {
-        void* p = base ? base + off : nullptr;
-        off += kvp_align_up(bytes, 256);
-        return p;
-    };
-    w.hist1 = (uint32_t*)take((size_t)R * 4096 * 4);
-    w.hist2 = (uint32_t*)take((size_t)R * 4096 * 4);
-    w.hist3 = (uint32_t*)take((size_t)R * 256 * 4);
-    w.zero_bytes = off;
-    w.sel = (uint32_t*)take((size_t)R * 4 * 4);
-    w.chunk_hist = (uint32_t*)take((size_t)R * nchunks * 257 * 4);
-    w.chunk_gt = (uint32_t*)take((size_t)R * nchunks * 4);
-    w.total_bytes = off;
-    return w;
-}
 
 // exclusive prefix sum over the 256 threads of the block (4 waves); lds: >= 4 words
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
@@ -138,9 +105,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_hist12_kernel(const float* __
     }
     for (int i = threadIdx.x; i < 4096; i += TK_THREADS) lh[i] = 0;
     uint32_t b1 = 0, k1 = 0;
-    if (PASS == 1) {
-        if (chunk == 0) w.hist3[(size_t)row * 256 + threadIdx.x] = 0;  // self-cleaning: read again only in K4
-    } else {
+    if (PASS == 2) {
+        if (chunk == 0) w.hist3[(size_t)row * 256 + threadIdx.x] = 0;  // self-cleaning: filled by K3, read by K4
         find_bin<4096>(w.hist1 + (size_t)row * 4096, k, scr, b1, k1);
         if (chunk == 0 && threadIdx.x == 0) {
             w.sel[row * 4 + 0] = b1;
@@ -152,7 +118,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_hist12_kernel(const float* __
     for (int j = 0; j < TK_PER; ++j) {
         const bool valid = base + j * TK_THREADS + threadIdx.x < S;
         if (PASS == 1) {
-            if (valid) atomicAdd(&lh[keys[j] >> 20], 1u);
+            topk_hist_add_bin(lh, keys[j] >> 20, valid);
         } else {
             if (valid && (keys[j] >> 20) == b1) atomicAdd(&lh[(keys[j] >> 8) & 0xFFFu], 1u);
         }
@@ -216,7 +182,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_hist8_kernel(const float* __r
 // ---- K4: ordered compaction --------------------------------------------------------------------
 __global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __restrict__ scores, int64_t row_stride,
                                                                 uint32_t S, uint32_t k, uint32_t nchunks, TopkWs w,
-                                                                int32_t* __restrict__ idx) {
+                                                                int32_t* __restrict__ idx, int64_t idx_stride,
+                                                                uint32_t tail_start, uint32_t tail_n) {
     __shared__ uint32_t scr[8];
     const uint32_t row = blockIdx.y, chunk = blockIdx.x;
     const float* rp = scores + (int64_t)row * row_stride;
@@ -267,7 +234,9 @@ __global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __r
     const uint32_t ex = block_excl_scan(cg | (ce << 16), scr, &tot);  // chunk <= 2048: both fields < 65536
     uint32_t g = gt_before + (ex & 0xFFFFu);
     uint32_t e = eq_before + (ex >> 16);
-    int32_t* out = idx + (size_t)row * k;
+    int32_t* out = idx + (int64_t)row * idx_stride;
+    if (chunk == 0)  // columns kept by construction (pad region after the selected ones)
+        for (uint32_t j = threadIdx.x; j < tail_n; j += TK_THREADS) out[k + j] = (int32_t)(tail_start + j);
 #pragma unroll
     for (int j = 0; j < TK_PER; ++j) {
         const bool valid = p0 + j < S;
@@ -283,9 +252,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __r
 }
 
 // k == S: every position is kept (compression_ratio so small that int(S*(1-r)) == S)
-__global__ void topk_iota_kernel(int32_t* __restrict__ idx, uint32_t S, uint64_t total) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x)
-        idx[i] = (int32_t)(i % S);
+// (also the k == 0 case of a call with a tail: only the tail columns are written)
+__global__ void topk_iota_kernel(int32_t* __restrict__ idx, int64_t idx_stride, uint32_t k, uint32_t tail_start, uint32_t tail_n) {
+    int32_t* out = idx + (int64_t)blockIdx.y * idx_stride;
+    const uint32_t n = k + tail_n;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = (int32_t)(i < k ? i : tail_start + (i - k));
 }
 
 }  // namespace
@@ -294,12 +266,52 @@ extern "C" size_t kvp_topk_workspace_bytes(int64_t R, int64_t S, int64_t k) {
     (void)k;
     if (R <= 0 || S <= 0) return 256;
     const int64_t nchunks = (S + TK_CHUNK - 1) / TK_CHUNK;
-    return carve_ws(nullptr, R, nchunks).total_bytes;
+    return topk_carve_ws(nullptr, R, nchunks).total_bytes;
+}
+
+int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, int64_t idx_stride,
+                     uint32_t tail_start, uint32_t tail_n, void* ws, size_t ws_bytes, bool ws_clean, bool hist1_ready,
+                     hipStream_t stream) {
+    if (R == 0 || k + tail_n == 0) return KVP_OK;
+    KVP_CHECK_ARG(S < ((int64_t)1 << 31) && R <= 65535, "topk: S=%ld or R=%ld too large", (long)S, (long)R);
+    KVP_CHECK_ARG(scores && idx, "topk: null pointer");
+    KVP_CHECK_ARG(row_stride >= S && idx_stride >= k + tail_n, "topk: row_stride %ld < S %ld or idx_stride %ld too small", (long)row_stride,
+                  (long)S, (long)idx_stride);
+    const int64_t nchunks = (S + TK_CHUNK - 1) / TK_CHUNK;
+    TopkWs w = topk_carve_ws(ws, R, nchunks);
+    if (k == S || k == 0) {  // every position / only the tail is kept: no selection needed
+        if (hist1_ready && ws && hipMemsetAsync(w.hist1, 0, (size_t)R * 4096 * 4, stream) != hipSuccess) {  // leave the workspace clean
+            kvp_set_error("topk: hipMemsetAsync failed");
+            return KVP_EHIP;
+        }
+        const uint32_t bx = (uint32_t)std::max<int64_t>(1, std::min<int64_t>((k + tail_n + 255) / 256, 256));
+        KVP_LAUNCH("topk_iota_kernel", stream, topk_iota_kernel<<<dim3(bx, (uint32_t)R), 256, 0, stream>>>(idx, idx_stride, (uint32_t)k, tail_start, tail_n));
+        KVP_CHECK_LAUNCH("topk(iota)");
+        return KVP_OK;
+    }
+    if (!ws || ws_bytes < w.total_bytes) {
+        kvp_set_error("topk: workspace too small (%zu < %zu)", ws_bytes, w.total_bytes);
+        return KVP_EWORKSPACE;
+    }
+    if (!ws_clean) {
+        KVP_CHECK_ARG(!hist1_ready, "topk: a fused first pass needs a clean workspace");
+        if (hipMemsetAsync(ws, 0, w.zero_bytes, stream) != hipSuccess) {
+            kvp_set_error("topk: hipMemsetAsync failed");
+            return KVP_EHIP;
+        }
+    }
+    const dim3 grid((uint32_t)nchunks, (uint32_t)R);
+    if (!hist1_ready)
+        KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<1><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
+    KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<2><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
+    KVP_LAUNCH("topk_hist8_kernel", stream, topk_hist8_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)nchunks, w));
+    KVP_LAUNCH("topk_write_kernel", stream, topk_write_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, (uint32_t)nchunks, w, idx, idx_stride, tail_start, tail_n));
+    KVP_CHECK_LAUNCH("topk");
+    return KVP_OK;
 }
 
 extern "C" int kvp_topk_select(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int order,
                                int32_t* idx, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
     KVP_CHECK_ARG(R >= 0 && S >= 0 && k >= 0 && k <= S, "topk: bad shape R=%ld S=%ld k=%ld", (long)R, (long)S, (long)k);
     const int ord = order & ~KVP_TOPK_WS_CLEAN;
     KVP_CHECK_ARG(ord == KVP_ORDER_POSITION || ord == KVP_ORDER_SCORE, "topk: bad order %d", order);
@@ -307,32 +319,6 @@ extern "C" int kvp_topk_select(const float* scores, int64_t R, int64_t S, int64_
         kvp_set_error("topk: KVP_ORDER_SCORE is not implemented yet (use KVP_ORDER_POSITION)");
         return KVP_EUNSUPPORTED;
     }
-    if (R == 0 || k == 0) return KVP_OK;
-    KVP_CHECK_ARG(S < ((int64_t)1 << 31) && R <= 65535, "topk: S=%ld or R=%ld too large", (long)S, (long)R);
-    KVP_CHECK_ARG(scores && idx, "topk: null pointer");
-    KVP_CHECK_ARG(row_stride >= S, "topk: row_stride %ld < S %ld", (long)row_stride, (long)S);
-    if (k == S) {
-        const uint64_t total = (uint64_t)R * (uint64_t)S;
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 2048);
-        KVP_LAUNCH("topk_iota_kernel", stream, topk_iota_kernel<<<blocks, 256, 0, stream>>>(idx, (uint32_t)S, total));
-        KVP_CHECK_LAUNCH("topk(iota)");
-        return KVP_OK;
-    }
-    const int64_t nchunks = (S + TK_CHUNK - 1) / TK_CHUNK;
-    TopkWs w = carve_ws(ws, R, nchunks);
-    if (!ws || ws_bytes < w.total_bytes) {
-        kvp_set_error("topk: workspace too small (%zu < %zu)", ws_bytes, w.total_bytes);
-        return KVP_EWORKSPACE;
-    }
-    if (!(order & KVP_TOPK_WS_CLEAN) && hipMemsetAsync(ws, 0, w.zero_bytes, stream) != hipSuccess) {
-        kvp_set_error("topk: hipMemsetAsync failed");
-        return KVP_EHIP;
-    }
-    const dim3 grid((uint32_t)nchunks, (uint32_t)R);
-    KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<1><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
-    KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<2><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
-    KVP_LAUNCH("topk_hist8_kernel", stream, topk_hist8_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)nchunks, w));
-    KVP_LAUNCH("topk_write_kernel", stream, topk_write_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, (uint32_t)nchunks, w, idx));
-    KVP_CHECK_LAUNCH("topk");
-    return KVP_OK;
+    return topk_select_impl(scores, R, S, row_stride, k, idx, k, 0, 0, ws, ws_bytes, (order & KVP_TOPK_WS_CLEAN) != 0, false,
+                            static_cast<hipStream_t>(stream_));
 }

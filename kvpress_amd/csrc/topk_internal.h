@@ -1,0 +1,76 @@
+// Internal interface of the radix select (topk.hip) for the fused compress entry points (compress.hip) and for the
+// scorers that accumulate the FIRST histogram pass while they write their scores (rownorm.hip, snapkv.hip).
+#pragma once
+#include "kvp_common.h"
+
+constexpr int TK_THREADS = 256;
+constexpr int TK_PER = 8;
+constexpr int TK_CHUNK = TK_THREADS * TK_PER;  // 2048 scores per workgroup
+
+struct TopkWs {
+    uint32_t* hist1;       // [R][4096]
+    uint32_t* hist2;       // [R][4096]
+    uint32_t* hist3;       // [R][256]
+    uint32_t* sel;         // [R][4] : b1, k1, b2, k2
+    uint32_t* chunk_hist;  // [R][nchunks][257] suffix counts of the last digit: [d] = #(digit >= d), [256] = 0
+    uint32_t* chunk_gt;    // [R][nchunks]
+    size_t zero_bytes;     // leading bytes that must be zeroed per call (hist1..hist3)
+    size_t total_bytes;
+};
+
+inline TopkWs topk_carve_ws(void* ws, int64_t R, int64_t nchunks) {
+    TopkWs w;
+    size_t off = 0;
+    char* base = static_cast<char*>(ws);
+    auto take = [&](size_t bytes) {
+        void* p = base ? base + off : nullptr;
+        off += kvp_align_up(bytes, 256);
+        return p;
+    };
+    w.hist1 = (uint32_t*)take((size_t)R * 4096 * 4);
+    w.hist2 = (uint32_t*)take((size_t)R * 4096 * 4);
+    w.hist3 = (uint32_t*)take((size_t)R * 256 * 4);
+    w.zero_bytes = off;
+    w.sel = (uint32_t*)take((size_t)R * 4 * 4);
+    w.chunk_hist = (uint32_t*)take((size_t)R * nchunks * 257 * 4);
+    w.chunk_gt = (uint32_t*)take((size_t)R * nchunks * 4);
+    w.total_bytes = off;
+    return w;
+}
+
+
+// ---- pass-1 histogram inside a score-producing kernel -------------------------------------------------------------
+// lds_hist: 4096 words, zeroed (and __syncthreads()-ed) by the caller; every thread of the wave must call add()
+// together (`valid` = this lane has a score).  Scores of one layer crowd into a handful of the 4096 (sign, exponent,
+// 3 mantissa bits) bins, so plain LDS atomics serialise; two rounds of wave-level aggregation take the two most
+// common bins out first.
+__device__ __forceinline__ void topk_hist_add_bin(uint32_t* lds_hist, uint32_t bin, bool valid) {
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const uint64_t todo = __ballot(valid);
+        if (todo == 0) return;
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t b0 = __shfl(bin, leader);
+        const uint64_t same = __ballot(valid && bin == b0);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lds_hist[b0], (uint32_t)__popcll(same));
+        valid = valid && bin != b0;
+    }
+    if (valid) atomicAdd(&lds_hist[bin], 1u);
+}
+__device__ __forceinline__ void topk_hist1_add(uint32_t* lds_hist, float score, bool valid) {
+    topk_hist_add_bin(lds_hist, float_to_key(score) >> 20, valid);
+}
+// after a __syncthreads(): add the block's counts to the row's global histogram
+__device__ __forceinline__ void topk_hist1_flush(const uint32_t* lds_hist, uint32_t* __restrict__ hist1_row) {
+    for (uint32_t i = threadIdx.x; i < 4096; i += blockDim.x) {
+        const uint32_t c = lds_hist[i];
+        if (c) atomicAdd(&hist1_row[i], c);
+    }
+}
+
+// Radix select of the k largest of scores[r, 0..S) per row r into idx[r * idx_stride + 0..k), ascending positions,
+// followed by tail_n extra indices tail_start, tail_start + 1, ... (pad columns that are kept by construction).
+// hist1_ready: w.hist1 already holds this call's first-pass histogram (a fused scorer produced it).
+int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, int64_t idx_stride,
+                     uint32_t tail_start, uint32_t tail_n, void* ws, size_t ws_bytes, bool ws_clean, bool hist1_ready,
+                     hipStream_t stream);

@@ -10,7 +10,6 @@ from dataclasses import dataclass
 import torch
 from torch import nn
 
-from kvpress_amd import _native
 from kvpress_amd.presses.snapkv_press import SnapKVPress
 
 
@@ -49,11 +48,7 @@ class PyramidKVPress(SnapKVPress):
         step = (hi - lo) / (module.config.num_hidden_layers - 1)
         return round(hi - module.layer_idx * step)
 
-    def compress(self, module: nn.Module, hidden_states: torch.Tensor, keys: torch.Tensor, values: torch.Tensor,
-                 attentions: torch.Tensor, kwargs: dict) -> tuple[torch.Tensor, torch.Tensor]:
-        if self.compression_ratio == 0:
-            return keys, values
-        scores = self.score(module, hidden_states, keys, values, attentions, kwargs)
-        n_kept = self.get_layer_budget(module, keys.shape[2])      # pyramidkv_press.py:100-101
-        indices = _native.topk_select(scores, n_kept)
-        return _native.gather_kv(keys, values, indices)
+    def n_kept(self, module: nn.Module, k_len: int) -> int:
+        """The per-layer budget replaces ``int(k_len * (1 - ratio))`` (pyramidkv_press.py:100-101); score, select and
+        gather are SnapKVPress's."""
+        return self.get_layer_budget(module, k_len)

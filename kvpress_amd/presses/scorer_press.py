@@ -48,14 +48,16 @@ class ScorerPress(BasePress):
         (scorer_press.py:35-74)."""
         raise NotImplementedError
 
+    def n_kept(self, module: nn.Module, k_len: int) -> int:
+        """Tokens kept per head: ``int(k_len * (1 - compression_ratio))`` in Python double arithmetic
+        (scorer_press.py:93-94); presses with per-layer budgets override this."""
+        return int(k_len * (1 - self.compression_ratio))
+
     def compress(self, module: nn.Module, hidden_states: torch.Tensor, keys: torch.Tensor, values: torch.Tensor,
                  attentions: torch.Tensor, kwargs: dict) -> tuple[torch.Tensor, torch.Tensor]:
         if self.compression_ratio == 0:
             return keys, values
 
         scores = self.score(module, hidden_states, keys, values, attentions, kwargs)
-
-        k_len = keys.shape[2]
-        n_kept = int(k_len * (1 - self.compression_ratio))
-        indices = _native.topk_select(scores, n_kept)        # int32 [B,H,n_kept], ascending position
-        return _native.gather_kv(keys, values, indices)      # contiguous [B,H,n_kept,D]
+        indices = _native.topk_select(scores, self.n_kept(module, keys.shape[2]))  # int32 [B,H,n_kept], ascending position
+        return _native.gather_kv(keys, values, indices)                             # contiguous [B,H,n_kept,D]

@@ -58,3 +58,21 @@ class SnapKVPress(ScorerPress):
         cos, sin = kwargs["position_embeddings"]
         return _native.snapkv_score_rope(q_pre, cos[:, -self.window_size:], sin[:, -self.window_size:], keys,
                                          self.kernel_size)
+
+    def compress(self, module: nn.Module, hidden_states: torch.Tensor, keys: torch.Tensor, values: torch.Tensor,
+                 attentions: torch.Tensor, kwargs: dict) -> tuple[torch.Tensor, torch.Tensor]:
+        """ScorerPress.compress (scorer_press.py:76-102) as ONE library call when the scores come from the window
+        queries (``attentions is None``): RoPE, two attention passes, pooling + first select pass, select, gather; the
+        window tokens are appended to the selection instead of being scored.  Given attention weights, or a
+        subclass with its own ``score``, the generic three-call sequence runs."""
+        if self.compression_ratio == 0:
+            return keys, values
+        if attentions is not None or type(self).score is not SnapKVPress.score:
+            return super().compress(module, hidden_states, keys, values, attentions, kwargs)
+        assert (
+            hidden_states.shape[1] > self.window_size
+        ), f"Query length {hidden_states.shape[1]} should be greater than the window size {self.window_size}"
+        q_pre = get_prerope_query_states(module, hidden_states[:, -self.window_size:])
+        cos, sin = kwargs["position_embeddings"]
+        return _native.snapkv_compress_rope(q_pre, cos[:, -self.window_size:], sin[:, -self.window_size:], keys, values,
+                                            self.kernel_size, self.n_kept(module, keys.shape[2]))

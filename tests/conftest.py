@@ -75,6 +75,12 @@ def fake_native(monkeypatch):
         scores.copy_(scores.mean(dim=1, keepdim=True).expand_as(scores).clone())
         return scores
 
+    def knorm_compress(keys, values, n_kept):
+        return gather_kv(keys, values, topk_select(rownorm_score(keys, -1.0), n_kept))
+
+    def snapkv_compress_rope(q_pre, cos, sin, keys, values, kernel_size, n_kept):
+        return gather_kv(keys, values, topk_select(snapkv_score_rope(q_pre, cos, sin, keys, kernel_size), n_kept))
+
     def ea_qstats(q, use_cov=True):
         mu, cov = O.ea_query_stats(q.float().numpy(), use_cov)
         return torch.from_numpy(mu.astype(np.float32)), (torch.from_numpy(cov.astype(np.float32)) if cov is not None else None)
@@ -85,7 +91,8 @@ def fake_native(monkeypatch):
 
     for name, fn in dict(rownorm_score=rownorm_score, topk_select=topk_select, gather_kv=gather_kv,
                          snapkv_score=snapkv_score, snapkv_score_rope=snapkv_score_rope, snapkv_score_from_attn=snapkv_score_from_attn,
-                         keydiff_score=keydiff_score, scores_head_mean_=scores_head_mean_, ea_qstats=ea_qstats, ea_score=ea_score).items():
+                         keydiff_score=keydiff_score, scores_head_mean_=scores_head_mean_, knorm_compress=knorm_compress,
+                         snapkv_compress_rope=snapkv_compress_rope, ea_qstats=ea_qstats, ea_score=ea_score).items():
         monkeypatch.setattr(_native, name, fn)
     return _native
 

@@ -476,3 +476,71 @@ def test_ea_full_chain_mfma_vs_oracle():
     got = native().ea_score(to_dev(s["keys"], "bf16"), to_dev(s["values"], "bf16"), mu, cov, s["n_sink"], True, 0.0).cpu().numpy()
     ns = s["n_sink"]
     assert_scores_close(got[..., ns:], want[..., ns:], RTOL, "ea_6000_B chain")
+
+
+# ---------------------------------------------------------------------------------------------
+# fused compress entry points == the modular sequence, bit for bit
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", KN)
+def test_fused_knorm_compress_equals_modular(name):
+    s = _inputs.make_case(name)
+    k, v = to_dev(s["keys"], s["dtype"]), to_dev(s["values"], s["dtype"])
+    N = native()
+    sc = N.rownorm_score(k, -1.0)
+    for n in sorted({0, 1, s["S"] // 3, s["S"] // 2, s["S"] - 1, s["S"]}):
+        ko, vo = N.knorm_compress(k, v, n)
+        wk, wv = N.gather_kv(k, v, N.topk_select(sc, n))
+        assert torch.equal(ko, wk) and torch.equal(vo, wv), f"{name} n={n}"
+    # strided views (every second token) and a second data set through the same cached workspace
+    k2, v2 = k[:, :, ::2], v[:, :, ::2]
+    n = k2.shape[2] // 2
+    ko, vo = N.knorm_compress(k2, v2, n)
+    wk, wv = N.gather_kv(k2, v2, N.topk_select(N.rownorm_score(k2, -1.0), n))
+    assert torch.equal(ko, wk) and torch.equal(vo, wv)
+
+
+@pytest.mark.parametrize("name", SK + [n for n, c in _inputs.CASES.items() if c["kind"] == "tova"])
+def test_fused_snapkv_compress_equals_modular(name):
+    s = _inputs.make_case(name)
+    dt = _inputs.torch_dtype(s["dtype"])
+    att, rot, hidden, (cos, sin) = _inputs.build_llama_attention(s, dt, DEV)
+    from kvpress_amd.utils import get_prerope_query_states
+
+    W, S = s["W"], s["S"]
+    k, v = to_dev(s["keys"], s["dtype"]), to_dev(s["values"], s["dtype"])
+    N = native()
+    with torch.no_grad():
+        q_pre = get_prerope_query_states(att, hidden[:, -W:])
+    c, si = cos[:, -W:], sin[:, -W:]
+    sc = N.snapkv_score_rope(q_pre, c, si, k, s["ks"])
+    # below / at / above the window size, generic sizes, everything kept
+    for n in sorted({1, max(1, W - 1), W, min(S, W + 1), S // 2, (2 * S) // 3, S - 1, S}):
+        ko, vo = N.snapkv_compress_rope(q_pre, c, si, k, v, s["ks"], n)
+        wk, wv = N.gather_kv(k, v, N.topk_select(sc, n))
+        assert torch.equal(ko, wk) and torch.equal(vo, wv), f"{name} n={n}"
+
+
+def test_fused_compress_without_clean_flag():
+    """flags = 0: the library zeroes the histogram region itself, whatever the workspace holds."""
+    import ctypes
+
+    N = native()
+    L = N.lib()
+    k = torch.randn(2, 4, 3000, 128, device=DEV, dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    n = 1234
+    nws = L.kvp_knorm_compress_workspace_bytes(2, 4, 3000, n)
+    ws = torch.full((nws,), 0xAB, dtype=torch.uint8, device=DEV)  # garbage
+    ko, vo = torch.empty(2, 4, n, 128, device=DEV, dtype=torch.bfloat16), torch.empty(2, 4, n, 128, device=DEV, dtype=torch.bfloat16)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    for _ in range(2):  # the second call reuses the (now clean) workspace, still with flags = 0
+        rc = L.kvp_knorm_compress(P(k), k.stride(0), k.stride(1), k.stride(2), P(v), v.stride(0), v.stride(1), v.stride(2), 2, 2, 4, 3000,
+                                  128, n, P(ko), P(vo), P(ws), nws, 0, st)
+        assert rc == 0, L.kvp_last_error()
+        wk, wv = N.gather_kv(k, v, N.topk_select(N.rownorm_score(k, -1.0), n))
+        assert torch.equal(ko, wk) and torch.equal(vo, wv)
+    # too small a workspace is an error, not a crash
+    rc = L.kvp_knorm_compress(P(k), k.stride(0), k.stride(1), k.stride(2), P(v), v.stride(0), v.stride(1), v.stride(2), 2, 2, 4, 3000, 128,
+                              n, P(ko), P(vo), P(ws), 1024, 0, st)
+    assert rc == -4 or rc != 0
