@@ -32,6 +32,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 LAYERS = 32  # Llama-3.1-8B
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md); with real operands the chip power-limits to ~1.44 GHz
 
 WORKLOADS = {
     # name: (press kind, S, ratio)
@@ -82,6 +83,13 @@ def kernel_bytes(name: str, kind: str, S: int, ratio: float) -> float:
         return ab["gather"]
     if name.startswith(("snapkv_p1", "snapkv_p2", "rownorm", "ea_logits")):
         return kbytes
+    return 0.0
+
+
+def kernel_flops(name: str, S: int) -> float:
+    """Algorithmic matrix-core flops of ONE launch (B=1; SURVEY §8d: 2 * H_q * W * S * D per QK^T pass)."""
+    if name.startswith(("snapkv_p1", "snapkv_p2")):
+        return 2.0 * H_Q * WINDOW * S * D
     return 0.0
 
 
@@ -226,6 +234,10 @@ def main():
                 "kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.workload),
                 "algorithmic_bytes_per_launch": kb, "avg_launch_us": round(cand[dom] * 1e3, 2),
+                # secondary bound of the same kernel: the window-attention passes are matrix-core / VALU work
+                "mfma": ({"achieved": round(kernel_flops(dom, S) * B / (cand[dom] * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": round(kernel_flops(dom, S) * B / (cand[dom] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+                         if kernel_flops(dom, S) else None),
                 "path": {
                     "algorithmic_bytes_per_layer": ab["total"] * B,
                     "achieved": round(ab["total"] * B / t_step / 1e9, 1),

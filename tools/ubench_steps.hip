@@ -246,6 +246,106 @@ __global__ __launch_bounds__(512, 1) void kd(float* out, const uint4* in, const 
     }
     out[blockIdx.x * 512 + threadIdx.x] = m + z;
 }
+// ---- LDS-DMA variant with TWO q-row blocks per wave: every K fragment read from LDS feeds two MFMA chains (64 q rows),
+// each wave covers half of the tile's sub-tiles -> same MFMA and softmax work per wave, half the LDS read traffic.
+template <int DSUBS, int NBUF>
+__global__ __launch_bounds__(512, 1) void kd2(float* out, const uint4* in, const char* kglob, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int DTILEB = DSUBS * 32 * 256;
+    constexpr int NLD = DTILEB / 16 / 512;
+    constexpr int WSUBS = DSUBS / 2;  // sub-tiles per wave and tile
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = lane & 31, kg = lane >> 5;
+    const uint32_t sub0 = (wv & 1) * WSUBS;
+    uint4 qf[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { qf[0][i] = in[(lane + i * 7) & 127]; qf[1][i] = in[(lane + i * 5 + 3) & 127]; }
+    float m[2] = {-1e30f, -1e30f}, z[2] = {0.f, 0.f};
+    const float c = 0.1275f;
+    const uint32_t head = blockIdx.x >> 5, chunk = blockIdx.x & 31;
+    const char* src = kglob + ((size_t)head << 25) + (size_t)chunk * DTILEB;
+    const size_t tstride = (size_t)32 * DTILEB;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const uint32_t lrow = wv * 4 + (lane >> 4), p = lane & 15;
+    auto request = [&](int tile, int i, int buf) {
+        const uint32_t row = i * 32 + lrow;
+        const char* g = src + (size_t)tile * tstride + row * 256 + ((p ^ (row & 15)) << 4);
+        unsigned char* l = lds + buf * DTILEB + (i * 32 + wv * 4) * 256;
+        const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)l);
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(g) : "memory");
+    };
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) request(b, i, b);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((NBUF - 2) * NLD));
+    __builtin_amdgcn_s_barrier();
+    int bc = 0;
+    for (int t = 0; t < tiles; ++t) {
+        const unsigned char* bufc = lds + bc * DTILEB;
+        const int bn = bc == 0 ? NBUF - 1 : bc - 1;
+        uint4 kf[2][8];
+        f32x16 acc[2];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) kf[0][ks] = kfrag(bufc, sub0, ks, n, kg);
+        // chain index ci = 2 * s + rb  (s = sub-tile of this wave, rb = q-row block); chain ci runs under the softmax of chain ci-1
+#pragma unroll
+        for (int ci = 0; ci < 2 * WSUBS; ++ci) {
+            const int s = ci >> 1, rb = ci & 1;
+            if (rb == 0 && s + 1 < WSUBS) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) kf[(s + 1) & 1][ks] = kfrag(bufc, sub0 + s + 1, ks, n, kg);
+            }
+            request(t + NBUF - 1, ci, bn);  // 2 * WSUBS == DSUBS == NLD requests per tile
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ci & 1][i] = 0.f;
+            if (ci == 0) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc[0] = mma(kf[0][ks], qf[0][ks], acc[0]);
+            } else {
+                const f32x16& ap = acc[(ci - 1) & 1];
+                const int prb = (ci - 1) & 1;
+                float tm = ap[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tm = fmaxf(tm, ap[r]);
+                const float mn = fmaxf(m[prb], tm), off = -mn * c;
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    acc[ci & 1] = mma(kf[s & 1][ks], qf[rb][ks], acc[ci & 1]);
+                    s0 += __builtin_amdgcn_exp2f(fmaf(ap[2 * ks], c, off));
+                    s1 += __builtin_amdgcn_exp2f(fmaf(ap[2 * ks + 1], c, off));
+                }
+                z[prb] = z[prb] * __builtin_amdgcn_exp2f(fmaf(m[prb], c, off)) + (s0 + s1);
+                m[prb] = mn;
+                __builtin_amdgcn_sched_group_barrier(0x2, 12, 0);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
+                }
+            }
+        }
+        softmax16(acc[(2 * WSUBS - 1) & 1], m[1], z[1], c);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070 | ((NBUF - 2) * NLD));
+        __builtin_amdgcn_s_barrier();
+        bc = bc + 1 == NBUF ? 0 : bc + 1;
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = m[0] + z[0] + m[1] + z[1];
+}
+template <int DSUBS, int NBUF>
+float rund2(float* out, const uint4* in, const char* kg, int tiles_override = 0) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    auto kern = kd2<DSUBS, NBUF>;
+    const int ldsb = NBUF * DSUBS * 32 * 256, tiles = tiles_override ? tiles_override : TILES * SUBS / DSUBS;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+    kern<<<256, 512, ldsb>>>(out, in, kg, tiles); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0); kern<<<256, 512, ldsb>>>(out, in, kg, tiles); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e6f / (tiles * DSUBS);  // per (32 keys x 32 rows) chain and wave, comparable with the other rows
+}
+
 template <int DSUBS, int NBUF, bool PIPE, int PAT = 0>
 float rund(float* out, const uint4* in, const char* kg, int tiles_override = 0) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -304,6 +404,8 @@ int main() {
         (void)hipMemcpy(in, hk.data() + 4096, 2048, hipMemcpyHostToDevice);
         printf("%-58s %6.0f\n", "LDS-DMA 128/3, head layout, RANDOM data", rund<4, 3, true, 1>(out, in, kg));
         printf("%-58s %6.0f\n", "LDS-DMA 128/3, head layout, RANDOM data, 32 tiles", rund<4, 3, true, 1>(out, in, kg, 32));
+        printf("%-58s %6.0f\n", "LDS-DMA 128/3, 64 q rows per wave, RANDOM data", rund2<4, 3>(out, in, kg));
+        printf("%-58s %6.0f\n", "LDS-DMA 128/3, 64 q rows per wave, RANDOM data, 32 tiles", rund2<4, 3>(out, in, kg, 32));
         R("regs only, pipelined, RANDOM Q", false, false, 0, true, false, 512)
         R("regs only, sequential, RANDOM Q", false, false, 0, false, false, 512)
     }
