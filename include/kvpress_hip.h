@@ -169,6 +169,13 @@ int kvp_scores_head_mean(float* scores, int64_t B, int64_t H, int64_t S, int64_t
 int kvp_prof_enable(int on);
 int kvp_prof_count(void);
 int kvp_prof_get(int i, const char** name, float* ms);
+/* kvp_prof_kernel_clock: with profiling enabled, snapkv_p1_mfma (the dominant kernel of the SnapKV path) measures the
+ * shader clock over its own lifetime (s_memtime / s_memrealtime); this returns the last value in MHz (0 if none). */
+int kvp_prof_kernel_clock(float* mhz);
+/* kvp_clock_probe: enqueue a one-wave kernel that spins spin_us microseconds and writes the shader clock (MHz, float, device
+ * memory) it saw: s_memtime ticks per 100 MHz s_memrealtime tick.  Enqueued right behind a kernel it shows the clock that
+ * kernel ran at (the governor is slow compared with a kernel). */
+int kvp_clock_probe(float* mhz_out, int spin_us, kvp_stream_t stream);
 
 #ifdef __cplusplus
 }

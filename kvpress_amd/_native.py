@@ -58,6 +58,8 @@ SIGNATURES = {
     "kvp_prof_enable": (c_int, [c_int]),
     "kvp_prof_count": (c_int, []),
     "kvp_prof_get": (c_int, [c_int, ctypes.POINTER(c_char_p), ctypes.POINTER(c_float)]),
+    "kvp_clock_probe": (c_int, [c_void_p, c_int, c_void_p]),
+    "kvp_prof_kernel_clock": (c_int, [ctypes.POINTER(c_float)]),
 }
 
 _lib = None
@@ -384,6 +386,23 @@ def gather_kv(keys: torch.Tensor, values: torch.Tensor, idx: torch.Tensor):
 
 
 # ------------------------------------------------------------------------------------------------
+def prof_kernel_clock() -> float:
+    """Shader clock (MHz) snapkv_p1_mfma measured inside its last profiled launch (0.0 if none)."""
+    v = c_float(0.0)
+    _check(lib().kvp_prof_kernel_clock(ctypes.byref(v)), "kvp_prof_kernel_clock")
+    return float(v.value)
+
+
+def clock_probe(device=None, spin_us: int = 20) -> torch.Tensor:
+    """Enqueue a shader-clock probe on the current stream; returns a 1-element float32 device tensor (MHz) that is valid
+    once the stream has run it."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = torch.zeros(1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().kvp_clock_probe(_p(out), int(spin_us), _stream(out)), "kvp_clock_probe")
+    return out
+
+
 def prof_enable(on: bool) -> None:
     """Turn the library's per-kernel HIP-event timing on/off (clears previous records)."""
     _check(lib().kvp_prof_enable(int(bool(on))), "kvp_prof_enable")

@@ -69,3 +69,41 @@ extern "C" int kvp_prof_get(int i, const char** name, float* ms) {
     *name = g_prof[i].name.c_str();
     return KVP_OK;
 }
+
+// ---- in-kernel clock of the dominant kernel (measurement aid) -------------------------------------------------------
+static thread_local float* g_clock_slot = nullptr;
+float* kvp_prof_clock_slot() {
+    if (!g_clock_slot && hipMalloc(&g_clock_slot, sizeof(float)) != hipSuccess) g_clock_slot = nullptr;
+    return g_clock_slot;
+}
+extern "C" int kvp_prof_kernel_clock(float* mhz) {
+    KVP_CHECK_ARG(mhz, "kvp_prof_kernel_clock: null pointer");
+    *mhz = 0.f;
+    if (!g_clock_slot) return KVP_OK;  // no profiled snapkv_p1_mfma launch yet
+    if (hipMemcpy(mhz, g_clock_slot, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        kvp_set_error("kvp_prof_kernel_clock: copy failed");
+        return KVP_EHIP;
+    }
+    return KVP_OK;
+}
+
+// ---- shader-clock probe (measurement aid) ------------------------------------------------------------------------
+// One wave spins for ~`spin_us` microseconds and reports shader-clock ticks (s_memtime) per 100 MHz real-time tick
+// (s_memrealtime): the core clock in MHz at that point of the stream.  The clock governor moves slowly compared with a
+// kernel, so a probe enqueued right behind a kernel shows the clock that kernel ran at.
+namespace {
+__global__ void clock_probe_kernel(float* out, uint32_t spin_ticks) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < spin_ticks) r1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) *out = (float)((double)(c1 - c0) / (double)(r1 - r0) * 100.0);
+}
+}  // namespace
+extern "C" int kvp_clock_probe(float* mhz_out, int spin_us, kvp_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KVP_CHECK_ARG(mhz_out && spin_us >= 1 && spin_us <= 100000, "clock_probe: bad arguments");
+    clock_probe_kernel<<<1, 64, 0, stream>>>(mhz_out, (uint32_t)spin_us * 100u);
+    KVP_CHECK_LAUNCH("clock_probe");
+    return KVP_OK;
+}

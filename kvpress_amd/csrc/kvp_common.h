@@ -32,6 +32,7 @@ void kvp_set_error(const char* fmt, ...);
 bool kvp_prof_enabled();
 void kvp_prof_begin(const char* name, hipStream_t stream);
 void kvp_prof_end(hipStream_t stream);
+float* kvp_prof_clock_slot();  // device float that snapkv_p1_mfma fills with its in-kernel shader clock (MHz) while profiling
 // every kernel launch of the library goes through this macro
 #define KVP_LAUNCH(name, stream, ...)                         \
     do {                                                      \

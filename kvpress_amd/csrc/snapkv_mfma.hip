@@ -131,8 +131,11 @@ __device__ __forceinline__ int ring_prev(int b) { return b == 0 ? MF_NBUF - 1 : 
 // =================================================================================================
 template <int DT>
 __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint32_t ngb, uint32_t nchunk,
-                                                                float* __restrict__ part_m, float* __restrict__ part_z) {
+                                                                float* __restrict__ part_m, float* __restrict__ part_z,
+                                                                float* __restrict__ clock_mhz) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[MF_NBUF * MF_TILEB];
+    // measurement aid (kvp_prof_*): shader-clock ticks per 100 MHz real-time tick over this workgroup's lifetime
+    const unsigned long long clk0 = clock_mhz ? __builtin_amdgcn_s_memtime() : 0, rt0 = clock_mhz ? __builtin_amdgcn_s_memrealtime() : 0;
     const uint32_t chunk = blockIdx.x, b = blockIdx.z;
     const uint32_t h = blockIdx.y / ngb, gb = blockIdx.y - h * ngb;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -143,12 +146,17 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
     const uint32_t hq = h * a.G + (active ? rg : 0);
 
     const KStream ks_(static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2, a.k_ss * 2, a.S);
+    const TileWalk tw(chunk, nchunk, a.S);
+    // the first two K tiles are requested BEFORE the Q fragments: one memory round trip for both
+    if (tw.ntiles > 0) {
+        ks_.request_tile(lds, tw.key0(0));
+        ks_.request_tile(lds + MF_TILEB, tw.key0(1));
+    }
     uint4 qf[8];
     load_qfrags(qf, static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)row0 * a.q_sw) * 2,
                 a.q_sw * 2, n, kg);
-    wait_all_landed();  // Q fragments are in; from here on vmcnt only counts the K stream
+    wait_all_landed();  // K tiles 0 and 1 and the Q fragments are in; from here on vmcnt only counts the K stream
 
-    const TileWalk tw(chunk, nchunk, a.S);
     float m = KVP_NEG_INF, z = 0.f;  // raw-logit running max / sum-exp of window row row0 + n over this lane's keys
     const float c = a.c;
     const uint32_t w = row0 + n;     // window row: token S-W+w sees keys <= S-W+w
@@ -182,9 +190,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
 
     // One tile = MF_SUBS sub-tiles of 32 keys; per sub-tile step: one DMA request for the tile two ahead, the LDS
     // fragment reads of the next sub-tile, and the MFMA chain of this sub-tile interleaved (1 MFMA : 6 VALU) with
-    // the softmax of the previous one.
-    auto compute = [&](uint32_t key0, const unsigned char* buf, unsigned char* bufr, uint32_t keyr) {
-        const bool need_mask = key0 + (MF_TILE - 1) > a.S - a.W;  // some (row, key) of this tile is masked / past S
+    // the softmax of the previous one.  Straight-line code (no masks: every tile but the last ones of a head).
+    auto compute_fast = [&](const unsigned char* buf, unsigned char* bufr, uint32_t keyr) {
         uint4 kf[2][8];
         f32x16 acc[2];
 #pragma unroll
@@ -199,13 +206,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[sub & 1][i] = 0.f;
-            if (sub == 0 || need_mask) {
-                if (sub > 0) softmax16(acc[(sub - 1) & 1], key0, sub - 1, true);
+            if (sub == 0) {
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc[sub & 1] = mma32<DT>(kf[sub & 1][ks], qf[ks], acc[sub & 1]);  // C[key][q row]
+                for (int ks = 0; ks < 8; ++ks) acc[0] = mma32<DT>(kf[0][ks], qf[ks], acc[0]);  // C[key][q row]
             } else {
-                // branch-free: MFMA chain of this sub-tile || softmax of the previous one
-                f32x16& ap = acc[(sub - 1) & 1];
+                // MFMA chain of this sub-tile || softmax of the previous one
+                const f32x16& ap = acc[(sub - 1) & 1];
                 float tm = ap[0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) tm = fmaxf(tm, ap[r]);
@@ -228,13 +234,30 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
                 }
             }
         }
-        softmax16(acc[(MF_SUBS - 1) & 1], key0, MF_SUBS - 1, need_mask);
+        f32x16 last = acc[(MF_SUBS - 1) & 1];
+        softmax16(last, 0, MF_SUBS - 1, false);
+    };
+    // the last tiles of a head (causal mask over the window, keys past S): chain, then the masked update, per sub-tile
+    auto compute_masked = [&](uint32_t key0, const unsigned char* buf, unsigned char* bufr, uint32_t keyr) {
+        for (int sub = 0; sub < MF_SUBS; ++sub) {
+            uint4 kf[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) kf[ks] = kfrag(buf, sub, ks, n, kg);
+            ks_.request(bufr, keyr, sub);
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc = mma32<DT>(kf[ks], qf[ks], acc);
+            softmax16(acc, key0, sub, true);
+        }
+    };
+    auto compute = [&](uint32_t key0, const unsigned char* buf, unsigned char* bufr, uint32_t keyr) {
+        if (key0 + (MF_TILE - 1) > a.S - a.W) compute_masked(key0, buf, bufr, keyr);  // some (row, key) is masked / past S
+        else compute_fast(buf, bufr, keyr);
     };
 
     if (tw.ntiles > 0) {
-        ks_.request_tile(lds, tw.key0(0));
-        ks_.request_tile(lds + MF_TILEB, tw.key0(1));
-        wait_tile_landed();
         __syncthreads();
         int bc = 0;
         for (uint32_t t = 0; t < tw.ntiles; ++t) {
@@ -259,6 +282,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
             part_z[o] = zz;
         }
     }
+    if (clock_mhz && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        *clock_mhz = r1 > rt0 ? (float)((double)(c1 - clk0) / (double)(r1 - rt0) * 100.0) : 0.f;
+    }
 }
 
 // =================================================================================================
@@ -280,6 +307,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
     const uint32_t Sm = a.S - a.W;
 
     const KStream ks_(static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2, a.k_ss * 2, a.S);
+    const TileWalk tw(chunk, gridDim.x, Sm);
+    if (tw.ntiles == 0) return;
+    // the first two K tiles are requested BEFORE the Q fragments and normalisers: one memory round trip for all
+    ks_.request_tile(lds, tw.key0(0));
+    ks_.request_tile(lds + MF_TILEB, tw.key0(1));
     uint4 qf[8];
     load_qfrags(qf, static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)row0 * a.q_sw) * 2,
                 a.q_sw * 2, n, kg);
@@ -288,9 +320,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
     const float* ars = rowstat + (size_t)(b * a.Hq + hq) * a.W + row0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ar[r] = -ars[(r & 3) + 8 * (r >> 2) + 4 * kg];
-    wait_all_landed();  // Q fragments and normalisers are in; from here on vmcnt only counts the K stream (+ the flush stores)
+    wait_all_landed();  // K tiles 0 and 1, Q fragments and normalisers are in; from here on vmcnt only counts the K stream (+ the flush stores)
 
-    const TileWalk tw(chunk, gridDim.x, Sm);
     const float c = a.c;
     float* cs = colsum + (size_t)(b * a.Hkv + h) * Sm;
     const uint32_t nact = 2 * min(4u, a.G - gb * 4);  // active waves in this workgroup
@@ -360,10 +391,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
         }
     };
 
-    if (tw.ntiles == 0) return;
-    ks_.request_tile(lds, tw.key0(0));
-    ks_.request_tile(lds + MF_TILEB, tw.key0(1));
-    wait_tile_landed();
     __syncthreads();
     int bc = 0;
     for (uint32_t t = 0; t < tw.ntiles; ++t) {
@@ -405,8 +432,9 @@ uint32_t snapkv_mfma_nchunk(const SnapArgs& a) { return mfma_nchunk_for(a, a.S);
 int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m, float* part_z, hipStream_t stream) {
     const uint32_t ngb = (a.G + 3) / 4;
     const dim3 grid(nchunk, a.Hkv * ngb, a.B);
-    if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
-    else KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
+    float* clk = kvp_prof_enabled() ? kvp_prof_clock_slot() : nullptr;  // in-kernel clock of pass 1 while profiling is on
+    if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, clk));
+    else KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, clk));
     KVP_CHECK_LAUNCH("snapkv_p1_mfma");
     return KVP_OK;
 }

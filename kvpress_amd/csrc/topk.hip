@@ -187,15 +187,17 @@ __global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __r
     __shared__ uint32_t scr[8];
     const uint32_t row = blockIdx.y, chunk = blockIdx.x;
     const float* rp = scores + (int64_t)row * row_stride;
-    // this thread's 8 consecutive positions (requested before the threshold is resolved)
+    // this thread's TK_PER consecutive positions (requested before the threshold is resolved)
     const uint32_t p0 = chunk * TK_CHUNK + threadIdx.x * TK_PER;
     uint32_t keys[TK_PER];
     const bool fast = (p0 + TK_PER <= S) && ((((uintptr_t)(rp + p0)) & 15u) == 0);
     if (fast) {
-        const float4 a = *reinterpret_cast<const float4*>(rp + p0);
-        const float4 b = *reinterpret_cast<const float4*>(rp + p0 + 4);
-        keys[0] = float_to_key(a.x); keys[1] = float_to_key(a.y); keys[2] = float_to_key(a.z); keys[3] = float_to_key(a.w);
-        keys[4] = float_to_key(b.x); keys[5] = float_to_key(b.y); keys[6] = float_to_key(b.z); keys[7] = float_to_key(b.w);
+#pragma unroll
+        for (int q = 0; q < TK_PER / 4; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(rp + p0 + 4 * q);
+            keys[4 * q + 0] = float_to_key(a.x); keys[4 * q + 1] = float_to_key(a.y);
+            keys[4 * q + 2] = float_to_key(a.z); keys[4 * q + 3] = float_to_key(a.w);
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < TK_PER; ++j) keys[j] = (p0 + j < S) ? float_to_key(rp[p0 + j]) : 0u;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __r
         ce += (valid && keys[j] == T) ? 1u : 0u;
     }
     uint32_t tot;
-    const uint32_t ex = block_excl_scan(cg | (ce << 16), scr, &tot);  // chunk <= 2048: both fields < 65536
+    const uint32_t ex = block_excl_scan(cg | (ce << 16), scr, &tot);  // chunk <= 4096: both fields < 65536
     uint32_t g = gt_before + (ex & 0xFFFFu);
     uint32_t e = eq_before + (ex >> 16);
     int32_t* out = idx + (int64_t)row * idx_stride;

@@ -4,7 +4,10 @@
 #include "kvp_common.h"
 
 constexpr int TK_THREADS = 256;
-constexpr int TK_PER = 8;
+#ifndef KVP_TK_PER
+#define KVP_TK_PER 8
+#endif
+constexpr int TK_PER = KVP_TK_PER;
 constexpr int TK_CHUNK = TK_THREADS * TK_PER;  // 2048 scores per workgroup
 
 struct TopkWs {
