@@ -126,6 +126,20 @@ int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
                   int64_t B, int64_t H, int64_t S, int64_t D,
                   const int32_t* idx, int64_t n, void* k_out, void* v_out, kvp_stream_t stream);
 
+/* ---- ChunkPress: per-chunk top-k (kvpress/presses/chunk_press.py:67-85) ---------------------------------------------
+ * scores[R, nseg * seg_len] contiguous; the k largest of EACH chunk of seg_len columns are selected (same tie rule as
+ * kvp_topk_select); idx[R, nseg * k] holds them chunk after chunk as row positions + pos_base, i.e. ascending overall. */
+size_t kvp_topk_segmented_workspace_bytes(int64_t R, int64_t nseg, int64_t seg_len, int64_t k);
+int kvp_topk_select_segmented(const float* scores, int64_t R, int64_t nseg, int64_t seg_len, int64_t k, int64_t pos_base,
+                              int order, int32_t* idx, void* ws, size_t ws_bytes, kvp_stream_t stream);
+
+/* ---- KeyRerotationPress.rerotate_keys after the gather (kvpress/presses/key_rerotation_press.py:50-128) ------------
+ * k: contiguous [B,H,n,D] keys gathered with idx[B*H, n] (ascending positions); in place
+ * k[b,h,j] <- k * cos(f) + rotate_half(k) * sin(f),  f = (j - idx[b,h,j]) * inv_freq[d mod D/2]  (inv_freq: D/2 floats,
+ * module.rotary_emb.inv_freq), cos/sin cast to the key dtype and every op rounded in it, as torch does. */
+int kvp_rerotate_keys(void* k, int dtype, int64_t B, int64_t H, int64_t n, int64_t D, const int32_t* idx,
+                      const float* inv_freq, kvp_stream_t stream);
+
 /* ---- fused ScorerPress.compress (scorer_press.py:76-102 with the scorer inlined) ---------------------------------
  * One call = score -> select n_kept -> gather into caller-allocated contiguous k_out / v_out [B,H,n_kept,D].  Same
  * kernels and results as the modular sequence kvp_*_score + kvp_topk_select + kvp_gather_kv; the score-writing kernel

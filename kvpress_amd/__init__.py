@@ -2,13 +2,16 @@
 
 Public API mirrors the reference for this path (same class names, dataclass fields and
 method signatures): BasePress, ScorerPress, KnormPress, SnapKVPress, ExpectedAttentionPress, the scorers that reuse
-the path's kernels (PyramidKVPress, TOVAPress, KeyDiffPress, StreamingLLMPress, RandomPress) and the
+the path's kernels (PyramidKVPress, TOVAPress, KeyDiffPress, StreamingLLMPress, RandomPress), the selection wrappers
+ChunkPress and KeyRerotationPress, and the
 "kv-press-text-generation" pipeline (kvpress_amd.pipeline, imported on first use).
 Everything below ``ScorerPress.compress`` runs in hand-written HIP kernels (gfx950) reached
 through the C ABI of include/kvpress_hip.h; there is no CPU or pure-PyTorch fallback.
 """
 from kvpress_amd.presses.base_press import BasePress
+from kvpress_amd.presses.chunk_press import ChunkPress
 from kvpress_amd.presses.expected_attention_press import ExpectedAttentionPress
+from kvpress_amd.presses.key_rerotation_press import KeyRerotationPress
 from kvpress_amd.presses.keydiff_press import KeyDiffPress
 from kvpress_amd.presses.knorm_press import KnormPress
 from kvpress_amd.presses.pyramidkv_press import PyramidKVPress
@@ -20,7 +23,7 @@ from kvpress_amd.presses.tova_press import TOVAPress
 
 __version__ = "0.1.0"
 __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
-           "KeyDiffPress", "StreamingLLMPress", "RandomPress", "KVPressTextGenerationPipeline"]
+           "KeyDiffPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "KeyRerotationPress", "KVPressTextGenerationPipeline"]
 
 
 def __getattr__(name):

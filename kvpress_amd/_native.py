@@ -53,6 +53,9 @@ SIGNATURES = {
                              _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_topk_workspace_bytes": (c_size_t, [_I64] * 3),
     "kvp_topk_select": (c_int, [c_void_p, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "kvp_topk_segmented_workspace_bytes": (c_size_t, [_I64] * 4),
+    "kvp_topk_select_segmented": (c_int, [c_void_p, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "kvp_rerotate_keys": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, c_void_p, c_void_p, c_void_p]),
     "kvp_gather_kv": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64,
                               c_void_p, _I64, c_void_p, c_void_p, c_void_p]),
     "kvp_prof_enable": (c_int, [c_int]),
@@ -290,6 +293,42 @@ def topk_select(scores: torch.Tensor, k: int, order: int = ORDER_POSITION) -> to
             _check(lib().kvp_topk_select(_p(s2), R, S, s2.stride(0) if R > 1 else S, int(k), int(order) | TOPK_WS_CLEAN, _p(idx),
                                          _p(ws), ws.numel(), _stream(s)), "kvp_topk_select")
     return idx.reshape(*lead, k)
+
+
+def topk_select_segmented(scores: torch.Tensor, seg_len: int, k: int, pos_base: int = 0) -> torch.Tensor:
+    """Per-chunk top-k: scores float32 [..., nseg * seg_len]; returns int32 [..., nseg * k] row positions (+ pos_base),
+    chunk after chunk (ascending)."""
+    if not scores.is_cuda:
+        raise KvpressHipError(f"kvpress_amd kernels need tensors on a HIP device, got {scores.device}")
+    s = scores.to(torch.float32).contiguous()
+    L = s.shape[-1]
+    assert L % seg_len == 0, (L, seg_len)
+    nseg = L // seg_len
+    lead = s.shape[:-1]
+    s2 = s.reshape(-1, L)
+    R = s2.shape[0]
+    idx = torch.empty((R, nseg * k), dtype=torch.int32, device=s.device)
+    if R and k:
+        with torch.cuda.device(s.device):
+            ws = torch.zeros(max(int(lib().kvp_topk_segmented_workspace_bytes(R, nseg, seg_len, k)), 256), dtype=torch.uint8, device=s.device)
+            _check(lib().kvp_topk_select_segmented(_p(s2), R, nseg, int(seg_len), int(k), int(pos_base), TOPK_WS_CLEAN, _p(idx), _p(ws),
+                                                   ws.numel(), _stream(s)), "kvp_topk_select_segmented")
+    return idx.reshape(*lead, nseg * k)
+
+
+def rerotate_keys_(keys_kept: torch.Tensor, idx: torch.Tensor, inv_freq: torch.Tensor) -> torch.Tensor:
+    """In place: re-rotate gathered keys [B,H,n,D] (kept at ascending positions idx [B,H,n]) to positions 0..n-1."""
+    _dev(keys_kept)
+    assert keys_kept.is_contiguous()
+    B, H, n, D = keys_kept.shape
+    idx = idx.to(torch.int32).contiguous()
+    assert idx.shape == (B, H, n)
+    inv = inv_freq.to(device=keys_kept.device, dtype=torch.float32).contiguous()
+    assert inv.numel() == D // 2
+    with torch.cuda.device(keys_kept.device):
+        _check(lib().kvp_rerotate_keys(_p(keys_kept), _DTYPES[keys_kept.dtype], B, H, n, D, _p(idx), _p(inv), _stream(keys_kept)),
+               "kvp_rerotate_keys")
+    return keys_kept
 
 
 def _clean_ws(kind: str, shape: tuple, nbytes: int, like: torch.Tensor) -> torch.Tensor:

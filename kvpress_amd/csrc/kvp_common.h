@@ -85,6 +85,28 @@ template <> __device__ __forceinline__ void unpack16<KVP_F16>(const uint4& v, fl
     }
 }
 
+// value rounded to the storage dtype and back (torch's eager ops round after every mul / add in the model dtype)
+template <int DT> __device__ __forceinline__ float round_dt(float x);
+template <> __device__ __forceinline__ float round_dt<KVP_F32>(float x) { return x; }
+template <> __device__ __forceinline__ float round_dt<KVP_F16>(float x) {
+    // opaque to the optimiser: written as (float)(_Float16)x, hipcc demotes the surrounding mul / add to f16 and then
+    // contracts them into v_fma_f16 -- one rounding where torch's separate half ops have two
+    float r;
+    asm("v_cvt_f16_f32 %0, %1\n\tv_cvt_f32_f16 %0, %0" : "=v"(r) : "v"(x));
+    return r;
+}
+template <> __device__ __forceinline__ float round_dt<KVP_BF16>(float x) {  // round-to-nearest-even to bf16
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7F800000u) == 0x7F800000u) return __uint_as_float(u & 0xFFFF0000u | ((u & 0xFFFFu) ? 0x00400000u : 0u));  // inf / nan
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xFFFF0000u);
+}
+// one RoPE output element with torch's rounding: round(round(a * ca) + round(b * sb)); __fmul_rn / __fadd_rn keep the
+// ops separately rounded as in torch's eager mul, mul, add (never contracted to an fma)
+template <int DT> __device__ __forceinline__ float rope_elem(float a, float ca, float b, float sb) {
+    return round_dt<DT>(__fadd_rn(round_dt<DT>(__fmul_rn(a, ca)), round_dt<DT>(__fmul_rn(b, sb))));
+}
+
 // 16-byte loads/stores with an optional non-temporal (streaming, read/write-once) hint
 typedef uint32_t kvp_u32x4 __attribute__((ext_vector_type(4)));
 template <bool NT> __device__ __forceinline__ uint4 ld16(const void* p) {

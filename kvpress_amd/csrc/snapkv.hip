@@ -152,15 +152,6 @@ __global__ __launch_bounds__(SK_THREADS) void snapkv_colsum_from_attn(const type
 }
 
 // ---- RoPE of the window queries: q*cos + rotate_half(q)*sin, with torch's per-op rounding --------
-template <int DT> __device__ __forceinline__ float round_dt(float x);
-template <> __device__ __forceinline__ float round_dt<KVP_F32>(float x) { return x; }
-template <> __device__ __forceinline__ float round_dt<KVP_F16>(float x) { return (float)(_Float16)x; }
-template <> __device__ __forceinline__ float round_dt<KVP_BF16>(float x) {  // round-to-nearest-even to bf16
-    uint32_t u = __float_as_uint(x);
-    if ((u & 0x7F800000u) == 0x7F800000u) return __uint_as_float(u & 0xFFFF0000u | ((u & 0xFFFFu) ? 0x00400000u : 0u));  // inf / nan
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return __uint_as_float(u & 0xFFFF0000u);
-}
 template <int DT> __device__ __forceinline__ void st_dt(typename Elem<DT>::T* p, float x);
 template <> __device__ __forceinline__ void st_dt<KVP_F32>(float* p, float x) { *p = x; }
 template <> __device__ __forceinline__ void st_dt<KVP_F16>(_Float16* p, float x) { *p = (_Float16)x; }
@@ -184,9 +175,8 @@ __global__ __launch_bounds__(SK_THREADS) void snapkv_rope_kernel(const typename 
         const typename Elem<DT>::T* cr = cosp + (int64_t)b * cs_sb + (int64_t)w * cs_sw;
         const typename Elem<DT>::T* sr = sinp + (int64_t)b * cs_sb + (int64_t)w * cs_sw;
         const float q0 = Elem<DT>::ld(qr + d), q1 = Elem<DT>::ld(qr + d + half);
-        // __fmul_rn / __fadd_rn: separately rounded ops as in torch's eager mul, mul, add (never contracted to an fma)
-        const float lo = round_dt<DT>(__fadd_rn(round_dt<DT>(__fmul_rn(q0, Elem<DT>::ld(cr + d))), round_dt<DT>(__fmul_rn(-q1, Elem<DT>::ld(sr + d)))));
-        const float hi = round_dt<DT>(__fadd_rn(round_dt<DT>(__fmul_rn(q1, Elem<DT>::ld(cr + d + half))), round_dt<DT>(__fmul_rn(q0, Elem<DT>::ld(sr + d + half)))));
+        const float lo = rope_elem<DT>(q0, Elem<DT>::ld(cr + d), -q1, Elem<DT>::ld(sr + d));
+        const float hi = rope_elem<DT>(q1, Elem<DT>::ld(cr + d + half), q0, Elem<DT>::ld(sr + d + half));
         typename Elem<DT>::T* o = out + (size_t)row * D;
         st_dt<DT>(o + d, lo);
         st_dt<DT>(o + d + half, hi);

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_hist8_kernel(const float* __r
 __global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __restrict__ scores, int64_t row_stride,
                                                                 uint32_t S, uint32_t k, uint32_t nchunks, TopkWs w,
                                                                 int32_t* __restrict__ idx, int64_t idx_stride,
-                                                                uint32_t tail_start, uint32_t tail_n) {
+                                                                uint32_t tail_start, uint32_t tail_n, uint32_t nseg,
+                                                                uint32_t seg_len, uint32_t pos_base) {
     __shared__ uint32_t scr[8];
     const uint32_t row = blockIdx.y, chunk = blockIdx.x;
     const float* rp = scores + (int64_t)row * row_stride;
@@ -237,8 +238,10 @@ __global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __r
     uint32_t g = gt_before + (ex & 0xFFFFu);
     uint32_t e = eq_before + (ex >> 16);
     int32_t* out = idx + (int64_t)row * idx_stride;
+    // segmented select: row = (outer row, segment); positions are reported relative to the outer row
+    const uint32_t off = pos_base + (nseg > 1 ? (row % nseg) * seg_len : 0u);
     if (chunk == 0)  // columns kept by construction (pad region after the selected ones)
-        for (uint32_t j = threadIdx.x; j < tail_n; j += TK_THREADS) out[k + j] = (int32_t)(tail_start + j);
+        for (uint32_t j = threadIdx.x; j < tail_n; j += TK_THREADS) out[k + j] = (int32_t)(off + tail_start + j);
 #pragma unroll
     for (int j = 0; j < TK_PER; ++j) {
         const bool valid = p0 + j < S;
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __r
         const bool ise = valid && keys[j] == T;
         if (isg || (ise && e < quota)) {
             const uint32_t rank = g + (e < quota ? e : quota);
-            if (rank < k) out[rank] = (int32_t)(p0 + j);
+            if (rank < k) out[rank] = (int32_t)(off + p0 + j);
         }
         g += isg ? 1u : 0u;
         e += ise ? 1u : 0u;
@@ -255,11 +258,13 @@ __global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __r
 
 // k == S: every position is kept (compression_ratio so small that int(S*(1-r)) == S)
 // (also the k == 0 case of a call with a tail: only the tail columns are written)
-__global__ void topk_iota_kernel(int32_t* __restrict__ idx, int64_t idx_stride, uint32_t k, uint32_t tail_start, uint32_t tail_n) {
+__global__ void topk_iota_kernel(int32_t* __restrict__ idx, int64_t idx_stride, uint32_t k, uint32_t tail_start, uint32_t tail_n,
+                                 uint32_t nseg, uint32_t seg_len, uint32_t pos_base) {
     int32_t* out = idx + (int64_t)blockIdx.y * idx_stride;
+    const uint32_t off = pos_base + (nseg > 1 ? (blockIdx.y % nseg) * seg_len : 0u);
     const uint32_t n = k + tail_n;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        out[i] = (int32_t)(i < k ? i : tail_start + (i - k));
+        out[i] = (int32_t)(off + (i < k ? i : tail_start + (i - k)));
 }
 
 }  // namespace
@@ -273,7 +278,7 @@ extern "C" size_t kvp_topk_workspace_bytes(int64_t R, int64_t S, int64_t k) {
 
 int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, int64_t idx_stride,
                      uint32_t tail_start, uint32_t tail_n, void* ws, size_t ws_bytes, bool ws_clean, bool hist1_ready,
-                     hipStream_t stream) {
+                     hipStream_t stream, uint32_t nseg, uint32_t seg_len, uint32_t pos_base) {
     if (R == 0 || k + tail_n == 0) return KVP_OK;
     KVP_CHECK_ARG(S < ((int64_t)1 << 31) && R <= 65535, "topk: S=%ld or R=%ld too large", (long)S, (long)R);
     KVP_CHECK_ARG(scores && idx, "topk: null pointer");
@@ -287,7 +292,7 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
             return KVP_EHIP;
         }
         const uint32_t bx = (uint32_t)std::max<int64_t>(1, std::min<int64_t>((k + tail_n + 255) / 256, 256));
-        KVP_LAUNCH("topk_iota_kernel", stream, topk_iota_kernel<<<dim3(bx, (uint32_t)R), 256, 0, stream>>>(idx, idx_stride, (uint32_t)k, tail_start, tail_n));
+        KVP_LAUNCH("topk_iota_kernel", stream, topk_iota_kernel<<<dim3(bx, (uint32_t)R), 256, 0, stream>>>(idx, idx_stride, (uint32_t)k, tail_start, tail_n, nseg, seg_len, pos_base));
         KVP_CHECK_LAUNCH("topk(iota)");
         return KVP_OK;
     }
@@ -307,7 +312,7 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
         KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<1><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
     KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<2><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
     KVP_LAUNCH("topk_hist8_kernel", stream, topk_hist8_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)nchunks, w));
-    KVP_LAUNCH("topk_write_kernel", stream, topk_write_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, (uint32_t)nchunks, w, idx, idx_stride, tail_start, tail_n));
+    KVP_LAUNCH("topk_write_kernel", stream, topk_write_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, (uint32_t)nchunks, w, idx, idx_stride, tail_start, tail_n, nseg, seg_len, pos_base));
     KVP_CHECK_LAUNCH("topk");
     return KVP_OK;
 }
@@ -323,4 +328,21 @@ extern "C" int kvp_topk_select(const float* scores, int64_t R, int64_t S, int64_
     }
     return topk_select_impl(scores, R, S, row_stride, k, idx, k, 0, 0, ws, ws_bytes, (order & KVP_TOPK_WS_CLEAN) != 0, false,
                             static_cast<hipStream_t>(stream_));
+}
+
+// Segmented select (ChunkPress, kvpress/presses/chunk_press.py:67-85): every row of scores[R, nseg * seg_len] is cut into
+// nseg chunks, the k largest of EACH chunk are selected, idx[R, nseg * k] holds them chunk after chunk as positions
+// in the row (+ pos_base) -- ascending overall.  One launch set for all R * nseg chunks.
+extern "C" size_t kvp_topk_segmented_workspace_bytes(int64_t R, int64_t nseg, int64_t seg_len, int64_t k) {
+    return kvp_topk_workspace_bytes(R * nseg, seg_len, k);
+}
+extern "C" int kvp_topk_select_segmented(const float* scores, int64_t R, int64_t nseg, int64_t seg_len, int64_t k, int64_t pos_base,
+                                         int order, int32_t* idx, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
+    KVP_CHECK_ARG(R >= 0 && nseg >= 1 && seg_len >= 1 && k >= 0 && k <= seg_len && pos_base >= 0, "topk_segmented: bad shape R=%ld nseg=%ld seg_len=%ld k=%ld",
+                  (long)R, (long)nseg, (long)seg_len, (long)k);
+    KVP_CHECK_ARG((order & ~KVP_TOPK_WS_CLEAN) == KVP_ORDER_POSITION, "topk_segmented: only KVP_ORDER_POSITION");
+    KVP_CHECK_ARG(R * nseg <= 65535 && pos_base + nseg * seg_len < ((int64_t)1 << 31), "topk_segmented: too many chunks (%ld) or positions", (long)(R * nseg));
+    // rows of the flat view: (r, segment) at scores + (r * nseg + segment) * seg_len
+    return topk_select_impl(scores, R * nseg, seg_len, seg_len, k, idx, k, 0, 0, ws, ws_bytes, (order & KVP_TOPK_WS_CLEAN) != 0, false,
+                            static_cast<hipStream_t>(stream_), (uint32_t)nseg, (uint32_t)seg_len, (uint32_t)pos_base);
 }

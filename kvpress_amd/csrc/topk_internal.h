@@ -76,4 +76,5 @@ __device__ __forceinline__ void topk_hist1_flush(const uint32_t* lds_hist, uint3
 // hist1_ready: w.hist1 already holds this call's first-pass histogram (a fused scorer produced it).
 int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, int64_t idx_stride,
                      uint32_t tail_start, uint32_t tail_n, void* ws, size_t ws_bytes, bool ws_clean, bool hist1_ready,
-                     hipStream_t stream);
+                     hipStream_t stream, uint32_t nseg = 1, uint32_t seg_len = 0, uint32_t pos_base = 0);
+// nseg > 1: rows are (outer row, segment) pairs and every reported position gets (row % nseg) * seg_len + pos_base added

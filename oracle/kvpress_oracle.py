@@ -39,6 +39,8 @@ __all__ = [
     "tova_score",
     "pyramidkv_budget",
     "streaming_llm_score",
+    "chunk_press_indices",
+    "rerotate_keys",
     "ea_query_stats",
     "ea_avg_rope",
     "ea_score",
@@ -362,3 +364,47 @@ def streaming_llm_score(B: int, H: int, k_len: int, compression_ratio: float, n_
     s = np.ones((B, H, k_len), dtype=np.float32)
     s[:, :, n_sink:n_sink + n_pruned] = 0
     return s
+
+
+# ----------------------------------------------------------------------------------------------
+# selection wrappers
+# ----------------------------------------------------------------------------------------------
+def _round_dtype(x: np.ndarray, dtype: str) -> np.ndarray:
+    """float32 values rounded (RNE) to ``dtype`` ("f32" | "f16" | "bf16") and returned as float32."""
+    x = np.asarray(x, dtype=np.float32)
+    if dtype == "f32":
+        return x
+    if dtype == "f16":
+        return x.astype(np.float16).astype(np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def chunk_press_indices(score_chunk, k_len: int, chunk_length: int, compression_ratio: float) -> np.ndarray:
+    """ChunkPress.compress's index set (chunk_press.py:67-83): for every chunk [i, i + L) the ``max(1, int(len * (1 - r)))``
+    best positions by ``score_chunk(i, j) -> scores[B,H,j-i]`` of that chunk alone, concatenated (each chunk in ascending
+    position order here; the reference keeps topk's order inside a chunk)."""
+    out = []
+    for i in range(0, k_len, chunk_length):
+        j = min(k_len, i + chunk_length)
+        sc = score_chunk(i, j)
+        n = max(1, int((j - i) * (1 - compression_ratio)))
+        out.append(i + topk_select(sc, n))
+    return np.concatenate(out, axis=-1).astype(np.int32)
+
+
+def rerotate_keys(keys_kept: np.ndarray, idx: np.ndarray, inv_freq: np.ndarray, dtype: str = "f32") -> np.ndarray:
+    """KeyRerotationPress.rerotate_keys after the gather (key_rerotation_press.py:50-128): token j of the kept
+    (position-sorted) keys moves from position idx[..., j] to position j: ``k * cos(f) + rotate_half(k) * sin(f)`` with
+    ``f = (j - idx) * inv_freq`` in float32, cos/sin cast to the key dtype and every product / sum rounded in it."""
+    k = np.asarray(keys_kept, dtype=np.float32)
+    n = k.shape[2]
+    delta = (np.arange(n, dtype=np.float32)[None, None, :] - idx.astype(np.float32))            # [B,H,n]
+    freqs = (delta[..., None] * np.asarray(inv_freq, dtype=np.float32)[None, None, None, :]).astype(np.float32)
+    emb = np.concatenate([freqs, freqs], axis=-1)
+    cos = _round_dtype(np.cos(emb.astype(np.float64)).astype(np.float32), dtype)
+    sin = _round_dtype(np.sin(emb.astype(np.float64)).astype(np.float32), dtype)
+    a = _round_dtype(k * cos, dtype)
+    b = _round_dtype(rotate_half(k) * sin, dtype)
+    return _round_dtype(a + b, dtype)

@@ -208,3 +208,33 @@ PIPELINE_CASES = {
     "pipe_ea": ("ea", dict(compression_ratio=0.4), 23, ["w9 w10 w11 w12 w13"], 6),
     "pipe_none": (None, {}, 40, ["w3"], 6),
 }
+
+
+# ---- selection wrappers: ChunkPress / KeyRerotationPress around a scorer ---------------------------
+WRAP_CASES = {
+    # name: wrapper, inner press kind, geometry (as CASES), wrapper parameters
+    "wrap_chunk_knorm": dict(wrapper="chunk", kind="knorm", B=2, H=2, G=1, S=1000, D=16, dtype="f32", data="A", seed=81,
+                             chunk_length=256, ratios=(0.25, 0.5, 0.9)),
+    "wrap_chunk_snapkv": dict(wrapper="chunk", kind="snapkv", B=1, H=2, G=2, S=700, D=16, dtype="f32", data="B", seed=82,
+                              chunk_length=200, W=8, ks=5, ratios=(0.5,)),
+    "wrap_chunk_knorm_bf16": dict(wrapper="chunk", kind="knorm", B=1, H=8, G=1, S=4096, D=128, dtype="bf16", data="B", seed=83,
+                                  chunk_length=1024, ratios=(0.5,)),
+    "wrap_chunk_keydiff_tail": dict(wrapper="chunk", kind="keydiff", B=1, H=2, G=1, S=515, D=64, dtype="f16", data="A", seed=84,
+                                    chunk_length=128, ratios=(0.3,)),
+    "wrap_rerot_knorm": dict(wrapper="rerot", kind="knorm", B=2, H=2, G=1, S=300, D=16, dtype="f32", data="A", seed=85, ratios=(0.5,)),
+    "wrap_rerot_knorm_bf16": dict(wrapper="rerot", kind="knorm", B=1, H=2, G=4, S=515, D=128, dtype="bf16", data="B", seed=86,
+                                  ratios=(0.5, 0.8)),
+    "wrap_rerot_streaming_f16": dict(wrapper="rerot", kind="streaming", B=1, H=2, G=1, S=257, D=64, dtype="f16", data="A", seed=87,
+                                     ratios=(0.4,)),
+}
+
+
+def make_wrap_case(name: str) -> dict:
+    CASES[name] = {k: v for k, v in WRAP_CASES[name].items() if k not in ("wrapper", "chunk_length")}
+    try:
+        s = make_case(name)
+    finally:
+        del CASES[name]
+    s["wrapper"] = WRAP_CASES[name]["wrapper"]
+    s["chunk_length"] = WRAP_CASES[name].get("chunk_length")
+    return s

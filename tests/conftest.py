@@ -81,6 +81,18 @@ def fake_native(monkeypatch):
     def snapkv_compress_rope(q_pre, cos, sin, keys, values, kernel_size, n_kept):
         return gather_kv(keys, values, topk_select(snapkv_score_rope(q_pre, cos, sin, keys, kernel_size), n_kept))
 
+    def topk_select_segmented(scores, seg_len, k, pos_base=0):
+        sc = scores.float().numpy()
+        nseg = sc.shape[-1] // seg_len
+        parts = [pos_base + c * seg_len + O.topk_select(sc[..., c * seg_len:(c + 1) * seg_len], k) for c in range(nseg)]
+        return torch.from_numpy(np.concatenate(parts, axis=-1).astype(np.int32))
+
+    def rerotate_keys_(keys_kept, idx, inv_freq):
+        name = {torch.float32: "f32", torch.float16: "f16", torch.bfloat16: "bf16"}[keys_kept.dtype]
+        out = O.rerotate_keys(keys_kept.float().numpy(), idx.numpy(), inv_freq.float().numpy(), name)
+        keys_kept.copy_(torch.from_numpy(out).to(keys_kept.dtype))
+        return keys_kept
+
     def ea_qstats(q, use_cov=True):
         mu, cov = O.ea_query_stats(q.float().numpy(), use_cov)
         return torch.from_numpy(mu.astype(np.float32)), (torch.from_numpy(cov.astype(np.float32)) if cov is not None else None)
@@ -91,7 +103,7 @@ def fake_native(monkeypatch):
 
     for name, fn in dict(rownorm_score=rownorm_score, topk_select=topk_select, gather_kv=gather_kv,
                          snapkv_score=snapkv_score, snapkv_score_rope=snapkv_score_rope, snapkv_score_from_attn=snapkv_score_from_attn,
-                         keydiff_score=keydiff_score, scores_head_mean_=scores_head_mean_, knorm_compress=knorm_compress,
+                         keydiff_score=keydiff_score, scores_head_mean_=scores_head_mean_, knorm_compress=knorm_compress, topk_select_segmented=topk_select_segmented, rerotate_keys_=rerotate_keys_,
                          snapkv_compress_rope=snapkv_compress_rope, ea_qstats=ea_qstats, ea_score=ea_score).items():
         monkeypatch.setattr(_native, name, fn)
     return _native

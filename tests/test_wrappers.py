@@ -1,0 +1,201 @@
+"""ChunkPress / KeyRerotationPress against the REAL reference's outputs (tests/golden/wrap_*.npz, made by
+oracle/gen_golden_wrappers.py).  CPU: oracle restatement and the host logic of the wrappers over oracle-backed entry
+points; GPU (marked): the same classes on the HIP kernels, plus kernel-level checks of the two new entry points."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _inputs
+from oracle import kvpress_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CHUNK = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "chunk"]
+REROT = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "rerot"]
+DEV = "cuda:0"
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, f"{name}.npz"))
+
+
+def inner_press(s, ratio):
+    import kvpress_amd as P
+
+    return {"knorm": lambda: P.KnormPress(ratio), "keydiff": lambda: P.KeyDiffPress(ratio),
+            "snapkv": lambda: P.SnapKVPress(ratio, window_size=s["W"], kernel_size=s["ks"]),
+            "streaming": lambda: P.StreamingLLMPress(ratio, n_sink=s["n_sink"])}[s["kind"]]()
+
+
+def wrapped(s, ratio):
+    import kvpress_amd as P
+
+    return P.ChunkPress(inner_press(s, ratio), chunk_length=s["chunk_length"]) if s["wrapper"] == "chunk" else P.KeyRerotationPress(inner_press(s, ratio))
+
+
+def oracle_chunk_scores(s, cos=None, sin=None):
+    """score_chunk(i, j) of the inner press restated by the oracle on chunk [i, j)."""
+    if s["kind"] == "knorm":
+        return lambda i, j: O.knorm_score(s["keys"][:, :, i:j])
+    if s["kind"] == "keydiff":
+        return lambda i, j: O.keydiff_score(s["keys"][:, :, i:j])
+    W = s["W"]
+
+    def snap(i, j):  # the wrapped SnapKV sees the chunk's hidden states but the FULL sequence's last-W rotary tables
+        h = s["hidden"][:, i:j]
+        q = O.snapkv_window_queries(h, s["wq"], None, cos, sin, s["Hq"], s["D"], W)
+        return O.snapkv_score(q, s["keys"][:, :, i:j], s["ks"])
+    return snap
+
+
+@pytest.mark.parametrize("name", CHUNK)
+def test_oracle_chunk_indices_match_reference(name):
+    s = _inputs.make_wrap_case(name)
+    g = gold(name)
+    att, rot, hidden, (cos, sin) = _inputs.build_llama_attention(s, torch.float32)
+    fn = oracle_chunk_scores(s, cos.numpy(), sin.numpy())
+    for i, r in enumerate(s["ratios"]):
+        idx = np.sort(O.chunk_press_indices(fn, s["S"], s["chunk_length"], r), axis=-1)
+        assert np.array_equal(idx, g[f"pos_{i}"]), f"{name} r={r}"
+
+
+@pytest.mark.parametrize("name", REROT)
+def test_oracle_rerotation_matches_reference(name):
+    s = _inputs.make_wrap_case(name)
+    g = gold(name)
+    att, rot, hidden, pe = _inputs.build_llama_attention(s, torch.float32)
+    inv = rot.inv_freq.numpy()
+    for i, r in enumerate(s["ratios"]):
+        for mode, dt in (("f32", "f32"), ("nat", s["dtype"])):
+            pos = g[f"pos_{i}"] if mode == "f32" else g[f"pos_nat_{i}"]
+            kk, _ = O.gather_kv(s["keys"], s["values"], pos)
+            got = O.rerotate_keys(kk, pos, inv, dt)
+            ref = g[f"kout_{mode}_{i}"]
+            if dt == "f32":
+                np.testing.assert_allclose(got, ref, rtol=1e-5, atol=2e-6)
+            else:  # per-op rounding in the key dtype: identical up to a 1-ulp flip where fp32 cos/sin round differently
+                ulp = 2.0 ** (-8 if dt == "bf16" else -11)
+                assert np.mean(got != ref) < 2e-3 and np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)) <= 2.1 * ulp
+
+
+def _run_wrapper(s, name, dev, dt):
+    g = gold(name)
+    att, rot, hidden, pe = _inputs.build_llama_attention(s, dt, dev)
+    att.rotary_emb = rot
+    keys = torch.from_numpy(s["keys"]).to(device=dev, dtype=dt)
+    posv = torch.arange(s["S"], dtype=torch.float32, device=dev)[None, None, :, None].expand(s["B"], s["H"], s["S"], s["D"]).contiguous()
+    kwargs = {"position_embeddings": pe}
+    out = []
+    with torch.no_grad():
+        for i, r in enumerate(s["ratios"]):
+            ko, vo = wrapped(s, r).compress(att, hidden, keys, posv, None, kwargs)
+            assert ko.is_contiguous() and ko.dtype == dt and tuple(ko.shape[:2]) == (s["B"], s["H"])
+            out.append((i, r, ko.float().cpu().numpy(), vo[..., 0].round().to(torch.int64).cpu().numpy()))
+        k0, v0 = wrapped(s, 0.0).compress(att, hidden, keys, posv, None, kwargs)
+        assert k0 is keys and v0 is posv
+    return g, out
+
+
+@pytest.mark.parametrize("name", CHUNK + REROT)
+def test_wrappers_match_reference_cpu(name, fake_native):
+    s = _inputs.make_wrap_case(name)
+    g, out = _run_wrapper(s, name, "cpu", torch.float32)
+    for i, r, ko, pos in out:
+        assert np.array_equal(pos, g[f"pos_{i}"]), f"{name} r={r}: kept positions"   # ours come out sorted
+        if s["wrapper"] == "rerot":
+            np.testing.assert_allclose(ko, g[f"kout_f32_{i}"], rtol=1e-5, atol=2e-6)
+        else:
+            wk, _ = O.gather_kv(s["keys"], s["values"], pos)
+            assert np.array_equal(ko, wk)
+
+
+def test_chunk_press_asserts(fake_native):
+    import kvpress_amd as P
+
+    with pytest.raises(AssertionError):
+        P.ChunkPress(press=P.ChunkPress(P.KnormPress(0.5)), chunk_length=8)
+    cp = P.ChunkPress(P.KnormPress(0.5), chunk_length=8)
+    cp.compression_ratio = 0.25
+    assert cp.press.compression_ratio == 0.25
+    k = torch.zeros(1, 1, 16, 4)
+    with pytest.raises(AssertionError):
+        cp.compress(None, torch.zeros(1, 16, 8), k, k, torch.zeros(1), {})
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CHUNK + REROT)
+def test_wrappers_match_reference_gpu_fp32(name):
+    s = _inputs.make_wrap_case(name)
+    g, out = _run_wrapper(s, name, DEV, torch.float32)
+    for i, r, ko, pos in out:
+        assert np.array_equal(pos, g[f"pos_{i}"]), f"{name} r={r}: kept positions"
+        if s["wrapper"] == "rerot":
+            np.testing.assert_allclose(ko, g[f"kout_f32_{i}"], rtol=1e-5, atol=4e-6)
+        else:
+            wk, _ = O.gather_kv(s["keys"], s["values"], pos)
+            assert np.array_equal(ko, wk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in REROT if _inputs.WRAP_CASES[n]["dtype"] != "f32"])
+def test_rerotation_native_dtype_gpu(name):
+    """bf16 / f16 keys: the kernel's per-op rounding against the reference's, on the reference's own kept positions."""
+    from kvpress_amd import _native
+
+    s = _inputs.make_wrap_case(name)
+    g = gold(name)
+    dt = _inputs.torch_dtype(s["dtype"])
+    att, rot, hidden, pe = _inputs.build_llama_attention(s, dt, DEV)
+    keys = torch.from_numpy(s["keys"]).to(device=DEV, dtype=dt)
+    ulp = 2.0 ** (-8 if s["dtype"] == "bf16" else -11)
+    for i, r in enumerate(s["ratios"]):
+        pos = torch.from_numpy(g[f"pos_nat_{i}"].astype(np.int32)).to(DEV)
+        ko, _ = _native.gather_kv(keys, keys, pos)
+        got = _native.rerotate_keys_(ko, pos, rot.inv_freq).float().cpu().numpy()
+        ref = g[f"kout_nat_{i}"]
+        assert np.mean(got != ref) < 2e-3, f"{name}: {np.mean(got != ref):.2e} of the elements differ"
+        assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)) <= 2.1 * ulp
+        # and bit-identical to the oracle's emulation of the same rounding wherever cosf/sinf agree with numpy
+        want = O.rerotate_keys(s["keys"][np.arange(s["B"])[:, None, None], np.arange(s["H"])[None, :, None], g[f"pos_nat_{i}"]],
+                               g[f"pos_nat_{i}"], rot.inv_freq.cpu().numpy(), s["dtype"])
+        assert np.mean(got != want) < 2e-3
+
+
+@pytest.mark.gpu
+def test_topk_segmented_vs_oracle():
+    from kvpress_amd import _native
+
+    rs = np.random.RandomState(9)
+    for R, nseg, L, k, base in ((4, 7, 100, 33, 0), (2, 3, 2048, 1024, 5), (8, 128, 1024, 512, 0), (3, 1, 77, 77, 1000), (1, 5, 64, 1, 0)):
+        sc = rs.standard_normal((R, nseg * L)).astype(np.float32)
+        sc[:, ::7] = 0.25  # ties inside every chunk
+        got = _native.topk_select_segmented(torch.from_numpy(sc).to(DEV), L, k, pos_base=base).cpu().numpy()
+        want = np.concatenate([base + c * L + O.topk_select(sc[:, c * L:(c + 1) * L], k) for c in range(nseg)], axis=-1)
+        assert got.dtype == np.int32 and np.array_equal(got, want), (R, nseg, L, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["wrap_chunk_knorm_bf16", "wrap_chunk_snapkv"])
+def test_chunk_press_batched_scoring_equals_per_chunk_loop(name):
+    """The chunks-as-batch scoring of ChunkPress gives exactly what scoring every chunk on its own gives."""
+    from kvpress_amd import _native
+
+    s = _inputs.make_wrap_case(name)
+    dt = _inputs.torch_dtype(s["dtype"])
+    att, rot, hidden, pe = _inputs.build_llama_attention(s, dt, DEV)
+    keys = torch.from_numpy(s["keys"]).to(device=DEV, dtype=dt)
+    values = torch.from_numpy(s["values"]).to(device=DEV, dtype=dt)
+    kwargs = {"position_embeddings": pe}
+    r, L = s["ratios"][0], s["chunk_length"]
+    with torch.no_grad():
+        ko, vo = wrapped(s, r).compress(att, hidden, keys, values, None, kwargs)
+        p = inner_press(s, r)
+        parts = []
+        for i in range(0, s["S"], L):
+            sc = p.score(att, hidden[:, i:i + L], keys[:, :, i:i + L], values[:, :, i:i + L], None, kwargs)
+            n = max(1, int(sc.shape[-1] * (1 - r)))
+            parts.append(i + _native.topk_select(sc, n))
+        wk, wv = _native.gather_kv(keys, values, torch.cat(parts, dim=-1))
+    assert torch.equal(ko, wk) and torch.equal(vo, wv)
