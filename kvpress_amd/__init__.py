@@ -10,10 +10,13 @@ through the C ABI of include/kvpress_hip.h; there is no CPU or pure-PyTorch fall
 """
 from kvpress_amd.presses.base_press import BasePress
 from kvpress_amd.presses.chunk_press import ChunkPress
+from kvpress_amd.presses.composed_press import ComposedPress
+from kvpress_amd.presses.decoding_press import DecodingPress, PrefillDecodingPress
 from kvpress_amd.presses.expected_attention_press import ExpectedAttentionPress
 from kvpress_amd.presses.key_rerotation_press import KeyRerotationPress
 from kvpress_amd.presses.keydiff_press import KeyDiffPress
 from kvpress_amd.presses.knorm_press import KnormPress
+from kvpress_amd.presses.per_layer_compression_press import PerLayerCompressionPress
 from kvpress_amd.presses.pyramidkv_press import PyramidKVPress
 from kvpress_amd.presses.random_press import RandomPress
 from kvpress_amd.presses.scorer_press import ScorerPress
@@ -23,7 +26,8 @@ from kvpress_amd.presses.tova_press import TOVAPress
 
 __version__ = "0.1.0"
 __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
-           "KeyDiffPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "KeyRerotationPress", "KVPressTextGenerationPipeline"]
+           "KeyDiffPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "KeyRerotationPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
+           "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
 
 
 def __getattr__(name):

@@ -11,10 +11,8 @@ cut back to its post-prefill length between questions.
     pipe(context, questions=[...], press=...)["answers"]
 
 Host-side differences to the reference, none of which changes a result:
-  * only prefill presses exist in this package (Knorm / SnapKV / ExpectedAttention and the ScorerPress family), so
-    the reference's DecodingPress / KeyRerotationPress / FinchPress / DMSPress special cases (:205-243) are absent;
-  * the stop-token test of the decode loop is read back every 8 tokens instead of per token (``.item()`` at
-    :303-307); tokens generated past the first stop are dropped, so the answer is the same;
+  * the reference's FinchPress / DMSPress / RestoreKVPress special cases (:224-243) are absent (those presses are not
+    part of this package); DecodingPress, PrefillDecodingPress and KeyRerotationPress are handled as there;
   * ``logits_to_keep`` is the transformers >= 4.50 name of ``num_logits_to_keep`` (:288).
 """
 from __future__ import annotations
@@ -28,6 +26,8 @@ from transformers import AutoModelForCausalLM, Cache, DynamicCache, Pipeline
 from transformers.pipelines import PIPELINE_REGISTRY
 
 from kvpress_amd.presses.base_press import BasePress
+from kvpress_amd.presses.decoding_press import DecodingPress, PrefillDecodingPress
+from kvpress_amd.presses.key_rerotation_press import KeyRerotationPress
 
 logger = logging.getLogger(__name__)
 
@@ -89,22 +89,31 @@ class KVPressTextGenerationPipeline(Pipeline):
     def _forward(self, input_tensors, max_new_tokens: int = 50, press: Optional[BasePress] = None,
                  cache: Optional[Cache] = None):
         """Prefill the context under the press, then one greedy answer per question (pipeline.py:173-246)."""
+        decoding = isinstance(press, (DecodingPress, PrefillDecodingPress))
+        if decoding and len(input_tensors["questions_ids"]) > 1:
+            raise ValueError("DecodingPress is not compatible with multiple questions. Please specify a single question.")
         device = self.model.device
         context_ids = input_tensors["context_ids"].to(device)
         context_length = context_ids.shape[1]
         if cache is None:
             cache = DynamicCache()
 
-        with press(self.model) if press is not None else contextlib.nullcontext():
+        # a pure DecodingPress does nothing during prefill (pipeline.py:217-219)
+        prefill_press = press if press is not None and not isinstance(press, DecodingPress) else None
+        with prefill_press(self.model) if prefill_press is not None else contextlib.nullcontext():
             self.model.model(input_ids=context_ids, past_key_values=cache)  # no lm_head during prefill
         logger.debug(f"Context Length: {context_length}")
         logger.debug(f"Compressed Context Length: {cache.get_seq_length()}")
 
         answers = []
-        for question_ids in input_tensors["questions_ids"]:
-            kept = [cache.get_seq_length(i) for i in range(len(cache))]
-            answers.append(self.generate_answer(question_ids.to(device), cache, context_length, max_new_tokens))
-            self._remove_answer_from_cache(cache, kept)
+        # decoding presses keep their hook for the answers (pipeline.py:230-233)
+        with press(self.model) if decoding else contextlib.nullcontext():
+            for question_ids in input_tensors["questions_ids"]:
+                if isinstance(press, KeyRerotationPress):
+                    context_length = cache.get_seq_length()  # re-rotated keys sit at positions 0..n-1 (:237-238)
+                kept = [cache.get_seq_length(i) for i in range(len(cache))]
+                answers.append(self.generate_answer(question_ids.to(device), cache, context_length, max_new_tokens))
+                self._remove_answer_from_cache(cache, kept)
         return answers
 
     @staticmethod
@@ -131,21 +140,15 @@ class KVPressTextGenerationPipeline(Pipeline):
         stop = [] if stop is None else (stop if isinstance(stop, (list, tuple)) else [stop])
         stop_ids = torch.tensor(stop, device=device, dtype=token.dtype) if stop else None
         next_pos = pos[:, -1:] + 1
-        # As in the reference, the stop test applies to the tokens produced inside this loop (not to the first one)
-        # and the stop token itself is kept.  The test is evaluated on the device and read back every 8 tokens only;
-        # tokens generated past a stop are cut off afterwards.
-        hits = []
+        # As in the reference, the stop test applies to the tokens produced inside this loop (not to the first one), the
+        # stop token itself is kept, and no forward pass runs after it (a decoding press would otherwise see extra steps).
         for i in range(max_new_tokens - 1):
             out = self.model(input_ids=token.view(1, 1), past_key_values=cache, position_ids=next_pos)
             token = out.logits[0, -1].argmax()
             generated.append(token)
             next_pos = next_pos + 1
-            if stop_ids is not None:
-                hits.append(torch.isin(token, stop_ids))
-                if (i % 8 == 7 or i == max_new_tokens - 2) and bool(torch.stack(hits).any()):
-                    first = int(torch.stack(hits).int().argmax())
-                    generated = generated[: first + 2]
-                    break
+            if stop_ids is not None and bool(torch.isin(token, stop_ids)):
+                break
         return str(self.tokenizer.decode(torch.stack(generated), skip_special_tokens=True))
 
 

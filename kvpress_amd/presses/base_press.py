@@ -6,7 +6,7 @@ attention forward during prefill the hook pulls K/V out of the HF cache, calls `
 writes the compressed K/V back.  Differences, all host-side:
   * prefill detection never synchronises: ``cache_position[-1] + 1 == q_len`` (:37-40, a
     device->host ``.item()``) is equivalent to "the cache held nothing before this forward",
-    i.e. ``kv_len == q_len``, which is read from tensor shapes;  transformers >= 5.x no longer
+    i.e. ``kv_len <= q_len`` after the layer's update, which is read from tensor shapes;  transformers >= 5.x no longer
     passes ``cache_position`` to the attention layer at all (SURVEY.md §8b);
   * layers are also located for decoder-only models that keep them under ``model.decoder``
     (OPT: BASELINE config 1), and ``rotary_emb`` is attached only when the model has one.
@@ -36,8 +36,10 @@ SUPPORTED_MODEL_NAMES = (
 
 
 def is_prefilling(kv_len: int, q_len: int) -> bool:
-    """True for the initial prefill: the cache holds exactly the q_len tokens of this forward."""
-    return int(kv_len) == int(q_len)
+    """True for the initial prefill: the cache held nothing before this forward, i.e. after the layer's update it holds
+    the q_len tokens of this forward -- or fewer, when an earlier press of a ComposedPress has already pruned them.
+    (A continuation or decoding step leaves kv_len = past + q_len > q_len.)"""
+    return int(kv_len) <= int(q_len)
 
 
 def _language_model(model):

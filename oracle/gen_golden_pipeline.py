@@ -21,8 +21,8 @@ sys.path.insert(0, os.path.join(REPO, "oracle"))
 def main():
     import gen_golden
     gen_golden._install_shims()
+    import kvpress
     import torch
-    from kvpress import ExpectedAttentionPress, KnormPress, SnapKVPress
     from kvpress.pipeline import KVPressTextGenerationPipeline
     from transformers import DynamicCache
 
@@ -43,8 +43,8 @@ def main():
 
     pipe = KVPressTextGenerationPipeline(model=model, tokenizer=tok)
     out = {}
-    for name, (kind, kw, n_words, questions, max_new) in _inputs.PIPELINE_CASES.items():
-        press = {None: lambda **k: None, "knorm": KnormPress, "snapkv": SnapKVPress, "ea": ExpectedAttentionPress}[kind](**kw)
+    for name, (spec, n_words, questions, max_new) in _inputs.PIPELINE_CASES.items():
+        press = _inputs.build_press(kvpress, spec)
         context = _inputs.tiny_context(n_words)
         cache = DynamicCache()
         res = pipe(context, questions=questions, press=press, max_new_tokens=max_new, cache=cache)

@@ -201,12 +201,38 @@ def tiny_context(n_words: int, seed: int = 0) -> str:
     return " ".join(TINY_WORDS[i] for i in rng.integers(0, len(TINY_WORDS), n_words))
 
 
+def build_press(ns, spec):
+    """Instantiate a press from a nested (class name, kwargs) spec in namespace ``ns`` -- the reference package ``kvpress``
+    or this package ``kvpress_amd``: the class names and constructor arguments are the same (that is the drop-in claim)."""
+    if spec is None:
+        return None
+    if isinstance(spec, list):
+        return [build_press(ns, x) for x in spec]
+    cls, kw = spec
+    is_spec = lambda v: (isinstance(v, tuple) and len(v) == 2 and isinstance(v[0], str) and isinstance(v[1], dict)) or \
+        (isinstance(v, list) and v and isinstance(v[0], tuple))
+    return getattr(ns, cls)(**{k: (build_press(ns, v) if is_spec(v) else v) for k, v in kw.items()})
+
+
+_KN = lambda r=0.0: ("KnormPress", dict(compression_ratio=r))
 PIPELINE_CASES = {
-    # name: (press kind, press kwargs, context words, questions, max_new_tokens)
-    "pipe_knorm": ("knorm", dict(compression_ratio=0.5), 120, ["w1 w2 w3", "w7"], 8),
-    "pipe_snapkv": ("snapkv", dict(compression_ratio=0.5, window_size=16, kernel_size=5), 150, ["w4 w5"], 8),
-    "pipe_ea": ("ea", dict(compression_ratio=0.4), 23, ["w9 w10 w11 w12 w13"], 6),
-    "pipe_none": (None, {}, 40, ["w3"], 6),
+    # name: (press spec, context words, questions, max_new_tokens)
+    "pipe_knorm": (_KN(0.5), 120, ["w1 w2 w3", "w7"], 8),
+    "pipe_snapkv": (("SnapKVPress", dict(compression_ratio=0.5, window_size=16, kernel_size=5)), 150, ["w4 w5"], 8),
+    "pipe_ea": (("ExpectedAttentionPress", dict(compression_ratio=0.4)), 23, ["w9 w10 w11 w12 w13"], 6),
+    "pipe_none": (None, 40, ["w3"], 6),
+    # SURVEY §8 f-2 .. f-4 through the pipeline
+    "pipe_tova": (("TOVAPress", dict(compression_ratio=0.5)), 90, ["w2 w8"], 6),
+    "pipe_keydiff": (("KeyDiffPress", dict(compression_ratio=0.3)), 77, ["w5"], 6),
+    "pipe_streaming_rerot": (("KeyRerotationPress", dict(press=("StreamingLLMPress", dict(compression_ratio=0.5, n_sink=4)))), 100, ["w6 w7", "w1"], 6),
+    "pipe_chunk": (("ChunkPress", dict(press=_KN(0.5), chunk_length=32)), 110, ["w3 w4"], 6),
+    "pipe_composed": (("ComposedPress", dict(presses=[_KN(0.25), _KN(0.5)])), 120, ["w9"], 6),
+    "pipe_decoding": (("DecodingPress", dict(base_press=_KN(), compression_interval=3, target_size=40, hidden_states_buffer_size=0)),
+                      60, ["w1 w2"], 14),
+    "pipe_prefill_decoding": (("PrefillDecodingPress", dict(
+        prefilling_press=_KN(0.5),
+        decoding_press=("DecodingPress", dict(base_press=_KN(), compression_interval=4, target_size=36, hidden_states_buffer_size=2)))),
+        80, ["w5 w6 w7"], 16),
 }
 
 
