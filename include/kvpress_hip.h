@@ -46,6 +46,9 @@ enum kvp_order { KVP_ORDER_POSITION = 0, KVP_ORDER_SCORE = 1 };
  * only been used by kvp_topk_select on ONE stream since.  The call then skips its memset: the histograms in
  * the workspace are self-cleaning (left zero on completion). */
 #define KVP_TOPK_WS_CLEAN 0x100
+/* OR-ed into `order`: select the k SMALLEST scores instead of the k largest (ties still go to the lowest position);
+ * AdaKVPress's bottom-k across heads (kvpress/presses/adakv_press.py:66-67) without negating the scores. */
+#define KVP_TOPK_SMALLEST 0x200
 
 int kvp_version(void);
 const char* kvp_last_error(void);
@@ -125,6 +128,11 @@ int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
                   const void* v, int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype,
                   int64_t B, int64_t H, int64_t S, int64_t D,
                   const int32_t* idx, int64_t n, void* k_out, void* v_out, kvp_stream_t stream);
+
+/* scores[r, idx[r, j]] = value for every j < n (AdaKVPress's safeguard `scores.scatter_(-1, top_indices, finfo.max)`,
+ * kvpress/presses/adakv_press.py:62-63); idx int32 [R, n] contiguous, scores rows row_stride elements apart. */
+int kvp_scores_fill_at(float* scores, int64_t R, int64_t S, int64_t row_stride, const int32_t* idx, int64_t n, float value,
+                       kvp_stream_t stream);
 
 /* ---- ChunkPress: per-chunk top-k (kvpress/presses/chunk_press.py:67-85) ---------------------------------------------
  * scores[R, nseg * seg_len] contiguous; the k largest of EACH chunk of seg_len columns are selected (same tie rule as

@@ -8,6 +8,7 @@ ChunkPress and KeyRerotationPress, and the
 Everything below ``ScorerPress.compress`` runs in hand-written HIP kernels (gfx950) reached
 through the C ABI of include/kvpress_hip.h; there is no CPU or pure-PyTorch fallback.
 """
+from kvpress_amd.presses.adakv_press import AdaKVPress
 from kvpress_amd.presses.base_press import BasePress
 from kvpress_amd.presses.chunk_press import ChunkPress
 from kvpress_amd.presses.composed_press import ComposedPress
@@ -26,7 +27,7 @@ from kvpress_amd.presses.tova_press import TOVAPress
 
 __version__ = "0.1.0"
 __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
-           "KeyDiffPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "KeyRerotationPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
+           "KeyDiffPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "KeyRerotationPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
            "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
 
 

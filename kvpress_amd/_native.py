@@ -55,6 +55,7 @@ SIGNATURES = {
     "kvp_topk_select": (c_int, [c_void_p, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_topk_segmented_workspace_bytes": (c_size_t, [_I64] * 4),
     "kvp_topk_select_segmented": (c_int, [c_void_p, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "kvp_scores_fill_at": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, c_float, c_void_p]),
     "kvp_rerotate_keys": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, c_void_p, c_void_p, c_void_p]),
     "kvp_gather_kv": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64,
                               c_void_p, _I64, c_void_p, c_void_p, c_void_p]),
@@ -264,8 +265,25 @@ def ea_score(keys: torch.Tensor, values: torch.Tensor, mu: torch.Tensor, cov: Op
     return scores
 
 
+TOPK_SMALLEST = 0x200
+
+
+def scores_fill_at_(scores: torch.Tensor, idx: torch.Tensor, value: float) -> torch.Tensor:
+    """In place: scores[..., idx[..., j]] = value (float32 scores [..., S] contiguous, int32 idx [..., n])."""
+    assert scores.dtype == torch.float32 and scores.is_contiguous() and scores.is_cuda
+    S = scores.shape[-1]
+    idx = idx.to(torch.int32).contiguous()
+    n = idx.shape[-1]
+    R = scores.numel() // S if S else 0
+    assert idx.numel() == R * n
+    with torch.cuda.device(scores.device):
+        _check(lib().kvp_scores_fill_at(_p(scores), R, S, S, _p(idx), n, float(value), _stream(scores)), "kvp_scores_fill_at")
+    return scores
+
+
 def topk_select(scores: torch.Tensor, k: int, order: int = ORDER_POSITION) -> torch.Tensor:
-    """Indices (int32 [..., k]) of the k largest scores per row of float32 scores[..., S]; ties -> lowest position."""
+    """Indices (int32 [..., k]) of the k largest scores per row of float32 scores[..., S]; ties -> lowest position.
+    ``order | TOPK_SMALLEST`` selects the k smallest instead."""
     if not scores.is_cuda:
         raise KvpressHipError(f"kvpress_amd kernels need tensors on a HIP device, got {scores.device}")
     s = scores.to(torch.float32)

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_hist12_kernel(const float* __
 #pragma unroll
     for (int j = 0; j < TK_PER; ++j) {
         const uint32_t i = base + j * TK_THREADS + threadIdx.x;
-        keys[j] = i < S ? float_to_key(rp[i]) : 0u;
+        keys[j] = i < S ? (float_to_key(rp[i]) ^ w.kmask) : 0u;
     }
     for (int i = threadIdx.x; i < 4096; i += TK_THREADS) lh[i] = 0;
     uint32_t b1 = 0, k1 = 0;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_hist8_kernel(const float* __r
 #pragma unroll
     for (int j = 0; j < TK_PER; ++j) {
         const uint32_t i = base + j * TK_THREADS + threadIdx.x;
-        keys[j] = i < S ? float_to_key(rp[i]) : 0u;
+        keys[j] = i < S ? (float_to_key(rp[i]) ^ w.kmask) : 0u;
     }
     lh[threadIdx.x] = 0;
     const uint32_t b1 = w.sel[row * 4 + 0], k1 = w.sel[row * 4 + 1];
@@ -196,12 +196,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __r
 #pragma unroll
         for (int q = 0; q < TK_PER / 4; ++q) {
             const float4 a = *reinterpret_cast<const float4*>(rp + p0 + 4 * q);
-            keys[4 * q + 0] = float_to_key(a.x); keys[4 * q + 1] = float_to_key(a.y);
-            keys[4 * q + 2] = float_to_key(a.z); keys[4 * q + 3] = float_to_key(a.w);
+            keys[4 * q + 0] = float_to_key(a.x) ^ w.kmask; keys[4 * q + 1] = float_to_key(a.y) ^ w.kmask;
+            keys[4 * q + 2] = float_to_key(a.z) ^ w.kmask; keys[4 * q + 3] = float_to_key(a.w) ^ w.kmask;
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < TK_PER; ++j) keys[j] = (p0 + j < S) ? float_to_key(rp[p0 + j]) : 0u;
+        for (int j = 0; j < TK_PER; ++j) keys[j] = (p0 + j < S) ? (float_to_key(rp[p0 + j]) ^ w.kmask) : 0u;
     }
     const uint32_t b1 = w.sel[row * 4 + 0], b2 = w.sel[row * 4 + 2], k2 = w.sel[row * 4 + 3];
     uint32_t b3, quota;
@@ -278,7 +278,7 @@ extern "C" size_t kvp_topk_workspace_bytes(int64_t R, int64_t S, int64_t k) {
 
 int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, int64_t idx_stride,
                      uint32_t tail_start, uint32_t tail_n, void* ws, size_t ws_bytes, bool ws_clean, bool hist1_ready,
-                     hipStream_t stream, uint32_t nseg, uint32_t seg_len, uint32_t pos_base) {
+                     hipStream_t stream, uint32_t nseg, uint32_t seg_len, uint32_t pos_base, bool smallest) {
     if (R == 0 || k + tail_n == 0) return KVP_OK;
     KVP_CHECK_ARG(S < ((int64_t)1 << 31) && R <= 65535, "topk: S=%ld or R=%ld too large", (long)S, (long)R);
     KVP_CHECK_ARG(scores && idx, "topk: null pointer");
@@ -286,6 +286,7 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
                   (long)S, (long)idx_stride);
     const int64_t nchunks = (S + TK_CHUNK - 1) / TK_CHUNK;
     TopkWs w = topk_carve_ws(ws, R, nchunks);
+    w.kmask = smallest ? 0xFFFFFFFFu : 0u;  // the k SMALLEST = the k largest of the complemented order-preserving keys
     if (k == S || k == 0) {  // every position / only the tail is kept: no selection needed
         if (hist1_ready && ws && hipMemsetAsync(w.hist1, 0, (size_t)R * 4096 * 4, stream) != hipSuccess) {  // leave the workspace clean
             kvp_set_error("topk: hipMemsetAsync failed");
@@ -320,14 +321,14 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
 extern "C" int kvp_topk_select(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int order,
                                int32_t* idx, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
     KVP_CHECK_ARG(R >= 0 && S >= 0 && k >= 0 && k <= S, "topk: bad shape R=%ld S=%ld k=%ld", (long)R, (long)S, (long)k);
-    const int ord = order & ~KVP_TOPK_WS_CLEAN;
+    const int ord = order & ~(KVP_TOPK_WS_CLEAN | KVP_TOPK_SMALLEST);
     KVP_CHECK_ARG(ord == KVP_ORDER_POSITION || ord == KVP_ORDER_SCORE, "topk: bad order %d", order);
     if (ord == KVP_ORDER_SCORE) {
         kvp_set_error("topk: KVP_ORDER_SCORE is not implemented yet (use KVP_ORDER_POSITION)");
         return KVP_EUNSUPPORTED;
     }
     return topk_select_impl(scores, R, S, row_stride, k, idx, k, 0, 0, ws, ws_bytes, (order & KVP_TOPK_WS_CLEAN) != 0, false,
-                            static_cast<hipStream_t>(stream_));
+                            static_cast<hipStream_t>(stream_), 1, 0, 0, (order & KVP_TOPK_SMALLEST) != 0);
 }
 
 // Segmented select (ChunkPress, kvpress/presses/chunk_press.py:67-85): every row of scores[R, nseg * seg_len] is cut into
@@ -344,5 +345,30 @@ extern "C" int kvp_topk_select_segmented(const float* scores, int64_t R, int64_t
     KVP_CHECK_ARG(R * nseg <= 65535 && pos_base + nseg * seg_len < ((int64_t)1 << 31), "topk_segmented: too many chunks (%ld) or positions", (long)(R * nseg));
     // rows of the flat view: (r, segment) at scores + (r * nseg + segment) * seg_len
     return topk_select_impl(scores, R * nseg, seg_len, seg_len, k, idx, k, 0, 0, ws, ws_bytes, (order & KVP_TOPK_WS_CLEAN) != 0, false,
-                            static_cast<hipStream_t>(stream_), (uint32_t)nseg, (uint32_t)seg_len, (uint32_t)pos_base);
+                            static_cast<hipStream_t>(stream_), (uint32_t)nseg, (uint32_t)seg_len, (uint32_t)pos_base, false);
+}
+
+// ---- scores[r, idx[r, j]] = value for j < n (AdaKVPress's safeguard: `scores.scatter_(-1, top_indices, finfo.max)`,
+// kvpress/presses/adakv_press.py:62-63) ----------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void fill_at_kernel(float* __restrict__ scores, int64_t row_stride, const int32_t* __restrict__ idx,
+                                                      uint32_t n, uint32_t S, float value) {
+    float* row = scores + (int64_t)blockIdx.y * row_stride;
+    const int32_t* ir = idx + (size_t)blockIdx.y * n;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const int32_t p = ir[j];
+        if (p >= 0 && (uint32_t)p < S) row[p] = value;
+    }
+}
+}  // namespace
+extern "C" int kvp_scores_fill_at(float* scores, int64_t R, int64_t S, int64_t row_stride, const int32_t* idx, int64_t n, float value,
+                                  kvp_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KVP_CHECK_ARG(R >= 0 && S >= 0 && n >= 0 && R <= 65535 && row_stride >= S, "fill_at: bad shape R=%ld S=%ld n=%ld", (long)R, (long)S, (long)n);
+    if (R * n == 0) return KVP_OK;
+    KVP_CHECK_ARG(scores && idx, "fill_at: null pointer");
+    const uint32_t bx = (uint32_t)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 1024));
+    KVP_LAUNCH("fill_at_kernel", stream, fill_at_kernel<<<dim3(bx, (uint32_t)R), 256, 0, stream>>>(scores, row_stride, idx, (uint32_t)n, (uint32_t)S, value));
+    KVP_CHECK_LAUNCH("fill_at");
+    return KVP_OK;
 }

@@ -18,6 +18,7 @@ struct TopkWs {
     uint32_t* chunk_hist;  // [R][nchunks][257] suffix counts of the last digit: [d] = #(digit >= d), [256] = 0
     uint32_t* chunk_gt;    // [R][nchunks]
     size_t zero_bytes;     // leading bytes that must be zeroed per call (hist1..hist3)
+    uint32_t kmask;        // XOR-ed into every key: 0 = k largest, 0xFFFFFFFF = k smallest
     size_t total_bytes;
 };
 
@@ -38,6 +39,7 @@ inline TopkWs topk_carve_ws(void* ws, int64_t R, int64_t nchunks) {
     w.chunk_hist = (uint32_t*)take((size_t)R * nchunks * 257 * 4);
     w.chunk_gt = (uint32_t*)take((size_t)R * nchunks * 4);
     w.total_bytes = off;
+    w.kmask = 0;
     return w;
 }
 
@@ -76,5 +78,5 @@ __device__ __forceinline__ void topk_hist1_flush(const uint32_t* lds_hist, uint3
 // hist1_ready: w.hist1 already holds this call's first-pass histogram (a fused scorer produced it).
 int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, int64_t idx_stride,
                      uint32_t tail_start, uint32_t tail_n, void* ws, size_t ws_bytes, bool ws_clean, bool hist1_ready,
-                     hipStream_t stream, uint32_t nseg = 1, uint32_t seg_len = 0, uint32_t pos_base = 0);
+                     hipStream_t stream, uint32_t nseg = 1, uint32_t seg_len = 0, uint32_t pos_base = 0, bool smallest = false);
 // nseg > 1: rows are (outer row, segment) pairs and every reported position gets (row % nseg) * seg_len + pos_base added

@@ -24,7 +24,7 @@ def main(argv):
     gen_golden._install_shims()
     import numpy as np
     import torch
-    from kvpress import ChunkPress, KeyDiffPress, KeyRerotationPress, KnormPress, SnapKVPress, StreamingLLMPress
+    from kvpress import AdaKVPress, ChunkPress, KeyDiffPress, KeyRerotationPress, KnormPress, SnapKVPress, StreamingLLMPress
 
     import _inputs
 
@@ -42,6 +42,8 @@ def main(argv):
             return StreamingLLMPress(compression_ratio=ratio, n_sink=s["n_sink"])
 
         def wrap(ratio):
+            if s["wrapper"] == "adakv":
+                return AdaKVPress(inner(ratio), alpha_safeguard=s["alpha"])
             return ChunkPress(inner(ratio), chunk_length=s["chunk_length"]) if s["wrapper"] == "chunk" else KeyRerotationPress(inner(ratio))
 
         out = {"ratios": np.asarray(s["ratios"], dtype=np.float64)}
@@ -51,6 +53,19 @@ def main(argv):
             keys = torch.from_numpy(s["keys"]).to(dt)
             posv = torch.arange(s["S"], dtype=torch.float32)[None, None, :, None].expand(s["B"], s["H"], s["S"], s["D"]).contiguous()
             kwargs = {"position_embeddings": pe}
+            if s["wrapper"] == "adakv":
+                # K/V stay untouched; the pruned (batch, head, position) triples land in module.masked_key_indices
+                # (adakv_press.py:70-75).  Stored: sorted flat indices head * S + position per batch element (float32 run).
+                if mode == "f32":
+                    att.config._attn_implementation = "sdpa"
+                    with torch.no_grad():
+                        for i, r in enumerate(s["ratios"]):
+                            ko, vo = wrap(r).compress(att, hidden, keys, posv, None, kwargs)
+                            assert ko is keys
+                            bi, hi, si = att.masked_key_indices
+                            flat = (hi * s["S"] + si).reshape(s["B"], -1)
+                            out[f"masked_{i}"] = torch.sort(flat, dim=-1).values.numpy().astype(np.int64)
+                continue
             with torch.no_grad():
                 for i, r in enumerate(s["ratios"]):
                     ko, vo = wrap(r).compress(att, hidden, keys, posv, None, kwargs)
@@ -66,7 +81,7 @@ def main(argv):
                             out[f"pos_nat_{i}"] = pos.numpy().astype(np.int32)
         path = os.path.join(outdir, f"{name}.npz")
         np.savez_compressed(path, **out)
-        print(name, os.path.getsize(path), {k: v.shape for k, v in out.items() if k.startswith("pos_")})
+        print(name, os.path.getsize(path), {k: v.shape for k, v in out.items() if k.startswith(("pos_", "masked_"))})
 
 
 if __name__ == "__main__":

@@ -40,6 +40,7 @@ __all__ = [
     "pyramidkv_budget",
     "streaming_llm_score",
     "chunk_press_indices",
+    "adakv_pruned",
     "rerotate_keys",
     "ea_query_stats",
     "ea_avg_rope",
@@ -408,3 +409,18 @@ def rerotate_keys(keys_kept: np.ndarray, idx: np.ndarray, inv_freq: np.ndarray, 
     a = _round_dtype(k * cos, dtype)
     b = _round_dtype(rotate_half(k) * sin, dtype)
     return _round_dtype(a + b, dtype)
+
+
+def adakv_pruned(scores: np.ndarray, compression_ratio: float, alpha_safeguard: float = 0.2) -> np.ndarray:
+    """AdaKVPress.compress's pruned set (adakv_press.py:56-75) as sorted flat indices ``h * S + s`` per batch element,
+    int64 [B, H * (S - n_kept)]: the n_safe = int(n_kept * alpha) best tokens of every head are protected (set to the
+    float maximum), then the lowest scores across all heads are pruned."""
+    sc = np.array(scores, dtype=np.float32, copy=True)
+    B, H, S = sc.shape
+    n_kept = int(S * (1 - compression_ratio))
+    n_safe = int(n_kept * alpha_safeguard)
+    if n_safe:
+        top = topk_select(sc, n_safe)
+        np.put_along_axis(sc, top.astype(np.int64), np.finfo(np.float32).max, axis=-1)
+    n_pruned = H * (S - n_kept)
+    return topk_select(-sc.reshape(B, H * S), n_pruned).astype(np.int64)

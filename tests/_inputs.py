@@ -227,6 +227,7 @@ PIPELINE_CASES = {
     "pipe_streaming_rerot": (("KeyRerotationPress", dict(press=("StreamingLLMPress", dict(compression_ratio=0.5, n_sink=4)))), 100, ["w6 w7", "w1"], 6),
     "pipe_chunk": (("ChunkPress", dict(press=_KN(0.5), chunk_length=32)), 110, ["w3 w4"], 6),
     "pipe_composed": (("ComposedPress", dict(presses=[_KN(0.25), _KN(0.5)])), 120, ["w9"], 6),
+    "pipe_adakv": (("AdaKVPress", dict(press=_KN(0.5), alpha_safeguard=0.2)), 90, ["w4", "w5 w6"], 6),
     "pipe_decoding": (("DecodingPress", dict(base_press=_KN(), compression_interval=3, target_size=40, hidden_states_buffer_size=0)),
                       60, ["w1 w2"], 14),
     "pipe_prefill_decoding": (("PrefillDecodingPress", dict(
@@ -250,17 +251,24 @@ WRAP_CASES = {
     "wrap_rerot_knorm": dict(wrapper="rerot", kind="knorm", B=2, H=2, G=1, S=300, D=16, dtype="f32", data="A", seed=85, ratios=(0.5,)),
     "wrap_rerot_knorm_bf16": dict(wrapper="rerot", kind="knorm", B=1, H=2, G=4, S=515, D=128, dtype="bf16", data="B", seed=86,
                                   ratios=(0.5, 0.8)),
+    "wrap_adakv_knorm": dict(wrapper="adakv", kind="knorm", B=2, H=4, G=1, S=300, D=16, dtype="f32", data="B", seed=88, alpha=0.2,
+                             ratios=(0.25, 0.5, 0.9)),
+    "wrap_adakv_snapkv": dict(wrapper="adakv", kind="snapkv", B=1, H=2, G=4, S=700, D=128, dtype="f32", data="B", seed=89, alpha=0.5,
+                              W=64, ks=5, ratios=(0.5,)),
+    "wrap_adakv_knorm_alpha0": dict(wrapper="adakv", kind="knorm", B=1, H=8, G=1, S=1000, D=64, dtype="f32", data="A", seed=90,
+                                    alpha=0.0, ratios=(0.7,)),
     "wrap_rerot_streaming_f16": dict(wrapper="rerot", kind="streaming", B=1, H=2, G=1, S=257, D=64, dtype="f16", data="A", seed=87,
                                      ratios=(0.4,)),
 }
 
 
 def make_wrap_case(name: str) -> dict:
-    CASES[name] = {k: v for k, v in WRAP_CASES[name].items() if k not in ("wrapper", "chunk_length")}
+    CASES[name] = {k: v for k, v in WRAP_CASES[name].items() if k not in ("wrapper", "chunk_length", "alpha")}
     try:
         s = make_case(name)
     finally:
         del CASES[name]
     s["wrapper"] = WRAP_CASES[name]["wrapper"]
     s["chunk_length"] = WRAP_CASES[name].get("chunk_length")
+    s["alpha"] = WRAP_CASES[name].get("alpha")
     return s

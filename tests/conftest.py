@@ -46,7 +46,12 @@ def fake_native(monkeypatch):
         return torch.from_numpy(-float(scale) * O.knorm_score(x.float().numpy()))  # scale * ||x||
 
     def topk_select(scores, k, order=0):
-        return torch.from_numpy(O.topk_select(scores.float().numpy(), k))
+        sc = scores.float().numpy()
+        return torch.from_numpy(O.topk_select(-sc if (order & 0x200) else sc, k))  # 0x200 = KVP_TOPK_SMALLEST
+
+    def scores_fill_at_(scores, idx, value):
+        scores.scatter_(-1, idx.to(torch.int64), value)
+        return scores
 
     def gather_kv(keys, values, idx):
         ko, vo = O.gather_kv(keys.numpy(), values.numpy(), idx.numpy())
@@ -103,7 +108,7 @@ def fake_native(monkeypatch):
 
     for name, fn in dict(rownorm_score=rownorm_score, topk_select=topk_select, gather_kv=gather_kv,
                          snapkv_score=snapkv_score, snapkv_score_rope=snapkv_score_rope, snapkv_score_from_attn=snapkv_score_from_attn,
-                         keydiff_score=keydiff_score, scores_head_mean_=scores_head_mean_, knorm_compress=knorm_compress, topk_select_segmented=topk_select_segmented, rerotate_keys_=rerotate_keys_,
+                         keydiff_score=keydiff_score, scores_head_mean_=scores_head_mean_, knorm_compress=knorm_compress, scores_fill_at_=scores_fill_at_, topk_select_segmented=topk_select_segmented, rerotate_keys_=rerotate_keys_,
                          snapkv_compress_rope=snapkv_compress_rope, ea_qstats=ea_qstats, ea_score=ea_score).items():
         monkeypatch.setattr(_native, name, fn)
     return _native

@@ -11,6 +11,7 @@ import _inputs
 from oracle import kvpress_oracle as O
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ADAKV = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "adakv"]
 CHUNK = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "chunk"]
 REROT = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "rerot"]
 DEV = "cuda:0"
@@ -31,6 +32,8 @@ def inner_press(s, ratio):
 def wrapped(s, ratio):
     import kvpress_amd as P
 
+    if s["wrapper"] == "adakv":
+        return P.AdaKVPress(inner_press(s, ratio), alpha_safeguard=s["alpha"])
     return P.ChunkPress(inner_press(s, ratio), chunk_length=s["chunk_length"]) if s["wrapper"] == "chunk" else P.KeyRerotationPress(inner_press(s, ratio))
 
 
@@ -110,6 +113,85 @@ def test_wrappers_match_reference_cpu(name, fake_native):
             assert np.array_equal(ko, wk)
 
 
+def _oracle_scores_full(s):
+    if s["kind"] == "knorm":
+        return O.knorm_score(s["keys"])
+    att, rot, hidden, (cos, sin) = _inputs.build_llama_attention(s, torch.float32)
+    q = O.snapkv_window_queries(s["hidden"], s["wq"], None, cos.numpy(), sin.numpy(), s["Hq"], s["D"], s["W"])
+    return O.snapkv_score(q, s["keys"], s["ks"])
+
+
+@pytest.mark.parametrize("name", ADAKV)
+def test_oracle_adakv_matches_reference(name):
+    s = _inputs.make_wrap_case(name)
+    g = gold(name)
+    sc = _oracle_scores_full(s)
+    for i, r in enumerate(s["ratios"]):
+        assert np.array_equal(O.adakv_pruned(sc, r, s["alpha"]), g[f"masked_{i}"]), f"{name} r={r}"
+
+
+def _run_adakv(s, name, dev):
+    g = gold(name)
+    att, rot, hidden, pe = _inputs.build_llama_attention(s, torch.float32, dev)
+    att.config._attn_implementation = "sdpa"
+    keys = torch.from_numpy(s["keys"]).to(dev)
+    values = torch.from_numpy(s["values"]).to(dev)
+    with torch.no_grad():
+        for i, r in enumerate(s["ratios"]):
+            ko, vo = wrapped(s, r).compress(att, hidden, keys, values, None, {"position_embeddings": pe})
+            assert ko is keys and vo is values                       # nothing is removed from the cache
+            bi, hi, si = att.masked_key_indices
+            n_pruned = s["H"] * (s["S"] - int(s["S"] * (1 - r)))
+            assert bi.shape == hi.shape == si.shape == (s["B"] * n_pruned,) and bi.dtype == torch.int64
+            assert torch.equal(bi.cpu(), torch.arange(s["B"]).repeat_interleave(n_pruned))
+            flat = (hi * s["S"] + si).reshape(s["B"], -1).cpu().numpy()
+            assert np.array_equal(flat, g[f"masked_{i}"]), f"{name} r={r}"  # ours come out sorted
+
+
+@pytest.mark.parametrize("name", ADAKV)
+def test_adakv_matches_reference_cpu(name, fake_native):
+    _run_adakv(_inputs.make_wrap_case(name), name, "cpu")
+
+
+def test_attention_patch_masks_keys():
+    """The patched attention function gives masked keys (numerically) zero weight while decoding and resets the mask on
+    the next prefill -- checked against attention over the physically pruned keys."""
+    from kvpress_amd.attention_patch import attention_patch, search_hyperplane
+
+    torch.manual_seed(0)
+    X = torch.randn(6, 12, 16) + 0.3
+    Y = search_hyperplane(X)
+    assert (torch.bmm(X, Y.unsqueeze(-1)) < -1e3).all()
+
+    def plain(module, q, k, v, mask, dropout, **kw):
+        w = torch.softmax(q @ k.repeat_interleave(q.shape[1] // k.shape[1], 1).transpose(-1, -2) / q.shape[-1] ** 0.5, -1)
+        return w @ v.repeat_interleave(q.shape[1] // k.shape[1], 1), w
+
+    patched = attention_patch(plain)
+    assert attention_patch(patched) is patched                     # idempotent
+
+    class M:
+        masked_key_indices = None
+    m = M()
+    B, Hq, Hkv, S, D = 2, 4, 2, 10, 8
+    q, k, v = torch.randn(B, Hq, 1, D), torch.randn(B, Hkv, S, D), torch.randn(B, Hkv, S, D)
+    b_idx = torch.tensor([0, 0, 1]); h_idx = torch.tensor([0, 1, 1]); s_idx = torch.tensor([3, 5, 0])
+    m.masked_key_indices = (b_idx, h_idx, s_idx)
+    out, w = patched(m, q, k.clone(), v, None, 0.0)
+    wg = w.view(B, Hkv, Hq // Hkv, 1, S)
+    assert float(wg[0, 0, :, 0, 3].max()) == 0.0 and float(wg[0, 1, :, 0, 5].max()) == 0.0 and float(wg[1, 1, :, 0, 0].max()) == 0.0
+    # same output as attention over the caches with those keys physically removed
+    for b, h, s_ in ((0, 0, 3), (1, 1, 0)):
+        keep = [i for i in range(S) if i != s_]
+        for gq in range(Hq // Hkv):
+            hq = h * (Hq // Hkv) + gq
+            ww = torch.softmax(q[b, hq] @ k[b, h, keep].T / D ** 0.5, -1)
+            assert torch.allclose(out[b, hq], ww @ v[b, h, keep], atol=1e-6)
+    # a prefill-shaped call (q_len == k_len) clears the mask
+    patched(m, torch.randn(B, Hq, S, D), k, v, None, 0.0)
+    assert m.masked_key_indices is None
+
+
 def test_chunk_press_asserts(fake_native):
     import kvpress_amd as P
 
@@ -136,6 +218,30 @@ def test_wrappers_match_reference_gpu_fp32(name):
         else:
             wk, _ = O.gather_kv(s["keys"], s["values"], pos)
             assert np.array_equal(ko, wk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ADAKV)
+def test_adakv_matches_reference_gpu(name):
+    _run_adakv(_inputs.make_wrap_case(name), name, DEV)
+
+
+@pytest.mark.gpu
+def test_topk_smallest_and_fill_at():
+    from kvpress_amd import _native
+
+    rs = np.random.RandomState(11)
+    sc = rs.standard_normal((3, 5000)).astype(np.float32)
+    sc[:, ::9] = -0.5                                            # ties
+    t = torch.from_numpy(sc).to(DEV)
+    for k in (1, 17, 2500, 4999, 5000):
+        got = _native.topk_select(t, k, _native.ORDER_POSITION | _native.TOPK_SMALLEST).cpu().numpy()
+        assert np.array_equal(got, O.topk_select(-sc, k)), k
+    idx = _native.topk_select(t, 100)
+    _native.scores_fill_at_(t, idx, 7.5)
+    want = sc.copy()
+    np.put_along_axis(want, idx.cpu().numpy().astype(np.int64), 7.5, axis=-1)
+    assert np.array_equal(t.cpu().numpy(), want)
 
 
 @pytest.mark.gpu
