@@ -21,7 +21,7 @@ if [[ "$WHAT" == *tests* ]]; then
 fi
 if [[ "$WHAT" == *bench* ]]; then
   for wl in knorm32k knorm128k snapkv128k ea128k; do
-    timeout 600 python bench.py --workload $wl --steps 20 --warmup 3 --profile-json gpurun_out/kern_$wl.json > gpurun_out/bench_$wl.log 2>&1
+    timeout 600 python bench.py --workload $wl --profile-json gpurun_out/kern_$wl.json > gpurun_out/bench_$wl.log 2>&1
     echo "bench[$wl] rc=$? $(tail -1 gpurun_out/bench_$wl.log | cut -c1-600)"
   done
 fi
