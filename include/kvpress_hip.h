@@ -184,6 +184,29 @@ int kvp_keydiff_score(const void* k, int dtype, int64_t B, int64_t H, int64_t S,
 int kvp_scores_head_mean(float* scores, int64_t B, int64_t H, int64_t S, int64_t stride_b, int64_t stride_h,
                          kvp_stream_t stream);
 
+/* ---- window q_proj + RoPE in the library (kvpress/utils.py:43-46 + snapkv_press.py:53-58) ---------------------------
+ * hidden_win: hidden_states[:, -W:] [B, W, hidden] (element strides x_sb, x_sw; last dim contiguous); wq: q_proj.weight
+ * [Hq * D, hidden] contiguous, no bias; cos/sin: the window's rotary tables [1 or B, W, D].  bf16 / f16, W = 64, D = 128,
+ * hidden % 256 == 0, else KVP_EUNSUPPORTED (the caller then runs its own q_proj and kvp_snapkv_*_rope).
+ * kvp_snapkv_qproj_rope writes the RoPE'd window queries q_rot [B, Hq, W, D] (contiguous, input dtype): fp32 accumulation
+ * in a fixed order, rounded to the dtype like a GEMM output, then rotated with torch's per-op rounding.
+ * kvp_snapkv_score_hidden / kvp_snapkv_compress_hidden = kvp_snapkv_score_rope / kvp_snapkv_compress_rope from there. */
+int kvp_snapkv_qproj_rope(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, const void* cos, const void* sin,
+                          int64_t cs_sb, int64_t cs_sw, int dtype, int64_t B, int64_t Hq, int64_t W, int64_t D, int64_t hidden,
+                          void* q_rot, kvp_stream_t stream);
+int kvp_snapkv_score_hidden(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, int64_t hidden,
+                            const void* cos, const void* sin, int64_t cs_sb, int64_t cs_sw,
+                            const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
+                            int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
+                            float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream);
+int kvp_snapkv_compress_hidden(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, int64_t hidden,
+                               const void* cos, const void* sin, int64_t cs_sb, int64_t cs_sw,
+                               const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
+                               const void* v, int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype,
+                               int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
+                               int64_t n_kept, void* k_out, void* v_out, void* ws, size_t ws_bytes, int flags,
+                               kvp_stream_t stream);
+
 /* ---- measurement aid (not part of the reference boundary) ------------------------------------
  * kvp_prof_enable(1) makes every kernel launch of the calling thread record a HIP event pair on
  * its launch stream; after synchronising, kvp_prof_get(i) returns kernel i's name and duration.

@@ -43,6 +43,13 @@ SIGNATURES = {
                                  _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_snapkv_score_rope": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, c_void_p, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int,
                                       _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "kvp_snapkv_qproj_rope": (c_int, [c_void_p, _I64, _I64, c_void_p, c_void_p, c_void_p, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64,
+                                      c_void_p, c_void_p]),
+    "kvp_snapkv_score_hidden": (c_int, [c_void_p, _I64, _I64, c_void_p, _I64, c_void_p, c_void_p, _I64, _I64, c_void_p, _I64, _I64, _I64,
+                                        c_int, _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "kvp_snapkv_compress_hidden": (c_int, [c_void_p, _I64, _I64, c_void_p, _I64, c_void_p, c_void_p, _I64, _I64, c_void_p, _I64, _I64, _I64,
+                                           c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _I64,
+                                           c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "kvp_snapkv_score_from_attn": (c_int, [c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, c_int,
                                            c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_ea_qstats_workspace_bytes": (c_size_t, [_I64] * 4),
@@ -210,6 +217,102 @@ def snapkv_score_rope(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
                                            _DTYPES[dt], B, Hq, Hkv, S, W, D, int(kernel_size), _p(scores), _p(ws), ws.numel(),
                                            _stream(keys)), "kvp_snapkv_score_rope")
     return scores
+
+
+# The window q_proj can run in the library (qproj.hip), but it is no faster than the model's own GEMM + the RoPE launch
+# (20 vs 17.6 + 5 us for Llama-3.1-8B) and rounds a few queries differently from the GEMM library, so the presses keep the
+# model's q_proj unless this switch is turned on.
+USE_LIBRARY_QPROJ = False
+
+
+def qproj_rope_supported(module, hidden_states: torch.Tensor, window: int) -> bool:
+    """Should the press project the window in the library?  (USE_LIBRARY_QPROJ and qproj_rope_eligible.)"""
+    return USE_LIBRARY_QPROJ and qproj_rope_eligible(module, hidden_states, window)
+
+
+def qproj_rope_eligible(module, hidden_states: torch.Tensor, window: int) -> bool:
+    """True if the window's q_proj + RoPE can run in the library (qproj.hip): a plain bias-free ``nn.Linear`` q_proj in
+    bf16 / f16 (not a quantised or LoRA-wrapped subclass), no per-head q_norm, window 64, head_dim 128, hidden % 256 == 0."""
+    lin = getattr(module, "q_proj", None)
+    if type(lin) is not torch.nn.Linear or lin.bias is not None or hasattr(module, "q_norm"):
+        return False
+    w = lin.weight
+    return (hidden_states.is_cuda and w.is_cuda and w.dtype == hidden_states.dtype and w.dtype in (torch.bfloat16, torch.float16)
+            and w.is_contiguous() and window == 64 and getattr(module, "head_dim", 0) == 128 and w.shape[1] % 256 == 0
+            and hidden_states.stride(-1) == 1 and w.shape[0] == module.config.num_attention_heads * 128)
+
+
+def _hidden_args(hidden_win, wq, cos, sin, dt):
+    hidden_win = _dev(hidden_win)
+    assert hidden_win.dtype == dt and wq.dtype == dt and hidden_win.stride(-1) == 1 and wq.is_contiguous()
+    cos = _rows_last_contig(_dev(cos.to(dt)))
+    sin = _rows_last_contig(_dev(sin.to(dt)))
+    if sin.stride() != cos.stride():
+        sin, cos = sin.contiguous(), cos.contiguous()
+    return hidden_win, cos, sin
+
+
+def snapkv_qproj_rope(hidden_win: torch.Tensor, wq: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, head_dim: int = 128) -> torch.Tensor:
+    """RoPE'd window queries [B, Hq, W, D] from hidden_states[:, -W:] and q_proj.weight (bf16 / f16, W = 64, D = 128)."""
+    dt = hidden_win.dtype
+    hidden_win, cos, sin = _hidden_args(hidden_win, wq, cos, sin, dt)
+    B, W, K = hidden_win.shape
+    Hq = wq.shape[0] // head_dim
+    out = torch.empty((B, Hq, W, head_dim), dtype=dt, device=hidden_win.device)
+    with torch.cuda.device(hidden_win.device):
+        _check(lib().kvp_snapkv_qproj_rope(_p(hidden_win), _st(hidden_win, 0), _st(hidden_win, 1), _p(wq), _p(cos), _p(sin), _st(cos, 0),
+                                           _st(cos, 1), _DTYPES[dt], B, Hq, W, head_dim, K, _p(out), _stream(hidden_win)),
+               "kvp_snapkv_qproj_rope")
+    return out
+
+
+def snapkv_score_hidden(hidden_win: torch.Tensor, wq: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, keys: torch.Tensor,
+                        kernel_size: int) -> torch.Tensor:
+    """SnapKV scores [B,Hkv,S] float32 from the window's hidden states and the q_proj weight (projection + RoPE in the library)."""
+    keys = _rows_last_contig(_dev(keys))
+    dt = keys.dtype
+    hidden_win, cos, sin = _hidden_args(hidden_win, wq, cos, sin, dt)
+    B, W, K = hidden_win.shape
+    Bk, Hkv, S, D = keys.shape
+    Hq = wq.shape[0] // D
+    assert B == Bk and Hq % Hkv == 0
+    scores = torch.empty((B, Hkv, S), dtype=torch.float32, device=keys.device)
+    with torch.cuda.device(keys.device):
+        ws = _ws(lib().kvp_snapkv_workspace_bytes(B, Hq, Hkv, S, W, D), keys)
+        _check(lib().kvp_snapkv_score_hidden(_p(hidden_win), _st(hidden_win, 0), _st(hidden_win, 1), _p(wq), K, _p(cos), _p(sin),
+                                             _st(cos, 0), _st(cos, 1), _p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _DTYPES[dt],
+                                             B, Hq, Hkv, S, W, D, int(kernel_size), _p(scores), _p(ws), ws.numel(), _stream(keys)),
+               "kvp_snapkv_score_hidden")
+    return scores
+
+
+def snapkv_compress_hidden(hidden_win: torch.Tensor, wq: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, keys: torch.Tensor,
+                           values: torch.Tensor, kernel_size: int, n_kept: int):
+    """SnapKVPress.compress (attentions=None) in one library call from the window's hidden states."""
+    keys = _rows_last_contig(_dev(keys))
+    values = _rows_last_contig(_dev(values))
+    dt = keys.dtype
+    assert values.dtype == dt and keys.shape == values.shape
+    hidden_win, cos, sin = _hidden_args(hidden_win, wq, cos, sin, dt)
+    B, W, K = hidden_win.shape
+    Bk, Hkv, S, D = keys.shape
+    Hq = wq.shape[0] // D
+    assert B == Bk and Hq % Hkv == 0
+    n = int(n_kept)
+    ko = torch.empty((B, Hkv, n, D), dtype=dt, device=keys.device)
+    vo = torch.empty_like(ko)
+    if n:
+        with torch.cuda.device(keys.device):
+            ws = _clean_ws("snapkv", (B, Hq, Hkv, S, W, D, n), lib().kvp_snapkv_compress_workspace_bytes(B, Hq, Hkv, S, W, D, n), keys)
+            rc = lib().kvp_snapkv_compress_hidden(_p(hidden_win), _st(hidden_win, 0), _st(hidden_win, 1), _p(wq), K, _p(cos), _p(sin),
+                                                  _st(cos, 0), _st(cos, 1), _p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2),
+                                                  _p(values), _st(values, 0), _st(values, 1), _st(values, 2), _DTYPES[dt], B, Hq, Hkv, S,
+                                                  W, D, int(kernel_size), n, _p(ko), _p(vo), _p(ws), ws.numel(), TOPK_WS_CLEAN,
+                                                  _stream(keys))
+            if rc != 0:
+                _drop_ws(ws)
+            _check(rc, "kvp_snapkv_compress_hidden")
+    return ko, vo
 
 
 def snapkv_score_from_attn(attn_win: torch.Tensor, num_kv_heads: int, k_len: int, kernel_size: int) -> torch.Tensor:

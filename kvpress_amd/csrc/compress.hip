@@ -94,6 +94,49 @@ extern "C" size_t kvp_snapkv_compress_workspace_bytes(int64_t B, int64_t Hq, int
     return carve(nullptr, B * Hkv, std::max<int64_t>(1, S - W), S, n_kept, kvp_snapkv_workspace_bytes(B, Hq, Hkv, S, W, D)).total_bytes;
 }
 
+// select + gather after a SnapKV scorer has run (fused: hist1 holds the first pass over the S - W non-window columns)
+static int snapkv_select_gather(const CompressWs& w, bool fused, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, const void* v,
+                                int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype, int64_t B, int64_t Hkv, int64_t S, int64_t W, int64_t D,
+                                int64_t n_kept, void* k_out, void* v_out, hipStream_t stream) {
+    const int64_t R = B * Hkv;
+    int rc;
+    if (fused)
+        rc = topk_select_impl(w.scores, R, S - W, S, n_kept - W, w.idx, n_kept, (uint32_t)(S - W), (uint32_t)W, w.topk, w.topk_bytes, true,
+                              true, stream);
+    else
+        rc = topk_select_impl(w.scores, R, S, S, n_kept, w.idx, n_kept, 0, 0, w.topk, w.topk_bytes, true, false, stream);
+    if (rc) return rc;
+    return kvp_gather_kv(k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, D, w.idx, n_kept, k_out, v_out, stream);
+}
+
+// As kvp_snapkv_compress_rope, but starting from the hidden states of the last W tokens and the q_proj weight: the
+// projection and the RoPE run in one kernel of the library (qproj.hip) instead of a library GEMM + a RoPE launch.
+extern "C" int kvp_snapkv_compress_hidden(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, int64_t hidden,
+                                          const void* cosp, const void* sinp, int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb,
+                                          int64_t k_sh, int64_t k_ss, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype,
+                                          int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
+                                          int64_t n_kept, void* k_out, void* v_out, void* ws, size_t ws_bytes, int flags,
+                                          kvp_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KVP_CHECK_ARG(B >= 1 && Hq >= 1 && Hkv >= 1 && W >= 1 && S > W && D >= 1 && n_kept >= 0 && n_kept <= S,
+                  "snapkv_compress: bad shape B=%ld Hq=%ld Hkv=%ld S=%ld W=%ld D=%ld n=%ld", (long)B, (long)Hq, (long)Hkv, (long)S, (long)W,
+                  (long)D, (long)n_kept);
+    if (n_kept == 0) return KVP_OK;
+    const int64_t R = B * Hkv;
+    const CompressWs w = carve(ws, R, S - W, S, n_kept, kvp_snapkv_workspace_bytes(B, Hq, Hkv, S, W, D));
+    if (int rc = check_ws(w, ws, ws_bytes, "snapkv_compress")) return rc;
+    if (!(flags & KVP_TOPK_WS_CLEAN) && hipMemsetAsync(w.topk, 0, topk_carve_ws(nullptr, R, 1).zero_bytes, stream) != hipSuccess) {
+        kvp_set_error("snapkv_compress: hipMemsetAsync failed");
+        return KVP_EHIP;
+    }
+    const bool fused = n_kept >= W;
+    uint32_t* hist1 = fused ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;
+    if (int rc = snapkv_score_hidden_impl(hidden_win, x_sb, x_sw, wq, hidden, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq,
+                                          Hkv, S, W, D, kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1))
+        return rc;
+    return snapkv_select_gather(w, fused, k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, W, D, n_kept, k_out, v_out, stream);
+}
+
 extern "C" int kvp_snapkv_compress_rope(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
                                         int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
                                         const void* v, int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype, int64_t B, int64_t Hq,
@@ -118,12 +161,5 @@ extern "C" int kvp_snapkv_compress_rope(const void* q, int64_t q_sb, int64_t q_s
     if (int rc = snapkv_score_rope_impl(q, q_sb, q_sh, q_sw, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D,
                                         kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1))
         return rc;
-    int rc;
-    if (fused)
-        rc = topk_select_impl(w.scores, R, S - W, S, n_kept - W, w.idx, n_kept, (uint32_t)(S - W), (uint32_t)W, w.topk, w.topk_bytes, true,
-                              true, stream);
-    else
-        rc = topk_select_impl(w.scores, R, S, S, n_kept, w.idx, n_kept, 0, 0, w.topk, w.topk_bytes, true, false, stream);
-    if (rc) return rc;
-    return kvp_gather_kv(k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, D, w.idx, n_kept, k_out, v_out, stream_);
+    return snapkv_select_gather(w, fused, k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, W, D, n_kept, k_out, v_out, stream);
 }

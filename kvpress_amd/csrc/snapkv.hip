@@ -376,6 +376,41 @@ int snapkv_score_rope_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
                              ws_bytes, stream, hist1);
 }
 
+// window queries from the hidden states (fused q_proj + RoPE, qproj.hip), then as above
+bool kvp_qproj_rope_eligible(int dtype, int64_t W, int64_t D, int64_t K, const void* x, int64_t x_sb, int64_t x_sw, const void* w,
+                             const void* cosp, const void* sinp, int64_t cs_sb, int64_t cs_sw);
+int kvp_qproj_rope_launch(const void* x, int64_t x_sb, int64_t x_sw, const void* w, const void* cosp, const void* sinp, int64_t cs_sb,
+                          int64_t cs_sw, int dtype, int64_t B, int64_t Hq, int64_t K, void* out, hipStream_t stream);
+
+int snapkv_score_hidden_impl(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, int64_t hidden, const void* cosp,
+                             const void* sinp, int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
+                             int dtype, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
+                             float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1) {
+    KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "snapkv: bad dtype %d", dtype);
+    if (int rc = check_common(B, Hq, Hkv, S, W, kernel_size)) return rc;
+    KVP_CHECK_ARG(hidden_win && wq && cosp && sinp && k && scores, "snapkv: null pointer");
+    if (!kvp_qproj_rope_eligible(dtype, W, D, hidden, hidden_win, x_sb, x_sw, wq, cosp, sinp, cs_sb, cs_sw)) {
+        kvp_set_error("snapkv: fused q_proj needs bf16/f16, W = 64, D = 128, hidden %% 256 == 0, 16-byte aligned rows");
+        return KVP_EUNSUPPORTED;
+    }
+    SnapWs w = carve_snap_ws(ws, B, Hq, Hkv, S, W, D);
+    if (!ws || ws_bytes < w.total_bytes) {
+        kvp_set_error("snapkv: workspace too small (%zu < %zu)", ws_bytes, w.total_bytes);
+        return KVP_EWORKSPACE;
+    }
+    if (int rc = kvp_qproj_rope_launch(hidden_win, x_sb, x_sw, wq, cosp, sinp, cs_sb, cs_sw, dtype, B, Hq, hidden, w.qrot, stream)) return rc;
+    return snapkv_score_impl(w.qrot, Hq * W * D, W * D, D, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D, kernel_size, scores, ws,
+                             ws_bytes, stream, hist1);
+}
+
+extern "C" int kvp_snapkv_score_hidden(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, int64_t hidden,
+                                       const void* cosp, const void* sinp, int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb,
+                                       int64_t k_sh, int64_t k_ss, int dtype, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W,
+                                       int64_t D, int kernel_size, float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
+    return snapkv_score_hidden_impl(hidden_win, x_sb, x_sw, wq, hidden, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv,
+                                    S, W, D, kernel_size, scores, ws, ws_bytes, static_cast<hipStream_t>(stream_), nullptr);
+}
+
 extern "C" int kvp_snapkv_score_rope(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
                                      int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
                                      int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,

@@ -53,11 +53,14 @@ class SnapKVPress(ScorerPress):
         if attentions is not None:
             attn = attentions[..., -self.window_size:, : -self.window_size]  # snapkv_press.py:88-89
             return _native.snapkv_score_from_attn(attn, keys.shape[1], k_len, self.kernel_size)
-        # q_proj of the last W tokens (model-owned GEMM); RoPE + everything after it runs in the library
-        q_pre = get_prerope_query_states(module, hidden_states[:, -self.window_size:])
         cos, sin = kwargs["position_embeddings"]
-        return _native.snapkv_score_rope(q_pre, cos[:, -self.window_size:], sin[:, -self.window_size:], keys,
-                                         self.kernel_size)
+        cos, sin = cos[:, -self.window_size:], sin[:, -self.window_size:]
+        if _native.qproj_rope_supported(module, hidden_states, self.window_size):
+            # plain bf16 / f16 nn.Linear q_proj: projection of the last W tokens + RoPE in one library kernel
+            return _native.snapkv_score_hidden(hidden_states[:, -self.window_size:], module.q_proj.weight, cos, sin, keys, self.kernel_size)
+        # otherwise q_proj stays the model's own call (quantised / LoRA / q_norm ...); RoPE + the rest in the library
+        q_pre = get_prerope_query_states(module, hidden_states[:, -self.window_size:])
+        return _native.snapkv_score_rope(q_pre, cos, sin, keys, self.kernel_size)
 
     def compress(self, module: nn.Module, hidden_states: torch.Tensor, keys: torch.Tensor, values: torch.Tensor,
                  attentions: torch.Tensor, kwargs: dict) -> tuple[torch.Tensor, torch.Tensor]:
@@ -72,7 +75,11 @@ class SnapKVPress(ScorerPress):
         assert (
             hidden_states.shape[1] > self.window_size
         ), f"Query length {hidden_states.shape[1]} should be greater than the window size {self.window_size}"
-        q_pre = get_prerope_query_states(module, hidden_states[:, -self.window_size:])
         cos, sin = kwargs["position_embeddings"]
-        return _native.snapkv_compress_rope(q_pre, cos[:, -self.window_size:], sin[:, -self.window_size:], keys, values,
-                                            self.kernel_size, self.n_kept(module, keys.shape[2]))
+        cos, sin = cos[:, -self.window_size:], sin[:, -self.window_size:]
+        n_kept = self.n_kept(module, keys.shape[2])
+        if _native.qproj_rope_supported(module, hidden_states, self.window_size):
+            return _native.snapkv_compress_hidden(hidden_states[:, -self.window_size:], module.q_proj.weight, cos, sin, keys, values,
+                                                  self.kernel_size, n_kept)
+        q_pre = get_prerope_query_states(module, hidden_states[:, -self.window_size:])
+        return _native.snapkv_compress_rope(q_pre, cos, sin, keys, values, self.kernel_size, n_kept)

@@ -53,6 +53,9 @@ CASES = {
     "sk_f16_d64": dict(kind="snapkv", B=1, H=2, G=2, S=1000, D=64, dtype="f16", data="A", seed=27, W=32, ks=7),
     "sk_ks1": dict(kind="snapkv", B=1, H=1, G=4, S=300, D=128, dtype="bf16", data="A", seed=28, W=64, ks=1),
     "sk_f32_d128": dict(kind="snapkv", B=1, H=2, G=4, S=700, D=128, dtype="f32", data="B", seed=29, W=64, ks=3),
+    # wider hidden states: the library's own window q_proj + RoPE kernel applies (hidden % 256 == 0)
+    "sk_h512_bf16": dict(kind="snapkv", B=2, H=2, G=4, S=300, D=128, dtype="bf16", data="B", seed=30, W=64, ks=5, hsz=512),
+    "sk_h1024_f16": dict(kind="snapkv", B=1, H=1, G=8, S=1000, D=128, dtype="f16", data="A", seed=40, W=64, ks=5, hsz=1024),
     # ---- ExpectedAttentionPress --------------------------------------------------------
     "ea_tiny": dict(kind="ea", B=2, H=2, G=2, S=100, D=16, dtype="f32", data="A", seed=31),
     "ea_23": dict(kind="ea", B=1, H=2, G=1, S=23, D=16, dtype="f32", data="A", seed=32,

@@ -98,6 +98,9 @@ def fake_native(monkeypatch):
         keys_kept.copy_(torch.from_numpy(out).to(keys_kept.dtype))
         return keys_kept
 
+    def qproj_rope_supported(module, hidden_states, window):
+        return False  # CPU tensors: the model's own q_proj + the oracle-backed rope path
+
     def ea_qstats(q, use_cov=True):
         mu, cov = O.ea_query_stats(q.float().numpy(), use_cov)
         return torch.from_numpy(mu.astype(np.float32)), (torch.from_numpy(cov.astype(np.float32)) if cov is not None else None)
@@ -108,7 +111,7 @@ def fake_native(monkeypatch):
 
     for name, fn in dict(rownorm_score=rownorm_score, topk_select=topk_select, gather_kv=gather_kv,
                          snapkv_score=snapkv_score, snapkv_score_rope=snapkv_score_rope, snapkv_score_from_attn=snapkv_score_from_attn,
-                         keydiff_score=keydiff_score, scores_head_mean_=scores_head_mean_, knorm_compress=knorm_compress, scores_fill_at_=scores_fill_at_, topk_select_segmented=topk_select_segmented, rerotate_keys_=rerotate_keys_,
+                         keydiff_score=keydiff_score, scores_head_mean_=scores_head_mean_, knorm_compress=knorm_compress, qproj_rope_supported=qproj_rope_supported, scores_fill_at_=scores_fill_at_, topk_select_segmented=topk_select_segmented, rerotate_keys_=rerotate_keys_,
                          snapkv_compress_rope=snapkv_compress_rope, ea_qstats=ea_qstats, ea_score=ea_score).items():
         monkeypatch.setattr(_native, name, fn)
     return _native
