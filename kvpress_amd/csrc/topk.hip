@@ -20,7 +20,9 @@
 // workspace per device and stream).  K1 can be skipped altogether when the kernel that WROTE the scores already
 // accumulated hist1 (topk_internal.h: topk_hist1_add / topk_hist1_flush; used by the fused compress entry points).
 //
-// Kernel boundaries order the passes (1.5-1.9 us each on MI355X, cheaper than a grid barrier);
+// Kernel boundaries order the passes (1.5-1.9 us each on MI355X).  A single cooperative launch with two grid-wide
+// barriers (arrive counter + spin, agent-scope fences = L2 write-back / invalidate on every one of the 8 XCDs) was
+// measured at 51 us (128 workgroups) to 131 us (512 workgroups) against 26-32 us for the three launches: not an option;
 // the only inter-workgroup traffic inside a launch is atomicAdd into the row histograms.
 #include "kvp_common.h"
 #include "topk_internal.h"
