@@ -119,6 +119,8 @@ int kvp_ea_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
  * indices of the k largest scores to idx[R, k] (int32).  torch.topk leaves ties unspecified;
  * here the LOWEST POSITION wins among equal scores, and -0.0 == +0.0.  0 <= k <= S. */
 size_t kvp_topk_workspace_bytes(int64_t R, int64_t S, int64_t k);
+/* workspace for order == KVP_ORDER_SCORE (the select's + the sort's); KVP_ORDER_POSITION needs only the one above */
+size_t kvp_topk_order_workspace_bytes(int64_t R, int64_t S, int64_t k);
 int kvp_topk_select(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int order,
                     int32_t* idx, void* ws, size_t ws_bytes, kvp_stream_t stream);
 

@@ -59,6 +59,7 @@ SIGNATURES = {
     "kvp_ea_score": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, c_void_p, c_void_p,
                              _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_topk_workspace_bytes": (c_size_t, [_I64] * 3),
+    "kvp_topk_order_workspace_bytes": (c_size_t, [_I64] * 3),
     "kvp_topk_select": (c_int, [c_void_p, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_topk_segmented_workspace_bytes": (c_size_t, [_I64] * 4),
     "kvp_topk_select_segmented": (c_int, [c_void_p, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -401,16 +402,20 @@ def topk_select(scores: torch.Tensor, k: int, order: int = ORDER_POSITION) -> to
     idx = torch.empty((R, k), dtype=torch.int32, device=s.device)
     if R and k:
         with torch.cuda.device(s.device):
-            nws = lib().kvp_topk_workspace_bytes(R, S, k)
-            # self-cleaning workspace: zeroed once per (device, stream, size), reused with KVP_TOPK_WS_CLEAN
-            stream = torch.cuda.current_stream(s.device)
-            key = (s.device.index, stream.cuda_stream, R, S)  # the layout (hence the clean region) depends on R and S
-            ws = _TOPK_WS.get(key)
-            if ws is None:
-                if len(_TOPK_WS) > 64:
-                    _TOPK_WS.clear()
-                ws = torch.zeros(max(int(nws), 256), dtype=torch.uint8, device=s.device)
-                _TOPK_WS[key] = ws
+            if (int(order) & 0xFF) == ORDER_SCORE:
+                # descending-score order: select + sort, in a workspace of its own (zero-filled: the select's histograms)
+                ws = torch.zeros(max(int(lib().kvp_topk_order_workspace_bytes(R, S, k)), 256), dtype=torch.uint8, device=s.device)
+            else:
+                nws = lib().kvp_topk_workspace_bytes(R, S, k)
+                # self-cleaning workspace: zeroed once per (device, stream, size), reused with KVP_TOPK_WS_CLEAN
+                stream = torch.cuda.current_stream(s.device)
+                key = (s.device.index, stream.cuda_stream, R, S)  # the layout (hence the clean region) depends on R and S
+                ws = _TOPK_WS.get(key)
+                if ws is None:
+                    if len(_TOPK_WS) > 64:
+                        _TOPK_WS.clear()
+                    ws = torch.zeros(max(int(nws), 256), dtype=torch.uint8, device=s.device)
+                    _TOPK_WS[key] = ws
             _check(lib().kvp_topk_select(_p(s2), R, S, s2.stride(0) if R > 1 else S, int(k), int(order) | TOPK_WS_CLEAN, _p(idx),
                                          _p(ws), ws.numel(), _stream(s)), "kvp_topk_select")
     return idx.reshape(*lead, k)

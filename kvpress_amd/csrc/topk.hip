@@ -271,6 +271,15 @@ __global__ void topk_iota_kernel(int32_t* __restrict__ idx, int64_t idx_stride, 
 
 }  // namespace
 
+// ordering step (topk_order.hip)
+size_t topk_order_workspace_bytes(int64_t R, int64_t k);
+int topk_order_by_score(const float* scores, int64_t R, int64_t row_stride, int64_t k, int32_t* idx, bool smallest, void* ws, size_t ws_bytes,
+                        hipStream_t stream);
+
+extern "C" size_t kvp_topk_order_workspace_bytes(int64_t R, int64_t S, int64_t k) {
+    return kvp_topk_workspace_bytes(R, S, k) + topk_order_workspace_bytes(R, k);
+}
+
 extern "C" size_t kvp_topk_workspace_bytes(int64_t R, int64_t S, int64_t k) {
     (void)k;
     if (R <= 0 || S <= 0) return 256;
@@ -325,12 +334,17 @@ extern "C" int kvp_topk_select(const float* scores, int64_t R, int64_t S, int64_
     KVP_CHECK_ARG(R >= 0 && S >= 0 && k >= 0 && k <= S, "topk: bad shape R=%ld S=%ld k=%ld", (long)R, (long)S, (long)k);
     const int ord = order & ~(KVP_TOPK_WS_CLEAN | KVP_TOPK_SMALLEST);
     KVP_CHECK_ARG(ord == KVP_ORDER_POSITION || ord == KVP_ORDER_SCORE, "topk: bad order %d", order);
-    if (ord == KVP_ORDER_SCORE) {
-        kvp_set_error("topk: KVP_ORDER_SCORE is not implemented yet (use KVP_ORDER_POSITION)");
-        return KVP_EUNSUPPORTED;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const bool smallest = (order & KVP_TOPK_SMALLEST) != 0;
+    const size_t sel_bytes = kvp_topk_workspace_bytes(R, S, k);
+    if (int rc = topk_select_impl(scores, R, S, row_stride, k, idx, k, 0, 0, ws, std::min(ws_bytes, sel_bytes), (order & KVP_TOPK_WS_CLEAN) != 0,
+                                  false, stream, 1, 0, 0, smallest))
+        return rc;
+    if (ord == KVP_ORDER_SCORE) {  // descending score (ascending for KVP_TOPK_SMALLEST), ties by position: sort the selection
+        KVP_CHECK_ARG(ws && ws_bytes >= sel_bytes, "topk: workspace too small for KVP_ORDER_SCORE");
+        return topk_order_by_score(scores, R, row_stride, k, idx, smallest, static_cast<char*>(ws) + sel_bytes, ws_bytes - sel_bytes, stream);
     }
-    return topk_select_impl(scores, R, S, row_stride, k, idx, k, 0, 0, ws, ws_bytes, (order & KVP_TOPK_WS_CLEAN) != 0, false,
-                            static_cast<hipStream_t>(stream_), 1, 0, 0, (order & KVP_TOPK_SMALLEST) != 0);
+    return KVP_OK;
 }
 
 // Segmented select (ChunkPress, kvpress/presses/chunk_press.py:67-85): every row of scores[R, nseg * seg_len] is cut into

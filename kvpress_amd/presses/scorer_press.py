@@ -10,8 +10,8 @@ Defined deviations (DESIGN.md "Parity contract"):
   * scores are float32 (the reference keeps the model dtype; bf16 scores tie ~1000-fold at the
     threshold and torch.topk's choice among ties is unspecified);
   * among equal scores the lowest position is kept;
-  * the retained tokens are stored in ascending position order (``order = "position"``), the
-    reference stores them in descending score order, which no reference test observes.
+  * the retained tokens are stored in ascending position order, the reference stores them in descending
+    score order, which no reference test observes (``_native.topk_select(..., ORDER_SCORE)`` gives that order).
 """
 from __future__ import annotations
 

@@ -46,6 +46,7 @@ __all__ = [
     "ea_avg_rope",
     "ea_score",
     "topk_select",
+    "topk_select_by_score",
     "topk_is_valid",
     "gather_kv",
     "compress",
@@ -92,6 +93,15 @@ def topk_select(scores: np.ndarray, k: int) -> np.ndarray:
         order = np.argsort(~flat[r], kind="stable")
         out[r] = np.sort(order[:k]).astype(np.int32)
     return out.reshape(*lead, k)
+
+
+def topk_select_by_score(scores: np.ndarray, k: int) -> np.ndarray:
+    """The same retained set as ``topk_select`` in DESCENDING SCORE order, ties by ascending position: the element order
+    ``scores.topk(k, sorted=True).indices`` has wherever the scores are distinct (scorer_press.py:95)."""
+    idx = topk_select(scores, k).astype(np.int64)
+    sc = np.take_along_axis(np.asarray(scores, dtype=np.float32), idx, axis=-1) + np.float32(0.0)  # -0.0 -> +0.0
+    order = np.argsort(-sc.astype(np.float64), axis=-1, kind="stable")  # stable: equal scores keep ascending position
+    return np.take_along_axis(idx, order, axis=-1).astype(np.int32)
 
 
 def topk_is_valid(scores: np.ndarray, idx: np.ndarray, k: int, rel_band: float = 0.0):

