@@ -282,7 +282,14 @@ def main():
         gsc = press.score(att, hidden, keys, values, None, kwargs)
         gidx = _native.topk_select(gsc, n_kept).cpu().numpy()
         ok, msg = O.topk_is_valid(sc, gidx, n_kept, rel_band=1e-3)
-        cpu = {"value": round(S / (LAYERS * t_cpu), 1), "unit": "tok/s", "cores": os.cpu_count(), "kind": "port",
+        try:  # threads the port really used: numpy's BLAS pool for the matrix products, one thread for everything else
+            from threadpoolctl import threadpool_info
+
+            blas_threads = max([int(p.get("num_threads", 1)) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+        except Exception:
+            blas_threads = 1
+        sample += f"; numpy ({blas_threads} BLAS threads for the matrix products, 1 thread elsewhere; {os.cpu_count()} cores visible)"
+        cpu = {"value": round(S / (LAYERS * t_cpu), 1), "unit": "tok/s", "cores": blas_threads, "kind": "port",
                "sample": sample, "ms_per_layer": round(t_cpu * 1e3, 1), "gpu_topk_valid_vs_oracle": bool(ok)}
 
     if rank == 0:
