@@ -647,3 +647,40 @@ def test_hidden_path_scores_and_compress(name):
         off = press.score(att, hidden, k, v, None, kw)
     assert torch.equal(on, got) and tuple(ko_on.shape) == (s["B"], s["H"], S // 2, s["D"])
     assert_scores_close(off.cpu().numpy()[..., :-W], got.cpu().numpy()[..., :-W], 2e-2, name)  # GEMM rounding of a few queries
+
+
+# ---------------------------------------------------------------------------------------------
+# degenerate shapes the reference's wrappers produce (ratio set to 1 through the attribute, one-token caches ...)
+# ---------------------------------------------------------------------------------------------
+def test_edge_cases_empty_and_tiny():
+    import kvpress_amd as P
+
+    N = native()
+    k = torch.randn(2, 3, 17, 64, device=DEV, dtype=torch.bfloat16)
+    v = torch.randn_like(k)
+    press = P.KnormPress(0.5)
+    press.compression_ratio = 1.0                      # wrappers bypass the constructor's assert (per_layer_compression_press.py:56-61)
+    ko, vo = press.compress(None, None, k, v, None, {})
+    assert tuple(ko.shape) == tuple(vo.shape) == (2, 3, 0, 64) and ko.dtype == k.dtype
+    # one-token cache: int(1 * 0.5) == 0 kept; int(1 * (1 - 0.4)) == 0 as well
+    k1, v1 = k[:, :, :1], v[:, :, :1]
+    ko, vo = P.KnormPress(0.4).compress(None, None, k1, v1, None, {})
+    assert tuple(ko.shape) == (2, 3, 0, 64)
+    # everything kept (a ratio so small that 1 - r == 1.0 in double, hence int(S * (1 - r)) == S): the very same rows, in order
+    ko, vo = P.KnormPress(1e-17).compress(None, None, k, v, None, {})
+    assert torch.equal(ko, k) and torch.equal(vo, v) and ko.data_ptr() != k.data_ptr()
+    # modular entry points with empty selections
+    sc = N.rownorm_score(k, -1.0)
+    assert tuple(N.topk_select(sc, 0).shape) == (2, 3, 0)
+    ko, vo = N.gather_kv(k, v, N.topk_select(sc, 0))
+    assert tuple(ko.shape) == (2, 3, 0, 64)
+    # a batch of one head and an odd head_dim (scalar kernels), non-contiguous views
+    k3 = torch.randn(1, 1, 33, 10, device=DEV, dtype=torch.float32)[:, :, ::3]
+    v3 = torch.randn(1, 1, 33, 10, device=DEV, dtype=torch.float32)[:, :, ::3]
+    ko, vo = P.KnormPress(0.5).compress(None, None, k3, v3, None, {})
+    idx = O.topk_select(O.knorm_score(k3.cpu().numpy()), 5)
+    wk, wv = O.gather_kv(k3.cpu().numpy(), v3.cpu().numpy(), idx)
+    assert np.array_equal(ko.cpu().numpy(), wk) and np.array_equal(vo.cpu().numpy(), wv)
+    # CPU tensors are refused loudly: there is no fallback
+    with pytest.raises(N.KvpressHipError):
+        N.rownorm_score(k.cpu(), -1.0)
