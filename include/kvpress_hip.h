@@ -179,6 +179,16 @@ size_t kvp_keydiff_workspace_bytes(int64_t B, int64_t H, int64_t S, int64_t D);
 int kvp_keydiff_score(const void* k, int dtype, int64_t B, int64_t H, int64_t S, int64_t D,
                       int64_t sb, int64_t sh, int64_t ss, float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream);
 
+/* ---- CURPress.score (kvpress/presses/cur_press.py:32-66) without the random projection ------------------------------
+ * k2 = sum_d k^2, v2 = sum_d v^2; with local_window_size w > 0 each is divided by its sum over the windows of w consecutive
+ * tokens (zero-padded tail); combined by leverage type; divided by the row sum; the first num_sinks positions are set to 1.
+ * scores: contiguous [B,H,S] float32. */
+enum kvp_cur_leverage { KVP_CUR_KEY = 0, KVP_CUR_VALUE = 1, KVP_CUR_KV_AVG = 2, KVP_CUR_KV_PRODUCT = 3 };
+size_t kvp_cur_workspace_bytes(int64_t B, int64_t H, int64_t S);
+int kvp_cur_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_ss,
+                  int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int leverage_type, int64_t local_window_size,
+                  int64_t num_sinks, float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream);
+
 /* ---- TOVAPress.score tail (kvpress/presses/tova_press.py:52-53) -----------------------------------
  * scores[b,h,s] <- mean over h' of scores[b,h',s] for every h, in place (`attn_weights.mean(1)` followed by
  * `.repeat(1, num_kv_heads, 1)`, applied to the per-kv-group means kvp_snapkv_score* produce with W = 1, kernel 1).

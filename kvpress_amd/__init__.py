@@ -12,6 +12,7 @@ from kvpress_amd.presses.adakv_press import AdaKVPress
 from kvpress_amd.presses.base_press import BasePress
 from kvpress_amd.presses.chunk_press import ChunkPress
 from kvpress_amd.presses.composed_press import ComposedPress
+from kvpress_amd.presses.cur_press import CURPress
 from kvpress_amd.presses.decoding_press import DecodingPress, PrefillDecodingPress
 from kvpress_amd.presses.expected_attention_press import ExpectedAttentionPress
 from kvpress_amd.presses.key_rerotation_press import KeyRerotationPress
@@ -27,7 +28,7 @@ from kvpress_amd.presses.tova_press import TOVAPress
 
 __version__ = "0.1.0"
 __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
-           "KeyDiffPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "KeyRerotationPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
+           "KeyDiffPress", "CURPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "KeyRerotationPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
            "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
 
 

@@ -35,6 +35,9 @@ SIGNATURES = {
     "kvp_snapkv_compress_rope": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, c_void_p, _I64, _I64, c_void_p, _I64, _I64, _I64,
                                          c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, _I64, c_int, _I64,
                                          c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "kvp_cur_workspace_bytes": (c_size_t, [_I64] * 3),
+    "kvp_cur_score": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, c_int, _I64, _I64,
+                              c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_keydiff_workspace_bytes": (c_size_t, [_I64] * 4),
     "kvp_keydiff_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_scores_head_mean": (c_int, [c_void_p, _I64, _I64, _I64, _I64, _I64, c_void_p]),
@@ -144,6 +147,26 @@ def rownorm_score(x: torch.Tensor, scale: float) -> torch.Tensor:
         _check(lib().kvp_rownorm_score(_p(x), _DTYPES[x.dtype], B, H, S, D, _st(x, 0), _st(x, 1), _st(x, 2),
                                        float(scale), _p(out), _stream(x)), "kvp_rownorm_score")
     return out
+
+
+CUR_LEVERAGE = {"key": 0, "value": 1, "kv_avg": 2, "kv_product": 3}
+
+
+def cur_score(keys: torch.Tensor, values: torch.Tensor, leverage_type: str, local_window_size: int, num_sinks: int) -> torch.Tensor:
+    """CUR leverage scores [B,H,S] float32 (local_window_size 0 = no local approximation)."""
+    keys = _rows_last_contig(_dev(keys))
+    values = _rows_last_contig(_dev(values))
+    assert keys.dtype == values.dtype and keys.shape[:3] == values.shape[:3] and keys.shape[3] == values.shape[3]
+    if leverage_type not in CUR_LEVERAGE:
+        raise ValueError("Unknown leverage type: choose from 'kv_avg', 'key', 'value' or 'kv_product'")
+    B, H, S, D = keys.shape
+    scores = torch.empty((B, H, S), dtype=torch.float32, device=keys.device)
+    with torch.cuda.device(keys.device):
+        ws = _ws(lib().kvp_cur_workspace_bytes(B, H, S), keys)
+        _check(lib().kvp_cur_score(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _p(values), _st(values, 0), _st(values, 1),
+                                   _st(values, 2), _DTYPES[keys.dtype], B, H, S, D, CUR_LEVERAGE[leverage_type], int(local_window_size),
+                                   int(num_sinks), _p(scores), _p(ws), ws.numel(), _stream(keys)), "kvp_cur_score")
+    return scores
 
 
 def keydiff_score(keys: torch.Tensor) -> torch.Tensor:

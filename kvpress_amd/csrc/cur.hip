@@ -1,0 +1,89 @@
+// kvp_cur_score: CURPress.score (kvpress/presses/cur_press.py:32-66), approximate leverage scores of keys and values.
+//   k2 = sum_d k^2, v2 = sum_d v^2                                   (:40-41)   two streaming passes (rownorm.hip, squared)
+//   local approximation: each is divided by its sum over windows of `w` consecutive tokens (zero-padded tail)   (:43-48)
+//   combined by leverage type: key | value | (k2 + v2) / 2 | k2 * v2                                              (:50-59)
+//   normalised by the row sum, first `num_sinks` positions set to 1                                               (:61-62)
+// The window / combine / normalise step works on the two [B*H, S] float vectors (L2-resident): one workgroup per row, two
+// sweeps (accumulate the row sum, then scale), fp32 throughout.
+#include "kvp_common.h"
+
+int kvp_rowsumsq_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh, int64_t ss,
+                        float* out, hipStream_t stream);
+
+namespace {
+
+constexpr int CU_THREADS = 1024;
+
+__device__ __forceinline__ float combine(int type, float a, float b) {
+    switch (type) {
+        case KVP_CUR_KEY: return a;
+        case KVP_CUR_VALUE: return b;
+        case KVP_CUR_KV_AVG: return (a + b) * 0.5f;
+        default: return a * b;
+    }
+}
+
+// window sum of x over the `w` tokens of position s's window (positions past S count as zero)
+__device__ __forceinline__ float window_sum(const float* __restrict__ x, uint32_t s, uint32_t S, uint32_t w) {
+    const uint32_t lo = s - s % w, hi = min(lo + w, S);
+    float t = 0.f;
+    for (uint32_t i = lo; i < hi; ++i) t += x[i];
+    return t;
+}
+
+__global__ __launch_bounds__(CU_THREADS) void cur_finalize_kernel(const float* __restrict__ k2, const float* __restrict__ v2, uint32_t S,
+                                                                  uint32_t w, int type, uint32_t num_sinks, float* __restrict__ scores) {
+    __shared__ float red[CU_THREADS / 64];
+    const float* kr = k2 + (size_t)blockIdx.x * S;
+    const float* vr = v2 + (size_t)blockIdx.x * S;
+    float* out = scores + (size_t)blockIdx.x * S;
+    float acc = 0.f;
+    for (uint32_t s = threadIdx.x; s < S; s += CU_THREADS) {
+        float a = kr[s], b = vr[s];
+        if (w) {
+            a = a / window_sum(kr, s, S, w);
+            b = b / window_sum(vr, s, S, w);
+        }
+        const float c = combine(type, a, b);
+        out[s] = c;
+        acc += c;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < CU_THREADS / 64; ++i) tot += red[i];
+    for (uint32_t s = threadIdx.x; s < S; s += CU_THREADS) out[s] = s < num_sinks ? 1.0f : out[s] / tot;  // same thread wrote out[s]
+}
+
+}  // namespace
+
+extern "C" size_t kvp_cur_workspace_bytes(int64_t B, int64_t H, int64_t S) {
+    if (B < 1 || H < 1 || S < 1) return 256;
+    return 2 * kvp_align_up((size_t)B * H * S * 4, 256);
+}
+
+extern "C" int kvp_cur_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, const void* v, int64_t v_sb, int64_t v_sh,
+                             int64_t v_ss, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int leverage_type,
+                             int64_t local_window_size, int64_t num_sinks, float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KVP_CHECK_ARG(B >= 1 && H >= 1 && S >= 1 && D >= 1 && B * H <= 65535, "cur: bad shape B=%ld H=%ld S=%ld D=%ld", (long)B, (long)H, (long)S,
+                  (long)D);
+    KVP_CHECK_ARG(leverage_type >= KVP_CUR_KEY && leverage_type <= KVP_CUR_KV_PRODUCT, "cur: unknown leverage type %d", leverage_type);
+    KVP_CHECK_ARG(local_window_size >= 0 && num_sinks >= 0, "cur: bad window / sinks");
+    KVP_CHECK_ARG(k && v && scores, "cur: null pointer");
+    const size_t half = kvp_align_up((size_t)B * H * S * 4, 256);
+    if (!ws || ws_bytes < 2 * half) {
+        kvp_set_error("cur: workspace too small (%zu < %zu)", ws_bytes, 2 * half);
+        return KVP_EWORKSPACE;
+    }
+    float* k2 = static_cast<float*>(ws);
+    float* v2 = reinterpret_cast<float*>(static_cast<char*>(ws) + half);
+    if (int rc = kvp_rowsumsq_launch(k, dtype, B, H, S, D, k_sb, k_sh, k_ss, k2, stream)) return rc;
+    if (int rc = kvp_rowsumsq_launch(v, dtype, B, H, S, D, v_sb, v_sh, v_ss, v2, stream)) return rc;
+    KVP_LAUNCH("cur_finalize_kernel", stream, cur_finalize_kernel<<<(uint32_t)(B * H), CU_THREADS, 0, stream>>>(
+        k2, v2, (uint32_t)S, (uint32_t)local_window_size, leverage_type, (uint32_t)std::min<int64_t>(num_sinks, S), scores));
+    KVP_CHECK_LAUNCH("cur");
+    return KVP_OK;
+}

@@ -31,6 +31,7 @@ constexpr int RN_UNROLL = 4;
 struct PlaneMap {
     uint32_t H, S;
     int64_t sb, sh, ss;  // element strides
+    bool squared;        // out = scale * sum of squares (CURPress) instead of scale * sqrt(sum of squares)
 };
 
 // HIST: the kernel also accumulates the top-k's first radix histogram of the scores it writes (hist1[bh][4096]).
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(RN_THREADS) void rownorm_vec_kernel(
             }
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-            const float sc = scale * sqrtf(acc);
+            const float sc = scale * (map.squared ? acc : sqrtf(acc));
             if (lir == 0 && s < S) ob[s] = sc;
             // 64 / LPR scores per wave: plain LDS atomics (the wave-aggregated topk_hist1_add costs more than it saves here)
             if (HIST && lir == 0 && s < S) atomicAdd(&lh[float_to_key(sc) >> 20], 1u);
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(RN_THREADS) void rownorm_scalar_kernel(
             const float f = Elem<DT>::ld(p + d);
             acc = fmaf(f, f, acc);
         }
-        out[(size_t)bh * map.S + s] = scale * sqrtf(acc);
+        out[(size_t)bh * map.S + s] = scale * (map.squared ? acc : sqrtf(acc));
     }
 }
 
@@ -146,8 +147,8 @@ int launch_rownorm(const void* x, PlaneMap map, uint32_t BH, uint32_t D, float s
 // Internal entry shared with the ExpectedAttention path (||V||) and the fused Knorm compress.
 // hist1 (nullable): [B*H][4096] first-pass radix histogram of the top-k over the rows (b, h); *hist1_done tells whether it
 // was produced (only the vector path does; the caller runs the separate pass otherwise).
-int kvp_rownorm_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh,
-                       int64_t ss, float scale, float* out, hipStream_t stream, uint32_t* hist1, bool* hist1_done) {
+static int rownorm_launch_impl(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh,
+                               int64_t ss, float scale, float* out, hipStream_t stream, uint32_t* hist1, bool* hist1_done, bool squared) {
     if (hist1_done) *hist1_done = false;
     KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "rownorm: bad dtype %d", dtype);
     KVP_CHECK_ARG(B >= 0 && H >= 0 && S >= 0 && D >= 1, "rownorm: bad shape B=%ld H=%ld S=%ld D=%ld", (long)B, (long)H,
@@ -160,7 +161,7 @@ int kvp_rownorm_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S
     if (!hist1 && H > 1 && sh == S * ss) { S *= H; H = 1; sh = 0; }
     if (!hist1 && H == 1 && B > 1 && sb == S * ss) { S *= B; B = 1; sb = 0; }
     KVP_CHECK_ARG(S < ((int64_t)1 << 31) && B * H <= 65535, "rownorm: shape too large (S=%ld, B*H=%ld)", (long)S, (long)(B * H));
-    PlaneMap map{(uint32_t)H, (uint32_t)S, sb, sh, ss};
+    PlaneMap map{(uint32_t)H, (uint32_t)S, sb, sh, ss, squared};
     const uint32_t BH = (uint32_t)(B * H);
     int done = 0;
     switch (dtype) {
@@ -171,6 +172,16 @@ int kvp_rownorm_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S
     if (hist1_done) *hist1_done = done != 0;
     KVP_CHECK_LAUNCH("rownorm");
     return KVP_OK;
+}
+
+int kvp_rownorm_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh,
+                       int64_t ss, float scale, float* out, hipStream_t stream, uint32_t* hist1, bool* hist1_done) {
+    return rownorm_launch_impl(x, dtype, B, H, S, D, sb, sh, ss, scale, out, stream, hist1, hist1_done, false);
+}
+// out[b,h,s] = sum_d x^2  (the row "energy" of CURPress, kvpress/presses/cur_press.py:40-41)
+int kvp_rowsumsq_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh, int64_t ss,
+                        float* out, hipStream_t stream) {
+    return rownorm_launch_impl(x, dtype, B, H, S, D, sb, sh, ss, 1.0f, out, stream, nullptr, nullptr, true);
 }
 
 extern "C" int kvp_rownorm_score(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb,

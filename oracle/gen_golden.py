@@ -51,7 +51,7 @@ def main(argv):
     _install_shims()
     import numpy as np
     import torch
-    from kvpress import (ExpectedAttentionPress, KeyDiffPress, KnormPress, PyramidKVPress, SnapKVPress,  # the reference
+    from kvpress import (CURPress, ExpectedAttentionPress, KeyDiffPress, KnormPress, PyramidKVPress, SnapKVPress,  # the reference
                          StreamingLLMPress, TOVAPress)
 
     import _inputs
@@ -70,6 +70,9 @@ def main(argv):
                 return SnapKVPress(compression_ratio=ratio, window_size=s["W"], kernel_size=s["ks"])
             if s["kind"] == "keydiff":
                 return KeyDiffPress(compression_ratio=ratio)
+            if s["kind"] == "cur":
+                return CURPress(compression_ratio=ratio, num_sinks=s.get("sinks", 4), leverage_type=s["leverage"],
+                                use_local_approximation=s.get("local", True), local_window_size=s.get("window", 16))
             if s["kind"] == "tova":
                 return TOVAPress(compression_ratio=ratio)
             if s["kind"] == "pyramid":

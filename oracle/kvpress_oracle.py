@@ -36,6 +36,7 @@ __all__ = [
     "snapkv_score",
     "snapkv_score_from_attentions",
     "keydiff_score",
+    "cur_score",
     "tova_score",
     "pyramidkv_budget",
     "streaming_llm_score",
@@ -434,3 +435,22 @@ def adakv_pruned(scores: np.ndarray, compression_ratio: float, alpha_safeguard: 
         np.put_along_axis(sc, top.astype(np.int64), np.finfo(np.float32).max, axis=-1)
     n_pruned = H * (S - n_kept)
     return topk_select(-sc.reshape(B, H * S), n_pruned).astype(np.int64)
+
+
+def cur_score(keys, values, leverage_type="kv_product", use_local_approximation=True, local_window_size=16, num_sinks=4, ctype=np.float64):
+    """CURPress.score without the random projection (cur_press.py:40-64)."""
+    k2 = (keys.astype(ctype) ** 2).sum(-1)
+    v2 = (values.astype(ctype) ** 2).sum(-1)
+    if use_local_approximation:
+        B, H, n = k2.shape
+        w = local_window_size
+        pad = (w - n % w) % w
+
+        def local(x):
+            xp = np.concatenate([x, np.zeros((B, H, pad), dtype=x.dtype)], axis=-1).reshape(B, H, -1, w)
+            return (xp / xp.sum(-1, keepdims=True)).reshape(B, H, -1)[:, :, :n]
+        k2, v2 = local(k2), local(v2)
+    sc = {"key": k2, "value": v2, "kv_avg": (k2 + v2) / 2, "kv_product": k2 * v2}[leverage_type]
+    sc = sc / sc.sum(-1, keepdims=True)
+    sc[:, :, :num_sinks] = 1.0
+    return sc.astype(np.float32)

@@ -75,6 +75,10 @@ CASES = {
     "kd_bf16_B": dict(kind="keydiff", B=1, H=8, G=1, S=3001, D=128, dtype="bf16", data="B", seed=43),
     "kd_f16_d64": dict(kind="keydiff", B=1, H=4, G=1, S=1000, D=64, dtype="f16", data="A", seed=44),
     "kd_d96_bf16": dict(kind="keydiff", B=2, H=3, G=1, S=515, D=96, dtype="bf16", data="B", seed=45),
+    "cur_tiny_d6": dict(kind="cur", B=2, H=2, G=1, S=100, D=6, dtype="f32", data="A", seed=46, leverage="kv_product"),
+    "cur_bf16_B": dict(kind="cur", B=1, H=8, G=1, S=3001, D=128, dtype="bf16", data="B", seed=47, leverage="kv_product"),
+    "cur_key_nolocal": dict(kind="cur", B=1, H=4, G=1, S=1000, D=64, dtype="f16", data="A", seed=48, leverage="key", local=False, sinks=0),
+    "cur_kvavg_w7": dict(kind="cur", B=2, H=3, G=1, S=515, D=96, dtype="bf16", data="B", seed=49, leverage="kv_avg", window=7),
     "tv_tiny": dict(kind="tova", B=2, H=2, G=2, S=100, D=16, dtype="f32", data="A", seed=51, W=1, ks=1),
     "tv_257": dict(kind="tova", B=2, H=2, G=4, S=257, D=128, dtype="bf16", data="A", seed=52, W=1, ks=1),
     "tv_4096_B": dict(kind="tova", B=1, H=2, G=4, S=4096, D=128, dtype="bf16", data="B", seed=53, W=1, ks=1),

@@ -10,7 +10,7 @@ import _inputs
 from oracle import kvpress_oracle as O
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-F2 = [n for n, c in _inputs.CASES.items() if c["kind"] in ("pyramid", "tova", "keydiff", "streaming")]
+F2 = [n for n, c in _inputs.CASES.items() if c["kind"] in ("pyramid", "tova", "keydiff", "streaming", "cur")]
 
 
 def make_press(s, ratio):
@@ -23,6 +23,9 @@ def make_press(s, ratio):
         return P.TOVAPress(compression_ratio=ratio)
     if k == "keydiff":
         return P.KeyDiffPress(compression_ratio=ratio)
+    if k == "cur":
+        return P.CURPress(compression_ratio=ratio, num_sinks=s.get("sinks", 4), leverage_type=s["leverage"],
+                          use_local_approximation=s.get("local", True), local_window_size=s.get("window", 16))
     return P.StreamingLLMPress(compression_ratio=ratio, n_sink=s["n_sink"])
 
 
@@ -42,6 +45,8 @@ def test_press_matches_reference_cpu(name, fake_native):
             assert (sc[..., -W:] > sc[..., :-W].max()).all()
         elif s["kind"] == "keydiff":
             np.testing.assert_allclose(sc, ref, rtol=0, atol=2e-6)
+        elif s["kind"] == "cur":
+            np.testing.assert_allclose(sc, ref, rtol=2e-4, atol=1e-30)
         else:
             assert np.array_equal(sc, ref)
         for i, r in enumerate(s["ratios"]):

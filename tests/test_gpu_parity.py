@@ -253,6 +253,22 @@ def test_ea_score_kernel_vs_oracle(name):
 
 
 KD = [n for n, c in _inputs.CASES.items() if c["kind"] == "keydiff"]
+CUR = [n for n, c in _inputs.CASES.items() if c["kind"] == "cur"]
+
+
+@pytest.mark.parametrize("name", CUR)
+def test_cur_kernel_vs_oracle(name):
+    """kvp_cur_score in the case's dtype against the float64 restatement on the same (dtype-exact) keys and values."""
+    s = _inputs.make_case(name)
+    k, v = to_dev(s["keys"], s["dtype"]), to_dev(s["values"], s["dtype"])
+    local, w, sinks = s.get("local", True), s.get("window", 16), s.get("sinks", 4)
+    got = native().cur_score(k, v, s["leverage"], w if local else 0, sinks).cpu().numpy()
+    assert_scores_close(got, O.cur_score(s["keys"], s["values"], s["leverage"], local, w, sinks), 2e-5, name)
+    for lev in ("key", "value", "kv_avg", "kv_product"):
+        got = native().cur_score(k[:, :, ::2], v[:, :, ::2], lev, 5, 2).cpu().numpy()   # strided views, odd window
+        assert_scores_close(got, O.cur_score(s["keys"][:, :, ::2], s["values"][:, :, ::2], lev, True, 5, 2), 2e-5, f"{name}/{lev}")
+    with pytest.raises(ValueError):
+        native().cur_score(k, v, "nope", 16, 4)
 
 
 @pytest.mark.parametrize("name", KD)
@@ -345,6 +361,9 @@ def make_press(s, ratio):
         return P.TOVAPress(compression_ratio=ratio)
     if s["kind"] == "keydiff":
         return P.KeyDiffPress(compression_ratio=ratio)
+    if s["kind"] == "cur":
+        return P.CURPress(compression_ratio=ratio, num_sinks=s.get("sinks", 4), leverage_type=s["leverage"],
+                          use_local_approximation=s.get("local", True), local_window_size=s.get("window", 16))
     if s["kind"] == "streaming":
         return P.StreamingLLMPress(compression_ratio=ratio, n_sink=s["n_sink"])
     return P.ExpectedAttentionPress(compression_ratio=ratio, n_future_positions=s["n_future"], n_sink=s["n_sink"],
@@ -373,6 +392,8 @@ def test_press_fp32_vs_reference(name):
             np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5, err_msg=name)
         elif s["kind"] == "streaming":
             assert np.array_equal(got, ref)
+        elif s["kind"] == "cur":
+            assert_scores_close(got, ref, 2e-5, name)
         elif s["kind"] == "ea":
             assert_scores_close(got[..., s["n_sink"]:], ref[..., s["n_sink"]:], RTOL, name)
             if s["n_sink"]:

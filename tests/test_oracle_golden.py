@@ -22,6 +22,8 @@ def oracle_scores(s, cos=None, sin=None):
         return O.knorm_score(s["keys"])
     if s["kind"] == "keydiff":
         return O.keydiff_score(s["keys"])
+    if s["kind"] == "cur":
+        return O.cur_score(s["keys"], s["values"], s["leverage"], s.get("local", True), s.get("window", 16), s.get("sinks", 4))
     if s["kind"] == "streaming":
         return O.streaming_llm_score(s["B"], s["H"], s["S"], 0.5, s["n_sink"])  # the fixture's scores are those of ratio 0.5
     import torch
