@@ -10,6 +10,7 @@ through the C ABI of include/kvpress_hip.h; there is no CPU or pure-PyTorch fall
 """
 from kvpress_amd.presses.adakv_press import AdaKVPress
 from kvpress_amd.presses.base_press import BasePress
+from kvpress_amd.presses.block_press import BlockPress
 from kvpress_amd.presses.chunk_press import ChunkPress
 from kvpress_amd.presses.composed_press import ComposedPress
 from kvpress_amd.presses.cur_press import CURPress
@@ -28,7 +29,7 @@ from kvpress_amd.presses.tova_press import TOVAPress
 
 __version__ = "0.1.0"
 __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
-           "KeyDiffPress", "CURPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "KeyRerotationPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
+           "KeyDiffPress", "CURPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "BlockPress", "KeyRerotationPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
            "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
 
 

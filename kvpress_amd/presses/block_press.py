@@ -1,0 +1,69 @@
+"""BlockPress (kvpress/presses/block_press.py:14-98): block-wise iterative compression (KeyDiff paper's prompt processing).
+
+The first ``n_kept`` tokens are the initial survivors; every following block of ``block_size`` tokens is appended to the
+survivors, the wrapped press scores that candidate list, and the best ``n_kept`` survive.  Per iteration on the library:
+``kvp_gather_kv`` (candidate K/V and the matching hidden-state slices), the wrapped press's ``score``, ``kvp_topk_select``
+with ``KVP_ORDER_SCORE`` -- the reference carries its survivors in torch.topk's descending-score order and position-aware
+scorers (SnapKV's window and pooling) see the candidates in that order, so the same order is kept here."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+from torch import nn
+
+from kvpress_amd import _native
+from kvpress_amd.presses.base_press import BasePress
+from kvpress_amd.presses.scorer_press import ScorerPress
+
+
+@dataclass
+class BlockPress(BasePress):
+    """Parameters
+    ----------
+    press : ScorerPress
+    block_size : int, default=128
+    """
+
+    press: ScorerPress
+    block_size: int = 128
+
+    def __post_init__(self):
+        assert isinstance(self.press, ScorerPress), "BlockPress requires a ScorerPress"
+
+    def post_init_from_model(self, model):
+        self.press.post_init_from_model(model)
+
+    @property
+    def compression_ratio(self):
+        return self.press.compression_ratio
+
+    @compression_ratio.setter
+    def compression_ratio(self, value):
+        self.press.compression_ratio = value
+
+    def compress(self, module: nn.Module, hidden_states: torch.Tensor, keys: torch.Tensor, values: torch.Tensor,
+                 attentions: torch.Tensor, kwargs: dict) -> tuple[torch.Tensor, torch.Tensor]:
+        if self.press.compression_ratio == 0:
+            return keys, values
+        assert attentions is None, "BlockPress does not support attentions."
+
+        bsz, num_kv, k_len, head_dim = keys.shape
+        block = self.block_size if self.block_size < k_len else k_len
+        n_kept = int(k_len * (1 - self.compression_ratio))
+        dev = keys.device
+        kept = torch.arange(n_kept, device=dev, dtype=torch.int32).expand(bsz, num_kv, -1)
+        # hidden states split over the kv heads so that one index list per (batch, head) gathers them (block_press.py:69)
+        states = hidden_states.view(bsz, k_len, num_kv, -1).transpose(1, 2)
+
+        for i in range(n_kept, k_len, block):
+            end = min(i + block, k_len)
+            new = torch.arange(i, end, device=dev, dtype=torch.int32).expand(bsz, num_kv, -1)
+            cand = torch.cat([kept, new], dim=-1).contiguous()
+            cand_states, _ = _native.gather_kv(states, states, cand)
+            cand_states = cand_states.transpose(1, 2).reshape(bsz, -1, hidden_states.shape[-1])
+            cand_keys, cand_values = _native.gather_kv(keys, values, cand)
+            scores = self.press.score(module, cand_states, cand_keys, cand_values, attentions, kwargs)
+            top = _native.topk_select(scores, n_kept, _native.ORDER_SCORE)        # positions in the candidate list
+            kept = torch.gather(cand, -1, top.to(torch.int64))
+        return _native.gather_kv(keys, values, kept.contiguous())

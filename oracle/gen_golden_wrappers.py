@@ -24,7 +24,7 @@ def main(argv):
     gen_golden._install_shims()
     import numpy as np
     import torch
-    from kvpress import AdaKVPress, ChunkPress, KeyDiffPress, KeyRerotationPress, KnormPress, SnapKVPress, StreamingLLMPress
+    from kvpress import AdaKVPress, BlockPress, ChunkPress, KeyDiffPress, KeyRerotationPress, KnormPress, SnapKVPress, StreamingLLMPress
 
     import _inputs
 
@@ -44,6 +44,8 @@ def main(argv):
         def wrap(ratio):
             if s["wrapper"] == "adakv":
                 return AdaKVPress(inner(ratio), alpha_safeguard=s["alpha"])
+            if s["wrapper"] == "block":
+                return BlockPress(inner(ratio), block_size=s["block_size"])
             return ChunkPress(inner(ratio), chunk_length=s["chunk_length"]) if s["wrapper"] == "chunk" else KeyRerotationPress(inner(ratio))
 
         out = {"ratios": np.asarray(s["ratios"], dtype=np.float64)}
@@ -70,7 +72,9 @@ def main(argv):
                 for i, r in enumerate(s["ratios"]):
                     ko, vo = wrap(r).compress(att, hidden, keys, posv, None, kwargs)
                     pos = vo[..., 0].round().to(torch.int64)
-                    if mode == "f32":
+                    if mode == "f32" and s["wrapper"] == "block":
+                        out[f"pos_{i}"] = pos.numpy().astype(np.int32)   # in the reference's own (descending-score) order
+                    elif mode == "f32":
                         if s["wrapper"] == "chunk":   # order inside a chunk is torch.topk's: store every chunk sorted
                             L = s["chunk_length"]
                             pos = torch.sort(pos, dim=-1).values  # chunks are disjoint position ranges: a global sort = per-chunk sort

@@ -258,6 +258,12 @@ WRAP_CASES = {
     "wrap_rerot_knorm": dict(wrapper="rerot", kind="knorm", B=2, H=2, G=1, S=300, D=16, dtype="f32", data="A", seed=85, ratios=(0.5,)),
     "wrap_rerot_knorm_bf16": dict(wrapper="rerot", kind="knorm", B=1, H=2, G=4, S=515, D=128, dtype="bf16", data="B", seed=86,
                                   ratios=(0.5, 0.8)),
+    "wrap_block_knorm": dict(wrapper="block", kind="knorm", B=2, H=2, G=1, S=300, D=16, dtype="f32", data="A", seed=91,
+                             block_size=32, ratios=(0.25, 0.5, 0.9)),
+    "wrap_block_keydiff": dict(wrapper="block", kind="keydiff", B=1, H=2, G=1, S=515, D=64, dtype="f32", data="B", seed=92,
+                               block_size=128, ratios=(0.5,)),
+    "wrap_block_snapkv": dict(wrapper="block", kind="snapkv", B=1, H=2, G=2, S=400, D=16, dtype="f32", data="B", seed=93,
+                              block_size=64, W=8, ks=5, ratios=(0.5,)),
     "wrap_adakv_knorm": dict(wrapper="adakv", kind="knorm", B=2, H=4, G=1, S=300, D=16, dtype="f32", data="B", seed=88, alpha=0.2,
                              ratios=(0.25, 0.5, 0.9)),
     "wrap_adakv_snapkv": dict(wrapper="adakv", kind="snapkv", B=1, H=2, G=4, S=700, D=128, dtype="f32", data="B", seed=89, alpha=0.5,
@@ -270,7 +276,7 @@ WRAP_CASES = {
 
 
 def make_wrap_case(name: str) -> dict:
-    CASES[name] = {k: v for k, v in WRAP_CASES[name].items() if k not in ("wrapper", "chunk_length", "alpha")}
+    CASES[name] = {k: v for k, v in WRAP_CASES[name].items() if k not in ("wrapper", "chunk_length", "alpha", "block_size")}
     try:
         s = make_case(name)
     finally:
@@ -278,4 +284,5 @@ def make_wrap_case(name: str) -> dict:
     s["wrapper"] = WRAP_CASES[name]["wrapper"]
     s["chunk_length"] = WRAP_CASES[name].get("chunk_length")
     s["alpha"] = WRAP_CASES[name].get("alpha")
+    s["block_size"] = WRAP_CASES[name].get("block_size")
     return s
