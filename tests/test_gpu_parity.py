@@ -705,3 +705,73 @@ def test_edge_cases_empty_and_tiny():
     # CPU tensors are refused loudly: there is no fallback
     with pytest.raises(N.KvpressHipError):
         N.rownorm_score(k.cpu(), -1.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# random shapes: ragged lengths, tile / chunk boundaries, every group size the matrix-core path takes
+# ---------------------------------------------------------------------------------------------
+def test_fuzz_shapes_snapkv_and_knorm():
+    import kvpress_amd as P
+
+    rs = np.random.RandomState(2024)
+    N = native()
+    lengths = [65, 66, 127, 128, 129, 191, 192, 193, 255, 256, 257, 1023, 1024, 1025, 1151, 1152, 2047, 2049]
+    for it in range(36):
+        B = int(rs.choice([1, 2]))
+        H = int(rs.choice([1, 2, 3]))
+        G = int(rs.choice([1, 2, 4, 8]))
+        S = int(lengths[it % len(lengths)] if it < 2 * len(lengths) else rs.randint(65, 3000))
+        dtname = "bf16" if it % 3 else "f16"
+        ratio = float(rs.choice([0.1, 0.37, 0.5, 0.77, 0.93]))
+        ks = int(rs.choice([1, 3, 5, 7]))
+        Hq, W, D = H * G, 64, 128
+        keys = _inputs.round_to(rs.standard_normal((B, H, S, D)).astype(np.float32) * rs.choice([0.3, 1.0, 3.0]), dtname)
+        values = _inputs.round_to(rs.standard_normal((B, H, S, D)).astype(np.float32), dtname)
+        q_win = _inputs.round_to(rs.standard_normal((B, Hq, W, D)).astype(np.float32), dtname)
+        k, v, q = to_dev(keys, dtname), to_dev(values, dtname), to_dev(q_win, dtname)
+        tag = f"it={it} B={B} H={H} G={G} S={S} {dtname} r={ratio} ks={ks}"
+        sc = N.snapkv_score(q, k, ks)
+        want = O.snapkv_score(q_win, keys, ks)
+        assert_scores_close(sc.cpu().numpy()[..., :-W], want[..., :-W], RTOL, tag)
+        n = int(S * (1 - ratio))
+        idx = N.topk_select(sc, n).cpu().numpy()
+        assert np.array_equal(idx, O.topk_select(sc.cpu().numpy(), n)), tag           # same scores -> same indices
+        ok, msg = O.topk_is_valid(want, idx, n, rel_band=1e-3)
+        assert ok, f"{tag}: {msg}"
+        # fused paths == modular paths
+        ko, vo = N.knorm_compress(k, v, n)
+        wk, wv = N.gather_kv(k, v, N.topk_select(N.rownorm_score(k, -1.0), n))
+        assert torch.equal(ko, wk) and torch.equal(vo, wv), tag
+        ones = torch.ones((1, W, D), device=DEV, dtype=k.dtype)
+        zeros = torch.zeros((1, W, D), device=DEV, dtype=k.dtype)
+        ko, vo = N.snapkv_compress_rope(q, ones, zeros, k, v, ks, n)                    # identity rotation: q_rot == q
+        wk, wv = N.gather_kv(k, v, torch.from_numpy(idx).to(DEV))
+        assert torch.equal(ko, wk) and torch.equal(vo, wv), tag
+
+
+def test_fuzz_shapes_expected_attention_score():
+    """kvp_ea_score over ragged lengths / group sizes / sink counts with synthetic statistics (symmetric PSD covariance)."""
+    rs = np.random.RandomState(77)
+    N = native()
+    for it in range(16):
+        B = int(rs.choice([1, 2]))
+        H = int(rs.choice([1, 2]))
+        G = int(rs.choice([1, 2, 4, 8]))
+        S = int(rs.choice([70, 127, 128, 129, 1000, 2047, 2049, 4097])) if it < 8 else int(rs.randint(70, 5000))
+        n_sink = int(rs.choice([0, 1, 4]))
+        dtname = "bf16" if it % 2 else "f16"
+        use_vnorm, use_cov = bool(it % 3), bool(it % 5)
+        eps = float(rs.choice([0.0, 0.01]))
+        Hq, D = H * G, 128
+        keys = _inputs.round_to(rs.standard_normal((B, H, S, D)).astype(np.float32), dtname)
+        values = _inputs.round_to(rs.standard_normal((B, H, S, D)).astype(np.float32) * 2.0, dtname)
+        mu = (rs.standard_normal((B, Hq, D)) * 0.5).astype(np.float32)
+        A = rs.standard_normal((B, Hq, D, 16)).astype(np.float32) * 0.3
+        cov = (A @ A.transpose(0, 1, 3, 2) + 0.05 * np.eye(D, dtype=np.float32)).astype(np.float32) if use_cov else None
+        want = O.ea_score(keys, values, mu, cov, n_sink, use_vnorm, eps)
+        got = N.ea_score(to_dev(keys, dtname), to_dev(values, dtname), torch.from_numpy(mu).to(DEV),
+                         torch.from_numpy(cov).to(DEV) if cov is not None else None, n_sink, use_vnorm, eps).cpu().numpy()
+        tag = f"it={it} B={B} H={H} G={G} S={S} {dtname} sink={n_sink} vnorm={use_vnorm} cov={use_cov} eps={eps}"
+        assert_scores_close(got[..., n_sink:], want[..., n_sink:], RTOL, tag)
+        if n_sink:
+            assert np.all(got[..., :n_sink] == np.float32(got[..., n_sink:].max()) + np.float32(1.0)), tag
