@@ -9,7 +9,7 @@
 #define ITER 4096
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-enum { OP_FMA, OP_ADD, OP_MAX3, OP_EXP, OP_MUL, OP_PKFMA, OP_PKADD, OP_CVTPK, OP_LOG, OP_RCP, OP_FMA_EXP_ADD, OP_DPP, OP_N };
+enum { OP_FMA, OP_ADD, OP_MAX3, OP_EXP, OP_MUL, OP_PKFMA, OP_PKADD, OP_CVTPK, OP_LOG, OP_RCP, OP_FMA_EXP_ADD, OP_DPP, OP_EXPLEG, OP_EXPF16, OP_N };
 
 template <int OP>
 __global__ void k(float* out, float seed) {
@@ -32,6 +32,8 @@ __global__ void k(float* out, float seed) {
                 if (OP == OP_MAX3) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(c), "v"(d));
                 if (OP == OP_EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i]));
                 if (OP == OP_LOG) asm volatile("v_log_f32 %0, %0" : "+v"(v[i]));
+                if (OP == OP_EXPLEG) asm volatile("v_exp_legacy_f32 %0, %0" : "+v"(v[i]));
+                if (OP == OP_EXPF16) asm volatile("v_exp_f16 %0, %0" : "+v"(v[i]));
                 if (OP == OP_RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(v[i]));
                 if (OP == OP_PKFMA && i < 8) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(c2), "v"(d2));
                 if (OP == OP_PKADD && i < 8) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(d2));
@@ -108,10 +110,10 @@ int main() {
     float* out; (void)hipMalloc(&out, 256 * 1024 * 4);
     printf("clock %.3f GHz; SIMD cycles per wave64 instruction at 1 / 2 / 4 waves per SIMD\n", ghz);
     const char* names[OP_N] = {"v_fma_f32", "v_add_f32", "v_max3_f32", "v_exp_f32", "v_mul_f32", "v_pk_fma_f32", "v_pk_add_f32",
-                               "v_cvt_pk_bf16_f32", "v_log_f32", "v_rcp_f32", "fma+exp+add (per instr)", "v_add_f32_dpp"};
+                               "v_cvt_pk_bf16_f32", "v_log_f32", "v_rcp_f32", "fma+exp+add (per instr)", "v_add_f32_dpp", "v_exp_legacy_f32", "v_exp_f16"};
 #define ROW(OP) printf("%-26s %6.2f %6.2f %6.2f\n", names[OP], run<OP>(1, out, ghz), run<OP>(2, out, ghz), run<OP>(4, out, ghz));
     ROW(OP_FMA) ROW(OP_ADD) ROW(OP_MUL) ROW(OP_MAX3) ROW(OP_EXP) ROW(OP_LOG) ROW(OP_RCP) ROW(OP_PKFMA) ROW(OP_PKADD) ROW(OP_CVTPK)
-    ROW(OP_FMA_EXP_ADD) ROW(OP_DPP)
+    ROW(OP_FMA_EXP_ADD) ROW(OP_DPP) ROW(OP_EXPLEG) ROW(OP_EXPF16)
     uint4* in; (void)hipMalloc(&in, 128 * sizeof(uint4)); (void)hipMemset(in, 0x3c, 128 * sizeof(uint4));
     printf("%-26s %6.2f %6.2f %6.2f\n", "v_mfma_f32_32x32x16_bf16", runm<0>(1, out, in, ghz), runm<0>(2, out, in, ghz), runm<0>(4, out, in, ghz));
     printf("%-26s %6.2f %6.2f %6.2f\n", "v_mfma_f32_16x16x32_bf16", runm<1>(1, out, in, ghz), runm<1>(2, out, in, ghz), runm<1>(4, out, in, ghz));
