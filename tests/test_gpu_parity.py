@@ -775,3 +775,20 @@ def test_fuzz_shapes_expected_attention_score():
         assert_scores_close(got[..., n_sink:], want[..., n_sink:], RTOL, tag)
         if n_sink:
             assert np.all(got[..., :n_sink] == np.float32(got[..., n_sink:].max()) + np.float32(1.0)), tag
+
+
+def test_snapkv_extreme_logit_spread():
+    """Keys aligned with a window query (logit ~ 2.5e4, far beyond the fp32 exponent range relative to their neighbours) in
+    different sub-tiles of several tiles: the running maximum of pass 1 must follow them (a variant that refreshed the
+    maximum only once per tile was measured at -2 us and dropped; this is the input that variant needed a fallback for)."""
+    rs = np.random.RandomState(5)
+    B, H, G, S, W, D = 1, 2, 4, 3000, 64, 128
+    keys = rs.standard_normal((B, H, S, D)).astype(np.float32)
+    q_win = rs.standard_normal((B, H * G, W, D)).astype(np.float32)
+    for pos, hq, w in ((100, 0, 3), (40 + 128 * 5, 5, 60), (2900, 7, 10)):   # sub-tile 3, 1 and 2 of their tiles
+        keys[0, hq // G, pos] = 200.0 * q_win[0, hq, w]
+    keys, q_win = _inputs.round_to(keys, "bf16"), _inputs.round_to(q_win, "bf16")
+    got = native().snapkv_score(to_dev(q_win, "bf16"), to_dev(keys, "bf16"), 5).cpu().numpy()
+    want = O.snapkv_score(q_win, keys, 5)
+    assert np.isfinite(got).all()
+    assert_scores_close(got[..., :-W], want[..., :-W], RTOL, "extreme logit spread")
