@@ -51,7 +51,7 @@ fi
 if [[ "$WHAT" == *prof* ]]; then
   cd /tmp
   for wl in snapkv128k knorm32k; do
-    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -o $wl -- python "$GRAFT_REPO_ROOT/bench.py" --workload $wl --steps 20 --warmup 3 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -o $wl -- python "$GRAFT_REPO_ROOT/bench.py" --workload $wl --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" 2>&1
     echo "prof[$wl] rc=$?"
     find "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -name "*kernel_trace.csv" -delete 2>/dev/null
     find "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -name "*.db" -delete 2>/dev/null
