@@ -242,7 +242,8 @@ SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, in
         off += kvp_align_up(bytes, 256);
         return p;
     };
-    const int64_t nchunk_max = (S + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC;
+    // generic kernels: one workgroup per 512 keys; MFMA kernels: up to one per 128-key tile, never more than 256 (snapkv_mfma_nchunk)
+    const int64_t nchunk_max = std::max<int64_t>((S + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC, std::min<int64_t>((S + 127) / 128, 256));
     const size_t rows = (size_t)B * Hq * W;
     w.bmax = (float*)take((size_t)std::max<int64_t>(4096, B * Hkv) * 4);
     w.part_m = (float*)take(rows * nchunk_max * 4);

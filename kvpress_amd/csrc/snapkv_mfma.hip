@@ -44,7 +44,7 @@ constexpr int MF_WAVES = MF_THREADS / 64;
 constexpr int MF_TILE = 128;         // keys per LDS tile
 constexpr int MF_SUBS = MF_TILE / 32;  // 32-key MFMA sub-tiles per tile == DMA requests per thread per tile
 constexpr int MF_NBUF = 3;           // LDS ring: computing t, landed/landing t+1, landing t+2
-constexpr int MF_CHUNK = 1024;       // minimum keys per workgroup
+constexpr int MF_CHUNK = 128;        // minimum keys per workgroup: one tile (measured: S=4k p1 22->13 us, p2 22->9 us vs 1024)
 constexpr int MF_ROWB = 256;         // bytes per key row (D = 128, 2-byte elements)
 constexpr int MF_TILEB = MF_TILE * MF_ROWB;
 static_assert(MF_TILEB / 16 / MF_THREADS == MF_SUBS, "one DMA request per thread per sub-tile step");
@@ -422,10 +422,11 @@ bool snapkv_mfma_eligible(const SnapArgs& a, int dtype) {
 static uint32_t mfma_nchunk_for(const SnapArgs& a, uint32_t nkeys) {
     const uint32_t ngb = (a.G + 3) / 4;
     const uint32_t planes = std::max<uint32_t>(1, a.B * a.Hkv * ngb);
-    const uint32_t by_keys = (nkeys + MF_CHUNK - 1) / MF_CHUNK;   // >= 1024 keys per workgroup
+    static const int minkeys = kvp_env_int("KVP_SK_MINKEYS", MF_CHUNK);
+    const uint32_t by_keys = (nkeys + minkeys - 1) / minkeys;   // >= MF_CHUNK keys per workgroup
     static const int slots = kvp_env_int("KVP_SK_SLOTS", 256);   // one 8-wave workgroup per CU
     const uint32_t by_cus = std::max<uint32_t>(1, (uint32_t)slots / planes);
-    return std::max<uint32_t>(1, std::min(by_keys, by_cus));
+    return std::max<uint32_t>(1, std::min(std::min(by_keys, by_cus), 256u));  // 256: what the partial-statistics workspace is sized for
 }
 uint32_t snapkv_mfma_nchunk(const SnapArgs& a) { return mfma_nchunk_for(a, a.S); }
 

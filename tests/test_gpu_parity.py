@@ -186,6 +186,18 @@ def test_snapkv_kernel_vs_oracle(name):
         assert ok, f"{name} r={r}: {msg}"
 
 
+@pytest.mark.parametrize("S,Hq", [(192, 4), (4160, 4), (33000, 2), (40000, 8)])
+def test_snapkv_kernel_many_chunks(S, Hq):
+    """One kv-head: the MFMA passes split S into as many single-tile workgroups as fit (up to 256) - the partial
+    statistics workspace and the all-masked partials of the window tiles are what this exercises."""
+    rs = np.random.RandomState(S)
+    q = _inputs.round_to(rs.standard_normal((1, Hq, 64, 128)).astype(np.float32), "bf16")
+    k = _inputs.round_to(rs.standard_normal((1, 1, S, 128)).astype(np.float32), "bf16")
+    want = O.snapkv_score(q, k, 5)
+    got = native().snapkv_score(to_dev(q, "bf16"), to_dev(k, "bf16"), 5).cpu().numpy()
+    assert_scores_close(got[..., :-64], want[..., :-64], RTOL, f"S={S}")
+
+
 @pytest.mark.parametrize("name", ["sk_tiny", "sk_257_A", "sk_f16_d64"])
 def test_snapkv_from_attentions(name):
     s = _inputs.make_case(name)

@@ -4,7 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from kvpress_amd import _native
 dev = "cuda:0"
-for S in (4096, 16384, 32768, 65536, 131072, 262144):
+import sys as _s
+SIZES = [int(x) for x in _s.argv[1:]] or [4096, 16384, 32768, 65536, 131072, 262144]
+for S in SIZES:
     g = torch.Generator(device=dev); g.manual_seed(0)
     k = torch.randn((1, 8, S, 128), generator=g, device=dev).to(torch.bfloat16)
     q = torch.randn((1, 32, 64, 128), generator=g, device=dev).to(torch.bfloat16)
