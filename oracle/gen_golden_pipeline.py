@@ -46,7 +46,7 @@ def main():
     for name, (spec, n_words, questions, max_new) in _inputs.PIPELINE_CASES.items():
         press = _inputs.build_press(kvpress, spec)
         context = _inputs.tiny_context(n_words)
-        cache = DynamicCache()
+        cache = _inputs.make_pipeline_cache(name, model.config)
         res = pipe(context, questions=questions, press=press, max_new_tokens=max_new, cache=cache)
         out[name] = {
             "answers": res["answers"],

@@ -241,7 +241,41 @@ PIPELINE_CASES = {
         prefilling_press=_KN(0.5),
         decoding_press=("DecodingPress", dict(base_press=_KN(), compression_interval=4, target_size=36, hidden_states_buffer_size=2)))),
         80, ["w5 w6 w7"], 16),
+    # QuantizedCache write-back of the hook (base_press.py:152-157) and the pipeline's answer removal
+    "pipe_knorm_quantized": (_KN(0.5), 120, ["w1 w2 w3", "w7"], 8),
+    "pipe_snapkv_quantized": (("SnapKVPress", dict(compression_ratio=0.5, window_size=16, kernel_size=5)), 150, ["w4 w5"], 8),
+    "pipe_none_quantized": (None, 40, ["w3"], 6),
 }
+# cases that run on a QuantizedCache instead of a DynamicCache
+PIPELINE_QUANTIZED = ("pipe_knorm_quantized", "pipe_snapkv_quantized", "pipe_none_quantized")
+
+
+def make_pipeline_cache(name: str, config):
+    from transformers import DynamicCache
+
+    return make_fixed_point_cache(config) if name in PIPELINE_QUANTIZED else DynamicCache()
+
+
+def make_fixed_point_cache(config, residual_length: int = 8):
+    """A transformers ``QuantizedCache`` whose layers use an in-test backend (optimum-quanto and hqq are not installed):
+    int8 fixed point with 4 fractional bits, stored as a plain sliceable tensor.  Everything else -- the residual buffer,
+    ``cumulative_length``, the re-quantisation on overflow -- is transformers' own ``QuantizedLayer``."""
+    import torch
+    from transformers.cache_utils import Cache, QuantizedCache, QuantizedLayer
+
+    class FixedPointLayer(QuantizedLayer):
+        def _quantize(self, tensor, axis):
+            self._float_dtype = tensor.dtype
+            return (tensor.float() * 16.0).round().clamp(-127, 127).to(torch.int8)
+
+        def _dequantize(self, q_tensor):
+            return (q_tensor.float() / 16.0).to(self._float_dtype)
+
+    class FixedPointCache(QuantizedCache):
+        def __init__(self, n_layers):
+            Cache.__init__(self, layers=[FixedPointLayer(8, 0, 0, 64, residual_length) for _ in range(n_layers)])
+
+    return FixedPointCache(config.num_hidden_layers)
 
 
 # ---- selection wrappers (SURVEY §8 f-3): ChunkPress / KeyRerotationPress around a scorer ---------------------------

@@ -26,7 +26,7 @@ def _run(name, device="cpu", dtype=None):
     spec, n_words, questions, max_new = _inputs.PIPELINE_CASES[name]
     model = _inputs.make_tiny_llama(dtype=dtype, device=device)
     pipe = pipeline("kv-press-text-generation", model=model, tokenizer=_inputs.make_tiny_tokenizer())
-    cache = DynamicCache()
+    cache = _inputs.make_pipeline_cache(name, model.config)
     res = pipe(_inputs.tiny_context(n_words), questions=questions, press=_inputs.build_press(kvpress_amd, spec), max_new_tokens=max_new,
                cache=cache)
     return res, [int(cache.get_seq_length(i)) for i in range(len(cache))]
