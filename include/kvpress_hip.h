@@ -85,6 +85,16 @@ int kvp_snapkv_score_rope(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_s
                           int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
                           float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream);
 
+/* FINCH scores (kvpress/presses/finch_press.py:56-83): the window attention of kvp_snapkv_score_rope for a window of ANY
+ * length W (the question that follows the context), no pooling; with normalize_scores != 0 window row w is weighted by its
+ * number of visible keys S - W + w before the mean over the window (:71-74).  Window columns = max + 1 (:82).
+ * Arguments and workspace (kvp_snapkv_workspace_bytes) as kvp_snapkv_score_rope. */
+int kvp_finch_score(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw,
+                    const void* cos, const void* sin, int64_t cs_sb, int64_t cs_sw,
+                    const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
+                    int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int normalize_scores,
+                    float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream);
+
 /* Same, when the attention layer returned its weights (snapkv_press.py:88-89):
  * attn is the [B,Hq,W,S-W] view attentions[..., -W:, :-W] (last dim contiguous). */
 int kvp_snapkv_score_from_attn(const void* attn, int64_t a_sb, int64_t a_sh, int64_t a_sw, int dtype,

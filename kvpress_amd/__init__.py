@@ -16,6 +16,7 @@ from kvpress_amd.presses.composed_press import ComposedPress
 from kvpress_amd.presses.cur_press import CURPress
 from kvpress_amd.presses.decoding_press import DecodingPress, PrefillDecodingPress
 from kvpress_amd.presses.expected_attention_press import ExpectedAttentionPress
+from kvpress_amd.presses.finch_press import FinchPress
 from kvpress_amd.presses.key_rerotation_press import KeyRerotationPress
 from kvpress_amd.presses.keydiff_press import KeyDiffPress
 from kvpress_amd.presses.knorm_press import KnormPress
@@ -29,7 +30,7 @@ from kvpress_amd.presses.tova_press import TOVAPress
 
 __version__ = "0.1.0"
 __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
-           "KeyDiffPress", "CURPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "BlockPress", "KeyRerotationPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
+           "KeyDiffPress", "CURPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
            "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
 
 

@@ -46,6 +46,8 @@ SIGNATURES = {
                                  _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_snapkv_score_rope": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, c_void_p, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int,
                                       _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "kvp_finch_score": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, c_void_p, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int,
+                                _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_snapkv_qproj_rope": (c_int, [c_void_p, _I64, _I64, c_void_p, c_void_p, c_void_p, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64,
                                       c_void_p, c_void_p]),
     "kvp_snapkv_score_hidden": (c_int, [c_void_p, _I64, _I64, c_void_p, _I64, c_void_p, c_void_p, _I64, _I64, c_void_p, _I64, _I64, _I64,
@@ -213,8 +215,13 @@ def snapkv_score(q_win: torch.Tensor, keys: torch.Tensor, kernel_size: int) -> t
     return scores
 
 
+def finch_score(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, keys: torch.Tensor, normalize_scores: bool) -> torch.Tensor:
+    """FINCH scores (finch_press.py:56-83) from the PRE-RoPE window queries [B,Hq,W,D] (any W) and the window's cos/sin."""
+    return snapkv_score_rope(q_pre, cos, sin, keys, 1, _finch_normalize=bool(normalize_scores))
+
+
 def snapkv_score_rope(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, keys: torch.Tensor,
-                      kernel_size: int) -> torch.Tensor:
+                      kernel_size: int, _finch_normalize=None) -> torch.Tensor:
     """SnapKV scores from the PRE-RoPE window queries [B,Hq,W,D] and the window's cos/sin [1 or B, W, D]:
     the RoPE (q*cos + rotate_half(q)*sin, rounded like torch does in the model dtype) runs in the library."""
     keys = _rows_last_contig(_dev(keys))
@@ -236,10 +243,11 @@ def snapkv_score_rope(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
     with torch.cuda.device(keys.device):
         nws = lib().kvp_snapkv_workspace_bytes(B, Hq, Hkv, S, W, D)
         ws = _ws(nws, keys)
-        _check(lib().kvp_snapkv_score_rope(_p(q_pre), _st(q_pre, 0), _st(q_pre, 1), _st(q_pre, 2), _p(cos), _p(sin),
-                                           _st(cos, 0), _st(cos, 1), _p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2),
-                                           _DTYPES[dt], B, Hq, Hkv, S, W, D, int(kernel_size), _p(scores), _p(ws), ws.numel(),
-                                           _stream(keys)), "kvp_snapkv_score_rope")
+        fn, last, what = ((lib().kvp_snapkv_score_rope, int(kernel_size), "kvp_snapkv_score_rope") if _finch_normalize is None
+                          else (lib().kvp_finch_score, int(_finch_normalize), "kvp_finch_score"))
+        _check(fn(_p(q_pre), _st(q_pre, 0), _st(q_pre, 1), _st(q_pre, 2), _p(cos), _p(sin), _st(cos, 0), _st(cos, 1), _p(keys),
+                  _st(keys, 0), _st(keys, 1), _st(keys, 2), _DTYPES[dt], B, Hq, Hkv, S, W, D, last, _p(scores), _p(ws), ws.numel(),
+                  _stream(keys)), what)
     return scores
 
 

@@ -293,10 +293,11 @@ extern "C" size_t kvp_snapkv_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv,
 int snapkv_score_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* k, int64_t k_sb,
                       int64_t k_sh, int64_t k_ss, int dtype, int64_t B, int64_t Hq, int64_t Hkv, int64_t S,
                       int64_t W, int64_t D, int kernel_size, float* scores, void* ws, size_t ws_bytes,
-                      hipStream_t stream, uint32_t* hist1) {
+                      hipStream_t stream, uint32_t* hist1, bool count_norm = false) {
     KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "snapkv: bad dtype %d", dtype);
     if (int rc = check_common(B, Hq, Hkv, S, W, kernel_size)) return rc;
     KVP_CHECK_ARG(D >= 1 && D <= 1024, "snapkv: unsupported head_dim %ld", (long)D);
+    const uint32_t norm_base = count_norm ? (uint32_t)(S - W) : 0;  // window row w sees S - W + w keys
     KVP_CHECK_ARG(q && k && scores, "snapkv: null pointer");
     SnapWs w = carve_snap_ws(ws, B, Hq, Hkv, S, W, D);
     if (!ws || ws_bytes < w.total_bytes) {
@@ -316,7 +317,7 @@ int snapkv_score_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, c
     if (snapkv_mfma_eligible(a, dtype)) {
         const uint32_t nchunk = snapkv_mfma_nchunk(a);
         if (int rc = snapkv_mfma_p1(a, dtype, nchunk, w.part_m, w.part_z, stream)) return rc;
-        KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_kernel<<<(nrows + 3) / 4, 256, 0, stream>>>(w.part_m, w.part_z, nrows, nchunk, w.rowstat));
+        KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_kernel<<<(nrows + 3) / 4, 256, 0, stream>>>(w.part_m, w.part_z, nrows, nchunk, w.rowstat, (uint32_t)W, norm_base));
         if (int rc = snapkv_mfma_p2(a, dtype, w.rowstat, w.colsum, stream)) return rc;
     } else {
         const uint32_t nchunk = (uint32_t)((S + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC);
@@ -328,7 +329,7 @@ int snapkv_score_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, c
         const dim3 g2(nchunk2, (uint32_t)Hkv, (uint32_t)B);
 #define KVP_SK_GENERIC(DT)                                                                                \
     KVP_LAUNCH("snapkv_p1_generic", stream, snapkv_p1_generic<DT><<<g1, SK_THREADS, lds1, stream>>>(a, nchunk, w.part_m, w.part_z));               \
-    KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_kernel<<<(nrows + 3) / 4, 256, 0, stream>>>(w.part_m, w.part_z, nrows, nchunk, w.rowstat)); \
+    KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_kernel<<<(nrows + 3) / 4, 256, 0, stream>>>(w.part_m, w.part_z, nrows, nchunk, w.rowstat, (uint32_t)W, norm_base)); \
     KVP_LAUNCH("snapkv_p2_generic", stream, snapkv_p2_generic<DT><<<g2, SK_THREADS, lds2, stream>>>(a, w.rowstat, w.colsum));
         if (dtype == KVP_F32) { KVP_SK_GENERIC(KVP_F32) }
         else if (dtype == KVP_F16) { KVP_SK_GENERIC(KVP_F16) }
@@ -350,7 +351,7 @@ extern "C" int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64
 int snapkv_score_rope_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
                            int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
                            int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
-                           float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1) {
+                           float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1, bool count_norm) {
     KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "snapkv: bad dtype %d", dtype);
     if (int rc = check_common(B, Hq, Hkv, S, W, kernel_size)) return rc;
     KVP_CHECK_ARG(D >= 2 && D <= 1024 && D % 2 == 0, "snapkv: RoPE needs an even head_dim (got %ld)", (long)D);
@@ -374,7 +375,7 @@ int snapkv_score_rope_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
 #undef KVP_SK_ROPE
     KVP_CHECK_LAUNCH("snapkv(rope)");
     return snapkv_score_impl(w.qrot, Hq * W * D, W * D, D, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D, kernel_size, scores, ws,
-                             ws_bytes, stream, hist1);
+                             ws_bytes, stream, hist1, count_norm);
 }
 
 // window queries from the hidden states (fused q_proj + RoPE, qproj.hip), then as above
@@ -417,7 +418,7 @@ extern "C" int kvp_snapkv_score_rope(const void* q, int64_t q_sb, int64_t q_sh, 
                                      int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
                                      float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
     return snapkv_score_rope_impl(q, q_sb, q_sh, q_sw, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D,
-                                  kernel_size, scores, ws, ws_bytes, static_cast<hipStream_t>(stream_), nullptr);
+                                  kernel_size, scores, ws, ws_bytes, static_cast<hipStream_t>(stream_), nullptr, false);
 }
 
 extern "C" int kvp_snapkv_score_from_attn(const void* attn, int64_t a_sb, int64_t a_sh, int64_t a_sw, int dtype, int64_t B,
@@ -442,4 +443,14 @@ extern "C" int kvp_snapkv_score_from_attn(const void* attn, int64_t a_sb, int64_
 #undef KVP_SK_ATTN
     KVP_CHECK_LAUNCH("snapkv(from_attn)");
     return finish_scores(w, B, Hq, Hkv, S, W, kernel_size, scores, stream);
+}
+
+// FINCH scores (finch_press.py:56-83): the window attention of kvp_snapkv_score_rope for an arbitrary window (the
+// question), each window row optionally weighted by its number of visible keys, no pooling.
+extern "C" int kvp_finch_score(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
+                               int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
+                               int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int normalize_scores,
+                               float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
+    return snapkv_score_rope_impl(q, q_sb, q_sh, q_sw, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D,
+                                  1, scores, ws, ws_bytes, static_cast<hipStream_t>(stream_), nullptr, normalize_scores != 0);
 }

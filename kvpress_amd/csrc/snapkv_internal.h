@@ -22,7 +22,7 @@ int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* co
 int snapkv_score_rope_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
                            int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
                            int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
-                           float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1);
+                           float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1, bool count_norm = false);
 int snapkv_score_hidden_impl(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, int64_t hidden, const void* cosp,
                              const void* sinp, int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
                              int dtype, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,

@@ -25,10 +25,11 @@ __device__ __forceinline__ void softmax_merge(float& m, float& z, float m2, floa
     m = mn;
 }
 
-// a[row] = M + log2(Z) from part_m/part_z [nrows][nchunk]; one wave per row.
+// a[row] = M + log2(Z) from part_m/part_z [nrows][nchunk]; one wave per row (rows = [.., W] window rows when norm_base is used).
 static __global__ __launch_bounds__(256) void softmax_combine_kernel(const float* __restrict__ part_m,
                                                               const float* __restrict__ part_z, uint32_t nrows,
-                                                              uint32_t nchunk, float* __restrict__ a) {
+                                                              uint32_t nchunk, float* __restrict__ a, uint32_t W = 0,
+                                                              uint32_t norm_base = 0) {
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     if (row >= nrows) return;
@@ -39,7 +40,9 @@ static __global__ __launch_bounds__(256) void softmax_combine_kernel(const float
         const float m2 = __shfl_xor(m, o), z2 = __shfl_xor(z, o);
         softmax_merge(m, z, m2, z2);
     }
-    if (lane == 0) a[row] = m + log2f(z);
+    // norm_base != 0 (FINCH, finch_press.py:71-74): window row w = row % W is weighted by its number of visible keys
+    // norm_base + w, i.e. its log2-normaliser is lowered by log2 of that count
+    if (lane == 0) a[row] = m + log2f(z) - (norm_base ? log2f((float)(norm_base + row % W)) : 0.f);
 }
 
 // Global max without same-address atomics (2048 atomicMax on one word cost ~12 ns each = 25 us):

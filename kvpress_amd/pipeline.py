@@ -27,6 +27,7 @@ from transformers.pipelines import PIPELINE_REGISTRY
 
 from kvpress_amd.presses.base_press import BasePress
 from kvpress_amd.presses.decoding_press import DecodingPress, PrefillDecodingPress
+from kvpress_amd.presses.finch_press import FinchPress
 from kvpress_amd.presses.key_rerotation_press import KeyRerotationPress
 
 logger = logging.getLogger(__name__)
@@ -109,7 +110,7 @@ class KVPressTextGenerationPipeline(Pipeline):
         # decoding presses keep their hook for the answers (pipeline.py:230-233)
         with press(self.model) if decoding else contextlib.nullcontext():
             for question_ids in input_tensors["questions_ids"]:
-                if isinstance(press, KeyRerotationPress):
+                if isinstance(press, KeyRerotationPress) or (isinstance(press, FinchPress) and press.rerotate_keys):
                     context_length = cache.get_seq_length()  # re-rotated keys sit at positions 0..n-1 (:237-238)
                 kept = [cache.get_seq_length(i) for i in range(len(cache))]
                 answers.append(self.generate_answer(question_ids.to(device), cache, context_length, max_new_tokens))

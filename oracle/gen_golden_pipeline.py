@@ -54,6 +54,17 @@ def main():
             "context_tokens": int(tok.encode("<s>" + context, add_special_tokens=False).__len__()),
         }
         print(name, out[name])
+    def ref_pipe(m, t):
+        for layer in m.model.layers:
+            layer.self_attn.register_forward_pre_hook(inject_cache_position, with_kwargs=True)
+        return KVPressTextGenerationPipeline(model=m, tokenizer=t)
+
+    for name in _inputs.FINCH_PIPELINE_CASES:
+        cache = DynamicCache()
+        res, press = _inputs.run_finch_pipeline(kvpress, ref_pipe, name, cache)
+        out[name] = {"answers": res["answers"], "cache_lengths": [int(cache.get_seq_length(i)) for i in range(len(cache))],
+                     "window_size": int(press.window_size)}
+        print(name, out[name])
     with open(os.path.join(REPO, "tests", "golden", "pipeline.json"), "w") as f:
         json.dump(out, f, indent=1)
 

@@ -262,6 +262,34 @@ def snapkv_score_from_attentions(attentions, H, window, kernel_size: int = 5, ct
     return _snapkv_from_window_attn(a, H, window, kernel_size, ctype)
 
 
+def finch_score(q_win, keys, normalize_scores: bool = True, ctype=np.float64) -> np.ndarray:
+    """FinchPress.score with ``attentions=None`` (finch_press.py:56-83) from the RoPE'd window queries [B,Hq,W,D]:
+    window attention as SnapKV (:66-69), every window row times its number of non-masked keys ``arange(S-W, S)``
+    (:71-74), mean over the window (:77) and the GQA group (:78-79), pad with max + 1 (:82).  [B,H,S] float32."""
+    q = np.asarray(q_win)
+    B, Hq, W, _ = q.shape
+    H, S = keys.shape[1], keys.shape[2]
+    attn = snapkv_window_attention(q, keys, ctype)                    # [B,Hq,W,S-W]
+    if normalize_scores:
+        attn = attn * np.arange(S - W, S, dtype=ctype)[None, None, :, None]
+    sc = attn.mean(axis=-2).reshape(B, H, Hq // H, S - W).mean(2)
+    fill = float(np.float32(sc.max())) + 1.0 if sc.size else 1.0
+    return np.concatenate([sc, np.full((B, H, W), fill, dtype=ctype)], axis=-1).astype(np.float32)
+
+
+def finch_indices(scores: np.ndarray, compression_ratio: float, chunk_length=None) -> np.ndarray:
+    """The kept positions of FinchPress.compress (finch_press.py:99-112), ascending (the order of the re-rotating
+    variant, :114): a global top-k, or per chunk ``max(1, int(len * (1 - ratio)))`` of every ``chunk_length`` block."""
+    S = scores.shape[-1]
+    if chunk_length is None:
+        return topk_select(scores, n_kept(S, compression_ratio))
+    parts = []
+    for i in range(0, S, chunk_length):
+        c = scores[..., i : i + chunk_length]
+        parts.append(i + topk_select(c, max(1, int(c.shape[-1] * (1 - compression_ratio)))))
+    return np.concatenate(parts, axis=-1).astype(np.int32)
+
+
 # --------------------------------------------------------------------------------------
 # ExpectedAttentionPress  (kvpress/presses/expected_attention_press.py:62-165)
 # --------------------------------------------------------------------------------------

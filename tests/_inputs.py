@@ -278,6 +278,25 @@ def make_fixed_point_cache(config, residual_length: int = 8):
     return FixedPointCache(config.num_hidden_layers)
 
 
+# FinchPress through the pipeline: context + delimiter + question in ONE prefill (the press must first register its delimiter
+# with the tokenizer and the embedding table, finch_press.py:139-151), then the question is asked again as usual.
+FINCH_PIPELINE_CASES = {
+    # name: (FinchPress kwargs, context words, question, max_new_tokens)
+    "pipe_finch": (dict(compression_ratio=0.5), 80, "w4 w5 w6", 8),
+    "pipe_finch_chunk_norerot": (dict(compression_ratio=0.5, chunk_length=20, rerotate_keys=False, normalize_scores=False), 90, "w9 w1", 6),
+}
+
+
+def run_finch_pipeline(ns, pipeline_factory, name, cache, dtype=None, device="cpu"):
+    """``ns``: the reference package or this one; ``pipeline_factory(model, tokenizer)`` -> the matching pipeline object."""
+    kw, n_words, question, max_new = FINCH_PIPELINE_CASES[name]
+    model, tok = make_tiny_llama(dtype=dtype, device=device), make_tiny_tokenizer()
+    press = ns.FinchPress(**kw)
+    tok = press.update_model_and_tokenizer(model, tok)
+    context = tiny_context(n_words) + " " + press.delimiter_token + " " + question
+    return pipeline_factory(model, tok)(context, questions=[question], press=press, max_new_tokens=max_new, cache=cache), press
+
+
 # ---- selection wrappers (SURVEY §8 f-3): ChunkPress / KeyRerotationPress around a scorer ---------------------------
 WRAP_CASES = {
     # name: wrapper, inner press kind, geometry (as CASES), wrapper parameters
@@ -307,6 +326,37 @@ WRAP_CASES = {
     "wrap_rerot_streaming_f16": dict(wrapper="rerot", kind="streaming", B=1, H=2, G=1, S=257, D=64, dtype="f16", data="A", seed=87,
                                      ratios=(0.4,)),
 }
+
+
+# ---- FinchPress: question-window scores, optional per-chunk selection and key re-rotation ---------------
+FINCH_CASES = {
+    # W = the question length (any); chunk_length > W / (1 - ratio) (finch_press.py:103)
+    "finch_tiny": dict(B=1, H=2, G=2, S=100, D=16, dtype="f32", data="A", seed=101, W=11, normalize=True, chunk_length=None,
+                       rerotate=True, ratios=(0.25, 0.5)),
+    "finch_nonorm_chunk": dict(B=2, H=2, G=1, S=300, D=16, dtype="f32", data="B", seed=102, W=7, normalize=False, chunk_length=64,
+                               rerotate=False, ratios=(0.5,)),
+    "finch_64_bf16": dict(B=1, H=2, G=4, S=1000, D=128, dtype="bf16", data="B", seed=103, W=64, normalize=True, chunk_length=256,
+                          rerotate=True, ratios=(0.5,)),
+    "finch_37_f16": dict(B=1, H=2, G=2, S=515, D=64, dtype="f16", data="A", seed=104, W=37, normalize=True, chunk_length=None,
+                         rerotate=True, ratios=(0.3, 0.8)),
+}
+
+
+def make_finch_case(name: str) -> dict:
+    extra = ("normalize", "chunk_length", "rerotate")
+    CASES[name] = dict({k: v for k, v in FINCH_CASES[name].items() if k not in extra}, kind="snapkv", ks=1)
+    try:
+        s = make_case(name)
+    finally:
+        del CASES[name]
+    s.update({k: FINCH_CASES[name][k] for k in extra})
+    return s
+
+
+def make_finch_press(mod, s: dict, ratio: float):
+    p = mod.FinchPress(compression_ratio=ratio, chunk_length=s["chunk_length"], normalize_scores=s["normalize"], rerotate_keys=s["rerotate"])
+    p.window_size = s["W"]  # what the embedding hook sets from the delimiter position (finch_press.py:133)
+    return p
 
 
 def make_wrap_case(name: str) -> dict:

@@ -73,6 +73,11 @@ def fake_native(monkeypatch):
         q_rot = q * c + O.rotate_half(q) * s  # snapkv_press.py:56-58
         return torch.from_numpy(O.snapkv_score(q_rot, keys.float().numpy(), kernel_size))
 
+    def finch_score(q_pre, cos, sin, keys, normalize_scores):
+        q = q_pre.double().numpy()
+        c, s = cos.double().numpy()[:, None], sin.double().numpy()[:, None]
+        return torch.from_numpy(O.finch_score(q * c + O.rotate_half(q) * s, keys.float().numpy(), bool(normalize_scores)))
+
     def snapkv_score_from_attn(attn_win, num_kv_heads, k_len, kernel_size):
         a = attn_win.double().numpy()
         B, Hq, W, Sm = a.shape
@@ -121,7 +126,7 @@ def fake_native(monkeypatch):
                                            cov.numpy() if cov is not None else None, n_sink, use_vnorm, eps))
 
     for name, fn in dict(rownorm_score=rownorm_score, topk_select=topk_select, gather_kv=gather_kv,
-                         snapkv_score=snapkv_score, snapkv_score_rope=snapkv_score_rope, snapkv_score_from_attn=snapkv_score_from_attn,
+                         snapkv_score=snapkv_score, snapkv_score_rope=snapkv_score_rope, finch_score=finch_score, snapkv_score_from_attn=snapkv_score_from_attn,
                          keydiff_score=keydiff_score, cur_score=cur_score, scores_head_mean_=scores_head_mean_, knorm_compress=knorm_compress, qproj_rope_supported=qproj_rope_supported, scores_fill_at_=scores_fill_at_, topk_select_segmented=topk_select_segmented, rerotate_keys_=rerotate_keys_,
                          snapkv_compress_rope=snapkv_compress_rope, ea_qstats=ea_qstats, ea_score=ea_score).items():
         monkeypatch.setattr(_native, name, fn)

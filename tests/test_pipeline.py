@@ -39,6 +39,24 @@ def test_pipeline_matches_reference_answers_cpu(name, fake_native):
     assert res["answers"] == GOLD[name]["answers"]
 
 
+def _run_finch(name, device="cpu", dtype=None):
+    from transformers import DynamicCache, pipeline
+
+    import kvpress_amd
+
+    cache = DynamicCache()
+    res, press = _inputs.run_finch_pipeline(kvpress_amd, lambda m, t: pipeline("kv-press-text-generation", model=m, tokenizer=t), name, cache,
+                                            dtype=dtype, device=device)
+    assert press.window_size == GOLD[name]["window_size"]
+    assert [int(cache.get_seq_length(i)) for i in range(len(cache))] == GOLD[name]["cache_lengths"]
+    assert res["answers"] == GOLD[name]["answers"]
+
+
+@pytest.mark.parametrize("name", list(_inputs.FINCH_PIPELINE_CASES))
+def test_finch_pipeline_matches_reference_answers_cpu(name, fake_native):
+    _run_finch(name)
+
+
 def test_single_question_and_registry(fake_native):
     from transformers import pipeline
 
@@ -113,3 +131,9 @@ def test_pipeline_matches_reference_answers_gpu(name):
     res, lengths = _run(name, device="cuda:0", dtype=torch.float32)
     assert lengths == GOLD[name]["cache_lengths"]
     assert res["answers"] == GOLD[name]["answers"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(_inputs.FINCH_PIPELINE_CASES))
+def test_finch_pipeline_matches_reference_answers_gpu(name):
+    _run_finch(name, device="cuda:0", dtype=torch.float32)
