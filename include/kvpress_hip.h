@@ -59,6 +59,13 @@ const char* kvp_last_error(void);
 int kvp_rownorm_score(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D,
                       int64_t sb, int64_t sh, int64_t ss, float scale, float* out, kvp_stream_t stream);
 
+/* ---- QFilterPress.score: -(q_filter * keys).sum(dim=-1)  (kvpress/presses/qfilter_press.py:79-82) ----------------
+ * out[b,h,s] = scale * sum_d x[b,h,s,d] * filt[h,d]   (scale = -1; filt = the layer's [H,D] slice of the learned
+ * Q-filters, same dtype as x, f_sh = element stride between heads, rows contiguous).  out contiguous [B,H,S] float32. */
+int kvp_rowdot_score(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D,
+                     int64_t sb, int64_t sh, int64_t ss, const void* filt, int64_t f_sh, float scale, float* out,
+                     kvp_stream_t stream);
+
 /* ---- SnapKVPress.score (kvpress/presses/snapkv_press.py:60-105) ----------------------------
  * q: RoPE'd queries of the last W tokens [B,Hq,W,D] (the host keeps q_proj + RoPE,
  *    snapkv_press.py:53-58 / utils.py:43-46: q_proj is a model-owned nn.Linear);

@@ -22,6 +22,7 @@ from kvpress_amd.presses.keydiff_press import KeyDiffPress
 from kvpress_amd.presses.knorm_press import KnormPress
 from kvpress_amd.presses.per_layer_compression_press import PerLayerCompressionPress
 from kvpress_amd.presses.pyramidkv_press import PyramidKVPress
+from kvpress_amd.presses.qfilter_press import QFilterPress
 from kvpress_amd.presses.random_press import RandomPress
 from kvpress_amd.presses.scorer_press import ScorerPress
 from kvpress_amd.presses.snapkv_press import SnapKVPress
@@ -30,7 +31,7 @@ from kvpress_amd.presses.tova_press import TOVAPress
 
 __version__ = "0.1.0"
 __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
-           "KeyDiffPress", "CURPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
+           "KeyDiffPress", "QFilterPress", "CURPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
            "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
 
 

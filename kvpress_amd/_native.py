@@ -28,6 +28,7 @@ SIGNATURES = {
     "kvp_version": (c_int, []),
     "kvp_last_error": (c_char_p, []),
     "kvp_rownorm_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_float, c_void_p, c_void_p]),
+    "kvp_rowdot_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_void_p, _I64, c_float, c_void_p, c_void_p]),
     "kvp_knorm_compress_workspace_bytes": (c_size_t, [_I64] * 4),
     "kvp_knorm_compress": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64,
                                    c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
@@ -148,6 +149,23 @@ def rownorm_score(x: torch.Tensor, scale: float) -> torch.Tensor:
     with torch.cuda.device(x.device):
         _check(lib().kvp_rownorm_score(_p(x), _DTYPES[x.dtype], B, H, S, D, _st(x, 0), _st(x, 1), _st(x, 2),
                                        float(scale), _p(out), _stream(x)), "kvp_rownorm_score")
+    return out
+
+
+def rowdot_score(x: torch.Tensor, filt: torch.Tensor, scale: float) -> torch.Tensor:
+    """out[b,h,s] = scale * <x[b,h,s,:], filt[h,:]>, float32 [B,H,S]; filt [H,D] in x's dtype (qfilter_press.py:79-82)."""
+    x = _rows_last_contig(_dev(x))
+    B, H, S, D = x.shape
+    filt = _dev(filt)
+    assert tuple(filt.shape) == (H, D), (filt.shape, x.shape)
+    if filt.dtype != x.dtype or filt.device != x.device:
+        filt = filt.to(device=x.device, dtype=x.dtype)
+    if filt.stride(-1) != 1:
+        filt = filt.contiguous()
+    out = torch.empty((B, H, S), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().kvp_rowdot_score(_p(x), _DTYPES[x.dtype], B, H, S, D, _st(x, 0), _st(x, 1), _st(x, 2), _p(filt), _st(filt, 0),
+                                      float(scale), _p(out), _stream(x)), "kvp_rowdot_score")
     return out
 
 

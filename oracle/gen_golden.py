@@ -51,8 +51,8 @@ def main(argv):
     _install_shims()
     import numpy as np
     import torch
-    from kvpress import (CURPress, ExpectedAttentionPress, KeyDiffPress, KnormPress, PyramidKVPress, SnapKVPress,  # the reference
-                         StreamingLLMPress, TOVAPress)
+    from kvpress import (CURPress, ExpectedAttentionPress, KeyDiffPress, KnormPress, PyramidKVPress, QFilterPress,  # the reference
+                         SnapKVPress, StreamingLLMPress, TOVAPress)
 
     import _inputs
 
@@ -70,6 +70,10 @@ def main(argv):
                 return SnapKVPress(compression_ratio=ratio, window_size=s["W"], kernel_size=s["ks"])
             if s["kind"] == "keydiff":
                 return KeyDiffPress(compression_ratio=ratio)
+            if s["kind"] == "qfilter":   # the published filters need the hub: seeded stand-ins, assigned directly
+                p = QFilterPress(compression_ratio=ratio)
+                p.q_filters = torch.from_numpy(_inputs.make_qfilters(s)).to(cur_dtype[0])
+                return p
             if s["kind"] == "cur":
                 return CURPress(compression_ratio=ratio, num_sinks=s.get("sinks", 4), leverage_type=s["leverage"],
                                 use_local_approximation=s.get("local", True), local_window_size=s.get("window", 16))
@@ -85,8 +89,12 @@ def main(argv):
 
         out = {"ratios": np.asarray(s["ratios"], dtype=np.float64)}
         captured = {}
+        cur_dtype = [torch.float32]
         for mode, dt in (("f32", torch.float32), ("nat", _inputs.torch_dtype(s["dtype"]))):
             att, rot, hidden, pe = _inputs.build_llama_attention(s, dt)
+            cur_dtype[0] = dt
+            if s["kind"] == "qfilter":
+                att.layer_idx = _inputs.QF_LAYER
             if s["kind"] == "pyramid":  # the budget reads the layer's position in the stack (pyramidkv_press.py:80-81)
                 att.config.num_hidden_layers = s["n_layers"]
                 att.layer_idx = s["layer_idx"]

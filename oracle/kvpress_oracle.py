@@ -369,6 +369,14 @@ def keydiff_score(keys: np.ndarray, ctype=np.float64) -> np.ndarray:
     return (-cos).astype(np.float32)
 
 
+def qfilter_score(keys: np.ndarray, q_filter: np.ndarray, ctype=np.float64) -> np.ndarray:
+    """QFilterPress.score (qfilter_press.py:79-82): ``-(q_filter[None, :, None] * keys).sum(-1)`` with the layer's
+    filters ``q_filter [H, D]``.  [B,H,S] float32."""
+    k = np.asarray(keys).astype(ctype)
+    f = np.asarray(q_filter).astype(ctype)
+    return (-(f[None, :, None, :] * k).sum(-1)).astype(np.float32)
+
+
 def tova_score(q_last, keys, ctype=np.float64) -> np.ndarray:
     """TOVAPress.score with ``attentions=None`` (tova_press.py:45-59) from the RoPE'd query of the LAST token
     ``q_last [B,Hq,1,D]``: window attention with window 1 (SnapKVPress.compute_window_attention, snapkv_press.py:41-69),

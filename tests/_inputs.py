@@ -88,6 +88,10 @@ CASES = {
                   n_layers=8, layer_idx=5, beta=20, ratios=(0.3, 0.5, 0.8)),
     "py_bf16_l7": dict(kind="pyramid", B=1, H=2, G=4, S=1000, D=128, dtype="bf16", data="A", seed=63, W=64, ks=5,
                        n_layers=8, layer_idx=7, beta=5, ratios=(0.5, 0.9)),
+    "qf_tiny_d6": dict(kind="qfilter", B=2, H=2, G=1, S=100, D=6, dtype="f32", data="A", seed=111),
+    "qf_bf16_B": dict(kind="qfilter", B=1, H=8, G=1, S=3001, D=128, dtype="bf16", data="B", seed=112),
+    "qf_f16_d64": dict(kind="qfilter", B=2, H=4, G=1, S=1000, D=64, dtype="f16", data="A", seed=113),
+    "qf_d96_f32": dict(kind="qfilter", B=1, H=3, G=1, S=515, D=96, dtype="f32", data="B", seed=114),
     "st_tiny": dict(kind="streaming", B=1, H=2, G=1, S=100, D=8, dtype="f32", data="A", seed=71),
     "st_sink0": dict(kind="streaming", B=2, H=2, G=1, S=257, D=8, dtype="f32", data="A", seed=72, n_sink=0),
 }
@@ -132,6 +136,15 @@ def make_case(name: str) -> dict:
         wq[:: max(1, s["D"] // 4)] *= 3.0
     s.update(keys=k, values=v, hidden=round_to(hid, s["dtype"]), wq=round_to(wq, s["dtype"]))
     return s
+
+
+QF_LAYERS, QF_LAYER = 3, 1   # the Q-filter cases: filters for 3 layers, the module under test is layer 1
+
+
+def make_qfilters(s: dict) -> np.ndarray:
+    """Stand-in for the learned Q-filters [num_layers, H, D] (the published ones need the hub), exact in the case dtype."""
+    rs = np.random.RandomState(s["seed"] + 2000)
+    return round_to(rs.standard_normal((QF_LAYERS, s["H"], s["D"])).astype(np.float32), s["dtype"])
 
 
 def torch_dtype(name: str):

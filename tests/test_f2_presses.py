@@ -10,7 +10,7 @@ import _inputs
 from oracle import kvpress_oracle as O
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-F2 = [n for n, c in _inputs.CASES.items() if c["kind"] in ("pyramid", "tova", "keydiff", "streaming", "cur")]
+F2 = [n for n, c in _inputs.CASES.items() if c["kind"] in ("pyramid", "tova", "keydiff", "streaming", "cur", "qfilter")]
 
 
 def make_press(s, ratio):
@@ -23,6 +23,10 @@ def make_press(s, ratio):
         return P.TOVAPress(compression_ratio=ratio)
     if k == "keydiff":
         return P.KeyDiffPress(compression_ratio=ratio)
+    if k == "qfilter":
+        p = P.QFilterPress(compression_ratio=ratio)
+        p.q_filters = torch.from_numpy(_inputs.make_qfilters(s))
+        return p
     if k == "cur":
         return P.CURPress(compression_ratio=ratio, num_sinks=s.get("sinks", 4), leverage_type=s["leverage"],
                           use_local_approximation=s.get("local", True), local_window_size=s.get("window", 16))
@@ -34,12 +38,16 @@ def test_press_matches_reference_cpu(name, fake_native):
     s = _inputs.make_case(name)
     g = np.load(os.path.join(GOLD, f"{name}.npz"))
     att, rot, hidden, pe = _inputs.build_llama_attention(s, torch.float32)
+    if s["kind"] == "qfilter":
+        att.layer_idx = _inputs.QF_LAYER
     keys, values = torch.from_numpy(s["keys"]), torch.from_numpy(s["values"])
     kwargs = {"position_embeddings": pe}
     with torch.no_grad():
         sc = make_press(s, 0.5).score(att, hidden, keys, values, None, kwargs).numpy()
         ref = g["scores_f32"]
-        if s["kind"] in ("pyramid", "tova"):
+        if s["kind"] == "qfilter":   # a signed dot product crossing zero: absolute tolerance
+            np.testing.assert_allclose(sc, ref, rtol=2e-4, atol=2e-5)
+        elif s["kind"] in ("pyramid", "tova"):
             W = s["W"]
             np.testing.assert_allclose(sc[..., :-W], ref[..., :-W], rtol=2e-4)
             assert (sc[..., -W:] > sc[..., :-W].max()).all()

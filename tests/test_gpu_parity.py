@@ -283,6 +283,21 @@ def test_cur_kernel_vs_oracle(name):
         native().cur_score(k, v, "nope", 16, 4)
 
 
+@pytest.mark.parametrize("name", [n for n, c in _inputs.CASES.items() if c["kind"] == "qfilter"])
+def test_rowdot_kernel_vs_oracle(name):
+    """kvp_rowdot_score in the case's dtype against the float64 restatement on the same (dtype-exact) keys and filters."""
+    s = _inputs.make_case(name)
+    k = to_dev(s["keys"], s["dtype"])
+    f = _inputs.make_qfilters(s)[_inputs.QF_LAYER]
+    ft = to_dev(f, s["dtype"])
+    got = native().rowdot_score(k, ft, -1.0).cpu().numpy()
+    np.testing.assert_allclose(got, O.qfilter_score(s["keys"], f), rtol=2e-5, atol=2e-5, err_msg=name)
+    # strided key view and a filter slice of a larger tensor
+    allf = to_dev(_inputs.make_qfilters(s), s["dtype"])
+    got2 = native().rowdot_score(k[:, :, ::2], allf[_inputs.QF_LAYER], 2.0).cpu().numpy()
+    np.testing.assert_allclose(got2, -2.0 * O.qfilter_score(s["keys"][:, :, ::2], f), rtol=2e-5, atol=4e-5, err_msg=name)
+
+
 @pytest.mark.parametrize("name", KD)
 def test_keydiff_kernel_vs_oracle(name):
     """kvp_keydiff_score in the case's dtype against the float64 restatement on the same (dtype-exact) keys."""
@@ -376,6 +391,10 @@ def make_press(s, ratio):
     if s["kind"] == "cur":
         return P.CURPress(compression_ratio=ratio, num_sinks=s.get("sinks", 4), leverage_type=s["leverage"],
                           use_local_approximation=s.get("local", True), local_window_size=s.get("window", 16))
+    if s["kind"] == "qfilter":
+        p = P.QFilterPress(compression_ratio=ratio)
+        p.q_filters = torch.from_numpy(_inputs.make_qfilters(s)).to(DEV)   # the press casts per call to the key dtype
+        return p
     if s["kind"] == "streaming":
         return P.StreamingLLMPress(compression_ratio=ratio, n_sink=s["n_sink"])
     return P.ExpectedAttentionPress(compression_ratio=ratio, n_future_positions=s["n_future"], n_sink=s["n_sink"],
@@ -389,6 +408,8 @@ def test_press_fp32_vs_reference(name):
     s = _inputs.make_case(name)
     g = gold(name)
     att, rot, hidden, pe = _inputs.build_llama_attention(s, torch.float32, DEV)
+    if s["kind"] == "qfilter":
+        att.layer_idx = _inputs.QF_LAYER
     keys, values = to_dev(s["keys"], "f32"), to_dev(s["values"], "f32")
     kwargs = {"position_embeddings": pe}
     with torch.no_grad():
@@ -402,6 +423,8 @@ def test_press_fp32_vs_reference(name):
             assert (got[..., -s["W"]:] > got[..., :-s["W"]].max()).all()
         elif s["kind"] == "keydiff":  # a cosine in [-1, 1] crossing zero: absolute tolerance
             np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5, err_msg=name)
+        elif s["kind"] == "qfilter":  # a signed dot product crossing zero
+            np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-5, err_msg=name)
         elif s["kind"] == "streaming":
             assert np.array_equal(got, ref)
         elif s["kind"] == "cur":
@@ -439,6 +462,8 @@ def test_press_native_dtype_runs_and_overlaps_reference(name):
     g = gold(name)
     dt = _inputs.torch_dtype(s["dtype"])
     att, rot, hidden, pe = _inputs.build_llama_attention(s, dt, DEV)
+    if s["kind"] == "qfilter":
+        att.layer_idx = _inputs.QF_LAYER
     keys, values = to_dev(s["keys"], s["dtype"]), to_dev(s["values"], s["dtype"])
     kwargs = {"position_embeddings": pe}
     with torch.no_grad():

@@ -22,6 +22,8 @@ def oracle_scores(s, cos=None, sin=None):
         return O.knorm_score(s["keys"])
     if s["kind"] == "keydiff":
         return O.keydiff_score(s["keys"])
+    if s["kind"] == "qfilter":
+        return O.qfilter_score(s["keys"], _inputs.make_qfilters(s)[_inputs.QF_LAYER])
     if s["kind"] == "cur":
         return O.cur_score(s["keys"], s["values"], s["leverage"], s.get("local", True), s.get("window", 16), s.get("sinks", 4))
     if s["kind"] == "streaming":
@@ -55,7 +57,7 @@ def test_oracle_scores_match_reference(name):
     assert sc.shape == ref.shape == (s["B"], s["H"], s["S"])
     # float32 reference vs float64 oracle: both approximate the same math
     # (KeyDiff: a cosine in [-1, 1] that crosses zero -> absolute tolerance)
-    np.testing.assert_allclose(sc, ref, rtol=2e-4, atol=2e-6 if s["kind"] == "keydiff" else 1e-30)
+    np.testing.assert_allclose(sc, ref, rtol=2e-4, atol=2e-6 if s["kind"] in ("keydiff", "qfilter") else 1e-30)
 
 
 @pytest.mark.parametrize("name", ALL)
