@@ -82,7 +82,7 @@ extern "C" int kvp_knorm_compress(const void* k, int64_t k_sb, int64_t k_sh, int
     }
     // -||k||, with the first radix histogram accumulated by the same kernel (vector path) -- knorm_press.py:38
     bool hist1_done = false;
-    uint32_t* hist1 = (n_kept < S) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;
+    uint32_t* hist1 = (n_kept < S && !topk_row_eligible(S)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;  // short rows: one-launch select
     if (int rc = kvp_rownorm_launch(k, dtype, B, H, S, D, k_sb, k_sh, k_ss, -1.0f, w.scores, stream, hist1, &hist1_done)) return rc;
     if (int rc = topk_select_impl(w.scores, R, S, S, n_kept, w.idx, n_kept, 0, 0, w.topk, w.topk_bytes, true, hist1_done, stream)) return rc;
     return kvp_gather_kv(k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, H, S, D, w.idx, n_kept, k_out, v_out, stream_);
@@ -100,9 +100,9 @@ static int snapkv_select_gather(const CompressWs& w, bool fused, const void* k, 
                                 int64_t n_kept, void* k_out, void* v_out, hipStream_t stream) {
     const int64_t R = B * Hkv;
     int rc;
-    if (fused)
+    if (fused)  // short rows carry no fused histogram: the select is one launch of its own (topk_row_eligible)
         rc = topk_select_impl(w.scores, R, S - W, S, n_kept - W, w.idx, n_kept, (uint32_t)(S - W), (uint32_t)W, w.topk, w.topk_bytes, true,
-                              true, stream);
+                              !topk_row_eligible(S - W), stream);
     else
         rc = topk_select_impl(w.scores, R, S, S, n_kept, w.idx, n_kept, 0, 0, w.topk, w.topk_bytes, true, false, stream);
     if (rc) return rc;
@@ -130,9 +130,9 @@ extern "C" int kvp_snapkv_compress_hidden(const void* hidden_win, int64_t x_sb, 
         return KVP_EHIP;
     }
     const bool fused = n_kept >= W;
-    uint32_t* hist1 = fused ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;
+    uint32_t* hist1 = (fused && !topk_row_eligible(S - W)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;
     if (int rc = snapkv_score_hidden_impl(hidden_win, x_sb, x_sw, wq, hidden, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq,
-                                          Hkv, S, W, D, kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1))
+                                          Hkv, S, W, D, kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1, fused))
         return rc;
     return snapkv_select_gather(w, fused, k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, W, D, n_kept, k_out, v_out, stream);
 }
@@ -157,9 +157,9 @@ extern "C" int kvp_snapkv_compress_rope(const void* q, int64_t q_sb, int64_t q_s
         return KVP_EHIP;
     }
     const bool fused = n_kept >= W;
-    uint32_t* hist1 = fused ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;
+    uint32_t* hist1 = (fused && !topk_row_eligible(S - W)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;
     if (int rc = snapkv_score_rope_impl(q, q_sb, q_sh, q_sw, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D,
-                                        kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1))
+                                        kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1, false, fused))
         return rc;
     return snapkv_select_gather(w, fused, k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, W, D, n_kept, k_out, v_out, stream);
 }

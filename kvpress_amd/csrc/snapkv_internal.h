@@ -18,12 +18,13 @@ int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m,
 int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, hipStream_t stream);
 
 // Score entry points with an optional fused first top-k histogram (hist1 [B*Hkv][4096] over the S - W non-pad columns;
-// the pad columns of `scores` are then left unwritten).  Defined in snapkv.hip, used by the fused compress (compress.hip).
+// the pad columns of `scores` are then left unwritten; skip_pad asks for that alone, without a histogram).  Defined in snapkv.hip, used by the fused compress (compress.hip).
 int snapkv_score_rope_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
                            int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
                            int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
-                           float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1, bool count_norm = false);
+                           float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1, bool count_norm = false,
+                           bool skip_pad = false);
 int snapkv_score_hidden_impl(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, int64_t hidden, const void* cosp,
                              const void* sinp, int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
                              int dtype, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
-                             float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1);
+                             float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1, bool skip_pad = false);

@@ -26,6 +26,10 @@
 // nor are direct global atomics for the (sparse) second-pass histogram: 260 k of them take 48 us against 14 us for the
 // workgroup-private LDS histograms + flush;
 // the only inter-workgroup traffic inside a launch is atomicAdd into the row histograms.
+//
+// SHORT rows (S <= 16384: decode-time compression, per-chunk / per-block selection, short prompts) are launch-bound in
+// that scheme (3-4 dependent launches of ~5 us each), so they take ONE launch instead: topk_row_kernel, one 1024-thread
+// workgroup per row, the row's keys in registers, three digit passes (8 + 12 + 12 bits) on an LDS histogram, same tie rule.
 #include "kvp_common.h"
 #include "topk_internal.h"
 
@@ -260,6 +264,184 @@ __global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __r
     }
 }
 
+// ---- one workgroup per row (short rows) ------------------------------------------------------------
+constexpr int TR_THREADS = 1024;
+constexpr int TR_WAVES = TR_THREADS / 64;
+
+// exclusive prefix sum over the 1024 threads of the block; lds: >= TR_WAVES words
+__device__ __forceinline__ uint32_t row_excl_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < TR_WAVES; ++i) {
+        const uint32_t x = lds[i];
+        if (i < w) woff += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + inc - v;
+}
+
+// find_bin for the 1024-thread block: thread 0 owns the highest bins.  lds: >= TR_WAVES + 2 words.
+template <int NB>
+__device__ __forceinline__ void row_find_bin(const uint32_t* hist, uint32_t k, uint32_t* lds, uint32_t& bin, uint32_t& krem) {
+    constexpr int PERB = NB >= TR_THREADS ? NB / TR_THREADS : 1;
+    const bool owner = NB >= TR_THREADS || threadIdx.x < NB;
+    const uint32_t rg = (NB >= TR_THREADS ? TR_THREADS : NB) - 1 - threadIdx.x;
+    uint32_t loc[PERB], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PERB; ++i) {
+        loc[i] = owner ? hist[rg * PERB + i] : 0u;
+        sum += loc[i];
+    }
+    uint32_t total;
+    const uint32_t excl = row_excl_scan(sum, lds, &total);
+    if (owner && excl < k && k <= excl + sum) {
+        uint32_t c = excl;
+#pragma unroll
+        for (int i = PERB - 1; i >= 0; --i) {
+            if (k > c && k <= c + loc[i]) {
+                lds[TR_WAVES] = rg * PERB + i;
+                lds[TR_WAVES + 1] = k - c;
+            }
+            c += loc[i];
+        }
+    }
+    __syncthreads();
+    bin = lds[TR_WAVES];
+    krem = lds[TR_WAVES + 1];
+    __syncthreads();
+}
+
+// thread t owns the PER consecutive positions t * PER ..: S <= 1024 * PER
+template <int PER>
+__global__ __launch_bounds__(TR_THREADS) void topk_row_kernel(const float* __restrict__ scores, int64_t row_stride, uint32_t S, uint32_t k,
+                                                              uint32_t kmask, int32_t* __restrict__ idx, int64_t idx_stride,
+                                                              uint32_t tail_start, uint32_t tail_n, uint32_t nseg, uint32_t seg_len,
+                                                              uint32_t pos_base) {
+    __shared__ uint32_t lh[TR_THREADS * PER > 4096 ? TR_THREADS * PER : 4096];  // histogram, then the staged output
+    __shared__ uint32_t scr[TR_WAVES + 2];
+    const uint32_t row = blockIdx.x;
+    const float* rp = scores + (int64_t)row * row_stride;
+    const uint32_t p0 = threadIdx.x * PER;
+    uint32_t keys[PER];
+    if (PER % 4 == 0 && p0 + PER <= S && ((((uintptr_t)(rp + p0)) & 15u) == 0)) {
+#pragma unroll
+        for (int q = 0; q < PER / 4; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(rp + p0 + 4 * q);
+            keys[4 * q + 0] = float_to_key(a.x) ^ kmask; keys[4 * q + 1] = float_to_key(a.y) ^ kmask;
+            keys[4 * q + 2] = float_to_key(a.z) ^ kmask; keys[4 * q + 3] = float_to_key(a.w) ^ kmask;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) keys[j] = (p0 + j < S) ? (float_to_key(rp[p0 + j]) ^ kmask) : 0u;
+    }
+    // Digits of 8 + 12 + 12 bits on an LDS histogram.  The kernel is bound by instruction issue (16 waves on 4 SIMDs), so
+    // a thread whose PER keys all fall into ONE bin adds them with a single weighted atomic: the first digit (sign + 7
+    // exponent bits) is then one wave-aggregated add per wave for typical scores, and rows of equal scores never
+    // serialise on one LDS address.  Everything else takes one plain LDS atomic per key.
+    const bool full = p0 + PER <= S;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        if (p0 + j < S) {
+            kmin = min(kmin, keys[j]);
+            kmax = max(kmax, keys[j]);
+        }
+    }
+    if (threadIdx.x < 256) lh[threadIdx.x] = 0;
+    __syncthreads();
+    {
+        const bool one = full && (kmin >> 24) == (kmax >> 24);
+        // (inline weighted form of topk_hist_add_bin<1>: the leader adds PER per matching lane)
+        const uint64_t todo = __ballot(one);
+        bool left = one;
+        if (todo) {
+            const int leader = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)(kmin >> 24), leader);
+            const uint64_t same = __ballot(one && (kmin >> 24) == b0);
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lh[b0], (uint32_t)__popcll(same) * PER);
+            left = one && (kmin >> 24) != b0;
+        }
+        if (left) atomicAdd(&lh[kmin >> 24], (uint32_t)PER);
+        if (!one) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if (p0 + j < S) atomicAdd(&lh[keys[j] >> 24], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t b1, k1;
+    row_find_bin<256>(lh, k, scr, b1, k1);
+    for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
+    __syncthreads();
+    if (full && (kmin >> 12) == (kmax >> 12)) {
+        if ((kmin >> 24) == b1) atomicAdd(&lh[(kmin >> 12) & 0xFFFu], (uint32_t)PER);
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (p0 + j < S && (keys[j] >> 24) == b1) atomicAdd(&lh[(keys[j] >> 12) & 0xFFFu], 1u);
+    }
+    __syncthreads();
+    uint32_t b2, k2;
+    row_find_bin<4096>(lh, k1, scr, b2, k2);
+    const uint32_t prefix = (b1 << 12) | b2;
+    for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
+    __syncthreads();
+    if (full && kmin == kmax) {
+        if ((kmin >> 12) == prefix) atomicAdd(&lh[kmin & 0xFFFu], (uint32_t)PER);
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (p0 + j < S && (keys[j] >> 12) == prefix) atomicAdd(&lh[keys[j] & 0xFFFu], 1u);
+    }
+    __syncthreads();
+    uint32_t b3, quota;
+    row_find_bin<4096>(lh, k2, scr, b3, quota);
+    const uint32_t T = (prefix << 12) | b3;
+
+    // ordered compaction: keys > T, and the first `quota` keys == T
+    uint32_t cg = 0, ce = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const bool valid = p0 + j < S;
+        cg += (valid && keys[j] > T) ? 1u : 0u;
+        ce += (valid && keys[j] == T) ? 1u : 0u;
+    }
+    uint32_t tot;
+    const uint32_t ex = row_excl_scan(cg | (ce << 16), scr, &tot);  // S <= 32768: both fields < 65536
+    uint32_t g = ex & 0xFFFFu, e = ex >> 16;
+    int32_t* out = idx + (int64_t)row * idx_stride;
+    const uint32_t off = pos_base + (nseg > 1 ? (row % nseg) * seg_len : 0u);
+    for (uint32_t j = threadIdx.x; j < tail_n; j += TR_THREADS) out[k + j] = (int32_t)(off + tail_start + j);
+    // the kept positions are ranked into LDS (the histogram is dead) and leave as one coalesced stream: a thread's own
+    // ranks are consecutive, so direct global stores would be 4-byte writes ~PER/2 words apart across the wave
+    int32_t* ob = reinterpret_cast<int32_t*>(lh);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const bool valid = p0 + j < S;
+        const bool isg = valid && keys[j] > T;
+        const bool ise = valid && keys[j] == T;
+        if (isg || (ise && e < quota)) {
+            const uint32_t rank = g + (e < quota ? e : quota);
+            if (rank < k) ob[rank] = (int32_t)(off + p0 + j);
+        }
+        g += isg ? 1u : 0u;
+        e += ise ? 1u : 0u;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < k; i += TR_THREADS) out[i] = ob[i];
+}
+
 // k == S: every position is kept (compression_ratio so small that int(S*(1-r)) == S)
 // (also the k == 0 case of a call with a tail: only the tail columns are written)
 __global__ void topk_iota_kernel(int32_t* __restrict__ idx, int64_t idx_stride, uint32_t k, uint32_t tail_start, uint32_t tail_n,
@@ -289,6 +471,12 @@ extern "C" size_t kvp_topk_workspace_bytes(int64_t R, int64_t S, int64_t k) {
     return topk_carve_ws(nullptr, R, nchunks).total_bytes;
 }
 
+// rows this short are selected by one workgroup each (topk_row_kernel); the scorers then skip their fused histogram
+bool topk_row_eligible(int64_t S) {
+    static const int64_t row_max = std::min<int64_t>(32768, kvp_env_int("KVP_TK_ROW_MAX", 16384));
+    return S >= 1 && S <= row_max;
+}
+
 int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, int64_t idx_stride,
                      uint32_t tail_start, uint32_t tail_n, void* ws, size_t ws_bytes, bool ws_clean, bool hist1_ready,
                      hipStream_t stream, uint32_t nseg, uint32_t seg_len, uint32_t pos_base, bool smallest) {
@@ -308,6 +496,21 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
         const uint32_t bx = (uint32_t)std::max<int64_t>(1, std::min<int64_t>((k + tail_n + 255) / 256, 256));
         KVP_LAUNCH("topk_iota_kernel", stream, topk_iota_kernel<<<dim3(bx, (uint32_t)R), 256, 0, stream>>>(idx, idx_stride, (uint32_t)k, tail_start, tail_n, nseg, seg_len, pos_base));
         KVP_CHECK_LAUNCH("topk(iota)");
+        return KVP_OK;
+    }
+    if (!hist1_ready && topk_row_eligible(S)) {  // short rows: one launch, no workspace
+        const uint32_t km = w.kmask;
+#define KVP_TR_CASE(P)                                                                                                                   \
+    KVP_LAUNCH("topk_row_kernel", stream, topk_row_kernel<P><<<(uint32_t)R, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, km, idx, \
+                                                                                                      idx_stride, tail_start, tail_n, nseg, seg_len, pos_base))
+        if (S <= 1024) KVP_TR_CASE(1);
+        else if (S <= 2048) KVP_TR_CASE(2);
+        else if (S <= 4096) KVP_TR_CASE(4);
+        else if (S <= 8192) KVP_TR_CASE(8);
+        else if (S <= 16384) KVP_TR_CASE(16);
+        else KVP_TR_CASE(32);
+#undef KVP_TR_CASE
+        KVP_CHECK_LAUNCH("topk(row)");
         return KVP_OK;
     }
     if (!ws || ws_bytes < w.total_bytes) {

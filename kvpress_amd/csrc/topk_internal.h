@@ -49,13 +49,14 @@ inline TopkWs topk_carve_ws(void* ws, int64_t R, int64_t nchunks) {
 // together (`valid` = this lane has a score).  Scores of one layer crowd into a handful of the 4096 (sign, exponent,
 // 3 mantissa bits) bins, so plain LDS atomics serialise; two rounds of wave-level aggregation take the two most
 // common bins out first.
+template <int ROUNDS = 2>
 __device__ __forceinline__ void topk_hist_add_bin(uint32_t* lds_hist, uint32_t bin, bool valid) {
 #pragma unroll
-    for (int round = 0; round < 2; ++round) {
+    for (int round = 0; round < ROUNDS; ++round) {
         const uint64_t todo = __ballot(valid);
         if (todo == 0) return;
         const int leader = __ffsll((unsigned long long)todo) - 1;
-        const uint32_t b0 = __shfl(bin, leader);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);  // leader is wave-uniform: no LDS round trip (ds_bpermute)
         const uint64_t same = __ballot(valid && bin == b0);
         if ((int)(threadIdx.x & 63) == leader) atomicAdd(&lds_hist[b0], (uint32_t)__popcll(same));
         valid = valid && bin != b0;
@@ -79,4 +80,6 @@ __device__ __forceinline__ void topk_hist1_flush(const uint32_t* lds_hist, uint3
 int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, int64_t idx_stride,
                      uint32_t tail_start, uint32_t tail_n, void* ws, size_t ws_bytes, bool ws_clean, bool hist1_ready,
                      hipStream_t stream, uint32_t nseg = 1, uint32_t seg_len = 0, uint32_t pos_base = 0, bool smallest = false);
+// S this short: one launch, one workgroup per row, no workspace and no use for a fused first histogram
+bool topk_row_eligible(int64_t S);
 // nseg > 1: rows are (outer row, segment) pairs and every reported position gets (row % nseg) * seg_len + pos_base added

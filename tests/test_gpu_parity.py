@@ -146,6 +146,34 @@ def test_topk_heavy_ties_and_edges():
     assert np.array_equal(got, O.topk_select(base[:, 100:20100], 777))
 
 
+@pytest.mark.parametrize("S", [1, 2, 63, 1023, 1024, 1025, 2048, 2049, 4096, 4097, 8191, 8193, 16383, 16384, 16385, 20000])
+def test_topk_short_rows_one_workgroup(S):
+    """Rows up to 16384 are selected by ONE workgroup per row (topk_row_kernel, every elements-per-thread variant, aligned
+    and unaligned rows); longer ones by the multi-workgroup passes: same indices either way, bit-exact against the oracle."""
+    rs = np.random.RandomState(S)
+    N = native()
+    R = 5
+    wide = rs.standard_normal((R, S + 3)).astype(np.float32)
+    flat = _inputs.round_to(-np.sqrt(rs.chisquare(64, size=(R, S + 3))).astype(np.float32), "bf16")   # heavy ties, one exponent
+    for sc_np in (wide, flat):
+        t = torch.from_numpy(sc_np).to(DEV)
+        for off in (0, 1, 3):                                  # row start alignment (float4 fast path or not)
+            view, ref = t[:, off:off + S], sc_np[:, off:off + S]
+            for k in sorted({1, max(1, S // 7), max(1, S // 2), max(1, S - 1), S}):
+                got = N.topk_select(view, k).cpu().numpy()
+                assert np.array_equal(got, O.topk_select(ref, k)), f"S={S} off={off} k={k}"
+            k = max(1, S // 3)
+            got = N.topk_select(view, k, N.ORDER_POSITION | N.TOPK_SMALLEST).cpu().numpy()
+            assert np.array_equal(got, O.topk_select(-ref, k)), f"S={S} off={off} smallest"
+    if S >= 4:   # segments as rows: positions are reported relative to the outer row (+ pos_base)
+        seg = S // 4
+        sc_np = np.ascontiguousarray(wide[:, : 4 * seg])
+        k = max(1, seg // 2)
+        got = N.topk_select_segmented(torch.from_numpy(sc_np).to(DEV), seg, k, pos_base=11).cpu().numpy()
+        want = np.concatenate([11 + c * seg + O.topk_select(sc_np[:, c * seg:(c + 1) * seg], k) for c in range(4)], axis=-1)
+        assert np.array_equal(got, want), f"S={S} segmented"
+
+
 @pytest.mark.parametrize("name", ["kn_tiny_d6", "kn_bf16_A", "kn_f16_ragged", "kn_d96_bf16", "kn_opt_geom"])
 def test_gather_bitexact(name):
     s = _inputs.make_case(name)
