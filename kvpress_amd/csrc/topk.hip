@@ -333,17 +333,22 @@ __global__ __launch_bounds__(TR_THREADS) void topk_row_kernel(const float* __res
     const uint32_t row = blockIdx.x;
     const float* rp = scores + (int64_t)row * row_stride;
     const uint32_t p0 = threadIdx.x * PER;
+    // positions past S carry key 0 and real keys are >= 1 (the lowest two NaN encodings share key 1): the padding sits at
+    // the bottom of every histogram, where a select of k <= S never reaches, so T >= 1 and no range checks are needed below
     uint32_t keys[PER];
     if (PER % 4 == 0 && p0 + PER <= S && ((((uintptr_t)(rp + p0)) & 15u) == 0)) {
 #pragma unroll
         for (int q = 0; q < PER / 4; ++q) {
             const float4 a = *reinterpret_cast<const float4*>(rp + p0 + 4 * q);
-            keys[4 * q + 0] = float_to_key(a.x) ^ kmask; keys[4 * q + 1] = float_to_key(a.y) ^ kmask;
-            keys[4 * q + 2] = float_to_key(a.z) ^ kmask; keys[4 * q + 3] = float_to_key(a.w) ^ kmask;
+            keys[4 * q + 0] = max(float_to_key(a.x) ^ kmask, 1u); keys[4 * q + 1] = max(float_to_key(a.y) ^ kmask, 1u);
+            keys[4 * q + 2] = max(float_to_key(a.z) ^ kmask, 1u); keys[4 * q + 3] = max(float_to_key(a.w) ^ kmask, 1u);
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < PER; ++j) keys[j] = (p0 + j < S) ? (float_to_key(rp[p0 + j]) ^ kmask) : 0u;
+        for (int j = 0; j < PER; ++j) {  // clamped address + arithmetic mask: no per-element lane masks held in SGPRs
+            const uint32_t inside = (uint32_t)((int32_t)(p0 + j - S) >> 31);  // all ones iff p0 + j < S  (S < 2^31)
+            keys[j] = max(float_to_key(rp[min(p0 + j, S - 1)]) ^ kmask, 1u) & inside;
+        }
     }
     // Digits of 8 + 12 + 12 bits on an LDS histogram.  The kernel is bound by instruction issue (16 waves on 4 SIMDs), so
     // a thread whose PER keys all fall into ONE bin adds them with a single weighted atomic: the first digit (sign + 7
@@ -353,10 +358,8 @@ __global__ __launch_bounds__(TR_THREADS) void topk_row_kernel(const float* __res
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        if (p0 + j < S) {
-            kmin = min(kmin, keys[j]);
-            kmax = max(kmax, keys[j]);
-        }
+        kmin = min(kmin, keys[j]);
+        kmax = max(kmax, keys[j]);
     }
     if (threadIdx.x < 256) lh[threadIdx.x] = 0;
     __syncthreads();
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_row_kernel(const float* __res
         if (!one) {
 #pragma unroll
             for (int j = 0; j < PER; ++j)
-                if (p0 + j < S) atomicAdd(&lh[keys[j] >> 24], 1u);
+                atomicAdd(&lh[keys[j] >> 24], 1u);
         }
     }
     __syncthreads();
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_row_kernel(const float* __res
     } else {
 #pragma unroll
         for (int j = 0; j < PER; ++j)
-            if (p0 + j < S && (keys[j] >> 24) == b1) atomicAdd(&lh[(keys[j] >> 12) & 0xFFFu], 1u);
+            if ((keys[j] >> 24) == b1) atomicAdd(&lh[(keys[j] >> 12) & 0xFFFu], 1u);
     }
     __syncthreads();
     uint32_t b2, k2;
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_row_kernel(const float* __res
     } else {
 #pragma unroll
         for (int j = 0; j < PER; ++j)
-            if (p0 + j < S && (keys[j] >> 12) == prefix) atomicAdd(&lh[keys[j] & 0xFFFu], 1u);
+            if ((keys[j] >> 12) == prefix) atomicAdd(&lh[keys[j] & 0xFFFu], 1u);
     }
     __syncthreads();
     uint32_t b3, quota;
@@ -413,12 +416,11 @@ __global__ __launch_bounds__(TR_THREADS) void topk_row_kernel(const float* __res
     uint32_t cg = 0, ce = 0;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        const bool valid = p0 + j < S;
-        cg += (valid && keys[j] > T) ? 1u : 0u;
-        ce += (valid && keys[j] == T) ? 1u : 0u;
+        cg += keys[j] > T ? 1u : 0u;
+        ce += keys[j] == T ? 1u : 0u;
     }
     uint32_t tot;
-    const uint32_t ex = row_excl_scan(cg | (ce << 16), scr, &tot);  // S <= 32768: both fields < 65536
+    const uint32_t ex = row_excl_scan(cg | (ce << 16), scr, &tot);  // S <= 16384: both fields < 65536
     uint32_t g = ex & 0xFFFFu, e = ex >> 16;
     int32_t* out = idx + (int64_t)row * idx_stride;
     const uint32_t off = pos_base + (nseg > 1 ? (row % nseg) * seg_len : 0u);
@@ -426,11 +428,13 @@ __global__ __launch_bounds__(TR_THREADS) void topk_row_kernel(const float* __res
     // the kept positions are ranked into LDS (the histogram is dead) and leave as one coalesced stream: a thread's own
     // ranks are consecutive, so direct global stores would be 4-byte writes ~PER/2 words apart across the wave
     int32_t* ob = reinterpret_cast<int32_t*>(lh);
+    // (the threshold through an SGPR: otherwise the 2 x PER lane masks of the counting loop above are kept alive across
+    // the scan for reuse here, which spills SGPRs)
+    const uint32_t Ts = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-        const bool valid = p0 + j < S;
-        const bool isg = valid && keys[j] > T;
-        const bool ise = valid && keys[j] == T;
+        const bool isg = keys[j] > Ts;
+        const bool ise = keys[j] == Ts;
         if (isg || (ise && e < quota)) {
             const uint32_t rank = g + (e < quota ? e : quota);
             if (rank < k) ob[rank] = (int32_t)(off + p0 + j);
@@ -473,7 +477,7 @@ extern "C" size_t kvp_topk_workspace_bytes(int64_t R, int64_t S, int64_t k) {
 
 // rows this short are selected by one workgroup each (topk_row_kernel); the scorers then skip their fused histogram
 bool topk_row_eligible(int64_t S) {
-    static const int64_t row_max = std::min<int64_t>(32768, kvp_env_int("KVP_TK_ROW_MAX", 16384));
+    static const int64_t row_max = std::min<int64_t>(16384, kvp_env_int("KVP_TK_ROW_MAX", 16384));  // 1024 threads x 16 keys
     return S >= 1 && S <= row_max;
 }
 
@@ -507,8 +511,7 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
         else if (S <= 2048) KVP_TR_CASE(2);
         else if (S <= 4096) KVP_TR_CASE(4);
         else if (S <= 8192) KVP_TR_CASE(8);
-        else if (S <= 16384) KVP_TR_CASE(16);
-        else KVP_TR_CASE(32);
+        else KVP_TR_CASE(16);
 #undef KVP_TR_CASE
         KVP_CHECK_LAUNCH("topk(row)");
         return KVP_OK;
