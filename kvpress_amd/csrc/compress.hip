@@ -95,12 +95,14 @@ extern "C" size_t kvp_snapkv_compress_workspace_bytes(int64_t B, int64_t Hq, int
 }
 
 // select + gather after a SnapKV scorer has run (fused: hist1 holds the first pass over the S - W non-window columns)
-static int snapkv_select_gather(const CompressWs& w, bool fused, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, const void* v,
+static int snapkv_select_gather(const CompressWs& w, bool fused, const float* colsum, float inv, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, const void* v,
                                 int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype, int64_t B, int64_t Hkv, int64_t S, int64_t W, int64_t D,
                                 int64_t n_kept, void* k_out, void* v_out, hipStream_t stream) {
     const int64_t R = B * Hkv;
     int rc;
-    if (fused)  // short rows carry no fused histogram: the select is one launch of its own (topk_row_eligible)
+    if (fused && colsum)  // short rows, kernel_size 5: pooling happens inside the select's loader
+        rc = topk_select_pooled_rows(colsum, R, S - W, inv, n_kept - W, w.idx, n_kept, (uint32_t)(S - W), (uint32_t)W, stream);
+    else if (fused)  // short rows carry no fused histogram: the select is one launch of its own (topk_row_eligible)
         rc = topk_select_impl(w.scores, R, S - W, S, n_kept - W, w.idx, n_kept, (uint32_t)(S - W), (uint32_t)W, w.topk, w.topk_bytes, true,
                               !topk_row_eligible(S - W), stream);
     else
@@ -131,10 +133,12 @@ extern "C" int kvp_snapkv_compress_hidden(const void* hidden_win, int64_t x_sb, 
     }
     const bool fused = n_kept >= W;
     uint32_t* hist1 = (fused && !topk_row_eligible(S - W)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;
+    const bool pooled = fused && topk_pooled_rows_eligible(S - W, kernel_size);  // short rows: pool + select in one launch
     if (int rc = snapkv_score_hidden_impl(hidden_win, x_sb, x_sw, wq, hidden, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq,
-                                          Hkv, S, W, D, kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1, fused))
+                                          Hkv, S, W, D, kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1,
+                                          pooled ? SNAP_FINISH_COLSUM : fused ? SNAP_FINISH_NO_PAD : SNAP_FINISH_FULL))
         return rc;
-    return snapkv_select_gather(w, fused, k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, W, D, n_kept, k_out, v_out, stream);
+    return snapkv_select_gather(w, fused, pooled ? snapkv_ws_colsum(w.scorer, B, Hq, Hkv, S, W, D) : nullptr, snapkv_pool_scale(Hq, Hkv, W, kernel_size), k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, W, D, n_kept, k_out, v_out, stream);
 }
 
 extern "C" int kvp_snapkv_compress_rope(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
@@ -158,8 +162,10 @@ extern "C" int kvp_snapkv_compress_rope(const void* q, int64_t q_sb, int64_t q_s
     }
     const bool fused = n_kept >= W;
     uint32_t* hist1 = (fused && !topk_row_eligible(S - W)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;
+    const bool pooled = fused && topk_pooled_rows_eligible(S - W, kernel_size);  // short rows: pool + select in one launch
     if (int rc = snapkv_score_rope_impl(q, q_sb, q_sh, q_sw, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D,
-                                        kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1, false, fused))
+                                        kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1, false,
+                                        pooled ? SNAP_FINISH_COLSUM : fused ? SNAP_FINISH_NO_PAD : SNAP_FINISH_FULL))
         return rc;
-    return snapkv_select_gather(w, fused, k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, W, D, n_kept, k_out, v_out, stream);
+    return snapkv_select_gather(w, fused, pooled ? snapkv_ws_colsum(w.scorer, B, Hq, Hkv, S, W, D) : nullptr, snapkv_pool_scale(Hq, Hkv, W, kernel_size), k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, W, D, n_kept, k_out, v_out, stream);
 }

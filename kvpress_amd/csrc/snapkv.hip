@@ -256,14 +256,18 @@ SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, in
 }
 
 // hist1 != nullptr (fused compress): scores[.., :S-W] are written and histogrammed, the pad columns are NOT filled
-// skip_pad without hist1: the same, for a select that needs no histogram (short rows, topk_row_kernel)
+// finish = SNAP_FINISH_NO_PAD without hist1: the same, for a select that needs no histogram (short rows, topk_row_kernel);
+// SNAP_FINISH_COLSUM: nothing is launched, the caller selects straight from w.colsum (topk_select_pooled_rows)
 int finish_scores(const SnapWs& w, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int kernel_size,
-                  float* scores, hipStream_t stream, uint32_t* hist1 = nullptr, bool skip_pad = false) {
+                  float* scores, hipStream_t stream, uint32_t* hist1 = nullptr, int finish = SNAP_FINISH_FULL) {
+    if (finish == SNAP_FINISH_COLSUM) return KVP_OK;
+    const bool skip_pad = finish != SNAP_FINISH_FULL;
     const uint32_t BH = (uint32_t)(B * Hkv);
     const uint64_t per_row = ((uint64_t)(S - W) + SK_THREADS - 1) / SK_THREADS;
     const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per_row, std::max<uint64_t>(1, 2048 / BH)));
     const int64_t G = Hq / Hkv;
-    const float inv = (float)(1.0 / ((double)G * (double)W * (double)kernel_size));
+    const float inv = snapkv_pool_scale(Hq, Hkv, W, kernel_size);
+    (void)G;
     if (hist1) {
         KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<true><<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.bmax, hist1));
         KVP_CHECK_LAUNCH("snapkv(pool+hist)");
@@ -295,10 +299,17 @@ extern "C" size_t kvp_snapkv_workspace_bytes(int64_t B, int64_t Hq, int64_t Hkv,
     return carve_snap_ws(nullptr, B, Hq, Hkv, S, W, D).total_bytes;
 }
 
+float* snapkv_ws_colsum(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D) {
+    return carve_snap_ws(ws, B, Hq, Hkv, S, W, D).colsum;
+}
+float snapkv_pool_scale(int64_t Hq, int64_t Hkv, int64_t W, int kernel_size) {
+    return (float)(1.0 / ((double)(Hq / Hkv) * (double)W * (double)kernel_size));
+}
+
 int snapkv_score_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* k, int64_t k_sb,
                       int64_t k_sh, int64_t k_ss, int dtype, int64_t B, int64_t Hq, int64_t Hkv, int64_t S,
                       int64_t W, int64_t D, int kernel_size, float* scores, void* ws, size_t ws_bytes,
-                      hipStream_t stream, uint32_t* hist1, bool count_norm = false, bool skip_pad = false) {
+                      hipStream_t stream, uint32_t* hist1, bool count_norm = false, int finish = SNAP_FINISH_FULL) {
     KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "snapkv: bad dtype %d", dtype);
     if (int rc = check_common(B, Hq, Hkv, S, W, kernel_size)) return rc;
     KVP_CHECK_ARG(D >= 1 && D <= 1024, "snapkv: unsupported head_dim %ld", (long)D);
@@ -342,7 +353,7 @@ int snapkv_score_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, c
 #undef KVP_SK_GENERIC
     }
     KVP_CHECK_LAUNCH("snapkv(p1/p2)");
-    return finish_scores(w, B, Hq, Hkv, S, W, kernel_size, scores, stream, hist1, skip_pad);
+    return finish_scores(w, B, Hq, Hkv, S, W, kernel_size, scores, stream, hist1, finish);
 }
 
 extern "C" int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* k, int64_t k_sb,
@@ -356,7 +367,7 @@ extern "C" int kvp_snapkv_score(const void* q, int64_t q_sb, int64_t q_sh, int64
 int snapkv_score_rope_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
                            int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
                            int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
-                           float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1, bool count_norm, bool skip_pad) {
+                           float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1, bool count_norm, int finish) {
     KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "snapkv: bad dtype %d", dtype);
     if (int rc = check_common(B, Hq, Hkv, S, W, kernel_size)) return rc;
     KVP_CHECK_ARG(D >= 2 && D <= 1024 && D % 2 == 0, "snapkv: RoPE needs an even head_dim (got %ld)", (long)D);
@@ -380,7 +391,7 @@ int snapkv_score_rope_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
 #undef KVP_SK_ROPE
     KVP_CHECK_LAUNCH("snapkv(rope)");
     return snapkv_score_impl(w.qrot, Hq * W * D, W * D, D, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D, kernel_size, scores, ws,
-                             ws_bytes, stream, hist1, count_norm, skip_pad);
+                             ws_bytes, stream, hist1, count_norm, finish);
 }
 
 // window queries from the hidden states (fused q_proj + RoPE, qproj.hip), then as above
@@ -392,7 +403,7 @@ int kvp_qproj_rope_launch(const void* x, int64_t x_sb, int64_t x_sw, const void*
 int snapkv_score_hidden_impl(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, int64_t hidden, const void* cosp,
                              const void* sinp, int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
                              int dtype, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
-                             float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1, bool skip_pad) {
+                             float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1, int finish) {
     KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "snapkv: bad dtype %d", dtype);
     if (int rc = check_common(B, Hq, Hkv, S, W, kernel_size)) return rc;
     KVP_CHECK_ARG(hidden_win && wq && cosp && sinp && k && scores, "snapkv: null pointer");
@@ -407,7 +418,7 @@ int snapkv_score_hidden_impl(const void* hidden_win, int64_t x_sb, int64_t x_sw,
     }
     if (int rc = kvp_qproj_rope_launch(hidden_win, x_sb, x_sw, wq, cosp, sinp, cs_sb, cs_sw, dtype, B, Hq, hidden, w.qrot, stream)) return rc;
     return snapkv_score_impl(w.qrot, Hq * W * D, W * D, D, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D, kernel_size, scores, ws,
-                             ws_bytes, stream, hist1, false, skip_pad);
+                             ws_bytes, stream, hist1, false, finish);
 }
 
 extern "C" int kvp_snapkv_score_hidden(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, int64_t hidden,
@@ -415,7 +426,7 @@ extern "C" int kvp_snapkv_score_hidden(const void* hidden_win, int64_t x_sb, int
                                        int64_t k_sh, int64_t k_ss, int dtype, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W,
                                        int64_t D, int kernel_size, float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
     return snapkv_score_hidden_impl(hidden_win, x_sb, x_sw, wq, hidden, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv,
-                                    S, W, D, kernel_size, scores, ws, ws_bytes, static_cast<hipStream_t>(stream_), nullptr, false);
+                                    S, W, D, kernel_size, scores, ws, ws_bytes, static_cast<hipStream_t>(stream_), nullptr, SNAP_FINISH_FULL);
 }
 
 extern "C" int kvp_snapkv_score_rope(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,

@@ -17,14 +17,20 @@ uint32_t snapkv_mfma_nchunk(const SnapArgs& a);
 int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m, float* part_z, hipStream_t stream);
 int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, hipStream_t stream);
 
+enum { SNAP_FINISH_FULL = 0,    // pool + scale into `scores`, pad columns = max + 1
+       SNAP_FINISH_NO_PAD = 1,  // pool + scale, pad columns left unwritten (fused compress: they are kept by construction)
+       SNAP_FINISH_COLSUM = 2 };  // stop after pass 2: the un-pooled column sums stay in the workspace (snapkv_ws_colsum)
+float* snapkv_ws_colsum(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D);
+float snapkv_pool_scale(int64_t Hq, int64_t Hkv, int64_t W, int kernel_size);  // 1 / (G * W * kernel_size)
+
 // Score entry points with an optional fused first top-k histogram (hist1 [B*Hkv][4096] over the S - W non-pad columns;
-// the pad columns of `scores` are then left unwritten; skip_pad asks for that alone, without a histogram).  Defined in snapkv.hip, used by the fused compress (compress.hip).
+// the pad columns of `scores` are then left unwritten).  finish: what happens after the two attention passes.  Defined in snapkv.hip, used by the fused compress (compress.hip).
 int snapkv_score_rope_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
                            int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
                            int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
                            float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1, bool count_norm = false,
-                           bool skip_pad = false);
+                           int finish = 0);
 int snapkv_score_hidden_impl(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, int64_t hidden, const void* cosp,
                              const void* sinp, int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
                              int dtype, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
-                             float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1, bool skip_pad = false);
+                             float* scores, void* ws, size_t ws_bytes, hipStream_t stream, uint32_t* hist1, int finish = 0);

@@ -322,13 +322,17 @@ __device__ __forceinline__ void row_find_bin(const uint32_t* hist, uint32_t k, u
     __syncthreads();
 }
 
-// thread t owns the PER consecutive positions t * PER ..: S <= 1024 * PER
-template <int PER>
+// thread t owns the PER consecutive positions t * PER ..: S <= 1024 * PER.
+// PAD >= 0 (fused SnapKV compress): `scores` holds the un-pooled column sums and the score of position p is
+// inv * (x[p-PAD] + ... + x[p+PAD]) with zeros outside the row -- snapkv_pool_kernel's arithmetic, term for term -- so the
+// pooling launch and the score round trip through memory disappear.
+template <int PER, int PAD>
 __global__ __launch_bounds__(TR_THREADS) void topk_row_kernel(const float* __restrict__ scores, int64_t row_stride, uint32_t S, uint32_t k,
-                                                              uint32_t kmask, int32_t* __restrict__ idx, int64_t idx_stride,
+                                                              uint32_t kmask, float inv, int32_t* __restrict__ idx, int64_t idx_stride,
                                                               uint32_t tail_start, uint32_t tail_n, uint32_t nseg, uint32_t seg_len,
                                                               uint32_t pos_base) {
-    __shared__ uint32_t lh[TR_THREADS * PER > 4096 ? TR_THREADS * PER : 4096];  // histogram, then the staged output
+    // histogram, then the staged output; with PAD >= 0 first the staged input row (one pad word per 16: conflict-free reads)
+    __shared__ uint32_t lh[TR_THREADS * PER + (PAD >= 0 ? TR_THREADS * PER / 16 + 1 : 0) > 4096 ? TR_THREADS * PER + (PAD >= 0 ? TR_THREADS * PER / 16 + 1 : 0) : 4096];
     __shared__ uint32_t scr[TR_WAVES + 2];
     const uint32_t row = blockIdx.x;
     const float* rp = scores + (int64_t)row * row_stride;
@@ -336,7 +340,36 @@ __global__ __launch_bounds__(TR_THREADS) void topk_row_kernel(const float* __res
     // positions past S carry key 0 and real keys are >= 1 (the lowest two NaN encodings share key 1): the padding sits at
     // the bottom of every histogram, where a select of k <= S never reaches, so T >= 1 and no range checks are needed below
     uint32_t keys[PER];
-    if (PER % 4 == 0 && p0 + PER <= S && ((((uintptr_t)(rp + p0)) & 15u) == 0)) {
+    if (PAD >= 0) {
+        // the row goes through LDS: coalesced global loads, then every thread reads its PER + 2 PAD consecutive inputs
+        // (direct loads would be 4-byte reads PER words apart across the wave, one cache line per lane and instruction)
+        constexpr int NIN = PER + 2 * (PAD > 0 ? PAD : 0);
+        float* st = reinterpret_cast<float*>(lh);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const uint32_t e = i * TR_THREADS + threadIdx.x;
+            if (e < S) st[e + (e >> 4)] = rp[e];
+        }
+        __syncthreads();
+        float in[NIN];
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int32_t pos = (int32_t)p0 + i - PAD;
+            const uint32_t inside = (uint32_t)(((pos - (int32_t)S) >> 31) & ~(pos >> 31));   // all ones iff 0 <= pos < S
+            const uint32_t c = (uint32_t)min(max(pos, 0), (int32_t)S - 1);
+            in[i] = __uint_as_float(__float_as_uint(st[c + (c >> 4)]) & inside);
+        }
+        __syncthreads();  // lh is the histogram from here on
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            float sum = 0.f;
+#pragma unroll
+            for (int d = 0; d <= 2 * (PAD > 0 ? PAD : 0); ++d) sum += in[j + d];
+            sum *= inv;
+            const uint32_t inside = (uint32_t)((int32_t)(p0 + j - S) >> 31);
+            keys[j] = max(float_to_key(sum) ^ kmask, 1u) & inside;
+        }
+    } else if (PER % 4 == 0 && p0 + PER <= S && ((((uintptr_t)(rp + p0)) & 15u) == 0)) {
 #pragma unroll
         for (int q = 0; q < PER / 4; ++q) {
             const float4 a = *reinterpret_cast<const float4*>(rp + p0 + 4 * q);
@@ -505,8 +538,8 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
     if (!hist1_ready && topk_row_eligible(S)) {  // short rows: one launch, no workspace
         const uint32_t km = w.kmask;
 #define KVP_TR_CASE(P)                                                                                                                   \
-    KVP_LAUNCH("topk_row_kernel", stream, topk_row_kernel<P><<<(uint32_t)R, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, km, idx, \
-                                                                                                      idx_stride, tail_start, tail_n, nseg, seg_len, pos_base))
+    KVP_LAUNCH("topk_row_kernel", stream, (topk_row_kernel<P, -1><<<(uint32_t)R, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, km, 1.f, idx, \
+                                                                                                           idx_stride, tail_start, tail_n, nseg, seg_len, pos_base)))
         if (S <= 1024) KVP_TR_CASE(1);
         else if (S <= 2048) KVP_TR_CASE(2);
         else if (S <= 4096) KVP_TR_CASE(4);
@@ -534,6 +567,27 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
     KVP_LAUNCH("topk_hist8_kernel", stream, topk_hist8_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)nchunks, w));
     KVP_LAUNCH("topk_write_kernel", stream, topk_write_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, (uint32_t)nchunks, w, idx, idx_stride, tail_start, tail_n, nseg, seg_len, pos_base));
     KVP_CHECK_LAUNCH("topk");
+    return KVP_OK;
+}
+
+// Fused SnapKV compress, short rows: select straight from the un-pooled column sums colsum[R][Sm] (avg_pool1d of width 5
+// + scale inside the select's loader).  Same indices as pooling first and selecting from the written scores.
+// (measured: saves the 5 us pooling launch up to 4096 columns -- 37.5 -> 36 us per SnapKV compress at 4k, 34 -> 32 us at
+// 1k; beyond that the loader's extra instructions in this issue-bound kernel cost as much as the launch they save)
+bool topk_pooled_rows_eligible(int64_t Sm, int kernel_size) { return kernel_size == 5 && Sm <= 4096 && topk_row_eligible(Sm); }
+int topk_select_pooled_rows(const float* colsum, int64_t R, int64_t Sm, float inv, int64_t k, int32_t* idx, int64_t idx_stride,
+                            uint32_t tail_start, uint32_t tail_n, hipStream_t stream) {
+    if (R == 0 || k + tail_n == 0) return KVP_OK;
+    KVP_CHECK_ARG(colsum && idx && R <= 65535 && k >= 0 && k <= Sm && topk_pooled_rows_eligible(Sm, 5), "topk(pooled): bad arguments");
+    if (k == Sm || k == 0) return topk_select_impl(colsum, R, Sm, Sm, k, idx, idx_stride, tail_start, tail_n, nullptr, 0, true, false, stream);
+#define KVP_TRP_CASE(P)                                                                                                                  \
+    KVP_LAUNCH("topk_row_kernel", stream, (topk_row_kernel<P, 2><<<(uint32_t)R, TR_THREADS, 0, stream>>>(colsum, Sm, (uint32_t)Sm, (uint32_t)k, 0u, inv, idx, \
+                                                                                                          idx_stride, tail_start, tail_n, 1u, 0u, 0u)))
+    if (Sm <= 1024) KVP_TRP_CASE(1);
+    else if (Sm <= 2048) KVP_TRP_CASE(2);
+    else KVP_TRP_CASE(4);
+#undef KVP_TRP_CASE
+    KVP_CHECK_LAUNCH("topk(pooled rows)");
     return KVP_OK;
 }
 

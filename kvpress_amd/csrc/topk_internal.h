@@ -82,4 +82,8 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
                      hipStream_t stream, uint32_t nseg = 1, uint32_t seg_len = 0, uint32_t pos_base = 0, bool smallest = false);
 // S this short: one launch, one workgroup per row, no workspace and no use for a fused first histogram
 bool topk_row_eligible(int64_t S);
+// select from un-pooled SnapKV column sums (kernel_size 5 pooling + scale `inv` inside the loader); rows as above
+bool topk_pooled_rows_eligible(int64_t Sm, int kernel_size);
+int topk_select_pooled_rows(const float* colsum, int64_t R, int64_t Sm, float inv, int64_t k, int32_t* idx, int64_t idx_stride,
+                            uint32_t tail_start, uint32_t tail_n, hipStream_t stream);
 // nseg > 1: rows are (outer row, segment) pairs and every reported position gets (row % nseg) * seg_len + pos_base added

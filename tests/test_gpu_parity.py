@@ -634,6 +634,24 @@ def test_fused_snapkv_compress_equals_modular(name):
         assert torch.equal(ko, wk) and torch.equal(vo, wv), f"{name} n={n}"
 
 
+@pytest.mark.parametrize("S", [70, 1087, 1089, 1500, 2112, 2113, 3000, 4160, 4161, 9000, 16448, 16449])
+def test_fused_snapkv_select_variants_equal_modular(S):
+    """The fused compress picks its select by row length (pool + select in one launch up to 4096 columns, one-launch select
+    up to 16384, multi-workgroup passes with a fused first histogram beyond): always the modular sequence's bytes."""
+    N = native()
+    g = torch.Generator(device=DEV); g.manual_seed(S)
+    k = torch.randn((2, 2, S, 128), generator=g, device=DEV).to(torch.bfloat16)
+    v = torch.randn((2, 2, S, 128), generator=g, device=DEV).to(torch.bfloat16)
+    q = torch.randn((2, 8, 64, 128), generator=g, device=DEV).to(torch.bfloat16)
+    ang = torch.rand((1, 64, 128), generator=g, device=DEV)
+    c, si = torch.cos(ang).to(torch.bfloat16), torch.sin(ang).to(torch.bfloat16)
+    sc = N.snapkv_score_rope(q, c, si, k, 5)
+    for n in sorted({64, 65, S // 2, (3 * S) // 4, S - 1}):
+        ko, vo = N.snapkv_compress_rope(q, c, si, k, v, 5, n)
+        wk, wv = N.gather_kv(k, v, N.topk_select(sc, n))
+        assert torch.equal(ko, wk) and torch.equal(vo, wv), f"S={S} n={n}"
+
+
 def test_fused_compress_without_clean_flag():
     """flags = 0: the library zeroes the histogram region itself, whatever the workspace holds."""
     import ctypes
