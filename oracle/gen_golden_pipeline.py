@@ -65,6 +65,12 @@ def main():
         out[name] = {"answers": res["answers"], "cache_lengths": [int(cache.get_seq_length(i)) for i in range(len(cache))],
                      "window_size": int(press.window_size)}
         print(name, out[name])
+    for name, (family, spec, n_words, questions, max_new) in _inputs.FAMILY_PIPELINE_CASES.items():
+        cache = DynamicCache()
+        res = ref_pipe(_inputs.make_tiny_model(family), _inputs.make_tiny_tokenizer())(
+            _inputs.tiny_context(n_words), questions=questions, press=_inputs.build_press(kvpress, spec), max_new_tokens=max_new, cache=cache)
+        out[name] = {"answers": res["answers"], "cache_lengths": [int(cache.get_seq_length(i)) for i in range(len(cache))]}
+        print(name, out[name])
     with open(os.path.join(REPO, "tests", "golden", "pipeline.json"), "w") as f:
         json.dump(out, f, indent=1)
 

@@ -202,6 +202,54 @@ def make_tiny_llama(seed: int = 0, dtype=None, device="cpu"):
     return model.to(device)
 
 
+def make_tiny_model(family: str, seed: int = 0, dtype=None, device="cpu"):
+    """The same tiny geometry for the other model families the reference lists as supported (base_press.py:27-34):
+    ``qwen3`` (per-head q_norm / k_norm), ``phi3`` (fused qkv_proj), ``mistral``, ``qwen2`` (q_proj with bias)."""
+    import torch
+    import transformers as T
+
+    common = dict(hidden_size=24, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=2, intermediate_size=48,
+                  vocab_size=64, max_position_embeddings=512, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    if family == "llama":
+        return make_tiny_llama(seed, dtype, device)
+    if family == "qwen3":
+        cfg, cls = T.Qwen3Config(head_dim=6, **common), T.Qwen3ForCausalLM
+    elif family == "qwen2":
+        cfg, cls = T.Qwen2Config(**common), T.Qwen2ForCausalLM
+    elif family == "mistral":
+        cfg, cls = T.MistralConfig(head_dim=6, sliding_window=None, **common), T.MistralForCausalLM
+    elif family == "phi3":
+        cfg, cls = T.Phi3Config(**common), T.Phi3ForCausalLM
+    else:
+        raise ValueError(family)
+    cfg._attn_implementation = "sdpa"
+    torch.manual_seed(seed)
+    model = cls(cfg).eval()
+    # random init leaves norm weights at 1 and biases at 0: perturb them so that q_norm / biases actually matter
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if name.endswith(("q_norm.weight", "k_norm.weight")):
+                prm.mul_(1.0 + 0.5 * torch.rand(prm.shape, generator=g))
+            elif name.endswith(("q_proj.bias", "k_proj.bias", "v_proj.bias")):
+                prm.add_(0.3 * torch.randn(prm.shape, generator=g))
+    if dtype is not None:
+        model = model.to(dtype)
+    return model.to(device)
+
+
+# other model families through the pipeline: name -> (family, press spec, context words, questions, max_new_tokens)
+FAMILY_PIPELINE_CASES = {
+    "pipe_qwen3_snapkv": ("qwen3", ("SnapKVPress", dict(compression_ratio=0.5, window_size=16, kernel_size=5)), 150, ["w4 w5"], 8),
+    "pipe_qwen3_ea": ("qwen3", ("ExpectedAttentionPress", dict(compression_ratio=0.4)), 60, ["w9 w10"], 6),
+    "pipe_phi3_snapkv": ("phi3", ("SnapKVPress", dict(compression_ratio=0.5, window_size=16, kernel_size=5)), 130, ["w1 w2"], 8),
+    "pipe_phi3_ea": ("phi3", ("ExpectedAttentionPress", dict(compression_ratio=0.5)), 70, ["w3"], 6),
+    "pipe_mistral_knorm": ("mistral", ("KnormPress", dict(compression_ratio=0.5)), 100, ["w7 w8", "w1"], 6),
+    "pipe_qwen2_tova": ("qwen2", ("TOVAPress", dict(compression_ratio=0.5)), 90, ["w2 w8"], 6),
+    "pipe_qwen2_snapkv": ("qwen2", ("SnapKVPress", dict(compression_ratio=0.3, window_size=8, kernel_size=3)), 90, ["w5"], 6),
+}
+
+
 def make_tiny_tokenizer():
     """Word-level tokenizer built in memory (no download): <unk>=0 <s>=1 </s>=2, then w0..w55; no chat template."""
     from tokenizers import Tokenizer, models, pre_tokenizers

@@ -57,6 +57,25 @@ def test_finch_pipeline_matches_reference_answers_cpu(name, fake_native):
     _run_finch(name)
 
 
+def _run_family(name, device="cpu", dtype=None):
+    from transformers import DynamicCache, pipeline
+
+    import kvpress_amd
+
+    family, spec, n_words, questions, max_new = _inputs.FAMILY_PIPELINE_CASES[name]
+    pipe = pipeline("kv-press-text-generation", model=_inputs.make_tiny_model(family, dtype=dtype, device=device), tokenizer=_inputs.make_tiny_tokenizer())
+    cache = DynamicCache()
+    res = pipe(_inputs.tiny_context(n_words), questions=questions, press=_inputs.build_press(kvpress_amd, spec), max_new_tokens=max_new, cache=cache)
+    assert [int(cache.get_seq_length(i)) for i in range(len(cache))] == GOLD[name]["cache_lengths"]
+    assert res["answers"] == GOLD[name]["answers"]
+
+
+@pytest.mark.parametrize("name", list(_inputs.FAMILY_PIPELINE_CASES))
+def test_model_families_match_reference_answers_cpu(name, fake_native):
+    """Qwen3 (q_norm), Phi3 (fused qkv_proj), Mistral, Qwen2 (projection biases): the supported families of base_press.py:27-34."""
+    _run_family(name)
+
+
 def test_single_question_and_registry(fake_native):
     from transformers import pipeline
 
@@ -137,3 +156,9 @@ def test_pipeline_matches_reference_answers_gpu(name):
 @pytest.mark.parametrize("name", list(_inputs.FINCH_PIPELINE_CASES))
 def test_finch_pipeline_matches_reference_answers_gpu(name):
     _run_finch(name, device="cuda:0", dtype=torch.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(_inputs.FAMILY_PIPELINE_CASES))
+def test_model_families_match_reference_answers_gpu(name):
+    _run_family(name, device="cuda:0", dtype=torch.float32)
