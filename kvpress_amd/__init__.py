@@ -4,7 +4,7 @@ Public API mirrors the reference for this path (same class names, dataclass fiel
 method signatures): BasePress, ScorerPress, KnormPress, SnapKVPress, ExpectedAttentionPress, the scorers that reuse
 the path's kernels (PyramidKVPress, TOVAPress, KeyDiffPress, StreamingLLMPress, RandomPress), the selection wrappers
 ChunkPress and KeyRerotationPress, and the
-"kv-press-text-generation" pipeline (kvpress_amd.pipeline, imported on first use).
+"kv-press-text-generation" pipeline (registered on import, like the reference).
 Everything below ``ScorerPress.compress`` runs in hand-written HIP kernels (gfx950) reached
 through the C ABI of include/kvpress_hip.h; there is no CPU or pure-PyTorch fallback.
 """
@@ -35,10 +35,5 @@ __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAtt
            "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
 
 
-def __getattr__(name):
-    # the pipeline pulls in transformers.pipelines (slow import): load it on first use
-    if name == "KVPressTextGenerationPipeline":
-        from kvpress_amd.pipeline import KVPressTextGenerationPipeline
-
-        return KVPressTextGenerationPipeline
-    raise AttributeError(f"module 'kvpress_amd' has no attribute {name!r}")
+# importing the package registers the "kv-press-text-generation" task, as `import kvpress` does (kvpress/__init__.py, pipeline.py:326-331)
+from kvpress_amd.pipeline import KVPressTextGenerationPipeline  # noqa: E402

@@ -233,6 +233,18 @@ def snapkv_score(q_win: torch.Tensor, keys: torch.Tensor, kernel_size: int) -> t
     return scores
 
 
+def _window_tables(cos: torch.Tensor, sin: torch.Tensor, B: int, W: int, D: int):
+    """The window's rotary tables as the library takes them: [1 or B, W, D] with equal strides.  A table with ONE row is
+    broadcast over the window (stride 0), which is what the reference's ``cos[:, -W:].unsqueeze(1)`` does when a decoding
+    step hands over the current position only (DecodingPress with a window scorer)."""
+    assert cos.shape == sin.shape and cos.shape[-1] == D and cos.shape[0] in (1, B) and cos.shape[-2] in (1, W), (cos.shape, (B, W, D))
+    if sin.stride() != cos.stride():
+        sin, cos = sin.contiguous(), cos.contiguous()
+    if cos.shape[-2] == 1 and W > 1:
+        cos, sin = cos.expand(-1, W, -1), sin.expand(-1, W, -1)
+    return cos, sin
+
+
 def finch_score(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, keys: torch.Tensor, normalize_scores: bool) -> torch.Tensor:
     """FINCH scores (finch_press.py:56-83) from the PRE-RoPE window queries [B,Hq,W,D] (any W) and the window's cos/sin."""
     return snapkv_score_rope(q_pre, cos, sin, keys, 1, _finch_normalize=bool(normalize_scores))
@@ -252,11 +264,7 @@ def snapkv_score_rope(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
     B, Hq, W, D = q_pre.shape
     Bk, Hkv, S, Dk = keys.shape
     assert B == Bk and D == Dk and Hq % Hkv == 0, (q_pre.shape, keys.shape)
-    assert cos.shape == sin.shape and cos.shape[-2:] == (W, D) and cos.shape[0] in (1, B), (cos.shape, q_pre.shape)
-    assert cos.stride() == sin.stride() or cos.shape[0] == 1
-    if sin.stride() != cos.stride():
-        sin = sin.contiguous()
-        cos = cos.contiguous()
+    cos, sin = _window_tables(cos, sin, B, W, D)
     scores = torch.empty((B, Hkv, S), dtype=torch.float32, device=keys.device)
     with torch.cuda.device(keys.device):
         nws = lib().kvp_snapkv_workspace_bytes(B, Hq, Hkv, S, W, D)
@@ -561,9 +569,7 @@ def snapkv_compress_rope(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tens
     B, Hq, W, D = q_pre.shape
     Bk, Hkv, S, Dk = keys.shape
     assert B == Bk and D == Dk and Hq % Hkv == 0, (q_pre.shape, keys.shape)
-    assert cos.shape == sin.shape and cos.shape[-2:] == (W, D) and cos.shape[0] in (1, B), (cos.shape, q_pre.shape)
-    if sin.stride() != cos.stride():
-        sin, cos = sin.contiguous(), cos.contiguous()
+    cos, sin = _window_tables(cos, sin, B, W, D)
     n = int(n_kept)
     ko = torch.empty((B, Hkv, n, D), dtype=dt, device=keys.device)
     vo = torch.empty_like(ko)

@@ -42,6 +42,14 @@ class ExpectedAttentionPress(ScorerPress):
         q_len = hidden_states.shape[1]
         h = hidden_states[:, self.n_sink:]
         query_states = get_prerope_query_states(module, h)
+        if query_states.shape[2] == 0:
+            # no query beyond the sinks (a DecodingPress buffer of <= n_sink hidden states): the reference's mean and
+            # covariance of an empty set are NaN (:74-80) and it carries on; so do we (the scores become NaN and the
+            # selection falls back to the tie rule) instead of failing in the statistics kernel
+            B, Hq, _, D = query_states.shape
+            mu = torch.full((B, Hq, D), float("nan"), dtype=torch.float32, device=query_states.device)
+            cov = torch.full((B, Hq, D, D), float("nan"), dtype=torch.float32, device=query_states.device) if self.use_covariance else None
+            return self.apply_avg_rope(module, mu, cov, q_len)
         mu, cov = _native.ea_qstats(query_states, self.use_covariance)
         return self.apply_avg_rope(module, mu, cov, q_len)
 

@@ -652,6 +652,22 @@ def test_fused_snapkv_select_variants_equal_modular(S):
         assert torch.equal(ko, wk) and torch.equal(vo, wv), f"S={S} n={n}"
 
 
+def test_snapkv_single_row_rotary_table_broadcasts():
+    """A decoding step hands over the rotary table of the current position only; the reference's ``cos[:, -W:]`` then
+    broadcasts that row over the whole window.  Same here (stride 0), identical to an explicitly repeated table."""
+    N = native()
+    g = torch.Generator(device=DEV); g.manual_seed(5)
+    k = torch.randn((1, 2, 300, 128), generator=g, device=DEV).to(torch.bfloat16)
+    v = torch.randn((1, 2, 300, 128), generator=g, device=DEV).to(torch.bfloat16)
+    q = torch.randn((1, 8, 64, 128), generator=g, device=DEV).to(torch.bfloat16)
+    ang = torch.rand((1, 1, 128), generator=g, device=DEV)
+    c1, s1 = torch.cos(ang).to(torch.bfloat16), torch.sin(ang).to(torch.bfloat16)
+    cw, sw = c1.repeat(1, 64, 1), s1.repeat(1, 64, 1)
+    assert torch.equal(N.snapkv_score_rope(q, c1, s1, k, 5), N.snapkv_score_rope(q, cw, sw, k, 5))
+    a, b = N.snapkv_compress_rope(q, c1, s1, k, v, 5, 150), N.snapkv_compress_rope(q, cw, sw, k, v, 5, 150)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_fused_compress_without_clean_flag():
     """flags = 0: the library zeroes the histogram region itself, whatever the workspace holds."""
     import ctypes
