@@ -66,6 +66,13 @@ int kvp_rowdot_score(const void* x, int dtype, int64_t B, int64_t H, int64_t S, 
                      int64_t sb, int64_t sh, int64_t ss, const void* filt, int64_t f_sh, float scale, float* out,
                      kvp_stream_t stream);
 
+/* ---- ObservedAttentionPress.score (kvpress/presses/observed_attention_press.py:42-48) --------------------------------
+ * attn: the attention weights the (eager) attention layer returned, [B,Hq,Sq,S] (element strides a_sb, a_sh, a_sq; last
+ * dim contiguous).  scores[b,h,s] = mean over the kv-head's G q-heads of sum_q attn[b,hq,q,s] / (S - s): the average
+ * weight key s receives from the queries that can see it.  scores contiguous [B,Hkv,S] float32. */
+int kvp_observed_attention_score(const void* attn, int64_t a_sb, int64_t a_sh, int64_t a_sq, int dtype,
+                                 int64_t B, int64_t Hq, int64_t Hkv, int64_t Sq, int64_t S, float* scores, kvp_stream_t stream);
+
 /* ---- SnapKVPress.score (kvpress/presses/snapkv_press.py:60-105) ----------------------------
  * q: RoPE'd queries of the last W tokens [B,Hq,W,D] (the host keeps q_proj + RoPE,
  *    snapkv_press.py:53-58 / utils.py:43-46: q_proj is a model-owned nn.Linear);

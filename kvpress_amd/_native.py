@@ -28,6 +28,7 @@ SIGNATURES = {
     "kvp_version": (c_int, []),
     "kvp_last_error": (c_char_p, []),
     "kvp_rownorm_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_float, c_void_p, c_void_p]),
+    "kvp_observed_attention_score": (c_int, [c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, c_void_p, c_void_p]),
     "kvp_rowdot_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_void_p, _I64, c_float, c_void_p, c_void_p]),
     "kvp_knorm_compress_workspace_bytes": (c_size_t, [_I64] * 4),
     "kvp_knorm_compress": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64,
@@ -149,6 +150,18 @@ def rownorm_score(x: torch.Tensor, scale: float) -> torch.Tensor:
     with torch.cuda.device(x.device):
         _check(lib().kvp_rownorm_score(_p(x), _DTYPES[x.dtype], B, H, S, D, _st(x, 0), _st(x, 1), _st(x, 2),
                                        float(scale), _p(out), _stream(x)), "kvp_rownorm_score")
+    return out
+
+
+def observed_attention_score(attentions: torch.Tensor, num_kv_heads: int) -> torch.Tensor:
+    """Average attention weight every key receives (observed_attention_press.py:42-48): attentions [B,Hq,Sq,S] -> [B,Hkv,S] float32."""
+    a = _rows_last_contig(_dev(attentions))
+    B, Hq, Sq, S = a.shape
+    assert Hq % num_kv_heads == 0, (a.shape, num_kv_heads)
+    out = torch.empty((B, num_kv_heads, S), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _check(lib().kvp_observed_attention_score(_p(a), _st(a, 0), _st(a, 1), _st(a, 2), _DTYPES[a.dtype], B, Hq, num_kv_heads, Sq, S,
+                                                  _p(out), _stream(a)), "kvp_observed_attention_score")
     return out
 
 

@@ -51,7 +51,8 @@ def main(argv):
     _install_shims()
     import numpy as np
     import torch
-    from kvpress import (CURPress, ExpectedAttentionPress, KeyDiffPress, KnormPress, PyramidKVPress, QFilterPress,  # the reference
+    from kvpress import (CURPress, ExpectedAttentionPress, KeyDiffPress, KnormPress, ObservedAttentionPress, PyramidKVPress,  # the reference
+                         QFilterPress,
                          SnapKVPress, StreamingLLMPress, TOVAPress)
 
     import _inputs
@@ -70,6 +71,8 @@ def main(argv):
                 return SnapKVPress(compression_ratio=ratio, window_size=s["W"], kernel_size=s["ks"])
             if s["kind"] == "keydiff":
                 return KeyDiffPress(compression_ratio=ratio)
+            if s["kind"] == "observed":
+                return ObservedAttentionPress(compression_ratio=ratio)
             if s["kind"] == "qfilter":   # the published filters need the hub: seeded stand-ins, assigned directly
                 p = QFilterPress(compression_ratio=ratio)
                 p.q_filters = torch.from_numpy(_inputs.make_qfilters(s)).to(cur_dtype[0])
@@ -101,6 +104,7 @@ def main(argv):
             keys = torch.from_numpy(s["keys"]).to(dt)
             values = torch.from_numpy(s["values"]).to(dt)
             kwargs = {"position_embeddings": pe}
+            attn = torch.from_numpy(_inputs.make_attentions(s)).to(dt) if s["kind"] == "observed" else None
             with torch.no_grad():
                 press = make_press(0.5)
                 if mode == "f32" and s["kind"] == "ea":
@@ -115,12 +119,12 @@ def main(argv):
                     q = get_prerope_query_states(att, hidden[:, -s["W"]:])
                     c, si = pe[0][:, -s["W"]:], pe[1][:, -s["W"]:]
                     captured["qwin_f32"] = ((q * c.unsqueeze(1)) + (rotate_half(q) * si.unsqueeze(1))).numpy()
-                sc = press.score(att, hidden, keys, values, None, kwargs)
+                sc = press.score(att, hidden, keys, values, attn, kwargs)
                 out[f"scores_{mode}"] = sc.float().numpy()
                 if mode == "f32":
                     for i, r in enumerate(s["ratios"]):
                         p = make_press(r)
-                        ko, vo = p.compress(att, hidden, keys, values, None, kwargs)
+                        ko, vo = p.compress(att, hidden, keys, values, attn, kwargs)
                         assert ko.shape == vo.shape and ko.is_contiguous()
                         out[f"nkept_{i}"] = np.int64(ko.shape[2])
                         n = ko.shape[2]  # int(S * (1 - r)) except for per-layer budgets (PyramidKV)

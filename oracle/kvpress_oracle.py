@@ -369,6 +369,15 @@ def keydiff_score(keys: np.ndarray, ctype=np.float64) -> np.ndarray:
     return (-cos).astype(np.float32)
 
 
+def observed_attention_score(attentions: np.ndarray, H: int, ctype=np.float64) -> np.ndarray:
+    """ObservedAttentionPress.score (observed_attention_press.py:42-48): ``attentions.sum(2)`` over the queries, divided
+    by ``arange(S, 0, -1)`` (how many queries can see each key), mean over the GQA group.  attentions [B,Hq,Sq,S]."""
+    a = np.asarray(attentions).astype(ctype)
+    B, Hq, _, S = a.shape
+    sc = a.sum(2) / np.arange(S, 0, -1, dtype=ctype)
+    return sc.reshape(B, H, Hq // H, S).mean(2).astype(np.float32)
+
+
 def qfilter_score(keys: np.ndarray, q_filter: np.ndarray, ctype=np.float64) -> np.ndarray:
     """QFilterPress.score (qfilter_press.py:79-82): ``-(q_filter[None, :, None] * keys).sum(-1)`` with the layer's
     filters ``q_filter [H, D]``.  [B,H,S] float32."""

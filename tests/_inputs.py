@@ -92,6 +92,9 @@ CASES = {
     "qf_bf16_B": dict(kind="qfilter", B=1, H=8, G=1, S=3001, D=128, dtype="bf16", data="B", seed=112),
     "qf_f16_d64": dict(kind="qfilter", B=2, H=4, G=1, S=1000, D=64, dtype="f16", data="A", seed=113),
     "qf_d96_f32": dict(kind="qfilter", B=1, H=3, G=1, S=515, D=96, dtype="f32", data="B", seed=114),
+    "oa_tiny": dict(kind="observed", B=2, H=2, G=2, S=100, D=8, dtype="f32", data="A", seed=121),
+    "oa_bf16": dict(kind="observed", B=1, H=2, G=4, S=700, D=8, dtype="bf16", data="A", seed=122),
+    "oa_f16_g1": dict(kind="observed", B=1, H=4, G=1, S=257, D=8, dtype="f16", data="A", seed=123),
     "st_tiny": dict(kind="streaming", B=1, H=2, G=1, S=100, D=8, dtype="f32", data="A", seed=71),
     "st_sink0": dict(kind="streaming", B=2, H=2, G=1, S=257, D=8, dtype="f32", data="A", seed=72, n_sink=0),
 }
@@ -145,6 +148,17 @@ def make_qfilters(s: dict) -> np.ndarray:
     """Stand-in for the learned Q-filters [num_layers, H, D] (the published ones need the hub), exact in the case dtype."""
     rs = np.random.RandomState(s["seed"] + 2000)
     return round_to(rs.standard_normal((QF_LAYERS, s["H"], s["D"])).astype(np.float32), s["dtype"])
+
+
+def make_attentions(s: dict) -> np.ndarray:
+    """Causal attention weights [B,Hq,S,S] for the ObservedAttention cases (what an eager attention layer returns), exact in
+    the case dtype."""
+    rs = np.random.RandomState(s["seed"] + 3000)
+    S = s["S"]
+    logits = 2.0 * rs.standard_normal((s["B"], s["Hq"], S, S)).astype(np.float32)
+    logits = np.where(np.triu(np.ones((S, S), bool), 1), -np.inf, logits)
+    p = np.exp(logits - logits.max(-1, keepdims=True))
+    return round_to((p / p.sum(-1, keepdims=True)).astype(np.float32), s["dtype"])
 
 
 def torch_dtype(name: str):
@@ -212,6 +226,10 @@ def make_tiny_model(family: str, seed: int = 0, dtype=None, device="cpu"):
                   vocab_size=64, max_position_embeddings=512, bos_token_id=1, eos_token_id=2, pad_token_id=0)
     if family == "llama":
         return make_tiny_llama(seed, dtype, device)
+    if family == "llama_eager":   # the attention layers return their weights (ObservedAttentionPress)
+        model = make_tiny_llama(seed, dtype, device)
+        model.config._attn_implementation = "eager"
+        return model
     if family == "qwen3":
         cfg, cls = T.Qwen3Config(head_dim=6, **common), T.Qwen3ForCausalLM
     elif family == "qwen2":
@@ -244,6 +262,8 @@ FAMILY_PIPELINE_CASES = {
     "pipe_qwen3_ea": ("qwen3", ("ExpectedAttentionPress", dict(compression_ratio=0.4)), 60, ["w9 w10"], 6),
     "pipe_phi3_snapkv": ("phi3", ("SnapKVPress", dict(compression_ratio=0.5, window_size=16, kernel_size=5)), 130, ["w1 w2"], 8),
     "pipe_phi3_ea": ("phi3", ("ExpectedAttentionPress", dict(compression_ratio=0.5)), 70, ["w3"], 6),
+    "pipe_eager_observed": ("llama_eager", ("ObservedAttentionPress", dict(compression_ratio=0.5)), 90, ["w2 w3", "w6"], 6),
+    "pipe_eager_snapkv_attn": ("llama_eager", ("SnapKVPress", dict(compression_ratio=0.5, window_size=8, kernel_size=5)), 90, ["w2 w3"], 6),
     "pipe_mistral_knorm": ("mistral", ("KnormPress", dict(compression_ratio=0.5)), 100, ["w7 w8", "w1"], 6),
     "pipe_qwen2_tova": ("qwen2", ("TOVAPress", dict(compression_ratio=0.5)), 90, ["w2 w8"], 6),
     "pipe_qwen2_snapkv": ("qwen2", ("SnapKVPress", dict(compression_ratio=0.3, window_size=8, kernel_size=3)), 90, ["w5"], 6),

@@ -10,7 +10,7 @@ import _inputs
 from oracle import kvpress_oracle as O
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-F2 = [n for n, c in _inputs.CASES.items() if c["kind"] in ("pyramid", "tova", "keydiff", "streaming", "cur", "qfilter")]
+F2 = [n for n, c in _inputs.CASES.items() if c["kind"] in ("pyramid", "tova", "keydiff", "streaming", "cur", "qfilter", "observed")]
 
 
 def make_press(s, ratio):
@@ -23,6 +23,8 @@ def make_press(s, ratio):
         return P.TOVAPress(compression_ratio=ratio)
     if k == "keydiff":
         return P.KeyDiffPress(compression_ratio=ratio)
+    if k == "observed":
+        return P.ObservedAttentionPress(compression_ratio=ratio)
     if k == "qfilter":
         p = P.QFilterPress(compression_ratio=ratio)
         p.q_filters = torch.from_numpy(_inputs.make_qfilters(s))
@@ -42,10 +44,13 @@ def test_press_matches_reference_cpu(name, fake_native):
         att.layer_idx = _inputs.QF_LAYER
     keys, values = torch.from_numpy(s["keys"]), torch.from_numpy(s["values"])
     kwargs = {"position_embeddings": pe}
+    attn = torch.from_numpy(_inputs.make_attentions(s)) if s["kind"] == "observed" else None
     with torch.no_grad():
-        sc = make_press(s, 0.5).score(att, hidden, keys, values, None, kwargs).numpy()
+        sc = make_press(s, 0.5).score(att, hidden, keys, values, attn, kwargs).numpy()
         ref = g["scores_f32"]
-        if s["kind"] == "qfilter":   # a signed dot product crossing zero: absolute tolerance
+        if s["kind"] == "observed":
+            np.testing.assert_allclose(sc, ref, rtol=2e-5, atol=1e-30)
+        elif s["kind"] == "qfilter":   # a signed dot product crossing zero: absolute tolerance
             np.testing.assert_allclose(sc, ref, rtol=2e-4, atol=2e-5)
         elif s["kind"] in ("pyramid", "tova"):
             W = s["W"]
@@ -58,7 +63,7 @@ def test_press_matches_reference_cpu(name, fake_native):
         else:
             assert np.array_equal(sc, ref)
         for i, r in enumerate(s["ratios"]):
-            ko, vo = make_press(s, r).compress(att, hidden, keys, values, None, kwargs)
+            ko, vo = make_press(s, r).compress(att, hidden, keys, values, attn, kwargs)
             n = int(g[f"nkept_{i}"])
             assert tuple(ko.shape) == tuple(vo.shape) == (s["B"], s["H"], n, s["D"])
             if s["kind"] == "streaming":  # sinks + most recent tokens, exactly the reference's set
@@ -67,7 +72,7 @@ def test_press_matches_reference_cpu(name, fake_native):
                 assert np.array_equal(ko.numpy(), wk) and np.array_equal(vo.numpy(), wv)
                 n_pruned = s["S"] - n
                 assert idx[0, 0].tolist() == list(range(s["n_sink"])) + list(range(s["n_sink"] + n_pruned, s["S"]))
-        k0, v0 = make_press(s, 0.0).compress(att, hidden, keys, values, None, kwargs)
+        k0, v0 = make_press(s, 0.0).compress(att, hidden, keys, values, attn, kwargs)
         assert k0 is keys and v0 is values
 
 

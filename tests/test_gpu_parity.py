@@ -326,6 +326,19 @@ def test_rowdot_kernel_vs_oracle(name):
     np.testing.assert_allclose(got2, -2.0 * O.qfilter_score(s["keys"][:, :, ::2], f), rtol=2e-5, atol=4e-5, err_msg=name)
 
 
+@pytest.mark.parametrize("name", [n for n, c in _inputs.CASES.items() if c["kind"] == "observed"])
+def test_observed_attention_kernel_vs_oracle(name):
+    """kvp_observed_attention_score in the case's dtype against the float64 restatement on the same (dtype-exact) weights,
+    also on a strided view (fewer query rows than keys: a later chunk of queries)."""
+    s = _inputs.make_case(name)
+    a = _inputs.make_attentions(s)
+    t = to_dev(a, s["dtype"])
+    assert_scores_close(native().observed_attention_score(t, s["H"]).cpu().numpy(), O.observed_attention_score(a, s["H"]), 2e-5, name)
+    half = s["S"] // 2
+    got = native().observed_attention_score(t[:, :, half:], s["H"]).cpu().numpy()
+    assert_scores_close(got, O.observed_attention_score(a[:, :, half:], s["H"]), 2e-5, name + "/rows")
+
+
 @pytest.mark.parametrize("name", KD)
 def test_keydiff_kernel_vs_oracle(name):
     """kvp_keydiff_score in the case's dtype against the float64 restatement on the same (dtype-exact) keys."""
@@ -419,6 +432,8 @@ def make_press(s, ratio):
     if s["kind"] == "cur":
         return P.CURPress(compression_ratio=ratio, num_sinks=s.get("sinks", 4), leverage_type=s["leverage"],
                           use_local_approximation=s.get("local", True), local_window_size=s.get("window", 16))
+    if s["kind"] == "observed":
+        return P.ObservedAttentionPress(compression_ratio=ratio)
     if s["kind"] == "qfilter":
         p = P.QFilterPress(compression_ratio=ratio)
         p.q_filters = torch.from_numpy(_inputs.make_qfilters(s)).to(DEV)   # the press casts per call to the key dtype
@@ -440,8 +455,9 @@ def test_press_fp32_vs_reference(name):
         att.layer_idx = _inputs.QF_LAYER
     keys, values = to_dev(s["keys"], "f32"), to_dev(s["values"], "f32")
     kwargs = {"position_embeddings": pe}
+    attn = to_dev(_inputs.make_attentions(s), "f32") if s["kind"] == "observed" else None
     with torch.no_grad():
-        sc = make_press(s, 0.5).score(att, hidden, keys, values, None, kwargs)
+        sc = make_press(s, 0.5).score(att, hidden, keys, values, attn, kwargs)
         assert sc.dtype == torch.float32 and tuple(sc.shape) == (s["B"], s["H"], s["S"])
         got = sc.cpu().numpy()
         ref = g["scores_f32"]
@@ -451,6 +467,8 @@ def test_press_fp32_vs_reference(name):
             assert (got[..., -s["W"]:] > got[..., :-s["W"]].max()).all()
         elif s["kind"] == "keydiff":  # a cosine in [-1, 1] crossing zero: absolute tolerance
             np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5, err_msg=name)
+        elif s["kind"] == "observed":
+            assert_scores_close(got, ref, 2e-5, name)
         elif s["kind"] == "qfilter":  # a signed dot product crossing zero
             np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-5, err_msg=name)
         elif s["kind"] == "streaming":
@@ -464,7 +482,7 @@ def test_press_fp32_vs_reference(name):
         else:
             assert_scores_close(got, ref, 1e-5, name)
         for i, r in enumerate(s["ratios"]):
-            ko, vo = make_press(s, r).compress(att, hidden, keys, values, None, kwargs)
+            ko, vo = make_press(s, r).compress(att, hidden, keys, values, attn, kwargs)
             n = int(g[f"nkept_{i}"])
             assert tuple(ko.shape) == tuple(vo.shape) == (s["B"], s["H"], n, s["D"])
             assert ko.is_contiguous() and vo.is_contiguous() and ko.dtype == keys.dtype
@@ -478,7 +496,7 @@ def test_press_fp32_vs_reference(name):
             wk, wv = O.gather_kv(s["keys"], s["values"], idx)
             assert np.array_equal(ko.cpu().numpy(), wk) and np.array_equal(vo.cpu().numpy(), wv)
         # ratio 0 returns the very same objects (scorer_press.py:86-87)
-        k0, v0 = make_press(s, 0.0).compress(att, hidden, keys, values, None, kwargs)
+        k0, v0 = make_press(s, 0.0).compress(att, hidden, keys, values, attn, kwargs)
         assert k0 is keys and v0 is values
 
 
@@ -494,12 +512,13 @@ def test_press_native_dtype_runs_and_overlaps_reference(name):
         att.layer_idx = _inputs.QF_LAYER
     keys, values = to_dev(s["keys"], s["dtype"]), to_dev(s["values"], s["dtype"])
     kwargs = {"position_embeddings": pe}
+    attn = to_dev(_inputs.make_attentions(s), s["dtype"]) if s["kind"] == "observed" else None
     with torch.no_grad():
-        sc = make_press(s, 0.5).score(att, hidden, keys, values, None, kwargs)
+        sc = make_press(s, 0.5).score(att, hidden, keys, values, attn, kwargs)
         ref_nat = g["scores_nat"]
         for i, r in enumerate(s["ratios"]):
             n = int(g[f"nkept_{i}"])
-            ko, vo = make_press(s, r).compress(att, hidden, keys, values, None, kwargs)
+            ko, vo = make_press(s, r).compress(att, hidden, keys, values, attn, kwargs)
             assert tuple(ko.shape) == (s["B"], s["H"], n, s["D"]) and ko.dtype == dt
             idx = native().topk_select(sc, n).cpu().numpy()
             if s["kind"] == "knorm":

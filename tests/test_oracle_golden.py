@@ -22,6 +22,8 @@ def oracle_scores(s, cos=None, sin=None):
         return O.knorm_score(s["keys"])
     if s["kind"] == "keydiff":
         return O.keydiff_score(s["keys"])
+    if s["kind"] == "observed":
+        return O.observed_attention_score(_inputs.make_attentions(s), s["H"])
     if s["kind"] == "qfilter":
         return O.qfilter_score(s["keys"], _inputs.make_qfilters(s)[_inputs.QF_LAYER])
     if s["kind"] == "cur":
