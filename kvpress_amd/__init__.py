@@ -14,7 +14,7 @@ from kvpress_amd.presses.block_press import BlockPress
 from kvpress_amd.presses.chunk_press import ChunkPress
 from kvpress_amd.presses.composed_press import ComposedPress
 from kvpress_amd.presses.cur_press import CURPress
-from kvpress_amd.presses.decoding_press import DecodingPress, PrefillDecodingPress
+from kvpress_amd.presses.decoding_press import CompressionRatioDecodingPress, DecodingPress, PrefillDecodingPress
 from kvpress_amd.presses.expected_attention_press import ExpectedAttentionPress
 from kvpress_amd.presses.finch_press import FinchPress
 from kvpress_amd.presses.key_rerotation_press import KeyRerotationPress
@@ -33,7 +33,7 @@ from kvpress_amd.presses.tova_press import TOVAPress
 __version__ = "0.1.0"
 __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
            "KeyDiffPress", "QFilterPress", "ObservedAttentionPress", "CURPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
-           "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
+           "CompressionRatioDecodingPress", "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
 
 
 # importing the package registers the "kv-press-text-generation" task, as `import kvpress` does (kvpress/__init__.py, pipeline.py:326-331)

@@ -10,7 +10,7 @@ from __future__ import annotations
 import logging
 from collections import defaultdict
 from contextlib import contextmanager
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import Optional
 
 import torch
@@ -136,6 +136,36 @@ class DecodingPress(BasePress):
                 yield
         finally:
             self.reset()
+
+
+@dataclass
+class CompressionRatioDecodingPress(DecodingPress):
+    """A decoding press that keeps a fixed FRACTION of all tokens seen so far instead of an absolute ``target_size``
+    (kvpress/presses/compression_ratio_decoding_press.py:9-50).  Needs the logical ``position_ids`` among the attention
+    layer's kwargs (the pipeline and ``generate`` pass them).
+
+    Parameters
+    ----------
+    base_press : ScorerPress
+    target_compression_ratio : float, default=0.5
+        Fraction of all tokens seen so far that is removed at a compression.
+    compression_interval, hidden_states_buffer_size : as DecodingPress
+    """
+
+    target_compression_ratio: float = 0.5
+    target_size: int = field(default=1, init=False)
+
+    def __post_init__(self):
+        super().__post_init__()
+        assert 0 <= self.target_compression_ratio < 1, "target_compression_ratio must be between 0 and 1"
+
+    def _resolve_target_size(self, kwargs: dict) -> int:
+        return max(1, int(self._resolve_total_tokens_seen(kwargs) * (1 - self.target_compression_ratio)))
+
+    def _resolve_total_tokens_seen(self, kwargs: dict) -> int:
+        if kwargs.get("position_ids") is not None:
+            return int(kwargs["position_ids"].max().item()) + 1
+        raise NotImplementedError("CompressionRatioDecodingPress requires logical position_ids in kwargs")
 
 
 @dataclass

@@ -322,6 +322,8 @@ PIPELINE_CASES = {
         prefilling_press=_KN(0.5),
         decoding_press=("DecodingPress", dict(base_press=_KN(), compression_interval=4, target_size=36, hidden_states_buffer_size=2)))),
         80, ["w5 w6 w7"], 16),
+    "pipe_ratio_decoding": (("CompressionRatioDecodingPress", dict(base_press=_KN(), target_compression_ratio=0.5, compression_interval=3,
+                                                                    hidden_states_buffer_size=4)), 70, ["w2 w3 w4"], 13),
     # QuantizedCache write-back of the hook (base_press.py:152-157) and the pipeline's answer removal
     "pipe_knorm_quantized": (_KN(0.5), 120, ["w1 w2 w3", "w7"], 8),
     "pipe_snapkv_quantized": (("SnapKVPress", dict(compression_ratio=0.5, window_size=16, kernel_size=5)), 150, ["w4 w5"], 8),

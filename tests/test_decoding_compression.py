@@ -113,3 +113,20 @@ def test_decoding_compression_gpu():
 @pytest.mark.gpu
 def test_all_scorers_under_decoding_press_gpu():
     _check_all_scorers_and_reuse("cuda:0", torch.bfloat16)
+
+
+def test_compression_ratio_decoding_press_target_size(fake_native):
+    """The reference's unit tests of CompressionRatioDecodingPress (tests/test_decoding_compression.py:235-270), verbatim."""
+    import kvpress_amd as P
+
+    press = P.CompressionRatioDecodingPress(base_press=P.KnormPress(), target_compression_ratio=0.5)
+    target = press._resolve_target_size({"position_ids": torch.tensor([[107]])})
+    assert target == 54
+    assert press._find_target_compression_ratio(58, target) == pytest.approx(1 - (54 / 58))
+    # logical positions win over the (compressed) cache position
+    assert press._resolve_target_size({"position_ids": torch.tensor([[107]]), "cache_position": torch.tensor([57])}) == 54
+    with pytest.raises(NotImplementedError, match="requires logical position_ids"):
+        press._resolve_target_size({"cache_position": torch.tensor([57])})
+    assert press._find_target_compression_ratio(50, target) == 0.0     # already below the target: no-op
+    with pytest.raises(AssertionError):
+        P.CompressionRatioDecodingPress(base_press=P.KnormPress(), target_compression_ratio=1.0)
