@@ -12,6 +12,7 @@ from kvpress_amd.presses.adakv_press import AdaKVPress
 from kvpress_amd.presses.base_press import BasePress
 from kvpress_amd.presses.block_press import BlockPress
 from kvpress_amd.presses.chunk_press import ChunkPress
+from kvpress_amd.presses.chunkkv_press import ChunkKVPress
 from kvpress_amd.presses.composed_press import ComposedPress
 from kvpress_amd.presses.cur_press import CURPress
 from kvpress_amd.presses.decoding_press import CompressionRatioDecodingPress, DecodingPress, PrefillDecodingPress
@@ -32,7 +33,7 @@ from kvpress_amd.presses.tova_press import TOVAPress
 
 __version__ = "0.1.0"
 __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
-           "KeyDiffPress", "QFilterPress", "ObservedAttentionPress", "CURPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
+           "KeyDiffPress", "QFilterPress", "ObservedAttentionPress", "CURPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "ChunkKVPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
            "CompressionRatioDecodingPress", "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
 
 

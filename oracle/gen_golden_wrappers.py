@@ -24,7 +24,7 @@ def main(argv):
     gen_golden._install_shims()
     import numpy as np
     import torch
-    from kvpress import AdaKVPress, BlockPress, ChunkPress, KeyDiffPress, KeyRerotationPress, KnormPress, SnapKVPress, StreamingLLMPress
+    from kvpress import AdaKVPress, BlockPress, ChunkKVPress, ChunkPress, KeyDiffPress, KeyRerotationPress, KnormPress, SnapKVPress, StreamingLLMPress
 
     import _inputs
 
@@ -46,6 +46,8 @@ def main(argv):
                 return AdaKVPress(inner(ratio), alpha_safeguard=s["alpha"])
             if s["wrapper"] == "block":
                 return BlockPress(inner(ratio), block_size=s["block_size"])
+            if s["wrapper"] == "chunkkv":
+                return ChunkKVPress(inner(ratio), chunk_length=s["chunk_length"])
             return ChunkPress(inner(ratio), chunk_length=s["chunk_length"]) if s["wrapper"] == "chunk" else KeyRerotationPress(inner(ratio))
 
         out = {"ratios": np.asarray(s["ratios"], dtype=np.float64)}

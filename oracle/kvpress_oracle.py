@@ -451,6 +451,24 @@ def chunk_press_indices(score_chunk, k_len: int, chunk_length: int, compression_
     return np.concatenate(out, axis=-1).astype(np.int32)
 
 
+def chunkkv_indices(scores: np.ndarray, chunk_length: int, compression_ratio: float) -> np.ndarray:
+    """Kept positions of ChunkKVPress.compress (chunkkv_press.py:80-116), ascending, the same for every batch element and
+    head: chunk score = mean over the chunk of the head-summed scores, top ``max(1, int(n_chunks * (1 - ratio)))`` chunks
+    of batch element 0.  (Fewer tokens than one chunk: the wrapped press's own top-k, :77-78 -- not handled here.)"""
+    sc = np.asarray(scores, dtype=np.float64)
+    S = sc.shape[-1]
+    n_full, tail = divmod(S, chunk_length)
+    assert n_full > 0
+    per_token = sc.sum(1)
+    cs = per_token[:, : n_full * chunk_length].reshape(sc.shape[0], n_full, chunk_length).mean(-1)
+    if tail:
+        cs = np.concatenate([cs, per_token[:, -tail:].mean(-1, keepdims=True)], -1)
+    n_kept = max(1, int(cs.shape[-1] * (1 - compression_ratio)))
+    top = topk_select(cs[:1].astype(np.float32), n_kept)[0]
+    pos = (top[:, None].astype(np.int64) * chunk_length + np.arange(chunk_length)[None]).reshape(-1)
+    return pos[pos < S].astype(np.int32)
+
+
 def rerotate_keys(keys_kept: np.ndarray, idx: np.ndarray, inv_freq: np.ndarray, dtype: str = "f32") -> np.ndarray:
     """KeyRerotationPress.rerotate_keys after the gather (key_rerotation_press.py:50-128): token j of the kept
     (position-sorted) keys moves from position idx[..., j] to position j: ``k * cos(f) + rotate_half(k) * sin(f)`` with

@@ -400,6 +400,12 @@ WRAP_CASES = {
                                block_size=128, ratios=(0.5,)),
     "wrap_block_snapkv": dict(wrapper="block", kind="snapkv", B=1, H=2, G=2, S=400, D=16, dtype="f32", data="B", seed=93,
                               block_size=64, W=8, ks=5, ratios=(0.5,)),
+    "wrap_chunkkv_knorm": dict(wrapper="chunkkv", kind="knorm", B=2, H=2, G=1, S=1000, D=16, dtype="f32", data="B", seed=94,
+                               chunk_length=20, ratios=(0.25, 0.5, 0.9)),
+    "wrap_chunkkv_snapkv_tail": dict(wrapper="chunkkv", kind="snapkv", B=1, H=2, G=2, S=707, D=16, dtype="f32", data="B", seed=95,
+                                     chunk_length=64, W=8, ks=5, ratios=(0.5, 0.97)),
+    "wrap_chunkkv_short": dict(wrapper="chunkkv", kind="knorm", B=1, H=2, G=1, S=15, D=16, dtype="f32", data="A", seed=96,
+                               chunk_length=20, ratios=(0.5,)),
     "wrap_adakv_knorm": dict(wrapper="adakv", kind="knorm", B=2, H=4, G=1, S=300, D=16, dtype="f32", data="B", seed=88, alpha=0.2,
                              ratios=(0.25, 0.5, 0.9)),
     "wrap_adakv_snapkv": dict(wrapper="adakv", kind="snapkv", B=1, H=2, G=4, S=700, D=128, dtype="f32", data="B", seed=89, alpha=0.5,

@@ -14,6 +14,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 ADAKV = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "adakv"]
 BLOCK = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "block"]
 CHUNK = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "chunk"]
+CHUNKKV = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "chunkkv"]
 REROT = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "rerot"]
 DEV = "cuda:0"
 
@@ -37,6 +38,8 @@ def wrapped(s, ratio):
         return P.AdaKVPress(inner_press(s, ratio), alpha_safeguard=s["alpha"])
     if s["wrapper"] == "block":
         return P.BlockPress(inner_press(s, ratio), block_size=s["block_size"])
+    if s["wrapper"] == "chunkkv":
+        return P.ChunkKVPress(inner_press(s, ratio), chunk_length=s["chunk_length"])
     return P.ChunkPress(inner_press(s, ratio), chunk_length=s["chunk_length"]) if s["wrapper"] == "chunk" else P.KeyRerotationPress(inner_press(s, ratio))
 
 
@@ -64,6 +67,32 @@ def test_oracle_chunk_indices_match_reference(name):
     for i, r in enumerate(s["ratios"]):
         idx = np.sort(O.chunk_press_indices(fn, s["S"], s["chunk_length"], r), axis=-1)
         assert np.array_equal(idx, g[f"pos_{i}"]), f"{name} r={r}"
+
+
+@pytest.mark.parametrize("name", CHUNKKV)
+def test_oracle_chunkkv_indices_match_reference(name):
+    s = _inputs.make_wrap_case(name)
+    g = gold(name)
+    sc = _oracle_scores_full(s)
+    for i, r in enumerate(s["ratios"]):
+        if s["S"] < s["chunk_length"]:   # no complete chunk: the wrapped press's own selection (in torch.topk's order there)
+            assert np.array_equal(O.topk_select(sc, O.n_kept(s["S"], r)), np.sort(g[f"pos_{i}"], axis=-1)), f"{name} r={r}"
+        else:
+            want = np.broadcast_to(O.chunkkv_indices(sc, s["chunk_length"], r), g[f"pos_{i}"].shape)
+            assert np.array_equal(want, g[f"pos_{i}"]), f"{name} r={r}"
+
+
+def _check_chunkkv(s, name, dev):
+    g, out = _run_wrapper(s, name, dev, torch.float32)
+    for i, r, ko, pos in out:
+        assert np.array_equal(pos, np.sort(g[f"pos_{i}"], axis=-1)), f"{name} r={r}: kept positions"
+        wk, _ = O.gather_kv(s["keys"], s["values"], pos)
+        assert np.array_equal(ko, wk)
+
+
+@pytest.mark.parametrize("name", CHUNKKV)
+def test_chunkkv_matches_reference_cpu(name, fake_native):
+    _check_chunkkv(_inputs.make_wrap_case(name), name, "cpu")
 
 
 @pytest.mark.parametrize("name", REROT)
@@ -269,6 +298,12 @@ def test_wrappers_match_reference_gpu_fp32(name):
         else:
             wk, _ = O.gather_kv(s["keys"], s["values"], pos)
             assert np.array_equal(ko, wk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CHUNKKV)
+def test_chunkkv_matches_reference_gpu(name):
+    _check_chunkkv(_inputs.make_wrap_case(name), name, DEV)
 
 
 @pytest.mark.gpu
