@@ -73,6 +73,17 @@ int kvp_rowdot_score(const void* x, int dtype, int64_t B, int64_t H, int64_t S, 
 int kvp_observed_attention_score(const void* attn, int64_t a_sb, int64_t a_sh, int64_t a_sq, int dtype,
                                  int64_t B, int64_t Hq, int64_t Hkv, int64_t Sq, int64_t S, float* scores, kvp_stream_t stream);
 
+/* ---- LagKVPress.score (kvpress/presses/lagkv_press.py:56-97), sequences of at least n_sink + 2 * lag_size tokens --------
+ * After n_sink sinks the sequence is cut into partitions of lag_size tokens; partition p is scored against partition
+ * p + 1: per-channel min / max of p + 1, tokens of p normalised with them, score = std over the channels (unbiased),
+ * softmax over the partition; K and V scores averaged; unless cross_scoring the score becomes rank / lag_size inside
+ * the partition (equal scores rank by position).  Sinks, the last complete partition and the remainder score 1.
+ * head_dim <= 512, lag_size <= 1024.  scores contiguous [B,H,S] float32.  (Shorter sequences: constant scores, host side.) */
+int kvp_lagkv_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
+                    const void* v, int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype,
+                    int64_t B, int64_t H, int64_t S, int64_t D, int64_t n_sink, int64_t lag_size, int cross_scoring,
+                    float* scores, kvp_stream_t stream);
+
 /* ---- SnapKVPress.score (kvpress/presses/snapkv_press.py:60-105) ----------------------------
  * q: RoPE'd queries of the last W tokens [B,Hq,W,D] (the host keeps q_proj + RoPE,
  *    snapkv_press.py:53-58 / utils.py:43-46: q_proj is a model-owned nn.Linear);

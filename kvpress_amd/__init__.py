@@ -21,6 +21,7 @@ from kvpress_amd.presses.finch_press import FinchPress
 from kvpress_amd.presses.key_rerotation_press import KeyRerotationPress
 from kvpress_amd.presses.keydiff_press import KeyDiffPress
 from kvpress_amd.presses.knorm_press import KnormPress
+from kvpress_amd.presses.lagkv_press import LagKVPress
 from kvpress_amd.presses.observed_attention_press import ObservedAttentionPress
 from kvpress_amd.presses.per_layer_compression_press import PerLayerCompressionPress
 from kvpress_amd.presses.pyramidkv_press import PyramidKVPress
@@ -33,7 +34,7 @@ from kvpress_amd.presses.tova_press import TOVAPress
 
 __version__ = "0.1.0"
 __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
-           "KeyDiffPress", "QFilterPress", "ObservedAttentionPress", "CURPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "ChunkKVPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
+           "KeyDiffPress", "LagKVPress", "QFilterPress", "ObservedAttentionPress", "CURPress", "StreamingLLMPress", "RandomPress", "ChunkPress", "ChunkKVPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
            "CompressionRatioDecodingPress", "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
 
 

@@ -29,6 +29,8 @@ SIGNATURES = {
     "kvp_last_error": (c_char_p, []),
     "kvp_rownorm_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_float, c_void_p, c_void_p]),
     "kvp_observed_attention_score": (c_int, [c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, c_void_p, c_void_p]),
+    "kvp_lagkv_score": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, _I64, c_int,
+                                c_void_p, c_void_p]),
     "kvp_rowdot_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_void_p, _I64, c_float, c_void_p, c_void_p]),
     "kvp_knorm_compress_workspace_bytes": (c_size_t, [_I64] * 4),
     "kvp_knorm_compress": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64,
@@ -162,6 +164,20 @@ def observed_attention_score(attentions: torch.Tensor, num_kv_heads: int) -> tor
     with torch.cuda.device(a.device):
         _check(lib().kvp_observed_attention_score(_p(a), _st(a, 0), _st(a, 1), _st(a, 2), _DTYPES[a.dtype], B, Hq, num_kv_heads, Sq, S,
                                                   _p(out), _stream(a)), "kvp_observed_attention_score")
+    return out
+
+
+def lagkv_score(keys: torch.Tensor, values: torch.Tensor, n_sink: int, lag_size: int, cross_scoring: bool) -> torch.Tensor:
+    """LagKV scores [B,H,S] float32 (lagkv_press.py:56-97) for S >= n_sink + 2 * lag_size."""
+    keys = _rows_last_contig(_dev(keys))
+    values = _rows_last_contig(_dev(values))
+    assert keys.dtype == values.dtype and keys.shape == values.shape
+    B, H, S, D = keys.shape
+    out = torch.empty((B, H, S), dtype=torch.float32, device=keys.device)
+    with torch.cuda.device(keys.device):
+        _check(lib().kvp_lagkv_score(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _p(values), _st(values, 0), _st(values, 1),
+                                     _st(values, 2), _DTYPES[keys.dtype], B, H, S, D, int(n_sink), int(lag_size), int(bool(cross_scoring)),
+                                     _p(out), _stream(keys)), "kvp_lagkv_score")
     return out
 
 

@@ -51,7 +51,7 @@ def main(argv):
     _install_shims()
     import numpy as np
     import torch
-    from kvpress import (CURPress, ExpectedAttentionPress, KeyDiffPress, KnormPress, ObservedAttentionPress, PyramidKVPress,  # the reference
+    from kvpress import (CURPress, ExpectedAttentionPress, KeyDiffPress, KnormPress, LagKVPress, ObservedAttentionPress, PyramidKVPress,  # the reference
                          QFilterPress,
                          SnapKVPress, StreamingLLMPress, TOVAPress)
 
@@ -71,6 +71,8 @@ def main(argv):
                 return SnapKVPress(compression_ratio=ratio, window_size=s["W"], kernel_size=s["ks"])
             if s["kind"] == "keydiff":
                 return KeyDiffPress(compression_ratio=ratio)
+            if s["kind"] == "lagkv":
+                return LagKVPress(compression_ratio=ratio, n_sink=s["n_sink"], lag_size=s["lag"], cross_scoring=s.get("cross", False))
             if s["kind"] == "observed":
                 return ObservedAttentionPress(compression_ratio=ratio)
             if s["kind"] == "qfilter":   # the published filters need the hub: seeded stand-ins, assigned directly

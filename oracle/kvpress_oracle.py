@@ -378,6 +378,35 @@ def observed_attention_score(attentions: np.ndarray, H: int, ctype=np.float64) -
     return sc.reshape(B, H, Hq // H, S).mean(2).astype(np.float32)
 
 
+def _lag_states_score(x, ctype):
+    """``_get_states_score`` (lagkv_press.py:88-97): x [B,H,P,L,D]; partition p against the min / max of partition p+1."""
+    ref, v = x[:, :, 1:], x[:, :, :-1]
+    mn, mx = ref.min(axis=-2, keepdims=True), ref.max(axis=-2, keepdims=True)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sd = ((v - mn) / (mx - mn)).std(axis=-1, ddof=1)             # torch.std: unbiased
+    e = np.exp(sd - sd.max(-1, keepdims=True))
+    return e / e.sum(-1, keepdims=True)                              # softmax over the partition's tokens
+
+
+def lagkv_score(keys, values, n_sink: int = 4, lag_size: int = 128, cross_scoring: bool = False, ctype=np.float64) -> np.ndarray:
+    """LagKVPress.score (lagkv_press.py:56-86).  Ranks (``argsort().argsort()``) break ties by position."""
+    k, v = np.asarray(keys).astype(ctype), np.asarray(values).astype(ctype)
+    B, H, S, D = k.shape
+    if S < n_sink + 2 * lag_size:                                    # :57-63
+        sc = np.ones((B, H, S), ctype)
+        if S > n_sink:
+            sc[:, :, n_sink:] = np.arange(S - n_sink, dtype=ctype) / (S - n_sink)
+        return sc.astype(np.float32)
+    end = n_sink + ((S - n_sink) // lag_size) * lag_size
+    ks = _lag_states_score(k[:, :, n_sink:end].reshape(B, H, -1, lag_size, D), ctype)
+    vs = _lag_states_score(v[:, :, n_sink:end].reshape(B, H, -1, lag_size, D), ctype)
+    sc = (ks + vs) / 2
+    if not cross_scoring:
+        sc = np.argsort(np.argsort(sc, axis=-1, kind="stable"), axis=-1, kind="stable") / lag_size
+    tail = lag_size + S - end
+    return np.concatenate([np.ones((B, H, n_sink), ctype), sc.reshape(B, H, -1), np.ones((B, H, tail), ctype)], axis=-1).astype(np.float32)
+
+
 def qfilter_score(keys: np.ndarray, q_filter: np.ndarray, ctype=np.float64) -> np.ndarray:
     """QFilterPress.score (qfilter_press.py:79-82): ``-(q_filter[None, :, None] * keys).sum(-1)`` with the layer's
     filters ``q_filter [H, D]``.  [B,H,S] float32."""

@@ -9,7 +9,7 @@ WHAT="${*:-tests bench}"
 python __graft_entry__.py > gpurun_out/build.log 2>&1; echo "build rc=$?"
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
 if [[ "$WHAT" == *tests* ]]; then
-  for grp in rownorm rowdot observed topk gather fused fuzz cur snapkv_kernel snapkv_from snapkv_fused ea_qstats ea_score full_chain keydiff head_mean tova_from random_press press_fp32 press_native; do
+  for grp in rownorm rowdot observed lagkv topk gather fused fuzz cur snapkv_kernel snapkv_from snapkv_fused ea_qstats ea_score full_chain keydiff head_mean tova_from random_press press_fp32 press_native; do
     timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --no-header -k "$grp" > gpurun_out/test_$grp.log 2>&1
     echo "tests[$grp] rc=$? $(tail -1 gpurun_out/test_$grp.log)"
   done

@@ -10,7 +10,7 @@ import _inputs
 from oracle import kvpress_oracle as O
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-F2 = [n for n, c in _inputs.CASES.items() if c["kind"] in ("pyramid", "tova", "keydiff", "streaming", "cur", "qfilter", "observed")]
+F2 = [n for n, c in _inputs.CASES.items() if c["kind"] in ("pyramid", "tova", "keydiff", "streaming", "cur", "qfilter", "observed", "lagkv")]
 
 
 def make_press(s, ratio):
@@ -23,6 +23,8 @@ def make_press(s, ratio):
         return P.TOVAPress(compression_ratio=ratio)
     if k == "keydiff":
         return P.KeyDiffPress(compression_ratio=ratio)
+    if k == "lagkv":
+        return P.LagKVPress(compression_ratio=ratio, n_sink=s["n_sink"], lag_size=s["lag"], cross_scoring=s.get("cross", False))
     if k == "observed":
         return P.ObservedAttentionPress(compression_ratio=ratio)
     if k == "qfilter":
@@ -48,7 +50,9 @@ def test_press_matches_reference_cpu(name, fake_native):
     with torch.no_grad():
         sc = make_press(s, 0.5).score(att, hidden, keys, values, attn, kwargs).numpy()
         ref = g["scores_f32"]
-        if s["kind"] == "observed":
+        if s["kind"] == "lagkv":
+            _inputs.assert_lag_scores_close(sc, ref, s, name)
+        elif s["kind"] == "observed":
             np.testing.assert_allclose(sc, ref, rtol=2e-5, atol=1e-30)
         elif s["kind"] == "qfilter":   # a signed dot product crossing zero: absolute tolerance
             np.testing.assert_allclose(sc, ref, rtol=2e-4, atol=2e-5)

@@ -326,6 +326,23 @@ def test_rowdot_kernel_vs_oracle(name):
     np.testing.assert_allclose(got2, -2.0 * O.qfilter_score(s["keys"][:, :, ::2], f), rtol=2e-5, atol=4e-5, err_msg=name)
 
 
+@pytest.mark.parametrize("name", [n for n, c in _inputs.CASES.items() if c["kind"] == "lagkv" and c["S"] >= c["n_sink"] + 2 * c["lag"]])
+def test_lagkv_kernel_vs_oracle(name):
+    """kvp_lagkv_score in the case's dtype against the float64 restatement on the same (dtype-exact) keys and values; the
+    raw (cross_scoring) scores also on strided views."""
+    s = _inputs.make_case(name)
+    k, v = to_dev(s["keys"], s["dtype"]), to_dev(s["values"], s["dtype"])
+    for cross in (False, True):
+        got = native().lagkv_score(k, v, s["n_sink"], s["lag"], cross).cpu().numpy()
+        _inputs.assert_lag_scores_close(got, O.lagkv_score(s["keys"], s["values"], s["n_sink"], s["lag"], cross), dict(s, cross=cross), f"{name}/{cross}")
+    S2 = s["S"] - 3
+    got = native().lagkv_score(k[:, :, 3:], v[:, :, 3:], s["n_sink"], s["lag"], True).cpu().numpy()
+    _inputs.assert_lag_scores_close(got, O.lagkv_score(s["keys"][:, :, 3:], s["values"][:, :, 3:], s["n_sink"], s["lag"], True),
+                                    dict(s, cross=True, S=S2), name + "/view")
+    with pytest.raises(Exception):
+        native().lagkv_score(k[:, :, : s["n_sink"] + s["lag"]], v[:, :, : s["n_sink"] + s["lag"]], s["n_sink"], s["lag"], False)
+
+
 @pytest.mark.parametrize("name", [n for n, c in _inputs.CASES.items() if c["kind"] == "observed"])
 def test_observed_attention_kernel_vs_oracle(name):
     """kvp_observed_attention_score in the case's dtype against the float64 restatement on the same (dtype-exact) weights,
@@ -432,6 +449,8 @@ def make_press(s, ratio):
     if s["kind"] == "cur":
         return P.CURPress(compression_ratio=ratio, num_sinks=s.get("sinks", 4), leverage_type=s["leverage"],
                           use_local_approximation=s.get("local", True), local_window_size=s.get("window", 16))
+    if s["kind"] == "lagkv":
+        return P.LagKVPress(compression_ratio=ratio, n_sink=s["n_sink"], lag_size=s["lag"], cross_scoring=s.get("cross", False))
     if s["kind"] == "observed":
         return P.ObservedAttentionPress(compression_ratio=ratio)
     if s["kind"] == "qfilter":
@@ -467,6 +486,8 @@ def test_press_fp32_vs_reference(name):
             assert (got[..., -s["W"]:] > got[..., :-s["W"]].max()).all()
         elif s["kind"] == "keydiff":  # a cosine in [-1, 1] crossing zero: absolute tolerance
             np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5, err_msg=name)
+        elif s["kind"] == "lagkv":
+            _inputs.assert_lag_scores_close(got, ref, s, name)
         elif s["kind"] == "observed":
             assert_scores_close(got, ref, 2e-5, name)
         elif s["kind"] == "qfilter":  # a signed dot product crossing zero

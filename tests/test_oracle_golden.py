@@ -22,6 +22,8 @@ def oracle_scores(s, cos=None, sin=None):
         return O.knorm_score(s["keys"])
     if s["kind"] == "keydiff":
         return O.keydiff_score(s["keys"])
+    if s["kind"] == "lagkv":
+        return O.lagkv_score(s["keys"], s["values"], s["n_sink"], s["lag"], s.get("cross", False))
     if s["kind"] == "observed":
         return O.observed_attention_score(_inputs.make_attentions(s), s["H"])
     if s["kind"] == "qfilter":
@@ -57,6 +59,8 @@ def test_oracle_scores_match_reference(name):
     sc = oracle_scores(s)
     ref = g["scores_f32"]
     assert sc.shape == ref.shape == (s["B"], s["H"], s["S"])
+    if s["kind"] == "lagkv":
+        return _inputs.assert_lag_scores_close(sc, ref, s, name)
     # float32 reference vs float64 oracle: both approximate the same math
     # (KeyDiff: a cosine in [-1, 1] that crosses zero -> absolute tolerance)
     np.testing.assert_allclose(sc, ref, rtol=2e-4, atol=2e-6 if s["kind"] in ("keydiff", "qfilter") else 1e-30)
