@@ -84,6 +84,20 @@ int kvp_lagkv_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
                     int64_t B, int64_t H, int64_t S, int64_t D, int64_t n_sink, int64_t lag_size, int cross_scoring,
                     float* scores, kvp_stream_t stream);
 
+/* ---- ThinKPress (kvpress/presses/think_press.py:56-85): key-channel pruning ----------------------------------------------
+ * kvp_think_channel_scores: scores[b,h,d] = mean over the kv-head's G q-heads and the W window rows of q[b,hq,w,d]^2
+ *   times mean over the S keys of k[b,h,s,d]^2 (:72-76); q = RoPE'd queries of the last W tokens [B,Hq,W,D].  head_dim <= 256.
+ *   scores contiguous [B,Hkv,D] float32.  The channels to prune are the n lowest: kvp_topk_select | KVP_TOPK_SMALLEST.
+ * kvp_zero_channels: x[b,h,s,idx[b,h,j]] = 0 for all s, j < n, IN PLACE (`keys.scatter_(-1, indices, 0)`, :81-82);
+ *   idx contiguous [B,H,n] int32, n <= 1024. */
+size_t kvp_think_workspace_bytes(int64_t B, int64_t H, int64_t S, int64_t D);
+int kvp_think_channel_scores(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw,
+                             const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,
+                             int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D,
+                             float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream);
+int kvp_zero_channels(void* x, int64_t sb, int64_t sh, int64_t ss, int dtype, int64_t B, int64_t H, int64_t S, int64_t D,
+                      const int32_t* idx, int64_t n, kvp_stream_t stream);
+
 /* ---- SnapKVPress.score (kvpress/presses/snapkv_press.py:60-105) ----------------------------
  * q: RoPE'd queries of the last W tokens [B,Hq,W,D] (the host keeps q_proj + RoPE,
  *    snapkv_press.py:53-58 / utils.py:43-46: q_proj is a model-owned nn.Linear);

@@ -31,6 +31,10 @@ SIGNATURES = {
     "kvp_observed_attention_score": (c_int, [c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, c_void_p, c_void_p]),
     "kvp_lagkv_score": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, _I64, c_int,
                                 c_void_p, c_void_p]),
+    "kvp_think_workspace_bytes": (c_size_t, [_I64] * 4),
+    "kvp_think_channel_scores": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, _I64,
+                                         c_void_p, c_void_p, c_size_t, c_void_p]),
+    "kvp_zero_channels": (c_int, [c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, c_void_p, _I64, c_void_p]),
     "kvp_rowdot_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_void_p, _I64, c_float, c_void_p, c_void_p]),
     "kvp_knorm_compress_workspace_bytes": (c_size_t, [_I64] * 4),
     "kvp_knorm_compress": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64,
@@ -179,6 +183,37 @@ def lagkv_score(keys: torch.Tensor, values: torch.Tensor, n_sink: int, lag_size:
                                      _st(values, 2), _DTYPES[keys.dtype], B, H, S, D, int(n_sink), int(lag_size), int(bool(cross_scoring)),
                                      _p(out), _stream(keys)), "kvp_lagkv_score")
     return out
+
+
+def think_channel_scores(q_win: torch.Tensor, keys: torch.Tensor) -> torch.Tensor:
+    """ThinK's per-channel scores [B,Hkv,D] float32 (think_press.py:72-76) from the RoPE'd window queries [B,Hq,W,D] and keys."""
+    keys = _rows_last_contig(_dev(keys))
+    q_win = _rows_last_contig(_dev(q_win))
+    if q_win.dtype != keys.dtype:
+        q_win = q_win.to(keys.dtype)
+    B, Hq, W, D = q_win.shape
+    Bk, Hkv, S, Dk = keys.shape
+    assert B == Bk and D == Dk and Hq % Hkv == 0, (q_win.shape, keys.shape)
+    out = torch.empty((B, Hkv, D), dtype=torch.float32, device=keys.device)
+    with torch.cuda.device(keys.device):
+        nws = lib().kvp_think_workspace_bytes(B, Hkv, S, D)
+        ws = _ws(nws, keys)
+        _check(lib().kvp_think_channel_scores(_p(q_win), _st(q_win, 0), _st(q_win, 1), _st(q_win, 2), _p(keys), _st(keys, 0), _st(keys, 1),
+                                              _st(keys, 2), _DTYPES[keys.dtype], B, Hq, Hkv, S, W, D, _p(out), _p(ws), ws.numel(), _stream(keys)),
+               "kvp_think_channel_scores")
+    return out
+
+
+def zero_channels_(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """x[b,h,:,idx[b,h,j]] = 0 in place (think_press.py:81-82); x [B,H,S,D] with a contiguous last dim, idx [B,H,n] int32."""
+    assert x.is_cuda and x.stride(-1) == 1, "zero_channels_ works in place on a device tensor with contiguous rows"
+    B, H, S, D = x.shape
+    assert idx.is_cuda and idx.device == x.device and tuple(idx.shape[:2]) == (B, H), (idx.shape, x.shape)
+    idx = idx.to(torch.int32).contiguous()
+    with torch.cuda.device(x.device):
+        _check(lib().kvp_zero_channels(_p(x), _st(x, 0), _st(x, 1), _st(x, 2), _DTYPES[x.dtype], B, H, S, D, _p(idx), idx.shape[2], _stream(x)),
+               "kvp_zero_channels")
+    return x
 
 
 def rowdot_score(x: torch.Tensor, filt: torch.Tensor, scale: float) -> torch.Tensor:

@@ -407,6 +407,26 @@ def lagkv_score(keys, values, n_sink: int = 4, lag_size: int = 128, cross_scorin
     return np.concatenate([np.ones((B, H, n_sink), ctype), sc.reshape(B, H, -1), np.ones((B, H, tail), ctype)], axis=-1).astype(np.float32)
 
 
+def think_channel_scores(q_win, keys, ctype=np.float64) -> np.ndarray:
+    """ThinKPress's per-channel scores (think_press.py:72-76): ``pow(queries, 2).mean(2)`` over the window, mean over the
+    GQA group, times ``pow(keys, 2).mean(2)`` over the tokens.  q_win [B,Hq,W,D] RoPE'd, keys [B,H,S,D] -> [B,H,D]."""
+    q, k = np.asarray(q_win).astype(ctype), np.asarray(keys).astype(ctype)
+    B, Hq, _, D = q.shape
+    H = k.shape[1]
+    qn = (q ** 2).mean(2).reshape(B, H, Hq // H, D).mean(2)
+    return (qn * (k ** 2).mean(2)).astype(np.float32)
+
+
+def think_prune(keys, scores, key_channel_compression_ratio: float):
+    """The pruned channels (ascending) and the keys with them zeroed (think_press.py:79-82): the
+    ``int(D * ratio)`` lowest-scoring channels per (batch, head); equal scores: lowest channel first."""
+    k = np.array(keys, copy=True)
+    D = k.shape[-1]
+    idx = topk_select(-np.asarray(scores, np.float32), int(D * key_channel_compression_ratio))
+    np.put_along_axis(k, np.broadcast_to(idx[:, :, None, :].astype(np.int64), k.shape[:3] + (idx.shape[-1],)), 0, axis=-1)
+    return idx, k
+
+
 def qfilter_score(keys: np.ndarray, q_filter: np.ndarray, ctype=np.float64) -> np.ndarray:
     """QFilterPress.score (qfilter_press.py:79-82): ``-(q_filter[None, :, None] * keys).sum(-1)`` with the layer's
     filters ``q_filter [H, D]``.  [B,H,S] float32."""

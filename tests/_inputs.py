@@ -467,6 +467,22 @@ def make_finch_press(mod, s: dict, ratio: float):
     return p
 
 
+# ---- ThinKPress: key-channel pruning -------------------------------------------------------------------------------
+THINK_CASES = {
+    "think_tiny": dict(B=2, H=2, G=2, S=100, D=16, dtype="f32", data="B", seed=141, W=8, ratios=(0.25, 0.5)),
+    "think_bf16": dict(B=1, H=2, G=4, S=700, D=128, dtype="bf16", data="B", seed=142, W=32, ratios=(0.5,)),
+    "think_f16_d64": dict(B=1, H=4, G=1, S=257, D=64, dtype="f16", data="B", seed=143, W=16, ratios=(0.2, 0.8)),
+}
+
+
+def make_think_case(name: str) -> dict:
+    CASES[name] = dict(THINK_CASES[name], kind="snapkv", ks=1)
+    try:
+        return make_case(name)
+    finally:
+        del CASES[name]
+
+
 def make_wrap_case(name: str) -> dict:
     CASES[name] = {k: v for k, v in WRAP_CASES[name].items() if k not in ("wrapper", "chunk_length", "alpha", "block_size")}
     try:

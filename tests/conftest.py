@@ -95,6 +95,13 @@ def fake_native(monkeypatch):
     def lagkv_score(keys, values, n_sink, lag_size, cross_scoring):
         return torch.from_numpy(O.lagkv_score(keys.float().numpy(), values.float().numpy(), n_sink, lag_size, cross_scoring))
 
+    def think_channel_scores(q_win, keys):
+        return torch.from_numpy(O.think_channel_scores(q_win.float().numpy(), keys.float().numpy()))
+
+    def zero_channels_(x, idx):
+        x.scatter_(-1, idx.long().unsqueeze(2).expand(-1, -1, x.shape[2], -1), 0)
+        return x
+
     def rowdot_score(x, filt, scale):
         return torch.from_numpy(np.float32(-scale) * O.qfilter_score(x.float().numpy(), filt.float().numpy()))
 
@@ -136,7 +143,7 @@ def fake_native(monkeypatch):
 
     for name, fn in dict(rownorm_score=rownorm_score, topk_select=topk_select, gather_kv=gather_kv,
                          snapkv_score=snapkv_score, snapkv_score_rope=snapkv_score_rope, finch_score=finch_score, snapkv_score_from_attn=snapkv_score_from_attn,
-                         keydiff_score=keydiff_score, rowdot_score=rowdot_score, lagkv_score=lagkv_score, observed_attention_score=observed_attention_score, cur_score=cur_score, scores_head_mean_=scores_head_mean_, knorm_compress=knorm_compress, qproj_rope_supported=qproj_rope_supported, scores_fill_at_=scores_fill_at_, topk_select_segmented=topk_select_segmented, rerotate_keys_=rerotate_keys_,
+                         keydiff_score=keydiff_score, rowdot_score=rowdot_score, think_channel_scores=think_channel_scores, zero_channels_=zero_channels_, lagkv_score=lagkv_score, observed_attention_score=observed_attention_score, cur_score=cur_score, scores_head_mean_=scores_head_mean_, knorm_compress=knorm_compress, qproj_rope_supported=qproj_rope_supported, scores_fill_at_=scores_fill_at_, topk_select_segmented=topk_select_segmented, rerotate_keys_=rerotate_keys_,
                          snapkv_compress_rope=snapkv_compress_rope, ea_qstats=ea_qstats, ea_score=ea_score).items():
         monkeypatch.setattr(_native, name, fn)
     return _native
