@@ -28,6 +28,7 @@ from kvpress_amd.presses.pyramidkv_press import PyramidKVPress
 from kvpress_amd.presses.qfilter_press import QFilterPress
 from kvpress_amd.presses.random_press import RandomPress
 from kvpress_amd.presses.scorer_press import ScorerPress
+from kvpress_amd.presses.simlayerkv_press import SimLayerKVPress
 from kvpress_amd.presses.snapkv_press import SnapKVPress
 from kvpress_amd.presses.streaming_llm_press import StreamingLLMPress
 from kvpress_amd.presses.think_press import ThinKPress
@@ -35,7 +36,7 @@ from kvpress_amd.presses.tova_press import TOVAPress
 
 __version__ = "0.1.0"
 __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
-           "KeyDiffPress", "LagKVPress", "QFilterPress", "ObservedAttentionPress", "CURPress", "StreamingLLMPress", "ThinKPress", "RandomPress", "ChunkPress", "ChunkKVPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
+           "KeyDiffPress", "LagKVPress", "QFilterPress", "ObservedAttentionPress", "CURPress", "StreamingLLMPress", "SimLayerKVPress", "ThinKPress", "RandomPress", "ChunkPress", "ChunkKVPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
            "CompressionRatioDecodingPress", "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
 
 

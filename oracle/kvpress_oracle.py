@@ -435,6 +435,13 @@ def qfilter_score(keys: np.ndarray, q_filter: np.ndarray, ctype=np.float64) -> n
     return (-(f[None, :, None, :] * k).sum(-1)).astype(np.float32)
 
 
+def simlayer_lazy_score(q_win, keys, n_initial: int, n_recent: int, ctype=np.float64) -> float:
+    """SimLayerKVPress.is_lazy's statistic (simlayerkv_press.py:49-56): window attention of the last queries (as SnapKV),
+    mean over batch, heads and window rows, then the mass on the first ``n_initial`` and the last ``n_recent`` keys."""
+    w = snapkv_window_attention(q_win, keys, ctype).mean(axis=(0, 1, 2))
+    return float(w[:n_initial].sum() + w[-n_recent:].sum())
+
+
 def tova_score(q_last, keys, ctype=np.float64) -> np.ndarray:
     """TOVAPress.score with ``attentions=None`` (tova_press.py:45-59) from the RoPE'd query of the LAST token
     ``q_last [B,Hq,1,D]``: window attention with window 1 (SnapKVPress.compute_window_attention, snapkv_press.py:41-69),

@@ -13,7 +13,7 @@ if [[ "$WHAT" == *tests* ]]; then
     timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --no-header -k "$grp" > gpurun_out/test_$grp.log 2>&1
     echo "tests[$grp] rc=$? $(tail -1 gpurun_out/test_$grp.log)"
   done
-  timeout 600 python -m pytest tests/test_pipeline.py tests/test_wrappers.py tests/test_finch.py tests/test_decoding_compression.py tests/test_reference_suite.py tests/test_think.py -m gpu -q --no-header > gpurun_out/test_pipeline.log 2>&1
+  timeout 600 python -m pytest tests/test_pipeline.py tests/test_wrappers.py tests/test_finch.py tests/test_decoding_compression.py tests/test_reference_suite.py tests/test_think.py tests/test_simlayer.py -m gpu -q --no-header > gpurun_out/test_pipeline.log 2>&1
   echo "tests[pipeline+wrappers+finch] rc=$? $(tail -1 gpurun_out/test_pipeline.log)"
   timeout 1200 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --no-header > gpurun_out/test_fullsize.log 2>&1
   echo "tests[fullsize] rc=$? $(tail -1 gpurun_out/test_fullsize.log)"
