@@ -27,6 +27,7 @@ from transformers.pipelines import PIPELINE_REGISTRY
 
 from kvpress_amd.presses.base_press import BasePress
 from kvpress_amd.presses.decoding_press import DecodingPress, PrefillDecodingPress
+from kvpress_amd.presses.dms_press import DMSPress
 from kvpress_amd.presses.finch_press import FinchPress
 from kvpress_amd.presses.key_rerotation_press import KeyRerotationPress
 
@@ -90,8 +91,9 @@ class KVPressTextGenerationPipeline(Pipeline):
     def _forward(self, input_tensors, max_new_tokens: int = 50, press: Optional[BasePress] = None,
                  cache: Optional[Cache] = None):
         """Prefill the context under the press, then one greedy answer per question (pipeline.py:173-246)."""
-        decoding = isinstance(press, (DecodingPress, PrefillDecodingPress))
-        if decoding and len(input_tensors["questions_ids"]) > 1:
+        is_decoding_press = isinstance(press, (DecodingPress, PrefillDecodingPress))
+        decoding = is_decoding_press or (isinstance(press, DMSPress) and press.decoding)   # pipeline.py:230-232
+        if is_decoding_press and len(input_tensors["questions_ids"]) > 1:
             raise ValueError("DecodingPress is not compatible with multiple questions. Please specify a single question.")
         device = self.model.device
         context_ids = input_tensors["context_ids"].to(device)

@@ -343,6 +343,8 @@ PIPELINE_CASES = {
         80, ["w5 w6 w7"], 16),
     "pipe_simlayer_lazy": (("SimLayerKVPress", dict(lazy_threshold=0.05, n_last=1, n_recent=16, n_initial=4)), 120, ["w2 w3"], 6),
     "pipe_simlayer_busy": (("SimLayerKVPress", dict(lazy_threshold=0.9, n_last=2, n_recent=16, n_initial=4)), 120, ["w2 w3"], 6),
+    "pipe_dms": (("DMSPress", dict(press=_KN(), threshold=-0.21, sliding_window_size=16)), 100, ["w2 w3", "w5"], 6),
+    "pipe_dms_decoding": (("DMSPress", dict(press=_KN(), threshold=-0.21, sliding_window_size=8, decoding=True)), 60, ["w2 w3"], 14),
     "pipe_ratio_decoding": (("CompressionRatioDecodingPress", dict(base_press=_KN(), target_compression_ratio=0.5, compression_interval=3,
                                                                     hidden_states_buffer_size=4)), 70, ["w2 w3 w4"], 13),
     # QuantizedCache write-back of the hook (base_press.py:152-157) and the pipeline's answer removal
