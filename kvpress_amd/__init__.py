@@ -16,6 +16,7 @@ from kvpress_amd.presses.chunkkv_press import ChunkKVPress
 from kvpress_amd.presses.composed_press import ComposedPress
 from kvpress_amd.presses.cur_press import CURPress
 from kvpress_amd.presses.dms_press import DMSPress
+from kvpress_amd.presses.duo_attention_press import DuoAttentionPress
 from kvpress_amd.presses.decoding_press import CompressionRatioDecodingPress, DecodingPress, PrefillDecodingPress
 from kvpress_amd.presses.expected_attention_press import ExpectedAttentionPress
 from kvpress_amd.presses.finch_press import FinchPress
@@ -37,7 +38,7 @@ from kvpress_amd.presses.tova_press import TOVAPress
 
 __version__ = "0.1.0"
 __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
-           "KeyDiffPress", "LagKVPress", "QFilterPress", "ObservedAttentionPress", "CURPress", "StreamingLLMPress", "SimLayerKVPress", "ThinKPress", "RandomPress", "ChunkPress", "ChunkKVPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "DMSPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
+           "KeyDiffPress", "LagKVPress", "QFilterPress", "ObservedAttentionPress", "CURPress", "StreamingLLMPress", "SimLayerKVPress", "ThinKPress", "RandomPress", "ChunkPress", "ChunkKVPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "DMSPress", "DuoAttentionPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
            "CompressionRatioDecodingPress", "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
 
 

@@ -308,6 +308,18 @@ def tiny_context(n_words: int, seed: int = 0) -> str:
     return " ".join(TINY_WORDS[i] for i in rng.integers(0, len(TINY_WORDS), n_words))
 
 
+def make_duo_press(ns, head_compression_ratio: float):
+    """DuoAttentionPress with seeded head scores instead of the published patterns (network), the way the reference's own
+    tests do it (tests/default_presses.py:38-42); works for the reference package and for this one."""
+    class OfflineDuoAttentionPress(ns.DuoAttentionPress):
+        @staticmethod
+        def load_attention_pattern(model):
+            n_layers, n_heads = model.config.num_hidden_layers, model.config.num_key_value_heads
+            return 2, 2, np.random.RandomState(7).rand(n_layers, n_heads)
+
+    return OfflineDuoAttentionPress(head_compression_ratio=head_compression_ratio)
+
+
 def build_press(ns, spec):
     """Instantiate a press from a nested (class name, kwargs) spec in namespace ``ns`` -- the reference package ``kvpress``
     or this package ``kvpress_amd``: the class names and constructor arguments are the same (that is the drop-in claim)."""
@@ -316,6 +328,8 @@ def build_press(ns, spec):
     if isinstance(spec, list):
         return [build_press(ns, x) for x in spec]
     cls, kw = spec
+    if cls == "DuoAttentionPress":
+        return make_duo_press(ns, **kw)
     is_spec = lambda v: (isinstance(v, tuple) and len(v) == 2 and isinstance(v[0], str) and isinstance(v[1], dict)) or \
         (isinstance(v, list) and v and isinstance(v[0], tuple))
     return getattr(ns, cls)(**{k: (build_press(ns, v) if is_spec(v) else v) for k, v in kw.items()})
@@ -345,6 +359,7 @@ PIPELINE_CASES = {
     "pipe_simlayer_busy": (("SimLayerKVPress", dict(lazy_threshold=0.9, n_last=2, n_recent=16, n_initial=4)), 120, ["w2 w3"], 6),
     "pipe_dms": (("DMSPress", dict(press=_KN(), threshold=-0.21, sliding_window_size=16)), 100, ["w2 w3", "w5"], 6),
     "pipe_dms_decoding": (("DMSPress", dict(press=_KN(), threshold=-0.21, sliding_window_size=8, decoding=True)), 60, ["w2 w3"], 14),
+    "pipe_duo": (("DuoAttentionPress", dict(head_compression_ratio=0.5)), 80, ["w2 w3", "w9"], 6),
     "pipe_ratio_decoding": (("CompressionRatioDecodingPress", dict(base_press=_KN(), target_compression_ratio=0.5, compression_interval=3,
                                                                     hidden_states_buffer_size=4)), 70, ["w2 w3 w4"], 13),
     # QuantizedCache write-back of the hook (base_press.py:152-157) and the pipeline's answer removal

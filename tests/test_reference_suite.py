@@ -63,6 +63,37 @@ def _presses_run(device, dtype):
                     assert 0 < n < 128
 
 
+def test_duo_attention_press(fake_native):
+    """tests/presses/test_duo_attention_press.py + the DuoAttention entry of test_presses_run: masks and bookkeeping."""
+    from transformers import DynamicCache
+
+    import kvpress_amd as P
+
+    model = _inputs.make_tiny_llama()
+    ids = torch.randint(3, 59, (2, 40), generator=torch.Generator().manual_seed(0))
+    for ratio in (0.2, 0.8):
+        press = _inputs.make_duo_press(P, ratio)
+        with pytest.raises(AssertionError):
+            press.compression_ratio
+        cache = DynamicCache()
+        with torch.no_grad(), press(model):
+            model(ids, past_key_values=cache)
+        n_stream = int(press.streaming_mask.sum())
+        assert n_stream == round(2 * 2 * ratio) and (press.sink_size, press.recent_size) == (2, 2)
+        assert cache.get_seq_length() == 40                                      # nothing is removed, streaming heads are masked
+        assert press.compression_ratio == pytest.approx(press.streaming_mask.float().mean().item() * (1 - 4 / 40))
+        for i, layer in enumerate(model.model.layers):
+            b, h, s_ = layer.self_attn.masked_key_indices
+            heads = torch.nonzero(press.streaming_mask[i]).flatten().tolist()
+            assert sorted(set(h.tolist())) == heads and len(b) == 2 * len(heads) * 36
+            assert int(s_.min()) == 2 and int(s_.max()) == 37 if len(heads) else True
+            layer.self_attn.masked_key_indices = None
+        with pytest.raises(AttributeError):
+            press.compression_ratio = 0.3
+    with pytest.raises(ValueError):
+        P.DuoAttentionPress(0.5).compress(model.model.layers[0].self_attn, None, torch.zeros(1, 2, 8, 6), None, None, {})
+
+
 def test_presses_run_cpu(fake_native):
     _presses_run("cpu", None)
 
