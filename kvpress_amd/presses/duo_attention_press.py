@@ -16,14 +16,21 @@ import torch
 from kvpress_amd.attention_patch import patch_attention_functions
 from kvpress_amd.presses.base_press import BasePress
 
-PATTERNS_DICT = {
-    "togethercomputer/Llama-2-7B-32K-Instruct": "Llama-2-7B-32K-Instruct/lr%3D0.02-reg%3D0.05-ctx%3D1000_32000-multi_passkey10",
-    "gradientai//Llama-3-8B-Instruct-Gradient-1048k": "Llama-3-8B-Instruct-Gradient-1048k/lr%3D0.02-reg%3D0.05-ctx%3D1000_32000-multi_passkey10",
-    "gradientai//Llama-3-8B-Instruct-Gradient-4194k": "Llama-3-8B-Instruct-Gradient-4194k/lr%3D0.02-reg%3D0.05-ctx%3D1000_32000-multi_passkey10",
-    "meta-llama/Meta-Llama-3.1-8B-Instruct": "Meta-Llama-3.1-8B-Instruct/lr=0.02-reg=0.05-ctx=1000_128000-multi_passkey10",
-    "mistralai/Mistral-7B-Instruct-v0.2": "Mistral-7B-Instruct-v0.2/lr%3D0.02-reg%3D0.05-ctx%3D1000_32000-multi_passkey10",
-    "mistralai/Mistral-7B-Instruct-v0.3": "Mistral-7B-Instruct-v0.3/lr%3D0.02-reg%3D0.05-ctx%3D1000_32000-multi_passkey10",
-}
+def _pattern_dirs() -> dict:
+    """checkpoint name -> directory of its published attention pattern in the DuoAttention repository
+    (duo_attention_press.py:18-25): ``<model>/lr=0.02-reg=0.05-ctx=1000_<max ctx>-multi_passkey10`` (the older entries
+    are stored URL-encoded there)."""
+    table = [("togethercomputer/", "Llama-2-7B-32K-Instruct", 32000, True), ("gradientai//", "Llama-3-8B-Instruct-Gradient-1048k", 32000, True),
+             ("gradientai//", "Llama-3-8B-Instruct-Gradient-4194k", 32000, True), ("meta-llama/", "Meta-Llama-3.1-8B-Instruct", 128000, False),
+             ("mistralai/", "Mistral-7B-Instruct-v0.2", 32000, True), ("mistralai/", "Mistral-7B-Instruct-v0.3", 32000, True)]
+    out = {}
+    for org, model, ctx, encoded in table:
+        eq = "%3D" if encoded else "="
+        out[org + model] = f"{model}/lr{eq}0.02-reg{eq}0.05-ctx{eq}1000_{ctx}-multi_passkey10"
+    return out
+
+
+PATTERNS_DICT = _pattern_dirs()
 
 
 @dataclass
