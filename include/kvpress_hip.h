@@ -98,6 +98,12 @@ int kvp_think_channel_scores(const void* q, int64_t q_sb, int64_t q_sh, int64_t 
 int kvp_zero_channels(void* x, int64_t sb, int64_t sh, int64_t ss, int dtype, int64_t B, int64_t H, int64_t S, int64_t D,
                       const int32_t* idx, int64_t n, kvp_stream_t stream);
 
+/* ---- CriticalKVPress.vwl1norm: `torch.norm(head_WoV, p=1, dim=-1)` (kvpress/presses/criticalkv_press.py:70-73) ---------
+ * out[r] = scale * sum_c |x[r,c]| over the rows of a 2-D view [R, N] (row_stride in elements, rows contiguous): the L1 norm of
+ * every token's value vector after the head's slice of the output projection (that projection is a plain library GEMM on the
+ * model's own o_proj weight and stays with the caller).  out contiguous [R] float32. */
+int kvp_rowl1_score(const void* x, int dtype, int64_t R, int64_t N, int64_t row_stride, float scale, float* out, kvp_stream_t stream);
+
 /* ---- SnapKVPress.score (kvpress/presses/snapkv_press.py:60-105) ----------------------------
  * q: RoPE'd queries of the last W tokens [B,Hq,W,D] (the host keeps q_proj + RoPE,
  *    snapkv_press.py:53-58 / utils.py:43-46: q_proj is a model-owned nn.Linear);

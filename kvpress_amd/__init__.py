@@ -14,6 +14,7 @@ from kvpress_amd.presses.block_press import BlockPress
 from kvpress_amd.presses.chunk_press import ChunkPress
 from kvpress_amd.presses.chunkkv_press import ChunkKVPress
 from kvpress_amd.presses.composed_press import ComposedPress
+from kvpress_amd.presses.criticalkv_press import CriticalAdaKVPress, CriticalKVPress
 from kvpress_amd.presses.cur_press import CURPress
 from kvpress_amd.presses.dms_press import DMSPress
 from kvpress_amd.presses.duo_attention_press import DuoAttentionPress
@@ -38,7 +39,7 @@ from kvpress_amd.presses.tova_press import TOVAPress
 
 __version__ = "0.1.0"
 __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
-           "KeyDiffPress", "LagKVPress", "QFilterPress", "ObservedAttentionPress", "CURPress", "StreamingLLMPress", "SimLayerKVPress", "ThinKPress", "RandomPress", "ChunkPress", "ChunkKVPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "DMSPress", "DuoAttentionPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
+           "KeyDiffPress", "LagKVPress", "QFilterPress", "ObservedAttentionPress", "CURPress", "StreamingLLMPress", "SimLayerKVPress", "ThinKPress", "RandomPress", "ChunkPress", "ChunkKVPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "CriticalKVPress", "CriticalAdaKVPress", "DMSPress", "DuoAttentionPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
            "CompressionRatioDecodingPress", "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
 
 

@@ -24,7 +24,7 @@ def main(argv):
     gen_golden._install_shims()
     import numpy as np
     import torch
-    from kvpress import AdaKVPress, BlockPress, ChunkKVPress, ChunkPress, KeyDiffPress, KeyRerotationPress, KnormPress, SnapKVPress, StreamingLLMPress
+    from kvpress import AdaKVPress, BlockPress, ChunkKVPress, ChunkPress, CriticalAdaKVPress, CriticalKVPress, KeyDiffPress, KeyRerotationPress, KnormPress, SnapKVPress, StreamingLLMPress
 
     import _inputs
 
@@ -46,6 +46,10 @@ def main(argv):
                 return AdaKVPress(inner(ratio), alpha_safeguard=s["alpha"])
             if s["wrapper"] == "block":
                 return BlockPress(inner(ratio), block_size=s["block_size"])
+            if s["wrapper"] == "critical":
+                return CriticalKVPress(inner(ratio))
+            if s["wrapper"] == "criticalada":
+                return CriticalAdaKVPress(inner(ratio), alpha_safeguard=s["alpha"])
             if s["wrapper"] == "chunkkv":
                 return ChunkKVPress(inner(ratio), chunk_length=s["chunk_length"])
             return ChunkPress(inner(ratio), chunk_length=s["chunk_length"]) if s["wrapper"] == "chunk" else KeyRerotationPress(inner(ratio))
@@ -57,14 +61,29 @@ def main(argv):
             keys = torch.from_numpy(s["keys"]).to(dt)
             posv = torch.arange(s["S"], dtype=torch.float32)[None, None, :, None].expand(s["B"], s["H"], s["S"], s["D"]).contiguous()
             kwargs = {"position_embeddings": pe}
-            if s["wrapper"] == "adakv":
+            if s["wrapper"] == "critical":
+                # a ScorerPress that reads the VALUES (||Wo v||_1): real values; the float32 run's scores and the kept sets
+                if mode == "f32":
+                    values = torch.from_numpy(s["values"]).to(dt)
+                    with torch.no_grad():
+                        for i, r in enumerate(s["ratios"]):
+                            p = wrap(r)
+                            sc = p.score(att, hidden, keys, values, None, kwargs)
+                            out[f"scores_{i}"] = sc.numpy()
+                            ko, vo = p.compress(att, hidden, keys, values, None, kwargs)
+                            n = ko.shape[2]
+                            assert n == int(s["S"] * (1 - r))
+                            out[f"pos_{i}"] = sc.topk(n, dim=-1).indices.sort(dim=-1).values.numpy().astype(np.int32)
+                continue
+            if s["wrapper"] in ("adakv", "criticalada"):
                 # K/V stay untouched; the pruned (batch, head, position) triples land in module.masked_key_indices
                 # (adakv_press.py:70-75).  Stored: sorted flat indices head * S + position per batch element (float32 run).
                 if mode == "f32":
                     att.config._attn_implementation = "sdpa"
                     with torch.no_grad():
                         for i, r in enumerate(s["ratios"]):
-                            ko, vo = wrap(r).compress(att, hidden, keys, posv, None, kwargs)
+                            vals = torch.from_numpy(s["values"]).to(dt) if s["wrapper"] == "criticalada" else posv
+                            ko, vo = wrap(r).compress(att, hidden, keys, vals, None, kwargs)
                             assert ko is keys
                             bi, hi, si = att.masked_key_indices
                             flat = (hi * s["S"] + si).reshape(s["B"], -1)

@@ -203,6 +203,10 @@ def build_llama_attention(s: dict, dtype, device="cpu"):
     att = LlamaAttention(cfg, layer_idx=0)
     with torch.no_grad():
         att.q_proj.weight.copy_(torch.from_numpy(s["wq"]))
+        # the other projections are seeded too (CriticalKV reads o_proj): module creation order must not matter
+        rs = np.random.RandomState(s["seed"] + 4000)
+        wo = (rs.standard_normal(tuple(att.o_proj.weight.shape)) * (1.0 / math.sqrt(att.o_proj.weight.shape[1]))).astype(np.float32)
+        att.o_proj.weight.copy_(torch.from_numpy(round_to(wo, s["dtype"])))
     rot = LlamaRotaryEmbedding(cfg)
     att = att.to(device=device, dtype=dtype)
     rot = rot.to(device)
@@ -444,6 +448,14 @@ WRAP_CASES = {
                                      chunk_length=64, W=8, ks=5, ratios=(0.5, 0.97)),
     "wrap_chunkkv_short": dict(wrapper="chunkkv", kind="knorm", B=1, H=2, G=1, S=15, D=16, dtype="f32", data="A", seed=96,
                                chunk_length=20, ratios=(0.5,)),
+    "wrap_critical_knorm": dict(wrapper="critical", kind="knorm", B=2, H=2, G=2, S=300, D=16, dtype="f32", data="B", seed=97,
+                                ratios=(0.25, 0.5, 0.9)),
+    "wrap_critical_snapkv_bf16": dict(wrapper="critical", kind="snapkv", B=1, H=2, G=4, S=700, D=128, dtype="bf16", data="B", seed=98,
+                                      W=64, ks=5, ratios=(0.5,)),
+    "wrap_criticalada_knorm": dict(wrapper="criticalada", kind="knorm", B=1, H=4, G=1, S=300, D=16, dtype="f32", data="B", seed=99,
+                                   alpha=0.2, ratios=(0.25, 0.5, 0.9)),
+    "wrap_criticalada_snapkv": dict(wrapper="criticalada", kind="snapkv", B=1, H=2, G=4, S=700, D=128, dtype="f32", data="B", seed=100,
+                                    alpha=0.5, W=64, ks=5, ratios=(0.5,)),
     "wrap_adakv_knorm": dict(wrapper="adakv", kind="knorm", B=2, H=4, G=1, S=300, D=16, dtype="f32", data="B", seed=88, alpha=0.2,
                              ratios=(0.25, 0.5, 0.9)),
     "wrap_adakv_snapkv": dict(wrapper="adakv", kind="snapkv", B=1, H=2, G=4, S=700, D=128, dtype="f32", data="B", seed=89, alpha=0.5,
