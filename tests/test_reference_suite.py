@@ -37,7 +37,8 @@ def _presses_run(device, dtype):
 
     model = _inputs.make_tiny_llama(dtype=dtype, device=device)
     ids = torch.randint(3, 59, (1, 128), generator=torch.Generator().manual_seed(0)).to(device)
-    for wrapper in (None, P.ComposedPress, P.KeyRerotationPress, P.AdaKVPress, P.ChunkPress, P.BlockPress):
+    for wrapper in (None, P.ComposedPress, P.KeyRerotationPress, P.AdaKVPress, P.ChunkPress, P.BlockPress, P.ChunkKVPress, P.CriticalKVPress,
+                    P.CriticalAdaKVPress, P.DMSPress):
         for cls, kw_list in _scorer_configs(P):
             for kwargs in kw_list:
                 press = _make(P, cls, kwargs, model)
@@ -47,6 +48,8 @@ def _presses_run(device, dtype):
                     press = P.ChunkPress(press=press, chunk_length=24)
                 elif wrapper is P.BlockPress:
                     press = P.BlockPress(press=press, block_size=32)
+                elif wrapper is P.DMSPress:
+                    press = P.DMSPress(press=press, threshold=-0.5, sliding_window_size=32)      # the reference's setting (:100)
                 elif wrapper is not None:
                     press = wrapper(press=press)
                 press.post_init_from_model(model)
@@ -55,9 +58,11 @@ def _presses_run(device, dtype):
                     model(ids, past_key_values=cache)
                 assert hasattr(press, "compression_ratio")
                 n = cache.get_seq_length()
-                if wrapper is P.AdaKVPress:
+                if wrapper in (P.AdaKVPress, P.CriticalAdaKVPress, P.DMSPress):
                     assert n == 128                                # head-wise pruning masks, nothing is removed
-                elif wrapper in (None, P.KeyRerotationPress, P.BlockPress) and cls is not P.PyramidKVPress:
+                    for layer in model.model.layers:
+                        layer.self_attn.masked_key_indices = None
+                elif wrapper in (None, P.KeyRerotationPress, P.BlockPress, P.CriticalKVPress) and cls is not P.PyramidKVPress:
                     assert n == int(128 * (1 - kwargs["compression_ratio"])), (cls.__name__, wrapper, n)
                 else:
                     assert 0 < n < 128
