@@ -1,12 +1,10 @@
 """kvpress_amd: MI355X-native score -> top-k -> gather hot path of NVIDIA/kvpress.
 
-Public API mirrors the reference for this path (same class names, dataclass fields and
-method signatures): BasePress, ScorerPress, KnormPress, SnapKVPress, ExpectedAttentionPress, the scorers that reuse
-the path's kernels (PyramidKVPress, TOVAPress, KeyDiffPress, StreamingLLMPress, RandomPress), the selection wrappers
-ChunkPress and KeyRerotationPress, and the
-"kv-press-text-generation" pipeline (registered on import, like the reference).
-Everything below ``ScorerPress.compress`` runs in hand-written HIP kernels (gfx950) reached
-through the C ABI of include/kvpress_hip.h; there is no CPU or pure-PyTorch fallback.
+The public API mirrors the reference's (same class names, dataclass fields and method signatures): BasePress / ScorerPress,
+the three core scorers (KnormPress, SnapKVPress, ExpectedAttentionPress), the scorers and wrappers that build on the same
+kernels (see __all__ and DESIGN.md section 8) and the "kv-press-text-generation" pipeline, registered on import like the
+reference's.  Everything below ``compress()`` runs in hand-written HIP kernels (gfx950) reached through the C ABI of
+include/kvpress_hip.h; there is no CPU or pure-PyTorch fallback.
 """
 from kvpress_amd.presses.adakv_press import AdaKVPress
 from kvpress_amd.presses.base_press import BasePress
