@@ -9,6 +9,9 @@
 //     first S - W columns for n_kept - W entries and the window positions are appended (they are the largest
 //     positions, so the ascending-position order is preserved).  n_kept < W (fewer survivors than window tokens) takes
 //     the unfused sequence.
+//   * short rows (<= 16384 scores, topk_row_eligible): the select is ONE launch (one workgroup per row) and takes no fused
+//     histogram; up to 4096 columns SnapKV's pooling + scaling also happen inside that launch's loader
+//     (topk_select_pooled_rows), so neither the pooling launch nor the score round trip exists.
 // Scores and indices live in the caller's workspace and never leave the device.
 #include "kvp_common.h"
 #include "snapkv_internal.h"
