@@ -11,10 +11,11 @@ The arithmetic is done in ``ctype`` (float64 by default: the "exact math" the
 fp32 reference and the fp32 HIP kernels both approximate to ~1e-6; float32 for
 the large cpu_baseline runs) and results are returned as float32.
 
-Parity pin: ``oracle/gen_golden.py`` runs the *real* reference (imported from
+Parity pin: ``oracle/gen_golden*.py`` run the *real* reference (imported from
 /root/reference, torch CPU, fp32 mode and bf16 mode) on the seeded inputs of
-``tests/_inputs.py`` and commits its outputs under ``tests/golden/``;
-``tests/test_oracle_golden.py`` checks this file against those fixtures.
+``tests/_inputs.py`` and commit its outputs under ``tests/golden/``;
+``tests/test_oracle_golden.py`` (scorers), ``tests/test_wrappers.py``, ``tests/test_finch.py``
+and ``tests/test_think.py`` check this file against those fixtures.
 Caveat stated by SURVEY.md §8(c): the reference's own tests hold no score
 values for SnapKV / ExpectedAttention and torch.topk's tie order is
 unspecified, so the pin is "reference executed here", not "reference's own
@@ -51,6 +52,18 @@ __all__ = [
     "topk_is_valid",
     "gather_kv",
     "compress",
+    "finch_score",
+    "finch_indices",
+    "observed_attention_score",
+    "lagkv_score",
+    "think_channel_scores",
+    "think_prune",
+    "qfilter_score",
+    "simlayer_lazy_score",
+    "chunkkv_indices",
+    "vwl1norm",
+    "critical_scores",
+    "criticalada_pruned",
 ]
 
 
