@@ -18,6 +18,7 @@ from kvpress_amd.presses.dms_press import DMSPress
 from kvpress_amd.presses.duo_attention_press import DuoAttentionPress
 from kvpress_amd.presses.decoding_press import CompressionRatioDecodingPress, DecodingPress, PrefillDecodingPress
 from kvpress_amd.presses.expected_attention_press import ExpectedAttentionPress
+from kvpress_amd.presses.expected_attention_with_stats import ExpectedAttentionStatsPress
 from kvpress_amd.presses.finch_press import FinchPress
 from kvpress_amd.presses.key_rerotation_press import KeyRerotationPress
 from kvpress_amd.presses.keydiff_press import KeyDiffPress
@@ -36,7 +37,7 @@ from kvpress_amd.presses.think_press import ThinKPress
 from kvpress_amd.presses.tova_press import TOVAPress
 
 __version__ = "0.1.0"
-__all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "PyramidKVPress", "TOVAPress",
+__all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAttentionPress", "ExpectedAttentionStatsPress", "PyramidKVPress", "TOVAPress",
            "KeyDiffPress", "LagKVPress", "QFilterPress", "ObservedAttentionPress", "CURPress", "StreamingLLMPress", "SimLayerKVPress", "ThinKPress", "RandomPress", "ChunkPress", "ChunkKVPress", "BlockPress", "KeyRerotationPress", "FinchPress", "AdaKVPress", "CriticalKVPress", "CriticalAdaKVPress", "DMSPress", "DuoAttentionPress", "ComposedPress", "PerLayerCompressionPress", "DecodingPress",
            "CompressionRatioDecodingPress", "PrefillDecodingPress", "KVPressTextGenerationPipeline"]
 

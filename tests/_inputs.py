@@ -324,6 +324,20 @@ def make_duo_press(ns, head_compression_ratio: float):
     return OfflineDuoAttentionPress(head_compression_ratio=head_compression_ratio)
 
 
+def make_ea_stats_press(ns, model_config=None, **kw):
+    """ExpectedAttentionStatsPress with seeded statistics assigned directly (the published ones need the hub): mean ~ N(0, 0.3),
+    covariance = A A^T / D + 0.1 I per (layer, head), for the tiny Llama geometry (2 layers, 4 heads, head_dim 6)."""
+    import torch
+
+    L, Hq, D = 2, 4, 6
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(L, Hq, D, D, generator=g)
+    press = ns.ExpectedAttentionStatsPress(**kw)
+    press.mu = 0.3 * torch.randn(L, Hq, D, generator=g)
+    press.cov = A @ A.transpose(-1, -2) / D + 0.1 * torch.eye(D)
+    return press
+
+
 def build_press(ns, spec):
     """Instantiate a press from a nested (class name, kwargs) spec in namespace ``ns`` -- the reference package ``kvpress``
     or this package ``kvpress_amd``: the class names and constructor arguments are the same (that is the drop-in claim)."""
@@ -334,6 +348,8 @@ def build_press(ns, spec):
     cls, kw = spec
     if cls == "DuoAttentionPress":
         return make_duo_press(ns, **kw)
+    if cls == "ExpectedAttentionStatsPress":
+        return make_ea_stats_press(ns, **kw)
     is_spec = lambda v: (isinstance(v, tuple) and len(v) == 2 and isinstance(v[0], str) and isinstance(v[1], dict)) or \
         (isinstance(v, list) and v and isinstance(v[0], tuple))
     return getattr(ns, cls)(**{k: (build_press(ns, v) if is_spec(v) else v) for k, v in kw.items()})
@@ -364,6 +380,8 @@ PIPELINE_CASES = {
     "pipe_dms": (("DMSPress", dict(press=_KN(), threshold=-0.21, sliding_window_size=16)), 100, ["w2 w3", "w5"], 6),
     "pipe_dms_decoding": (("DMSPress", dict(press=_KN(), threshold=-0.21, sliding_window_size=8, decoding=True)), 60, ["w2 w3"], 14),
     "pipe_duo": (("DuoAttentionPress", dict(head_compression_ratio=0.5)), 80, ["w2 w3", "w9"], 6),
+    "pipe_ea_stats": (("ExpectedAttentionStatsPress", dict(compression_ratio=0.5, n_sink=2, n_future_positions=64)), 90, ["w2 w3", "w7"], 6),
+    "pipe_ea_stats_nocov": (("ExpectedAttentionStatsPress", dict(compression_ratio=0.3, use_covariance=False, use_vnorm=False)), 50, ["w1"], 6),
     "pipe_ratio_decoding": (("CompressionRatioDecodingPress", dict(base_press=_KN(), target_compression_ratio=0.5, compression_interval=3,
                                                                     hidden_states_buffer_size=4)), 70, ["w2 w3 w4"], 13),
     # QuantizedCache write-back of the hook (base_press.py:152-157) and the pipeline's answer removal
