@@ -37,6 +37,54 @@ __global__ __launch_bounds__(TH_THREADS) void colsumsq_kernel(const typename Ele
     }
 }
 
+// the same partials through 16-byte loads: LPR adjacent lanes own one row (rownorm.hip's layout), a lane keeps the sums of its
+// 8 (4 for fp32) channels over the rows it visits, the row groups of the block are combined through LDS.  grid.x blocks stride
+// over the rows of (b, h) together; partial[bh][block][d].
+template <int DT, int LPR>
+__global__ __launch_bounds__(TH_THREADS) void colsumsq_vec_kernel(const typename Elem<DT>::T* __restrict__ x, int64_t sb, int64_t sh, int64_t ss,
+                                                                  uint32_t H, uint32_t S, uint32_t chunks, float* __restrict__ partial) {
+    using T = typename Elem<DT>::T;
+    constexpr int PER16 = Elem<DT>::PER16;
+    constexpr int GPB = TH_THREADS / LPR;
+    constexpr int UNROLL = 4;
+    __shared__ float red[GPB][LPR * PER16 + 1];
+    const uint32_t bh = blockIdx.y;
+    const uint32_t b = bh / H, h = bh - b * H;
+    const T* __restrict__ base = x + (int64_t)b * sb + (int64_t)h * sh;
+    const uint32_t lir = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const uint32_t g = blockIdx.x * GPB + grp, TG = gridDim.x * GPB;
+    float acc[PER16];
+#pragma unroll
+    for (int j = 0; j < PER16; ++j) acc[j] = 0.f;
+    for (uint32_t s0 = g; s0 < S; s0 += TG * UNROLL) {
+        uint4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const uint32_t s = s0 + u * TG;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (s < S && lir < chunks) v[u] = *reinterpret_cast<const uint4*>(base + (int64_t)s * ss + (size_t)lir * PER16);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            float f[PER16];
+            unpack16<DT>(v[u], f);
+#pragma unroll
+            for (int j = 0; j < PER16; ++j) acc[j] = fmaf(f[j], f[j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PER16; ++j) red[grp][lir * PER16 + j] = acc[j];
+    __syncthreads();
+    const uint32_t D = chunks * PER16;
+    float* __restrict__ out = partial + ((size_t)bh * gridDim.x + blockIdx.x) * D;
+    for (uint32_t d = threadIdx.x; d < D; d += TH_THREADS) {
+        float t = 0.f;
+#pragma unroll 4
+        for (int r = 0; r < GPB; ++r) t += red[r][d];
+        out[d] = t;
+    }
+}
+
 // scores[bh][d] = (mean over the group's q-heads and window rows of q^2) * (sum of the partials / S)
 template <int DT>
 __global__ __launch_bounds__(TH_THREADS) void think_finish_kernel(const float* __restrict__ partial, uint32_t nchunk, const typename Elem<DT>::T* __restrict__ q,
@@ -100,20 +148,37 @@ extern "C" int kvp_think_channel_scores(const void* q, int64_t q_sb, int64_t q_s
         kvp_set_error("think: workspace too small (%zu < %zu)", ws_bytes, need);
         return KVP_EWORKSPACE;
     }
-    const uint32_t nchunk = (uint32_t)((S + TH_ROWS - 1) / TH_ROWS), BH = (uint32_t)(B * Hkv);
+    uint32_t nchunk = (uint32_t)((S + TH_ROWS - 1) / TH_ROWS);
+    const uint32_t BH = (uint32_t)(B * Hkv);
+    const size_t es = (size_t)kvp_elem_size(dtype), rowbytes = (size_t)D * es;
+    const bool vec = rowbytes % 16 == 0 && rowbytes <= 1024 && ((uintptr_t)k % 16 == 0) && (k_sb * es) % 16 == 0 && (k_sh * es) % 16 == 0 &&
+                     (k_ss * es) % 16 == 0;
+    if (vec) nchunk = std::max<uint32_t>(1, std::min<uint32_t>(nchunk, 2048 / std::max<uint32_t>(1, BH)));  // blocks striding over the rows
     uint32_t Dp = 1;
     while (Dp < (uint32_t)D) Dp <<= 1;   // power of two: TH_THREADS / Dp row phases
     const size_t lds = (size_t)(TH_THREADS / Dp) * D * 4;
     float* partial = static_cast<float*>(ws);
+    const uint32_t chunks = (uint32_t)(rowbytes / 16);
+    int lpr = 1;
+    while (lpr < 64 && (uint32_t)lpr < chunks) lpr <<= 1;
+#define KVP_TH_VEC(DT, L)                                                                                                                    \
+    case L:                                                                                                                                  \
+        KVP_LAUNCH("colsumsq_vec_kernel", stream, (colsumsq_vec_kernel<DT, L><<<dim3(nchunk, BH), TH_THREADS, 0, stream>>>(static_cast<const Elem<DT>::T*>(k), k_sb, k_sh, \
+                                                                                                                         k_ss, (uint32_t)Hkv, (uint32_t)S, chunks, partial))); \
+        break;
 #define KVP_TH(DT)                                                                                                                           \
-    KVP_LAUNCH("colsumsq_kernel", stream, colsumsq_kernel<DT><<<dim3(nchunk, BH), TH_THREADS, lds, stream>>>(static_cast<const Elem<DT>::T*>(k), k_sb, k_sh, k_ss, \
-                                                                                                             (uint32_t)Hkv, (uint32_t)S, (uint32_t)D, Dp, partial)); \
+    if (vec) {                                                                                                                               \
+        switch (lpr) { KVP_TH_VEC(DT, 1) KVP_TH_VEC(DT, 2) KVP_TH_VEC(DT, 4) KVP_TH_VEC(DT, 8) KVP_TH_VEC(DT, 16) KVP_TH_VEC(DT, 32) KVP_TH_VEC(DT, 64) } \
+    } else                                                                                                                                   \
+        KVP_LAUNCH("colsumsq_kernel", stream, colsumsq_kernel<DT><<<dim3(nchunk, BH), TH_THREADS, lds, stream>>>(static_cast<const Elem<DT>::T*>(k), k_sb, k_sh, k_ss, \
+                                                                                                                 (uint32_t)Hkv, (uint32_t)S, (uint32_t)D, Dp, partial)); \
     KVP_LAUNCH("think_finish_kernel", stream, think_finish_kernel<DT><<<BH, TH_THREADS, 0, stream>>>(partial, nchunk, static_cast<const Elem<DT>::T*>(q), q_sb, q_sh, \
                                                                                                      q_sw, (uint32_t)Hkv, (uint32_t)(Hq / Hkv), (uint32_t)W, (uint32_t)S, (uint32_t)D, scores))
     if (dtype == KVP_F32) { KVP_TH(KVP_F32); }
     else if (dtype == KVP_F16) { KVP_TH(KVP_F16); }
     else { KVP_TH(KVP_BF16); }
 #undef KVP_TH
+#undef KVP_TH_VEC
     KVP_CHECK_LAUNCH("think(channel scores)");
     return KVP_OK;
 }
