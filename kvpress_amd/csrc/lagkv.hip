@@ -8,7 +8,8 @@
 // replaced by its rank inside the partition divided by lag_size (`argsort().argsort() / lag_size`).  Sinks, the last
 // complete partition and the remainder score 1.
 //
-// One workgroup (4 waves) per (b, h, partition): a wave per token row, lanes across the channels (coalesced rows), channel
+// One workgroup (4 waves) per (b, h, partition).  Fast path (rows of whole 16-byte vectors, <= 1 KiB): LPR adjacent lanes own a
+// row, one dwordx4 load each (2.8 TB/s of algorithmic bytes at 128k keys); otherwise a wave per token row, lanes across the channels; channel
 // min / max of the reference partition in registers -> LDS, two-pass standard deviation in registers, softmax and ranking
 // over the <= 1024 tokens of the partition in LDS.  K and V are each read twice (as reference and as data): HBM / L2 bound.
 // Ranks are exact integers; equal scores rank by position (torch.argsort leaves their order open).
@@ -28,6 +29,8 @@ struct LagArgs {
     uint32_t H, S, D, n_sink, lag, n_scored;      // n_scored partitions get a real score
     int cross;
 };
+
+__device__ void lag_softmax(float* __restrict__ out, uint32_t lag, float* __restrict__ scr);
 
 // softmax(std over channels of the normalised rows) of partition `part` of x, into out[0..lag)
 template <int DT>
@@ -98,7 +101,12 @@ __device__ void lag_states_score(const typename Elem<DT>::T* __restrict__ base, 
         if (lane == 0) out[r] = sqrtf(sq / (float)(D - 1));
     }
     __syncthreads();
-    // ---- softmax over the partition's tokens ----
+    lag_softmax(out, lag, scr);
+}
+
+// softmax over out[0..lag), in place (all threads; ends with a barrier)
+__device__ void lag_softmax(float* __restrict__ out, uint32_t lag, float* __restrict__ scr) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float m = -INFINITY;
     for (uint32_t r = threadIdx.x; r < lag; r += LG_THREADS) m = fmaxf(m, out[r]);
     m = wave_max(m);
@@ -120,21 +128,8 @@ __device__ void lag_states_score(const typename Elem<DT>::T* __restrict__ base, 
     __syncthreads();
 }
 
-template <int DT>
-__global__ __launch_bounds__(LG_THREADS) void lagkv_score_kernel(LagArgs a, float* __restrict__ scores) {
-    extern __shared__ float lg_lds[];
-    float* sk = lg_lds;                 // [lag]
-    float* sv = sk + a.lag;             // [lag]
-    float* cmin = sv + a.lag;           // [LG_WAVES][D]
-    float* cmax = cmin + LG_WAVES * a.D;
-    __shared__ float scr[LG_WAVES];
-    using T = typename Elem<DT>::T;
-    const uint32_t part = blockIdx.x, bh = blockIdx.y;
-    const uint32_t b = bh / a.H, h = bh - b * a.H;
-    const uint32_t row0 = a.n_sink + part * a.lag;
-    lag_states_score<DT>(static_cast<const T*>(a.k) + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh, a.k_ss, a.D, a.lag, row0, cmin, cmax, sk, scr);
-    lag_states_score<DT>(static_cast<const T*>(a.v) + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh, a.v_ss, a.D, a.lag, row0, cmin, cmax, sv, scr);
-    float* out = scores + (size_t)bh * a.S + row0;
+// average of the K and V scores, then the raw score (cross_scoring) or its rank inside the partition / lag_size
+__device__ void lag_finish(float* __restrict__ sk, const float* __restrict__ sv, const LagArgs& a, float* __restrict__ out) {
     for (uint32_t i = threadIdx.x; i < a.lag; i += LG_THREADS) sk[i] = (sk[i] + sv[i]) / 2.f;
     __syncthreads();
     if (a.cross) {
@@ -151,6 +146,113 @@ __global__ __launch_bounds__(LG_THREADS) void lagkv_score_kernel(LagArgs a, floa
         }
         out[i] = (float)rank / (float)a.lag;
     }
+}
+
+template <int DT>
+__global__ __launch_bounds__(LG_THREADS) void lagkv_score_kernel(LagArgs a, float* __restrict__ scores) {
+    extern __shared__ float lg_lds[];
+    float* sk = lg_lds;                 // [lag]
+    float* sv = sk + a.lag;             // [lag]
+    float* cmin = sv + a.lag;           // [LG_WAVES][D]
+    float* cmax = cmin + LG_WAVES * a.D;
+    __shared__ float scr[LG_WAVES];
+    using T = typename Elem<DT>::T;
+    const uint32_t part = blockIdx.x, bh = blockIdx.y;
+    const uint32_t b = bh / a.H, h = bh - b * a.H;
+    const uint32_t row0 = a.n_sink + part * a.lag;
+    lag_states_score<DT>(static_cast<const T*>(a.k) + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh, a.k_ss, a.D, a.lag, row0, cmin, cmax, sk, scr);
+    lag_states_score<DT>(static_cast<const T*>(a.v) + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh, a.v_ss, a.D, a.lag, row0, cmin, cmax, sv, scr);
+    lag_finish(sk, sv, a, scores + (size_t)bh * a.S + row0);
+}
+
+// ---- the same through 16-byte loads: LPR adjacent lanes own one row (rownorm.hip's layout) -------------------------------
+// a lane keeps min / max of ITS 8 (4 for fp32) channels over the reference rows it visits; the block's row groups are
+// combined through LDS; the per-row mean and variance are xor-shuffle reductions over the LPR lanes of the row.
+template <int DT, int LPR>
+__device__ void lag_states_score_vec(const typename Elem<DT>::T* __restrict__ base, int64_t ss, uint32_t chunks, uint32_t lag, uint32_t row0,
+                                     float* __restrict__ cmin, float* __restrict__ cmax, float* __restrict__ out, float* __restrict__ scr) {
+    constexpr int PER16 = Elem<DT>::PER16;
+    constexpr int GPB = LG_THREADS / LPR;
+    const uint32_t lir = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const uint32_t D = chunks * PER16;
+    const bool live = lir < chunks;
+    float mn[PER16], mx[PER16];
+#pragma unroll
+    for (int j = 0; j < PER16; ++j) { mn[j] = INFINITY; mx[j] = -INFINITY; }
+    if (live)
+        for (uint32_t r = grp; r < lag; r += GPB) {
+            float f[PER16];
+            unpack16<DT>(*reinterpret_cast<const uint4*>(base + (int64_t)(row0 + lag + r) * ss + (size_t)lir * PER16), f);
+#pragma unroll
+            for (int j = 0; j < PER16; ++j) { mn[j] = fminf(mn[j], f[j]); mx[j] = fmaxf(mx[j], f[j]); }
+        }
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < PER16; ++j) {
+            cmin[grp * D + lir * PER16 + j] = mn[j];
+            cmax[grp * D + lir * PER16 + j] = mx[j];
+        }
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < PER16; ++j) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (int g = 0; g < GPB; ++g) {
+                lo = fminf(lo, cmin[g * D + lir * PER16 + j]);
+                hi = fmaxf(hi, cmax[g * D + lir * PER16 + j]);
+            }
+            mn[j] = lo;
+            mx[j] = hi;
+        }
+    }
+    // rows of the scored partition: every row group walks the same number of rounds (the shuffles below need whole waves)
+    for (uint32_t r0 = 0; r0 < lag; r0 += GPB) {
+        const uint32_t r = r0 + grp;
+        float y[PER16], sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < PER16; ++j) y[j] = 0.f;
+        if (live && r < lag) {
+            float f[PER16];
+            unpack16<DT>(*reinterpret_cast<const uint4*>(base + (int64_t)(row0 + r) * ss + (size_t)lir * PER16), f);
+#pragma unroll
+            for (int j = 0; j < PER16; ++j) {
+                y[j] = (f[j] - mn[j]) / (mx[j] - mn[j]);
+                sum += y[j];
+            }
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum / (float)D;
+        float sq = 0.f;
+        if (live && r < lag) {
+#pragma unroll
+            for (int j = 0; j < PER16; ++j) sq += (y[j] - mean) * (y[j] - mean);
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        if (lir == 0 && r < lag) out[r] = sqrtf(sq / (float)(D - 1));
+    }
+    __syncthreads();
+    lag_softmax(out, lag, scr);
+}
+
+template <int DT, int LPR>
+__global__ __launch_bounds__(LG_THREADS) void lagkv_score_vec_kernel(LagArgs a, uint32_t chunks, float* __restrict__ scores) {
+    extern __shared__ float lg_lds[];
+    constexpr int GPB = LG_THREADS / LPR;
+    float* sk = lg_lds;
+    float* sv = sk + a.lag;
+    float* cmin = sv + a.lag;            // [GPB][D]
+    float* cmax = cmin + GPB * a.D;
+    __shared__ float scr[LG_WAVES];
+    using T = typename Elem<DT>::T;
+    const uint32_t part = blockIdx.x, bh = blockIdx.y;
+    const uint32_t b = bh / a.H, h = bh - b * a.H;
+    const uint32_t row0 = a.n_sink + part * a.lag;
+    lag_states_score_vec<DT, LPR>(static_cast<const T*>(a.k) + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh, a.k_ss, chunks, a.lag, row0, cmin, cmax, sk, scr);
+    lag_states_score_vec<DT, LPR>(static_cast<const T*>(a.v) + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh, a.v_ss, chunks, a.lag, row0, cmin, cmax, sv, scr);
+    lag_finish(sk, sv, a, scores + (size_t)bh * a.S + row0);
 }
 
 // sinks, the last complete partition and the remainder: 1
@@ -183,8 +285,30 @@ extern "C" int kvp_lagkv_score(const void* k, int64_t k_sb, int64_t k_sh, int64_
     const uint32_t BH = (uint32_t)(B * H);
     const uint32_t scored_end = (uint32_t)(n_sink + (n_part - 1) * lag_size);
     KVP_LAUNCH("lagkv_ones_kernel", stream, lagkv_ones_kernel<<<dim3((uint32_t)std::min<int64_t>((S + 255) / 256, 1024), BH), 256, 0, stream>>>(scores, (uint32_t)S, (uint32_t)n_sink, scored_end));
-    const size_t lds = ((size_t)2 * lag_size + (size_t)2 * LG_WAVES * D) * 4;
     const dim3 grid(a.n_scored, BH);
+    const size_t es = (size_t)kvp_elem_size(dtype), rowbytes = (size_t)D * es;
+    auto al16 = [&](int64_t st) { return ((size_t)st * es) % 16 == 0; };
+    const bool vec = rowbytes % 16 == 0 && rowbytes <= 1024 && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && al16(k_sb) && al16(k_sh) && al16(k_ss) &&
+                     al16(v_sb) && al16(v_sh) && al16(v_ss);
+    if (a.n_scored && vec) {
+        const uint32_t chunks = (uint32_t)(rowbytes / 16);
+        int lpr = 1;
+        while (lpr < 64 && (uint32_t)lpr < chunks) lpr <<= 1;
+        const size_t ldsv = ((size_t)2 * lag_size + (size_t)2 * (LG_THREADS / lpr) * D) * 4;
+#define KVP_LG_VEC(DT, L)                                                                                                                  \
+    case L:                                                                                                                                \
+        KVP_LAUNCH("lagkv_score_vec_kernel", stream, (lagkv_score_vec_kernel<DT, L><<<grid, LG_THREADS, ldsv, stream>>>(a, chunks, scores))); \
+        break;
+#define KVP_LG_DT(DT) switch (lpr) { KVP_LG_VEC(DT, 1) KVP_LG_VEC(DT, 2) KVP_LG_VEC(DT, 4) KVP_LG_VEC(DT, 8) KVP_LG_VEC(DT, 16) KVP_LG_VEC(DT, 32) KVP_LG_VEC(DT, 64) }
+        if (dtype == KVP_F32) { KVP_LG_DT(KVP_F32) }
+        else if (dtype == KVP_F16) { KVP_LG_DT(KVP_F16) }
+        else { KVP_LG_DT(KVP_BF16) }
+#undef KVP_LG_DT
+#undef KVP_LG_VEC
+        KVP_CHECK_LAUNCH("lagkv");
+        return KVP_OK;
+    }
+    const size_t lds = ((size_t)2 * lag_size + (size_t)2 * LG_WAVES * D) * 4;
     if (a.n_scored) {
         if (dtype == KVP_F32) KVP_LAUNCH("lagkv_score_kernel", stream, lagkv_score_kernel<KVP_F32><<<grid, LG_THREADS, lds, stream>>>(a, scores));
         else if (dtype == KVP_F16) KVP_LAUNCH("lagkv_score_kernel", stream, lagkv_score_kernel<KVP_F16><<<grid, LG_THREADS, lds, stream>>>(a, scores));
