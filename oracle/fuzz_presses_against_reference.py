@@ -105,6 +105,45 @@ def main(argv):
             exact = iname in ("knorm", "streaming") and wname != "pyramid"
             if miss > (0 if exact else max(1, n // 100)):   # a near-tie between float32 and float64 arithmetic may swap one token
                 msgs.append(f"{wname}: {miss} of {n} kept positions differ")
+        # ---- head-wise maskers (AdaKV / CriticalAdaKV: module.masked_key_indices) and CriticalKV / Finch (real values) -----
+        if iname in ("knorm", "keydiff"):
+            alpha = float(rs.choice([0.0, 0.2, 0.5]))
+            for wname, mk in (("adakv", lambda ns: ns.AdaKVPress(imk(ns), alpha_safeguard=alpha)),
+                              ("criticalada", lambda ns: ns.CriticalAdaKVPress(imk(ns), alpha_safeguard=alpha))):
+                got = []
+                with torch.no_grad():
+                    for ns in (R, P):
+                        att.masked_key_indices = None
+                        mk(ns).compress(att, hidden, keys.clone(), values.clone(), None, kwargs)
+                        b_, h_, s_ = att.masked_key_indices
+                        got.append(np.sort((h_ * S + s_).numpy()))
+                att.masked_key_indices = None
+                if got[0].shape != got[1].shape or (got[0] != got[1]).any():
+                    msgs.append(f"{wname}: masked sets differ ({np.setdiff1d(got[0], got[1]).size} entries)")
+            with torch.no_grad():
+                a = R.CriticalKVPress(imk(R)).compress(att, hidden, keys.clone(), values.clone(), None, kwargs)[0]
+                b = P.CriticalKVPress(imk(P)).compress(att, hidden, keys.clone(), values.clone(), None, kwargs)[0]
+            ka = set(map(bytes, a.reshape(-1, D).numpy()))   # rows are distinct: compare the kept key rows as sets
+            kb = set(map(bytes, b.reshape(-1, D).numpy()))
+            if len(ka ^ kb) > 2 * max(1, a.shape[2] // 100):
+                msgs.append(f"critical: {len(ka ^ kb) // 2} kept rows differ")
+        fin_kw = dict(chunk_length=None if rs.rand() < 0.5 else chunk + int(W / (1 - ratio)) + 1, normalize_scores=bool(rs.rand() < 0.5),
+                      rerotate_keys=bool(rs.rand() < 0.5))
+        if int(S * (1 - ratio)) >= W and (fin_kw["chunk_length"] is None or min(max(1, int(n * (1 - ratio))) for n in
+                                                                                   [fin_kw["chunk_length"]] * (S // fin_kw["chunk_length"]) + ([S % fin_kw["chunk_length"]] if S % fin_kw["chunk_length"] else [])) >= W):
+            outs = []
+            with torch.no_grad():
+                for ns in (R, P):
+                    f = ns.FinchPress(ratio, **fin_kw)
+                    f.window_size = W
+                    outs.append(f.compress(att, hidden, keys.clone(), posv.clone(), None, kwargs)[1][..., 0].round().long().sort(dim=-1).values.numpy())
+            n = outs[0].shape[-1]
+            if outs[0].shape != outs[1].shape:
+                msgs.append(f"finch: kept {outs[1].shape[-1]} vs reference {n}")
+            else:
+                miss = max(n - len(np.intersect1d(x, y)) for x, y in zip(outs[0].reshape(-1, n), outs[1].reshape(-1, n)))
+                if miss > max(1, n // 100):
+                    msgs.append(f"finch{fin_kw}: {miss} of {n} kept positions differ")
         bad += bool(msgs)
         print(f"round {it}: inner={iname} H={H} G={G} S={S} D={D} W={W} r={ratio} chunk={chunk} block={block} -> {'OK' if not msgs else msgs}", flush=True)
     mp.undo()
