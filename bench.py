@@ -14,10 +14,14 @@ roofline: the dominant library kernel (largest average duration, HIP events on i
           stream via kvp_prof_*), its algorithmic bytes / duration vs the 8 TB/s HBM peak;
           ``path`` holds the same for the whole compress() against SURVEY §8(d)'s
           algorithmic bytes per layer.
-cpu_baseline: the numpy oracle (oracle/kvpress_oracle.py, a port of the reference algorithm)
-          timed on this box's host cores on the same workload (N=1, rank 0 only).
-Multi-GPU: one process per GPU (torch.distributed.run), batch sharded one element per GPU, no
-collective on the data path; only the timing is max-reduced over ranks.
+cpu_baseline: the reference's own op sequence in plain PyTorch (oracle/torch_path.py, pinned bit for bit to the
+          real reference by tests/test_oracle_golden.py) timed on this box's host cores on the same workload, bf16
+          (as users run it) and float32, torch.get_num_threads() threads (N=1, rank 0 only); the numpy oracle's time
+          is kept as a secondary field.
+Multi-GPU: one process per GPU, batch sharded one element per GPU, no collective on the data path; only
+          the timing is max-reduced over ranks.  `python bench.py --gpus N` launches the N ranks itself (it re-executes
+          under torch.distributed.run on 127.0.0.1 when WORLD_SIZE is not set); under an external launcher it reads
+          RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 """
 import argparse
 import json
@@ -83,6 +87,8 @@ def kernel_bytes(name: str, kind: str, S: int, ratio: float) -> float:
         return ab["gather"]
     if name.startswith(("snapkv_p1", "snapkv_p2", "rownorm", "ea_logits")):
         return kbytes
+    if name.startswith("ea_qstats_mfma"):
+        return S * H_Q * D * 2  # Q [B, S, H_q * D] read once for the statistics
     return 0.0
 
 
@@ -93,16 +99,35 @@ def kernel_flops(name: str, S: int) -> float:
     return 0.0
 
 
+def csrc_digest() -> str:
+    """sha256 over the kernel sources: a PMC summary is only quoted for the build it was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "kvpress_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_name: str, workload: str):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary of this same command
-    (profiles/r01_pmc_summary_<workload>.txt; separate --pmc passes).  MI355X_MICROARCH.md §HBM: FETCH_SIZE and
+    """(HBM bytes per launch of `kernel_name`, provenance).  The counters cannot be read from inside this process: they come
+    from the rocprofv3 --pmc passes of this same command (`scripts/gpu_check.sh pmc`, separate passes, no tracing), whose
+    summary is committed as profiles/r02_pmc_summary_<workload>.txt together with the digest of the kernel sources it was
+    measured on.  A summary of a different build is NOT quoted (traffic = null).  MI355X_MICROARCH.md §HBM: FETCH_SIZE and
     WRITE_SIZE are in KiB and on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads -> doubled."""
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_summary_{workload}.txt")
+    rel = os.path.join("profiles", f"r02_pmc_summary_{workload}.txt")
+    path = os.path.join(ROOT, rel)
     if not os.path.exists(path):
-        return None
+        return None, f"{rel} missing"
     fetch = write = None
     inside = False
+    digest = None
     for line in open(path):
+        if line.startswith("# csrc_digest"):
+            digest = line.split()[-1]
         if line.startswith("=="):
             inside = kernel_name in line
         elif inside:
@@ -111,9 +136,11 @@ def pmc_traffic(kernel_name: str, workload: str):
                 fetch = float(f[1])
             if len(f) == 2 and f[0] == "WRITE_SIZE":
                 write = float(f[1])
+    if digest != csrc_digest():
+        return None, f"{rel} is from another build (digest {digest}, this build {csrc_digest()}): not quoted"
     if fetch is None or write is None:
-        return None
-    return int((2.0 * fetch + write) * 1024)
+        return None, f"{rel} has no FETCH_SIZE / WRITE_SIZE for {kernel_name}"
+    return int((2.0 * fetch + write) * 1024), f"{rel} (rocprofv3 --pmc passes of this command on this build, digest {digest})"
 
 
 def build_module(device):
@@ -146,6 +173,125 @@ def make_press(kind, ratio):
     return P.ExpectedAttentionPress(compression_ratio=ratio)
 
 
+def launcher_argv(n_gpus: int, argv: list) -> list:
+    """Command line that turns `python bench.py --gpus N ...` into N ranks on this node: one process per GPU, rendezvous on
+    127.0.0.1 (the container hostname may not resolve), a free port.  Matches the reference's process-per-GPU model
+    (evaluation/evaluate.sh:15-28); the ranks exchange nothing but the step time."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def timed_steps(step, steps: int, warmup: int, world: int, sync) -> float:
+    """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + device sync on both sides; returns this rank's seconds."""
+    for _ in range(warmup):
+        step()
+    sync()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    return time.perf_counter() - t0
+
+
+def result_line(args, world: int, B: int, S: int, t_step: float, config: dict, roofline, cpu, metric: str, dtype: str = "bf16") -> dict:
+    assert world == args.gpus
+    return {"metric": metric, "value": round(world * B * S / (LAYERS * t_step), 1), "unit": "tok/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(t_step * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic", "config": config, "roofline": roofline, "cpu_baseline": cpu}
+
+
+def cpu_baseline(workload, press, att, rot, hidden, keys, values, kwargs, n_kept):
+    """The reference's pure-PyTorch path on the host CPU cores of THIS box, same run, same tensors (north_star):
+    oracle/torch_path.py = ScorerPress.compress (scorer_press.py:76-102) + the scorer, restated op for op and pinned bit for
+    bit to the real reference (tests/test_oracle_golden.py).  bf16 as users run it and float32 ("O32"); 1 warm-up + timed
+    runs, median; threads = torch.get_num_threads().  ExpectedAttention's 4.4-TFLOP q_proj makes one run ~10 s: one timed
+    run per dtype there.  The numpy float32 port (oracle/kvpress_oracle.py) is timed once as a secondary figure, and the GPU
+    path's retained set is checked against the float32 CPU scores while they are at hand."""
+    import numpy as np
+    import torch
+
+    from kvpress_amd import _native
+    from oracle import kvpress_oracle as O
+    from oracle import torch_path as TP
+
+    kind, S, ratio = WORKLOADS[workload]
+    threads = torch.get_num_threads()
+    n_timed = 1 if kind == "ea" else 3
+    att_cpu = {torch.bfloat16: build_module(torch.device("cpu"))[0]}
+    att_cpu[torch.float32] = build_module(torch.device("cpu"))[0].float()
+    rot_cpu = build_module(torch.device("cpu"))[1]
+    res, sc32 = {}, None
+    with torch.no_grad():
+        for dt in (torch.bfloat16, torch.float32):
+            m = att_cpu[dt]
+            m.rotary_emb = rot_cpu
+            h, k, v = hidden.cpu().to(dt), keys.cpu().to(dt), values.cpu().to(dt)
+            kw = {"position_embeddings": tuple(t.cpu().to(dt) for t in kwargs["position_embeddings"])}
+            times = []
+            for i in range(1 + n_timed):
+                t0 = time.perf_counter()
+                ko, vo, idx = TP.torch_compress(TP.SCORERS[kind], ratio, m, h, k, v, kw)
+                if i:
+                    times.append(time.perf_counter() - t0)
+            assert tuple(ko.shape) == (k.shape[0], H_KV, n_kept, D)
+            res[dt] = sorted(times)[len(times) // 2]
+            if dt == torch.float32:
+                sc32 = TP.SCORERS[kind](m, h, k, v, kw).numpy()
+            del h, k, v, ko, vo
+    # GPU retained set vs the float32 CPU scores (tie-tolerant, 1e-3 band)
+    gsc = press.score(att, hidden, keys, values, None, kwargs)
+    gidx = _native.topk_select(gsc, n_kept).cpu().numpy()
+    ok, _ = O.topk_is_valid(sc32, gidx, n_kept, rel_band=1e-3)
+    # secondary: the numpy float32 port of the same algorithm (the round-1 baseline)
+    port_ms = None
+    if kind != "ea":
+        k_np, v_np = keys.float().cpu().numpy(), values.float().cpu().numpy()
+        if kind == "snapkv":
+            with torch.no_grad():
+                q_np = press.compute_window_queries(att, hidden, WINDOW, kwargs["position_embeddings"]).float().cpu().numpy()
+        t0 = time.perf_counter()
+        sc = O.snapkv_score(q_np, k_np, 5, ctype=np.float32) if kind == "snapkv" else O.knorm_score(k_np, ctype=np.float32)
+        O.compress(sc, k_np, v_np, ratio)
+        port_ms = round((time.perf_counter() - t0) * 1e3, 1)
+    t = res[torch.bfloat16]
+    return {"value": round(S / (LAYERS * t), 1), "unit": "tok/s", "cores": threads, "kind": "torch-restatement",
+            "sample": f"one full {workload} layer (B=1, H_kv={H_KV}, S={S}) per run: score + topk + gather of the reference in plain PyTorch "
+                      f"(oracle/torch_path.py), bf16 module and tensors, 1 warm-up + {n_timed} timed run(s), median; "
+                      f"torch.get_num_threads() = {threads}, os.cpu_count() = {os.cpu_count()}; tok/s extrapolates one layer x {LAYERS}",
+            "ms_per_layer": round(t * 1e3, 1), "ms_per_layer_fp32": round(res[torch.float32] * 1e3, 1),
+            "numpy_port_ms_per_layer": port_ms, "gpu_topk_valid_vs_cpu_fp32_scores": bool(ok)}
+
+
+def stub_main(args, world: int, rank: int):
+    """(tests) The N-rank path of this file -- launcher, rank environment, batch sharding, barrier-bracketed timing, MAX over ranks,
+    one JSON line from rank 0 -- with the press replaced by a host sleep; runs under gloo on CPU."""
+    kind, S, ratio = WORKLOADS[args.workload]
+    lo, hi = shard_batch(world, world, rank)
+    B = hi - lo
+    local = timed_steps(lambda: time.sleep(args.stub_step * 1e-3 * (1 + rank)), args.steps, args.warmup, world, lambda: None)
+    t_step = aggregate_time(local, world) / args.steps
+    if rank == 0:
+        cfg = {"workload": args.workload, "press": kind, "batch_per_gpu": B, "seq_len": S, "stub_step_ms": args.stub_step,
+               "parallelism": f"batch-sharded x{world}, no collective"}
+        print(json.dumps(result_line(args, world, B, S, t_step, cfg, None, None, "stub (launcher test)", dtype="none")), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,7 +303,15 @@ def main():
                          "ramped (they take ~100 steps; with a short warm-up the same build reads 10 %% slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-json", default=None, help="also dump the per-kernel HIP-event table here")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL); gloo + --stub-step exercises the launcher on CPU (tests)")
+    ap.add_argument("--stub-step", type=float, default=None, metavar="MS",
+                    help="(tests) replace the press by a host sleep of MS milliseconds: launcher / sharding / timing path without a GPU")
     args = ap.parse_args()
+
+    # ---- `python bench.py --gpus N`, no launcher around it: become N ranks (one process per GPU, torch.distributed.run) ----
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        os.execvp(sys.executable, launcher_argv(args.gpus, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -165,13 +319,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU"
+    stub = args.stub_step is not None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    if stub:
+        return stub_main(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    assert torch.cuda.device_count() > local_rank, f"rank {rank}: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible on this node"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -202,19 +360,8 @@ def main():
         for _ in range(25):
             out = step()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    local = time.perf_counter() - t0
+    local = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize)
+    out = step()
     total = aggregate_time(local, world)
     t_step = total / args.steps
     n_kept = int(S * (1 - ratio))
@@ -240,7 +387,8 @@ def main():
             ach = kb / (cand[dom] * 1e-3) / 1e9
             roofline = {
                 "kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.workload),
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.workload)[0],
+                "traffic_source": pmc_traffic(dom, args.workload)[1],
                 "algorithmic_bytes_per_launch": kb, "avg_launch_us": round(cand[dom] * 1e3, 2),
                 # secondary bound of the same kernel: the window-attention passes are matrix-core / VALU work
                 "mfma": ({"achieved": round(kernel_flops(dom, S) * B / (cand[dom] * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS,
@@ -260,60 +408,18 @@ def main():
                            "kernels_avg_ms": {k: a for k, (a, _) in avg.items()},
                            "launches_per_step": {k: c for k, (_, c) in avg.items()}}, f, indent=1)
 
-    # ---- CPU baseline: the numpy oracle on the same workload (rank 0, N=1 only) ------------------
+    # ---- CPU baseline (rank 0, N=1 only): the reference's op sequence in plain PyTorch on this box's host cores -------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import kvpress_oracle as O
-
-        k_np = keys.float().cpu().numpy()
-        v_np = values.float().cpu().numpy()
-        f32 = np.float32
-        sample = f"full {args.workload} layer (B=1, H_kv={H_KV}, S={S}), numpy float32 port of the reference"
-        with torch.no_grad():
-            if kind == "snapkv":
-                q_np = press.compute_window_queries(att, hidden, WINDOW, pe).float().cpu().numpy()
-            elif kind == "ea":
-                # the statistics need all S queries (1 GiB in fp32 per 8 heads): sample 1/8 of the heads' work
-                mu, cov = press.get_query_statistics(att, hidden)
-                mu_np, cov_np = mu.cpu().numpy(), cov.cpu().numpy()
-                sample += "; query statistics taken from the GPU (kernel-only baseline)"
-        t0 = time.perf_counter()
-        if kind == "snapkv":
-            sc = O.snapkv_score(q_np, k_np, 5, ctype=f32)
-        elif kind == "knorm":
-            sc = O.knorm_score(k_np, ctype=f32)
-        else:
-            sc = O.ea_score(k_np, v_np, mu_np, cov_np, 4, True, 0.0, ctype=f32)
-        ko, vo, idx = O.compress(sc, k_np, v_np, ratio)
-        t_cpu = time.perf_counter() - t0
-        # cross-check while we are here: GPU retained set is a valid top-k of the oracle's scores
-        gsc = press.score(att, hidden, keys, values, None, kwargs)
-        gidx = _native.topk_select(gsc, n_kept).cpu().numpy()
-        ok, msg = O.topk_is_valid(sc, gidx, n_kept, rel_band=1e-3)
-        try:  # threads the port really used: numpy's BLAS pool for the matrix products, one thread for everything else
-            from threadpoolctl import threadpool_info
-
-            blas_threads = max([int(p.get("num_threads", 1)) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
-        except Exception:
-            blas_threads = 1
-        sample += f"; numpy ({blas_threads} BLAS threads for the matrix products, 1 thread elsewhere; {os.cpu_count()} cores visible)"
-        cpu = {"value": round(S / (LAYERS * t_cpu), 1), "unit": "tok/s", "cores": blas_threads, "kind": "port",
-               "sample": sample, "ms_per_layer": round(t_cpu * 1e3, 1), "gpu_topk_valid_vs_oracle": bool(ok)}
+        cpu = cpu_baseline(args.workload, press, att, rot, hidden, keys, values, kwargs, n_kept)
 
     if rank == 0:
-        value = world * B * S / (LAYERS * t_step)
-        line = {
-            "metric": "press ms/layer + prefill tok/s, Llama-3.1-8B 128k ctx, SnapKV ratio=0.5" if args.workload == "snapkv128k"
-            else f"press ms/layer + prefill tok/s, Llama-3.1-8B, {args.workload}",
-            "value": round(value, 1), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(t_step * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": args.workload, "press": kind, "compression_ratio": ratio, "batch_per_gpu": B,
-                       "seq_len": S, "n_kept": n_kept, "h_q": H_Q, "h_kv": H_KV, "head_dim": D, "layers_for_tok_s": LAYERS,
-                       "parallelism": f"batch-sharded x{world}, no collective", "prewarm_ms": args.prewarm_ms},
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
-        print(json.dumps(line), flush=True)
+        metric = ("press ms/layer + prefill tok/s, Llama-3.1-8B 128k ctx, SnapKV ratio=0.5" if args.workload == "snapkv128k"
+                  else f"press ms/layer + prefill tok/s, Llama-3.1-8B, {args.workload}")
+        cfg = {"workload": args.workload, "press": kind, "compression_ratio": ratio, "batch_per_gpu": B, "seq_len": S, "n_kept": n_kept,
+               "h_q": H_Q, "h_kv": H_KV, "head_dim": D, "layers_for_tok_s": LAYERS, "parallelism": f"batch-sharded x{world}, no collective",
+               "prewarm_ms": args.prewarm_ms}
+        print(json.dumps(result_line(args, world, B, S, t_step, cfg, roofline, cpu, metric)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

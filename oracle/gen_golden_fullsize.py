@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Reference outputs at BASELINE.json's FULL sizes (configs 2-4): runs the REAL reference (NVIDIA/kvpress imported from
+/root/reference) on the host CPU over the CPU-seeded inputs of tests/_fullsize.py and commits compact fixtures
+(tests/golden/full_*.npz) for tests/test_gpu_fullsize.py.  Test infrastructure only; the GPU box never sees /root/reference.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_fullsize.py [case ...]
+
+Per case:
+  * "O32" run (module and tensors in float32 -- SURVEY §8c): every 8th score, the torch.topk membership bitmask, the
+    threshold per row and all scores within 4e-3 of it (tests/_fullsize.py: pack_reference);
+  * "Obf" run (bf16 as users run it): the bf16 scores (bit patterns) and the reference's own top-k membership (pack_native);
+  * timings of both runs on this container's cores (recorded in the fixture; BASELINE.md quotes them).
+"""
+import os
+import sys
+import time
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "tests"))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(argv):
+    from gen_golden import _install_shims
+
+    _install_shims()
+    import numpy as np
+    import torch
+    from kvpress import ExpectedAttentionPress, KnormPress, SnapKVPress  # the reference
+
+    import _fullsize as F
+    import bench
+
+    outdir = os.path.join(REPO, "tests", "golden")
+    for name in argv or list(F.FULL_CASES):
+        spec = F.FULL_CASES[name]
+        S, ratio = spec["S"], spec["ratio"]
+        n_kept = int(S * (1 - ratio))
+        keys, values = F.make_kv(spec)
+        hidden = F.make_hidden(spec)
+        att, rot = bench.build_module(torch.device("cpu"))   # bf16 module, seeded
+        press = {"knorm": lambda: KnormPress(compression_ratio=ratio),
+                 "snapkv": lambda: SnapKVPress(compression_ratio=ratio, window_size=F.WINDOW, kernel_size=5),
+                 "ea": lambda: ExpectedAttentionPress(compression_ratio=ratio)}[spec["kind"]]()
+        out = {}
+        with torch.no_grad():
+            pe_bf = rot(hidden, torch.arange(S)[None])
+            # ---- Obf: the reference as users run it ---------------------------------------------------------------
+            t0 = time.perf_counter()
+            sc_nat = press.score(att, hidden, keys, values, None, {"position_embeddings": pe_bf})
+            t_nat = time.perf_counter() - t0
+            assert sc_nat.dtype == torch.bfloat16 and tuple(sc_nat.shape) == (1, F.H_KV, S)
+            out.update(F.pack_native(sc_nat, n_kept))
+            ko, vo = press.compress(att, hidden, keys, values, None, {"position_embeddings": pe_bf})
+            assert tuple(ko.shape) == (1, F.H_KV, n_kept, F.D)
+            del ko, vo
+            # ---- O32: same code, float32 module and tensors --------------------------------------------------------
+            att32 = att.float()
+            att32.rotary_emb = rot
+            h32, k32, v32 = hidden.float(), keys.float(), values.float()
+            pe32 = rot(h32, torch.arange(S)[None])
+            t0 = time.perf_counter()
+            sc32 = press.score(att32, h32, k32, v32, None, {"position_embeddings": pe32})
+            t_f32 = time.perf_counter() - t0
+        pad = {"knorm": (0, 0), "snapkv": (S - F.WINDOW, S), "ea": (0, 4)}[spec["kind"]]
+        out.update(F.pack_reference(sc32, n_kept, *pad))
+        out["ref_seconds"] = np.asarray([t_nat, t_f32])
+        out["ref_threads"] = np.int64(torch.get_num_threads())
+        path = os.path.join(outdir, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        # calibration printout for the dtype-faithful check: how far from the bf16 threshold do O32-kept / O32-dropped positions sit?
+        kept32 = torch.from_numpy(np.unpackbits(out["kept_bits"], axis=-1)[:, :S].astype(bool))
+        nat = sc_nat[0].float()
+        kept_nat = torch.from_numpy(np.unpackbits(out["nat_kept_bits"], axis=-1)[:, :S].astype(bool))
+        t = nat.masked_fill(~kept_nat, float("inf")).amin(-1, keepdim=True)
+        ulp = 2.0 ** -8 * t.abs()
+        worst_drop = float((((nat - t) / ulp).masked_fill(kept32, 0)).amax())     # dropped by O32 although this many ulps above
+        worst_keep = float((((t - nat) / ulp).masked_fill(~kept32, 0)).amax())    # kept by O32 although this many ulps below
+        overlap = float((kept32 & kept_nat).sum()) / (F.H_KV * n_kept)
+        print(f"{name}: {os.path.getsize(path)} bytes; reference {t_nat:.1f} s (bf16) / {t_f32:.1f} s (fp32) on {torch.get_num_threads()} threads; "
+              f"band entries {len(out['band_pos'])}; O32-vs-Obf overlap {overlap:.4f}, worst ulps above/below threshold {worst_drop:.1f}/{worst_keep:.1f}", flush=True)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -55,3 +55,47 @@ def test_algorithmic_bytes_match_survey():
     assert bench.algorithmic_bytes("knorm", 32768, 0.5)["total"] == 201326592       # config 2
     assert bench.algorithmic_bytes("ea", 131072, 0.7)["total"] == 1932730368        # config 4
     assert bench.algorithmic_bytes("ea", 131072, 0.7)["n_kept"] == 39321
+
+
+def _run_bench(cmd):
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line from rank 0, got {len(lines)}: {r.stdout[-500:]}"
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it becomes two ranks (one process per GPU; here gloo + a stub step of
+    2 ms on rank 0 and 4 ms on rank 1): one JSON line, n_gpus == 2, the step time is the slowest rank's, value is the aggregate."""
+    import bench
+
+    line = _run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-step", "2", "--steps", "5", "--warmup", "1"])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert 4.0 <= line["ms_per_step"] < 40.0, line["ms_per_step"]          # max over ranks: rank 1 sleeps 4 ms per step
+    S = bench.WORKLOADS["snapkv128k"][1]
+    assert abs(line["value"] - 2 * S / (bench.LAYERS * line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
+    assert line["config"]["batch_per_gpu"] == 1 and "no collective" in line["config"]["parallelism"]
+
+
+def test_bench_under_external_launcher():
+    """The driver's form: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N (ranks from the environment)."""
+    line = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                       "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-step", "1",
+                       "--steps", "3", "--warmup", "1"])
+    assert line["n_gpus"] == 2 and line["ms_per_step"] >= 2.0
+
+
+def test_bench_refuses_a_rank_count_mismatch():
+    import subprocess
+
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-step", "1"], capture_output=True, text=True,
+                       timeout=120, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "one rank per GPU" in r.stderr

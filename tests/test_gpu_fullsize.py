@@ -1,7 +1,10 @@
-"""Parity at BASELINE.json's full sizes (configs 1-4) through size-independent properties and a
-plain-PyTorch fp32 restatement evaluated on the GPU (the CPU oracle would need minutes at 128k):
+"""Parity at BASELINE.json's full sizes (configs 1-4) against the REAL reference and through size-independent properties:
 
-  * scores  : |kernel - torch fp32| <= 1e-3 relative (north_star tolerance);
+  * reference: tests/golden/full_*.npz hold the outputs of NVIDIA/kvpress itself (oracle/gen_golden_fullsize.py, float32-mode
+              "O32" and bf16 "Obf" runs on the CPU-seeded inputs of tests/_fullsize.py): kernel scores within 1e-3 of the
+              reference's float32 scores, retained set identical up to the tolerance band at the threshold (SURVEY §8c i-ii),
+              and the dtype-faithful check against the reference's own bf16 scores with a bf16-ulp band (§8c iii);
+  * scores  : additionally |kernel - torch fp32 restatement on the GPU| <= 1e-3 relative on every position;
   * top-k   : indices ascending/unique/in range; partition property (every kept score >= every
               dropped score); the multiset of kept score values equals torch.topk's on the same
               scores; idempotence (selecting all kept again returns them all);
@@ -58,22 +61,31 @@ def llama_module():
     return bench.build_module(torch.device(DEV))
 
 
-def make_kv(S, seed, structured=False):
-    g = torch.Generator(device=DEV)
-    g.manual_seed(seed)
-    k = torch.randn((1, H_KV, S, D), generator=g, device=DEV)
-    v = torch.randn((1, H_KV, S, D), generator=g, device=DEV)
-    if structured:
-        k = k * torch.exp(0.5 * torch.randn((1, H_KV, 1, D), generator=g, device=DEV))
-        k[:, :, :4] *= 8
-    return k.to(torch.bfloat16), v.to(torch.bfloat16)
+def full_case(name):
+    """CPU-seeded full-size inputs (tests/_fullsize.py) on the GPU + the reference fixture."""
+    import os
+
+    import _fullsize as F
+
+    spec = F.FULL_CASES[name]
+    keys, values = (t.to(DEV) for t in F.make_kv(spec))
+    hidden = F.make_hidden(spec).to(DEV)
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{name}.npz"))
+    return spec, keys, values, hidden, fx
+
+
+# overlap of the float32-selected set with the bf16 reference's own torch.topk choice, measured when the fixtures were made
+# (oracle/gen_golden_fullsize.py prints it); the tests allow 1 % below.  All disagreements sit within 2 bf16 ulps of the threshold.
+NATIVE_OVERLAP = {"full_knorm32k": 0.9961, "full_snapkv128k": 0.9420, "full_snapkv128k_B": 0.9837, "full_ea128k": 0.9975}
+NATIVE_ULPS = 3
 
 
 def test_config2_knorm_32k():
+    import _fullsize as F
     import kvpress_amd as P
 
-    S = 32768
-    keys, values = make_kv(S, 2)
+    spec, keys, values, hidden, fx = full_case("full_knorm32k")
+    S = spec["S"]
     kc, vc = keys.clone(), values.clone()
     press = P.KnormPress(0.5)
     sc = press.score(None, None, keys, values, None, {})
@@ -83,6 +95,10 @@ def test_config2_knorm_32k():
     assert ko.shape == (1, H_KV, 16384, D) and ko.dtype == torch.bfloat16
     check_topk_and_gather(sc, keys, values, 16384, ko, vo)
     assert torch.equal(keys, kc) and torch.equal(values, vc), "inputs must not be modified"
+    idx = _native().topk_select(sc, 16384)
+    worst, differ = F.check_against_reference(fx, sc, idx)
+    overlap, _ = F.check_against_native(fx, idx, S, NATIVE_ULPS, NATIVE_OVERLAP["full_knorm32k"] - 0.01)
+    print(f"knorm32k vs reference: max rel err {worst:.2e}, {differ} set differences (in band), overlap with bf16 reference {overlap:.4f}")
 
 
 def torch_snapkv_reference(q_win, keys, kernel_size):
@@ -101,15 +117,14 @@ def torch_snapkv_reference(q_win, keys, kernel_size):
     return torch.nn.functional.pad(sc, (0, W), value=sc.max().item() + 1)
 
 
-@pytest.mark.parametrize("S,structured", [(131072, False), (131072 - 1000 + 37, True)])
-def test_config3_snapkv_128k(S, structured):
+@pytest.mark.parametrize("name", ["full_snapkv128k", "full_snapkv128k_B"])
+def test_config3_snapkv_128k(name):
+    import _fullsize as F
     import kvpress_amd as P
 
-    keys, values = make_kv(S, 3, structured)
+    spec, keys, values, hidden, fx = full_case(name)
+    S = spec["S"]
     att, rot = llama_module()
-    g = torch.Generator(device=DEV)
-    g.manual_seed(33)
-    hidden = torch.randn((1, S, HIDDEN), generator=g, device=DEV, dtype=torch.bfloat16)
     with torch.no_grad():
         pe = rot(hidden, torch.arange(S, device=DEV)[None])
         press = P.SnapKVPress(0.5)
@@ -126,6 +141,13 @@ def test_config3_snapkv_128k(S, structured):
         check_topk_and_gather(sc, keys, values, n, ko, vo)
         idx = _native().topk_select(sc, n)
         assert (idx[..., -64:] == torch.arange(S - 64, S, device=DEV, dtype=torch.int32)).all(), "window must be kept"
+        # the REAL reference at this size (float32 mode and bf16)
+        worst, differ = F.check_against_reference(fx, sc, idx)
+        overlap, _ = F.check_against_native(fx, idx, S, NATIVE_ULPS, NATIVE_OVERLAP[name] - 0.01)
+        print(f"{name} vs reference: max rel err {worst:.2e}, {differ} set differences (in band), overlap with bf16 reference {overlap:.4f}")
+        # the fused one-call compress keeps exactly the selected rows
+        e = idx.long().unsqueeze(-1).expand(-1, -1, -1, D)
+        assert torch.equal(ko, keys.gather(2, e)) and torch.equal(vo, values.gather(2, e))
 
 
 def test_config1_opt125m_plumbing():
@@ -183,12 +205,11 @@ def test_config4_expected_attention_128k():
     restatement of expected_attention_press.py:62-165 with torch ops on the GPU."""
     import kvpress_amd as P
 
-    S, n_sink, nfut = 131072, 4, 512
-    keys, values = make_kv(S, 4, True)
+    import _fullsize as F
+
+    spec, keys, values, hidden, fx = full_case("full_ea128k")
+    S, n_sink, nfut = spec["S"], 4, 512
     att, rot = llama_module()
-    g = torch.Generator(device=DEV)
-    g.manual_seed(44)
-    hidden = torch.randn((1, S, HIDDEN), generator=g, device=DEV, dtype=torch.bfloat16)
     press = P.ExpectedAttentionPress(0.7)
     with torch.no_grad():
         sc = press.score(att, hidden, keys, values, None, {})
@@ -226,3 +247,7 @@ def test_config4_expected_attention_128k():
         ko, vo = press.compress(att, hidden, keys, values, None, {})
         assert ko.shape == (1, H_KV, n, D)
         check_topk_and_gather(sc, keys, values, n, ko, vo)
+        idx = _native().topk_select(sc, n)
+        worst, differ = F.check_against_reference(fx, sc, idx)
+        overlap, _ = F.check_against_native(fx, idx, S, NATIVE_ULPS, NATIVE_OVERLAP["full_ea128k"] - 0.01)
+        print(f"ea128k vs reference: max rel err {worst:.2e}, {differ} set differences (in band), overlap with bf16 reference {overlap:.4f}")

@@ -132,3 +132,38 @@ def test_snapkv_from_attentions_path_equals_computed():
     attn[:, :, -s["W"]:, : s["S"] - s["W"]] = wa
     b = O.snapkv_score_from_attentions(attn, s["H"], s["W"], s["ks"])
     np.testing.assert_allclose(a, b, rtol=1e-6)
+
+
+# ---- the plain-PyTorch restatement that bench.py times as the CPU baseline (oracle/torch_path.py) ---------------------
+TORCH_PATH_CASES = [n for n in ALL if _inputs.spec(n)["kind"] in ("knorm", "snapkv", "ea")
+                    and _inputs.spec(n)["use_covariance"] and _inputs.spec(n)["use_vnorm"] and _inputs.spec(n)["epsilon"] == 0.0]
+
+
+@pytest.mark.parametrize("name", TORCH_PATH_CASES)
+def test_torch_path_is_the_reference_op_for_op(name):
+    """oracle/torch_path.py run on the seeded inputs reproduces the REAL reference's scores bit for bit, in float32 mode and
+    in the case's native dtype (same torch ops in the same order on the same CPU backend)."""
+    import torch
+
+    from oracle import torch_path as TP
+
+    s = _inputs.make_case(name)
+    g = load(name)
+    for mode, dt in (("f32", torch.float32), ("nat", _inputs.torch_dtype(s["dtype"]))):
+        att, rot, hidden, pe = _inputs.build_llama_attention(s, dt)
+        keys, values = torch.from_numpy(s["keys"]).to(dt), torch.from_numpy(s["values"]).to(dt)
+        kw = {"position_embeddings": pe}
+        with torch.no_grad():
+            if s["kind"] == "knorm":
+                sc = TP.knorm_score(att, hidden, keys, values, kw)
+            elif s["kind"] == "snapkv":
+                sc = TP.snapkv_score(att, hidden, keys, values, kw, W=s["W"], ks=s["ks"])
+            else:
+                sc = TP.ea_score(att, hidden, keys, values, kw, n_future=s["n_future"], n_sink=s["n_sink"])
+        ref = torch.from_numpy(g[f"scores_{mode}"])
+        assert torch.equal(sc.float(), ref), f"{name}/{mode}: max diff {(sc.float() - ref).abs().max()}"
+        if mode == "f32":
+            for i, r in enumerate(s["ratios"]):
+                ko, vo, idx = TP.torch_compress(lambda *a: sc, r, att, hidden, keys, values, kw)
+                assert ko.shape[2] == int(g[f"nkept_{i}"])
+                assert np.array_equal(np.sort(idx.numpy(), -1), g[f"idx_f32_{i}"])

@@ -13,7 +13,6 @@ Prints one JSON line per workload: ms/layer of the torch path and of the HIP pat
 """
 import argparse
 import json
-import math
 import os
 import sys
 
@@ -21,84 +20,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
-from torch.nn import functional as F  # noqa: E402
 
 import bench  # noqa: E402  (module geometry + build_module)
 
 
-def repeat_kv(x, n_rep):
-    B, H, S, D = x.shape
-    return x if n_rep == 1 else x[:, :, None].expand(B, H, n_rep, S, D).reshape(B, H * n_rep, S, D)
-
-
-def rotate_half(x):
-    h = x.shape[-1] // 2
-    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
-
-
-def knorm_score(module, hidden, keys, values, kwargs):
-    return -keys.norm(dim=-1)                                                    # knorm_press.py:38
-
-
-def snapkv_score(module, hidden, keys, values, kwargs, W=64, ks=5):
-    B, H, S, D = keys.shape
-    Hq = module.config.num_attention_heads
-    q = module.q_proj(hidden[:, -W:]).view(B, W, Hq, D).transpose(1, 2)          # utils.py:43-46
-    cos, sin = kwargs["position_embeddings"]
-    cos, sin = cos[:, -W:], sin[:, -W:]
-    q = (q * cos.unsqueeze(1)) + (rotate_half(q) * sin.unsqueeze(1))             # snapkv_press.py:56-58
-    k = repeat_kv(keys, Hq // H)                                                 # :61
-    attn = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(D)                     # :62
-    mask = torch.ones_like(attn) * float("-inf")                                 # :63
-    attn = attn + torch.triu(mask, diagonal=S - W + 1)                           # :64-65
-    attn = F.softmax(attn, dim=-1, dtype=torch.float32).to(q.dtype)              # :66
-    attn = attn[..., :-W]                                                        # :67
-    sc = attn.mean(dim=-2)                                                       # :95
-    sc = F.avg_pool1d(sc, kernel_size=ks, padding=ks // 2, stride=1)             # :96
-    sc = sc.view(B, H, Hq // H, S - W).mean(2)                                   # :99-100
-    return F.pad(sc, (0, W), value=sc.max().item() + 1)                          # :103
-
-
-def ea_score(module, hidden, keys, values, kwargs, n_future=512, n_sink=4):
-    B, H, S, D = keys.shape
-    Hq = module.config.num_attention_heads
-    G = Hq // H
-    keys, values = keys[:, :, n_sink:], values[:, :, n_sink:]                    # expected_attention_press.py:137-139
-    h = hidden[:, n_sink:]                                                       # :70
-    q = module.q_proj(h).view(B, S - n_sink, Hq, D).transpose(1, 2)              # :71
-    mu = q.mean(dim=2, keepdim=True)                                             # :74
-    qc = q - mu
-    cov = torch.einsum("bnsi,bnsj->bnij", qc, qc) / h.shape[1]                   # :79-80
-    mu = mu.squeeze(2)
-    pos = torch.arange(S, S + n_future, device=keys.device).unsqueeze(0)         # :110
-    cos, sin = module.rotary_emb(mu, pos)                                        # :112
-    cos, sin = cos[0], sin[0]
-    Id = torch.eye(D, device=cos.device, dtype=cos.dtype)                        # :114-119
-    P = torch.zeros((D, D), device=cos.device, dtype=cos.dtype)
-    P[D // 2:, : D // 2], P[: D // 2, D // 2:] = torch.eye(D // 2), -torch.eye(D // 2)
-    R = (cos.unsqueeze(1) * Id + sin.unsqueeze(1) * P).mean(dim=0).to(mu.device)  # :120
-    mu = torch.matmul(mu, R.T)                                                   # :121
-    cov = torch.matmul(R, torch.matmul(cov, R.T))                                # :123
-    kt = repeat_kv(keys, G).transpose(2, 3)                                      # :148
-    sc = torch.matmul(mu.unsqueeze(2), kt).squeeze(2) / math.sqrt(D)             # :149
-    sc = sc + torch.einsum("bhin,bhij,bhjn->bhn", kt, cov, kt) / D / 2           # :151
-    sc = F.softmax(sc, dim=-1)                                                   # :152
-    sc = sc.view(B, H, G, S - n_sink).mean(dim=2)                                # :155-156
-    sc = sc * values.norm(dim=-1)                                                # :159-160 (epsilon = 0)
-    return F.pad(sc, (n_sink, 0), value=sc.max().item() + 1)                     # :163
-
-
-def torch_compress(score_fn, ratio, module, hidden, keys, values, kwargs):
-    sc = score_fn(module, hidden, keys, values, kwargs)                          # scorer_press.py:90
-    n_kept = int(keys.shape[2] * (1 - ratio))                                    # :93-94
-    idx = sc.topk(n_kept, dim=-1).indices                                        # :95
-    idx = idx.unsqueeze(-1).expand(-1, -1, -1, module.head_dim)                  # :96
-    return keys.gather(2, idx).contiguous(), values.gather(2, idx).contiguous(), idx[..., 0]  # :99-100
+from oracle.torch_path import SCORERS, torch_compress  # noqa: E402  (the cited restatement of the reference's op sequence)
 
 
 WORKLOADS = {"knorm32k": ("knorm", 32768, 0.5), "knorm128k": ("knorm", 131072, 0.5), "snapkv128k": ("snapkv", 131072, 0.5),
              "ea128k": ("ea", 131072, 0.7)}
-SCORERS = {"knorm": knorm_score, "snapkv": snapkv_score, "ea": ea_score}
 
 
 def timed(fn, reps):
