@@ -7,7 +7,12 @@
 
 Per case:
   * "O32" run (module and tensors in float32 -- SURVEY §8c): every 8th score, the torch.topk membership bitmask, the
-    threshold per row and all scores within 4e-3 of it (tests/_fullsize.py: pack_reference);
+    threshold per row and all scores within 4e-3 of it (tests/_fullsize.py: pack_reference).
+    SnapKV: the float32 run consumes the window queries of the bf16 MODEL (the reference's own lines snapkv_press.py:53-58
+    executed in bf16, handed to the float32 run through a q_proj hook + identity rotary tables), because that is what a
+    bf16 model hands the press and what the kernels consume; everything after the query projection and RoPE
+    (snapkv_press.py:61-105) is the reference's code in float32.  The all-float32 run (float32 queries, never rounded) is
+    kept as `sub_pure`: it differs from any bf16-model run by the rounding of q, cos and sin (up to ~5e-3 on structured keys);
   * "Obf" run (bf16 as users run it): the bf16 scores (bit patterns) and the reference's own top-k membership (pack_native);
   * timings of both runs on this container's cores (recorded in the fixture; BASELINE.md quotes them).
 """
@@ -65,6 +70,21 @@ def main(argv):
             t0 = time.perf_counter()
             sc32 = press.score(att32, h32, k32, v32, None, {"position_embeddings": pe32})
             t_f32 = time.perf_counter() - t0
+            if spec["kind"] == "snapkv":
+                from kvpress.utils import get_prerope_query_states
+                from transformers.models.llama.modeling_llama import rotate_half
+
+                W = F.WINDOW
+                att.rotary_emb = rot
+                q = get_prerope_query_states(att.to(torch.bfloat16), hidden[:, -W:])                      # snapkv_press.py:53 (bf16 model)
+                cos, sin = pe_bf[0][:, -W:], pe_bf[1][:, -W:]
+                q_rot = (q * cos.unsqueeze(1)) + (rotate_half(q) * sin.unsqueeze(1))                     # :56-58 (bf16)
+                att32 = att.float()
+                handle = att32.q_proj.register_forward_hook(lambda m, i, o: q_rot.float().transpose(1, 2).reshape(1, W, F.H_Q * F.D))
+                pe_id = (torch.ones((1, S, F.D)), torch.zeros((1, S, F.D)))
+                out["sub_pure"] = sc32[0, :, F.SUB_OFFSET::F.SUBSAMPLE].numpy().astype(np.float32)
+                sc32 = press.score(att32, h32, k32, v32, None, {"position_embeddings": pe_id})          # :61-105 in float32
+                handle.remove()
         pad = {"knorm": (0, 0), "snapkv": (S - F.WINDOW, S), "ea": (0, 4)}[spec["kind"]]
         out.update(F.pack_reference(sc32, n_kept, *pad))
         out["ref_seconds"] = np.asarray([t_nat, t_f32])

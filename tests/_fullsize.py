@@ -96,6 +96,10 @@ def check_against_reference(fx, scores: torch.Tensor, idx: torch.Tensor, rtol: f
     rel = ((got - sub).abs() / sub.abs().clamp_min(1e-30))[:, numeric]
     worst = float(rel.max())
     assert worst <= rtol, f"scores differ from the reference by {worst:.3e} (subsample)"
+    if "sub_pure" in fx:   # all-float32 reference run (queries never rounded to bf16): differs by the model's bf16 q / cos / sin
+        pure = torch.from_numpy(fx["sub_pure"])
+        rel_pure = ((got - pure).abs() / pure.abs().clamp_min(1e-30))[:, numeric]
+        assert rel_pure.max() <= 2e-2, f"scores differ from the all-float32 reference by {float(rel_pure.max()):.3e}"
     kept_ref = torch.from_numpy(np.unpackbits(fx["kept_bits"], axis=-1)[:, :S].astype(bool))
     kept = torch.zeros((H, S), dtype=torch.bool)
     kept.scatter_(1, idx[0].long().cpu(), True)
