@@ -523,8 +523,9 @@ def test_press_fp32_vs_reference(name):
 
 @pytest.mark.parametrize("name", [n for n, c in _inputs.CASES.items() if c["dtype"] != "f32"])
 def test_press_native_dtype_runs_and_overlaps_reference(name):
-    """bf16 / f16 module and tensors, as in production.  The reference rounds to bf16 after every op,
-    so only a set overlap is asserted here (SURVEY §8c iii); Knorm is exact up to ties."""
+    """bf16 / f16 module and tensors, as in production, against the reference's own native-dtype scores (SURVEY §8c iii):
+    Knorm is exact up to ties; the others agree with the reference outside a few-ulp band around its threshold and overlap
+    its own top-k to within 2 % of what the float32-mode reference itself achieves."""
     s = _inputs.make_case(name)
     g = gold(name)
     dt = _inputs.torch_dtype(s["dtype"])
@@ -547,10 +548,45 @@ def test_press_native_dtype_runs_and_overlaps_reference(name):
                 ok, msg = O.topk_is_valid(ref_nat, idx, n)
                 assert ok, msg
             else:
+                # dtype-faithful rule (SURVEY §8c iii): the reference rounds to the model dtype after every op, so its own score of a
+                # position is defined to a few units in the last place only.  Outside that band around ITS threshold the
+                # float32-selected set must agree with it; inside, either choice is a valid top-k of the reference's scores.
+                ulps = NATIVE_ULPS.get(s["kind"])
+                R = ref_nat.reshape(-1, ref_nat.shape[-1]).astype(np.float64)
                 ref_idx = O.topk_select(ref_nat, n)
-                inter = np.mean([len(np.intersect1d(a, b)) / max(n, 1)
-                                 for a, b in zip(idx.reshape(-1, n), ref_idx.reshape(-1, n))])
-                assert inter >= 0.85, f"{name} r={r}: overlap with the bf16 reference {inter:.3f}"
+                inter = 1.0
+                for sc_row, mine, theirs in zip(R, idx.reshape(-1, n), ref_idx.reshape(-1, n)):
+                    if n == 0 or n == sc_row.size:
+                        continue
+                    inter = min(inter, len(np.intersect1d(mine, theirs)) / n)
+                    if ulps is None:
+                        continue
+                    t = np.sort(sc_row)[::-1][n - 1]
+                    band = ulps * (2.0 ** -8 if s["dtype"] == "bf16" else 2.0 ** -11) * abs(t)
+                    kept = np.zeros(sc_row.shape, bool)
+                    kept[mine] = True
+                    assert not (~kept & (sc_row > t + band)).any(), f"{name} r={r}: dropped a position more than {ulps} ulps above the reference's threshold"
+                    assert not (kept & (sc_row < t - band)).any(), f"{name} r={r}: kept a position more than {ulps} ulps below the reference's threshold"
+                floor = NATIVE_OVERLAP.get(name, 0.0) - 0.02
+                assert inter >= floor, f"{name} r={r}: overlap with the bf16 reference's own top-k {inter:.3f} < {floor:.3f}"
+
+
+# Band (units in the last place of the model dtype, relative to the threshold) inside which the native-dtype reference's scores
+# are not defined more precisely than its own rounding chain; measured on the fixtures as the largest distance from the
+# reference's threshold at which the float32-mode reference ("O32") and the native-dtype reference disagree (snapkv <= 8.4,
+# ea <= 3.5, tova <= 16.8, cur <= 3.0, observed <= 1.9), with a margin.  KeyDiff / QFilter / LagKV scores are differences of
+# nearly equal numbers (cosine similarity, filter projections, ranks): their reference values are dominated by rounding, so only
+# the overlap floor applies there.
+NATIVE_ULPS = {"snapkv": 12, "pyramid": 12, "ea": 6, "tova": 24, "cur": 6, "observed": 4}
+# smallest overlap (over the case's ratios and rows) between the float32-mode reference's top-k and the native-dtype reference's
+# own, measured when the fixtures were made; the kernels select like the float32-mode reference, the test allows 0.02 below.
+NATIVE_OVERLAP = {
+    "sk_257_A": 0.745, "sk_257_B": 0.745, "sk_4096": 0.993, "sk_f16_d64": 0.995, "sk_ks1": 0.915, "sk_h512_bf16": 0.915,
+    "sk_h1024_f16": 0.995, "ea_257_A": 0.961, "ea_1500_B": 0.993, "ea_nocov": 0.992, "ea_novnorm_eps": 0.99, "ea_eps_sink0": 0.973,
+    "ea_6000_B": 0.997, "kd_bf16_A": 0.995, "kd_bf16_B": 0.995, "kd_f16_d64": 0.997, "kd_d96_bf16": 0.99, "cur_bf16_B": 0.995,
+    "cur_key_nolocal": 0.995, "cur_kvavg_w7": 0.99, "tv_257": 0.98, "tv_4096_B": 0.996, "py_bf16_l7": 0.99, "qf_bf16_B": 0.995,
+    "qf_f16_d64": 0.995, "lag_bf16": 0.959, "lag_cross_f16": 0.716, "oa_bf16": 0.995, "oa_f16_g1": 1.0,
+}
 
 
 @pytest.mark.parametrize("name", SK)
