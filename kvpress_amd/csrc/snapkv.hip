@@ -228,6 +228,7 @@ struct SnapWs {
     float* part_z;
     float* rowstat;
     float* colsum;
+    float* colsum2;  // G > 4 (two group-blocks per kv-head in the MFMA pass 2): the second block's column sums, added in a fixed order
     float* bmax;  // per-workgroup maxima of the pool kernel (<= 4096)
     void* qrot;   // [B,Hq,W,D] RoPE'd window queries (kvp_snapkv_score_rope)
     size_t total_bytes;
@@ -250,6 +251,7 @@ SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, in
     w.part_z = (float*)take(rows * nchunk_max * 4);
     w.rowstat = (float*)take(rows * 4);
     w.colsum = (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4);
+    w.colsum2 = Hq / std::max<int64_t>(1, Hkv) > 4 ? (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4) : nullptr;
     w.qrot = take((size_t)B * Hq * W * D * 4);
     w.total_bytes = off;
     return w;
@@ -334,7 +336,7 @@ int snapkv_score_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, c
         const uint32_t nchunk = snapkv_mfma_nchunk(a);
         if (int rc = snapkv_mfma_p1(a, dtype, nchunk, w.part_m, w.part_z, stream)) return rc;
         KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_kernel<<<(nrows + 3) / 4, 256, 0, stream>>>(w.part_m, w.part_z, nrows, nchunk, w.rowstat, (uint32_t)W, norm_base));
-        if (int rc = snapkv_mfma_p2(a, dtype, w.rowstat, w.colsum, stream)) return rc;
+        if (int rc = snapkv_mfma_p2(a, dtype, w.rowstat, w.colsum, w.colsum2, stream)) return rc;
     } else {
         const uint32_t nchunk = (uint32_t)((S + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC);
         const size_t lds1 = ((size_t)SK_SUB * (D + 1) + 2 * (size_t)W) * 4;

@@ -15,7 +15,8 @@ struct SnapArgs {
 bool snapkv_mfma_eligible(const SnapArgs& a, int dtype);
 uint32_t snapkv_mfma_nchunk(const SnapArgs& a);
 int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m, float* part_z, hipStream_t stream);
-int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, hipStream_t stream);
+// colsum2: scratch of the size of colsum, needed when G > 4 (the second group-block's sums; merged in a fixed order: deterministic)
+int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, float* colsum2, hipStream_t stream);
 
 enum { SNAP_FINISH_FULL = 0,    // pool + scale into `scores`, pad columns = max + 1
        SNAP_FINISH_NO_PAD = 1,  // pool + scale, pad columns left unwritten (fused compress: they are kept by construction)

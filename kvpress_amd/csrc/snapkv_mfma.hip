@@ -309,7 +309,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
 // =================================================================================================
 template <int DT>
 __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint32_t ngb, const float* __restrict__ rowstat,
-                                                                float* __restrict__ colsum) {
+                                                                float* __restrict__ colsum, float* __restrict__ colsum2) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[MF_NBUF * MF_TILEB];
     __shared__ float red[2][MF_WAVES][MF_TILE];
     const uint32_t chunk = blockIdx.x, b = blockIdx.z;
@@ -339,7 +339,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
     wait_all_landed();  // K tiles 0 and 1, Q fragments and normalisers are in; from here on vmcnt only counts the K stream (+ the flush stores)
 
     const float c = a.c;
-    float* cs = colsum + (size_t)(b * a.Hkv + h) * Sm;
+    // group-block 0 owns colsum, group-block 1 (G > 4) its own slab: no float atomics, the two are added afterwards in a fixed order
+    float* cs = (gb == 0 ? colsum : colsum2) + (size_t)(b * a.Hkv + h) * Sm;
     const uint32_t nact = 2 * min(4u, a.G - gb * 4);  // active waves in this workgroup
 
     // column sums of P = 2^(L2 - a_row) over this wave's 32 q rows for the 32 keys of one finished sub-tile
@@ -401,8 +402,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
             if (kk < Sm) {
                 float s = red[par][0][threadIdx.x];
                 for (uint32_t w = 1; w < nact; ++w) s += red[par][w][threadIdx.x];
-                if (ngb == 1) cs[kk] = s;
-                else atomicAdd(&cs[kk], s);
+                cs[kk] = s;
             }
         }
     };
@@ -462,18 +462,24 @@ int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m,
     return KVP_OK;
 }
 
-int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, hipStream_t stream) {
+namespace {
+__global__ __launch_bounds__(256) void add_slab_kernel(float* __restrict__ x, const float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] += y[i];
+}
+}  // namespace
+
+int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, float* colsum2, hipStream_t stream) {
     const uint32_t ngb = (a.G + 3) / 4;
     const uint32_t Sm = a.S - a.W;
-    if (ngb > 1) {
-        if (hipMemsetAsync(colsum, 0, (size_t)a.B * a.Hkv * Sm * 4, stream) != hipSuccess) {
-            kvp_set_error("snapkv_p2_mfma: memset failed");
-            return KVP_EHIP;
-        }
-    }
+    KVP_CHECK_ARG(ngb <= 2 && (ngb == 1 || colsum2), "snapkv_p2_mfma: G = %u needs the second column-sum slab", a.G);
     const dim3 grid(mfma_nchunk_for(a, Sm), a.Hkv * ngb, a.B);
-    if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum));
-    else KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum));
+    if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
+    else KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
     KVP_CHECK_LAUNCH("snapkv_p2_mfma");
+    if (ngb == 2) {  // colsum += colsum2, always in this order: run-to-run identical scores (float atomics were not)
+        const size_t n = (size_t)a.B * a.Hkv * Sm;
+        KVP_LAUNCH("add_slab_kernel", stream, add_slab_kernel<<<(unsigned)std::min<size_t>((n + 255) / 256, 4096), 256, 0, stream>>>(colsum, colsum2, n));
+        KVP_CHECK_LAUNCH("snapkv_p2_mfma(add)");
+    }
     return KVP_OK;
 }

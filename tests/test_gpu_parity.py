@@ -967,3 +967,19 @@ def test_snapkv_extreme_logit_spread():
     want = O.snapkv_score(q_win, keys, 5)
     assert np.isfinite(got).all()
     assert_scores_close(got[..., :-W], want[..., :-W], RTOL, "extreme logit spread")
+
+
+@pytest.mark.parametrize("G", [5, 8])
+def test_snapkv_mfma_group_blocks_are_deterministic(G):
+    """G > 4 splits a kv-head's query heads over two workgroups in pass 2; their column sums are merged in a fixed order (no
+    float atomics): two runs give bit-identical scores, and they match the oracle."""
+    g = torch.Generator().manual_seed(77)
+    S = 5000
+    keys = torch.randn((2, 2, S, 128), generator=g).to(torch.bfloat16).to(DEV)
+    q = (torch.randn((2, 2 * G, 64, 128), generator=g) * 1.2).to(torch.bfloat16).to(DEV)
+    a = native().snapkv_score(q, keys, 5)
+    for _ in range(3):
+        assert torch.equal(a, native().snapkv_score(q, keys, 5))
+    ref = O.snapkv_score(q.float().cpu().numpy(), keys.float().cpu().numpy(), 5)
+    got = a.cpu().numpy()
+    np.testing.assert_allclose(got[..., :-64], ref[..., :-64], rtol=1e-3)
