@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 from typing import Optional
 
@@ -19,7 +20,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libkvpress_hip.so")
 KVP_F32, KVP_F16, KVP_BF16 = 0, 1, 2
 ORDER_POSITION, ORDER_SCORE = 0, 1
 TOPK_WS_CLEAN = 0x100
-_TOPK_WS: dict = {}  # (device index, stream, R, S) -> zero-initialised, self-cleaning workspace
+_TOPK_WS: dict = {}  # (thread, device index, stream, R, S) -> zero-initialised, self-cleaning workspace
+_TOPK_WS_LOCK = threading.Lock()
 _DTYPES = {torch.float32: KVP_F32, torch.float16: KVP_F16, torch.bfloat16: KVP_BF16}
 
 # name -> (restype, argtypes); mirrors include/kvpress_hip.h line by line
@@ -546,14 +548,13 @@ def topk_select(scores: torch.Tensor, k: int, order: int = ORDER_POSITION) -> to
                 # self-cleaning workspace: zeroed once per (device, stream, size), reused with KVP_TOPK_WS_CLEAN
                 stream = torch.cuda.current_stream(s.device)
                 key = (s.device.index, stream.cuda_stream, R, S)  # the layout (hence the clean region) depends on R and S
-                ws = _TOPK_WS.get(key)
-                if ws is None:
-                    if len(_TOPK_WS) > 64:
-                        _TOPK_WS.clear()
-                    ws = torch.zeros(max(int(nws), 256), dtype=torch.uint8, device=s.device)
-                    _TOPK_WS[key] = ws
-            _check(lib().kvp_topk_select(_p(s2), R, S, s2.stride(0) if R > 1 else S, int(k), int(order) | TOPK_WS_CLEAN, _p(idx),
-                                         _p(ws), ws.numel(), _stream(s)), "kvp_topk_select")
+                ws = _cached_ws(key, nws, s.device)
+            try:
+                _check(lib().kvp_topk_select(_p(s2), R, S, s2.stride(0) if R > 1 else S, int(k), int(order) | TOPK_WS_CLEAN, _p(idx),
+                                             _p(ws), ws.numel(), _stream(s)), "kvp_topk_select")
+            except KvpressHipError:
+                _drop_ws(ws)  # a failed call may leave dirty histograms behind: never reuse this workspace as "clean"
+                raise
     return idx.reshape(*lead, k)
 
 
@@ -598,18 +599,26 @@ def _clean_ws(kind: str, shape: tuple, nbytes: int, like: torch.Tensor) -> torch
     histogram region clean, so it is passed with KVP_TOPK_WS_CLEAN from then on."""
     stream = torch.cuda.current_stream(like.device)
     key = (kind, like.device.index, stream.cuda_stream) + tuple(shape)
-    ws = _TOPK_WS.get(key)
-    if ws is None:
-        if len(_TOPK_WS) > 64:
-            _TOPK_WS.clear()
-        ws = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
-        _TOPK_WS[key] = ws
+    return _cached_ws(key, nbytes, like.device)
+
+
+def _cached_ws(key: tuple, nbytes: int, device) -> torch.Tensor:
+    """One zero-filled workspace per (calling thread, key): two Python threads never share one, even on the same stream."""
+    key = (threading.get_ident(),) + tuple(key)
+    with _TOPK_WS_LOCK:
+        ws = _TOPK_WS.get(key)
+        if ws is None:
+            if len(_TOPK_WS) > 64:
+                _TOPK_WS.clear()
+            ws = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            _TOPK_WS[key] = ws
     return ws
 
 
 def _drop_ws(ws: torch.Tensor):
-    for key in [k for k, v in _TOPK_WS.items() if v is ws]:
-        del _TOPK_WS[key]
+    with _TOPK_WS_LOCK:
+        for key in [k for k, v in _TOPK_WS.items() if v is ws]:
+            del _TOPK_WS[key]
 
 
 def knorm_compress(keys: torch.Tensor, values: torch.Tensor, n_kept: int):

@@ -11,8 +11,8 @@ cut back to its post-prefill length between questions.
     pipe(context, questions=[...], press=...)["answers"]
 
 Host-side differences to the reference, none of which changes a result:
-  * the reference's FinchPress / DMSPress / RestoreKVPress special cases (:224-243) are absent (those presses are not
-    part of this package); DecodingPress, PrefillDecodingPress and KeyRerotationPress are handled as there;
+  * FinchPress (delimiter token, :224-232), DMSPress, DecodingPress, PrefillDecodingPress and KeyRerotationPress are handled as
+    there; the RestoreKVPress special case (:243) is absent (that press is not part of this package);
   * ``logits_to_keep`` is the transformers >= 4.50 name of ``num_logits_to_keep`` (:288).
 """
 from __future__ import annotations

@@ -35,10 +35,17 @@ SUPPORTED_MODEL_NAMES = (
 )
 
 
-def is_prefilling(kv_len: int, q_len: int) -> bool:
-    """True for the initial prefill: the cache held nothing before this forward, i.e. after the layer's update it holds
-    the q_len tokens of this forward -- or fewer, when an earlier press of a ComposedPress has already pruned them.
-    (A continuation or decoding step leaves kv_len = past + q_len > q_len.)"""
+def is_prefilling(kv_len: int, q_len: int, kwargs: dict | None = None) -> bool:
+    """True for the initial prefill.  When the model passes ``cache_position`` (transformers < 5.3) the reference's own rule
+    applies, ``cache_position[-1] + 1 == q_len`` (base_press.py:37-40): it is right whatever the cache layer stores (a
+    pre-allocated static cache, a sliding-window layer).  transformers >= 5.3 no longer passes it; then the
+    tensor shapes decide without a device sync: the cache held nothing before this forward, i.e. after the layer's update it
+    holds the q_len tokens of this forward -- or fewer, when an earlier press of a ComposedPress has already pruned them (a
+    continuation or decoding step leaves kv_len = past + q_len > q_len).  That shape rule needs a cache whose stored length is
+    its logical length (DynamicCache / QuantizedCache)."""
+    cache_position = None if kwargs is None else kwargs.get("cache_position")
+    if cache_position is not None:
+        return int(cache_position[-1]) + 1 == int(q_len)
     return int(kv_len) <= int(q_len)
 
 
@@ -74,7 +81,7 @@ class BasePress:
 
         # Don't compress after pre-filling
         kv_len = cache.get_seq_length(module.layer_idx) if _is_quantized(cache) else cache_layer.keys.shape[2]
-        if not is_prefilling(kv_len, q_len):
+        if not is_prefilling(kv_len, q_len, kwargs):
             return output
 
         keys, values = extract_keys_and_values(cache, module.layer_idx)

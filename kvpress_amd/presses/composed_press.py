@@ -20,6 +20,16 @@ class ComposedPress(BasePress):
 
     def __post_init__(self):
         self.compression_ratio = None
+        # composed_press.py:31-34 forbids AdaKVPress / KVzipPress here.  The same holds for every press that records
+        # ``module.masked_key_indices`` relative to the cache it saw: a later pruning press would silently invalidate them.
+        from kvpress_amd.presses.adakv_press import AdaKVPress
+        from kvpress_amd.presses.criticalkv_press import CriticalAdaKVPress
+        from kvpress_amd.presses.dms_press import DMSPress
+        from kvpress_amd.presses.duo_attention_press import DuoAttentionPress
+
+        masking = (AdaKVPress, CriticalAdaKVPress, DMSPress, DuoAttentionPress)
+        assert not any(isinstance(press, masking) for press in self.presses), \
+            "ComposedPress cannot contain presses that mask keys through module.masked_key_indices (AdaKVPress, CriticalAdaKVPress, DMSPress, DuoAttentionPress)"
 
     def post_init_from_model(self, model):
         for press in self.presses:

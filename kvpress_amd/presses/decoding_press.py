@@ -102,7 +102,7 @@ class DecodingPress(BasePress):
         cache = kwargs["past_key_values"]
         q_len = hidden_states.shape[1]
         layer_idx = module.layer_idx
-        if is_prefilling(_kv_len(cache, layer_idx), q_len):
+        if is_prefilling(_kv_len(cache, layer_idx), q_len, kwargs):
             return output                                   # still pre-filling: nothing to do
 
         self.hidden_states_buffer[layer_idx].append(hidden_states.detach().clone())
@@ -186,13 +186,13 @@ class PrefillDecodingPress(BasePress):
             if p is not None:
                 p.post_init_from_model(model)
 
-    def _phase_press(self, kv_len: int, q_len: int):
-        if is_prefilling(kv_len, q_len) and self.prefilling_press is not None:
+    def _phase_press(self, kv_len: int, q_len: int, kwargs: dict | None = None):
+        if is_prefilling(kv_len, q_len, kwargs) and self.prefilling_press is not None:
             return self.prefilling_press
         return self.decoding_press
 
     def compress(self, module, hidden_states, keys, values, attentions, kwargs):
-        press = self._phase_press(keys.shape[2], hidden_states.shape[1])
+        press = self._phase_press(keys.shape[2], hidden_states.shape[1], kwargs)
         if press is None:
             logger.warning("No compression applied during prefill or decoding phase")
             return keys, values

@@ -33,6 +33,9 @@ def _pattern_dirs() -> dict:
 PATTERNS_DICT = _pattern_dirs()
 
 
+_PATTERN_CACHE: dict = {}   # checkpoint name -> (sink_size, recent_size, head_scores)
+
+
 @dataclass
 class DuoAttentionPress(BasePress):
     """DuoAttention (https://arxiv.org/abs/2410.10819).
@@ -85,15 +88,19 @@ class DuoAttentionPress(BasePress):
 
     @staticmethod
     def load_attention_pattern(model):
-        """(sink_size, recent_size, head_scores [n_layers, n_kv_heads]) from the DuoAttention repository (:105-122)."""
-        import json
-        from io import StringIO
-        from urllib.request import urlopen
-
+        """(sink_size, recent_size, head_scores [n_layers, n_kv_heads]) from the DuoAttention repository (:105-122); fetched once per
+        checkpoint name (the reference memoises with ``@cached``), 30 s timeout per request.  The reference's
+        ``on_the_fly_scoring`` (calibrating the patterns on the spot) is not part of this package."""
         name = model.config.name_or_path
         assert name in PATTERNS_DICT, f"Checkpoint {name} not in {list(PATTERNS_DICT.keys())}"
-        url = f"https://raw.githubusercontent.com/mit-han-lab/duo-attention/refs/heads/main/attn_patterns/{PATTERNS_DICT[name]}/"
-        config = json.loads(urlopen(url + "config.json").read().decode())
-        text = urlopen(url + "full_attention_heads.tsv").read().decode()
-        head_scores = np.clip(np.loadtxt(StringIO(text), dtype=float, delimiter="\t"), 0, 1)
-        return config["sink_size"], config["recent_size"], head_scores
+        if name not in _PATTERN_CACHE:
+            import json
+            from io import StringIO
+            from urllib.request import urlopen
+
+            url = f"https://raw.githubusercontent.com/mit-han-lab/duo-attention/refs/heads/main/attn_patterns/{PATTERNS_DICT[name]}/"
+            config = json.loads(urlopen(url + "config.json", timeout=30).read().decode())
+            text = urlopen(url + "full_attention_heads.tsv", timeout=30).read().decode()
+            head_scores = np.clip(np.loadtxt(StringIO(text), dtype=float, delimiter="\t"), 0, 1)
+            _PATTERN_CACHE[name] = (config["sink_size"], config["recent_size"], head_scores)
+        return _PATTERN_CACHE[name]

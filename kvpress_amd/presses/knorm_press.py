@@ -31,6 +31,6 @@ class KnormPress(ScorerPress):
         A subclass that overrides ``score`` gets the generic three-call sequence."""
         if self.compression_ratio == 0:
             return keys, values
-        if type(self).score is not KnormPress.score:
+        if type(self).score is not KnormPress.score or self.kept_order != "position":
             return super().compress(module, hidden_states, keys, values, attentions, kwargs)
         return _native.knorm_compress(keys, values, self.n_kept(module, keys.shape[2]))

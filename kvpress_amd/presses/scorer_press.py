@@ -11,7 +11,13 @@ Defined deviations (DESIGN.md "Parity contract"):
     threshold and torch.topk's choice among ties is unspecified);
   * among equal scores the lowest position is kept;
   * the retained tokens are stored in ascending position order, the reference stores them in descending
-    score order, which no reference test observes (``_native.topk_select(..., ORDER_SCORE)`` gives that order).
+    score order, which no reference test observes.  CONSEQUENCE for chains: a position-dependent press running AFTER a
+    ScorerPress on the already-pruned cache (ComposedPress([Knorm, SnapKV / StreamingLLM / ExpectedAttention]),
+    PrefillDecodingPress with such a decoding press) sees the survivors in position order here and in score order in the
+    reference, so its "last W tokens" / sinks are different tokens: such chains are NOT reference-equivalent by default.
+    ``kept_order = "score"`` (class attribute, settable per instance) stores the survivors in the reference's order
+    (descending score, ties by position: ``KVP_ORDER_SCORE``) for reference-exact chaining; pinned by
+    tests/test_host_hook.py::test_kept_order_switch.
 """
 from __future__ import annotations
 
@@ -38,6 +44,7 @@ class ScorerPress(BasePress):
     """
 
     compression_ratio: float = 0.0
+    kept_order = "position"   # "position" (ascending, default) | "score" (the reference's torch.topk order); not a dataclass field
 
     def __post_init__(self):
         assert 0 <= self.compression_ratio < 1, "Compression ratio must be between 0 and 1"
@@ -59,5 +66,6 @@ class ScorerPress(BasePress):
             return keys, values
 
         scores = self.score(module, hidden_states, keys, values, attentions, kwargs)
-        indices = _native.topk_select(scores, self.n_kept(module, keys.shape[2]))  # int32 [B,H,n_kept], ascending position
+        order = _native.ORDER_SCORE if self.kept_order == "score" else _native.ORDER_POSITION
+        indices = _native.topk_select(scores, self.n_kept(module, keys.shape[2]), order)  # int32 [B,H,n_kept]
         return _native.gather_kv(keys, values, indices)                             # contiguous [B,H,n_kept,D]

@@ -70,7 +70,7 @@ class SnapKVPress(ScorerPress):
         subclass with its own ``score``, the generic three-call sequence runs."""
         if self.compression_ratio == 0:
             return keys, values
-        if attentions is not None or type(self).score is not SnapKVPress.score:
+        if attentions is not None or type(self).score is not SnapKVPress.score or self.kept_order != "position":
             return super().compress(module, hidden_states, keys, values, attentions, kwargs)
         assert (
             hidden_states.shape[1] > self.window_size

@@ -133,3 +133,49 @@ def test_compression_ratio_is_a_plain_settable_attribute():
     assert p.compression_ratio == 1.0 and (p.window_size, p.kernel_size) == (64, 5)
     e = P.ExpectedAttentionPress()
     assert (e.n_future_positions, e.n_sink, e.use_covariance, e.use_vnorm, e.epsilon) == (512, 4, True, True, 0.0)
+
+
+def test_prefill_detection_prefers_cache_position():
+    """with ``cache_position`` in the kwargs the reference's own rule decides (base_press.py:37-40), whatever the
+    stored cache length is (static / pre-allocated caches); without it (transformers >= 5.3) the shapes decide."""
+    from kvpress_amd.presses.base_press import is_prefilling
+
+    # static cache: stored length 4096, prompt of 100 tokens -> still the prefill
+    assert is_prefilling(4096, 100, {"cache_position": torch.arange(0, 100)})
+    # continuation chunk of 100 tokens after 300 cached ones: not a prefill, although a sliding layer may store only 100
+    assert not is_prefilling(100, 100, {"cache_position": torch.arange(300, 400)})
+    # decoding step
+    assert not is_prefilling(257, 1, {"cache_position": torch.tensor([256])})
+    # no cache_position: DynamicCache shapes
+    assert is_prefilling(100, 100, {}) and is_prefilling(60, 100) and not is_prefilling(101, 1, {})
+
+
+def test_composed_press_rejects_masking_presses():
+    """composed_press.py:31-34 forbids AdaKVPress inside a ComposedPress; here every press that writes masked_key_indices is."""
+    import kvpress_amd as P
+
+    P.ComposedPress([P.KnormPress(0.2), P.SnapKVPress(0.3)])
+    for bad in (P.AdaKVPress(P.KnormPress(0.2)), P.DMSPress(P.KnormPress(), threshold=0.0)):
+        with pytest.raises(AssertionError):
+            P.ComposedPress([P.KnormPress(0.2), bad])
+
+
+def test_kept_order_switch(fake_native):
+    """Default: survivors in ascending position order.  ``kept_order = "score"``: the reference's order (torch.topk: descending
+    score), which makes a chain with a position-dependent second stage reference-exact."""
+    import kvpress_amd as P
+
+    rs = np.random.RandomState(5)
+    keys = torch.from_numpy(rs.standard_normal((1, 2, 40, 6)).astype(np.float32))
+    values = torch.from_numpy(rs.standard_normal((1, 2, 40, 6)).astype(np.float32))
+    module = type("M", (), {"head_dim": 6})()
+    press = P.KnormPress(0.5)
+    kp, vp = press.compress(module, None, keys, values, None, {})
+    press.kept_order = "score"
+    ks, vs = press.compress(module, None, keys, values, None, {})
+    scores = -keys.norm(dim=-1)
+    ref_idx = scores.topk(20, dim=-1).indices                      # scorer_press.py:95 (descending score)
+    e = ref_idx.unsqueeze(-1).expand(-1, -1, -1, 6)
+    assert torch.equal(ks, keys.gather(2, e)) and torch.equal(vs, values.gather(2, e))
+    e = ref_idx.sort(-1).values.unsqueeze(-1).expand(-1, -1, -1, 6)
+    assert torch.equal(kp, keys.gather(2, e)) and torch.equal(vp, values.gather(2, e))
