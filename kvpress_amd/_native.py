@@ -15,7 +15,8 @@ from typing import Optional
 import torch  # must be imported before the .so so that it binds to torch's libamdhip64.so.7
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkvpress_hip.so")
+# KVPRESS_HIP_LIB: an alternative build of the same library (kernel labs under tools/); unset in production
+LIB_PATH = os.environ.get("KVPRESS_HIP_LIB") or os.path.join(_HERE, "lib", "libkvpress_hip.so")
 
 KVP_F32, KVP_F16, KVP_BF16 = 0, 1, 2
 ORDER_POSITION, ORDER_SCORE = 0, 1

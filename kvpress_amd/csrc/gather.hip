@@ -145,7 +145,7 @@ extern "C" int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t 
     const int wg_per_cu = kvp_env_int("KVP_GA_WG_PER_CU", 8);
     const uint64_t bx_cap = std::max<uint64_t>(1, ((uint64_t)256 * wg_per_cu + BH - 1) / BH);
     const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap));
-    const bool nt = kvp_env_int("KVP_GA_NT", 0) != 0;
+    const bool nt = kvp_env_int("KVP_GA_NT", 1) != 0;  // streaming (non-temporal) loads / stores: the copy must not displace K from the memory-side cache nor leave its output there as dirty lines -- the next window-attention pass pays for both (measured: its K stream 79 -> 50 us)
 #define KVP_GA_CASE(L)                                                                                                   \
     case L:                                                                                                              \
         if (nt) KVP_LAUNCH("gather_vec_kernel", stream, gather_vec_kernel<L, true><<<dim3(bx, BH), GA_THREADS, 0, stream>>>(a)); \

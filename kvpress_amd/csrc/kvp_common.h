@@ -97,7 +97,7 @@ template <> __device__ __forceinline__ float round_dt<KVP_F16>(float x) {
 }
 template <> __device__ __forceinline__ float round_dt<KVP_BF16>(float x) {  // round-to-nearest-even to bf16
     uint32_t u = __float_as_uint(x);
-    if ((u & 0x7F800000u) == 0x7F800000u) return __uint_as_float(u & 0xFFFF0000u | ((u & 0xFFFFu) ? 0x00400000u : 0u));  // inf / nan
+    if ((u & 0x7F800000u) == 0x7F800000u) return __uint_as_float((u & 0xFFFF0000u) | ((u & 0xFFFFu) ? 0x00400000u : 0u));  // inf / nan
     u += 0x7FFFu + ((u >> 16) & 1u);
     return __uint_as_float(u & 0xFFFF0000u);
 }

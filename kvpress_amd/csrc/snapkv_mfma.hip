@@ -30,6 +30,7 @@
 #include "kvp_common.h"
 #include "softmax_stats.h"
 #include "snapkv_internal.h"
+#include "snapkv_asm.inc"
 
 #include <vector>
 
@@ -304,6 +305,146 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
     }
 }
 
+// values handed to an asm block through "s" constraints must sit in SGPRs: make their uniformity explicit
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ float uni(float x) { return __uint_as_float(uni(__float_as_uint(x))); }
+template <typename T> __device__ __forceinline__ T* uni(T* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    return (T*)(uintptr_t)(((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v));
+}
+
+// =================================================================================================
+// pass 1 with the hand-scheduled tile loop (snapkv_asm.inc, generated by tools/gen_stage_asm.py)
+// =================================================================================================
+// Same work decomposition, K stream and partial statistics as snapkv_p1_mfma.  The steady state -- every group of three
+// tiles that needs no mask and has its two prefetch tiles inside the workgroup's walk -- runs as ONE asm block with fixed
+// registers: per 32-key sub-tile ("stage") the MFMA chain of sub-tile s, the row maximum of s-1 and the exp / sum of s-2
+// (three accumulators), the fragment reads of s+1 and one LDS-DMA request for the tile two ahead, interleaved so that the
+// VALU / transcendental work issues in the shadow of the MFMAs (tools/ubench_issue.hip, ubench_stage.hip).  The last tiles
+// of a walk (>= 2, plus the masked ones at the end of a head) take the C++ path below with the statistics handed over.
+// Requires all eight waves active (G % 4 == 0).
+template <int DT>
+__global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_asm(SnapArgs a, uint32_t ngb, uint32_t nchunk,
+                                                               float* __restrict__ part_m, float* __restrict__ part_z) {
+    constexpr int NB = KVP_P1_NBUF;   // ring depth of this kernel: NB - 1 tiles of 32 KiB in flight per workgroup (cold K from HBM
+                                      // needs more than the two of the three-buffer ring: measured 3.5 TB/s with two)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NB * MF_TILEB];
+    const uint32_t chunk = blockIdx.x, b = blockIdx.z;
+    const uint32_t h = blockIdx.y / ngb, gb = blockIdx.y - h * ngb;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t n = lane & 31, kg = lane >> 5;
+    const uint32_t hq = h * a.G + gb * 4 + (wv >> 1);
+    const uint32_t row0 = (wv & 1) * 32;
+
+    const char* kbase = static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2;
+    const KStream ks_(kbase, a.k_ss * 2, a.S);
+    const TileWalk tw(chunk, nchunk, a.S);
+    if (tw.ntiles > 0) {
+#pragma unroll
+        for (int i = 0; i < NB - 1; ++i) ks_.request_tile(lds + i * MF_TILEB, tw.key0(i));
+    }
+    const char* qrow = static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)(row0 + n) * a.q_sw) * 2 + kg * 16;
+    // tiles for the asm loop: the leading unmasked ones (every key <= S - W).  Its requests run NB - 1 tiles ahead with the tile
+    // index clamped to the walk's last tile and no per-row clamp: if that last tile is ragged (rows past S), the C++ loop below
+    // must be the one that requests it.
+    uint32_t nfast = 0;
+    while (nfast < tw.ntiles && tw.kbeg + nfast * tw.tstride + (MF_TILE - 1) <= a.S - a.W) ++nfast;
+    const bool last_full = tw.klast + (MF_TILE - 1) <= a.S - 1;
+    const uint32_t nasm = last_full ? nfast : min(nfast, tw.ntiles >= (uint32_t)NB ? tw.ntiles - NB : 0u);
+
+    float m = KVP_NEG_INF, z = 0.f;
+    const float c = a.c;
+    if (nasm) {
+        const uint32_t ldsbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+        uint32_t la[8], vo[4];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) la[ks] = ldsbase + n * MF_ROWB + (((ks * 2 + kg) ^ (n & 15)) << 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vo[i] = (uint32_t)((i * 32 + ks_.lrow) * ks_.k_ssb) + ks_.choff;
+        const uint32_t m0base = ldsbase + wv * 1024;
+        const char* gnext = kbase + (int64_t)tw.key0(NB - 1) * ks_.k_ssb;   // first tile the block requests (clamped)
+        const uint32_t gstride = (uint32_t)(tw.tstride * ks_.k_ssb);
+        const uint32_t nadv = tw.ntiles >= (uint32_t)NB ? tw.ntiles - NB : 0;   // the request address advances while the next tile exists
+        if (DT == KVP_BF16)
+            asm volatile(KVP_P1_ASM_BF16
+                         : "=&v"(m), "=&v"(z)
+                         : "v"(qrow), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(la[0]), "v"(la[1]), "v"(la[2]), "v"(la[3]), "v"(la[4]),
+                           "v"(la[5]), "v"(la[6]), "v"(la[7]), "s"(uni(m0base)), "s"(uni(gnext)), "s"(uni(gstride)), "s"(uni(nasm)), "s"(uni(c)), "s"(uni(nadv))
+                         : KVP_P1_ASM_CLOBBERS);
+        else
+            asm volatile(KVP_P1_ASM_F16
+                         : "=&v"(m), "=&v"(z)
+                         : "v"(qrow), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(la[0]), "v"(la[1]), "v"(la[2]), "v"(la[3]), "v"(la[4]),
+                           "v"(la[5]), "v"(la[6]), "v"(la[7]), "s"(uni(m0base)), "s"(uni(gnext)), "s"(uni(gstride)), "s"(uni(nasm)), "s"(uni(c)), "s"(uni(nadv))
+                         : KVP_P1_ASM_CLOBBERS);
+    } else if (tw.ntiles > 0) {
+        wait_all_landed();
+        __syncthreads();
+    }
+
+    // ---- the remaining tiles (and every masked one): plain path, same protocol (tile t visible, tiles t+1 .. t+NB-2 in flight) ----
+    if (nasm < tw.ntiles) {
+        uint4 qf[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(qrow + ks * 32);
+        const uint32_t w = row0 + n;
+        int bc = nasm % NB;   // ring position of tile nasm
+        for (uint32_t t = nasm; t < tw.ntiles; ++t) {
+            const unsigned char* buf = lds + bc * MF_TILEB;
+            unsigned char* bufr = lds + ((bc + NB - 1) % NB) * MF_TILEB;   // the previous tile's buffer: everybody left it at the last barrier
+            const uint32_t key0 = tw.key0(t), keyr = tw.key0(t + NB - 1);
+            const bool masked = key0 + (MF_TILE - 1) > a.S - a.W;
+            for (int sub = 0; sub < MF_SUBS; ++sub) {
+                uint4 kf[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) kf[ks] = kfrag(buf, sub, ks, n, kg);
+                ks_.request(bufr, keyr, sub);
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc = mma32<DT>(kf[ks], qf[ks], acc);
+                if (masked) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t kk = key0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                        if (kk >= a.S || kk > a.S - a.W + w) acc[r] = KVP_NEG_INF;
+                    }
+                }
+                float tm = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tm = fmaxf(tm, acc[r]);
+                const float mn = fmaxf(m, tm);
+                if (mn != KVP_NEG_INF) {
+                    const float off = -mn * c;
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        s0 += fast_exp2(fmaf(acc[r], c, off));
+                        s1 += fast_exp2(fmaf(acc[r + 1], c, off));
+                    }
+                    z = z * fast_exp2(fmaf(m, c, off)) + (s0 + s1);
+                    m = mn;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (MF_SUBS * (NB - 2)));   // only the newer tiles' requests may still be in flight
+            __syncthreads();
+            bc = (bc + 1) % NB;
+        }
+    }
+    wait_all_landed();
+
+    float mm = m == KVP_NEG_INF ? KVP_NEG_INF : m * c, zz = z;
+    const float m2 = __shfl_xor(mm, 32), z2 = __shfl_xor(zz, 32);
+    softmax_merge(mm, zz, m2, z2);
+    if (kg == 0) {
+        const size_t o = ((size_t)(b * a.Hq + hq) * a.W + row0 + n) * nchunk + chunk;
+        part_m[o] = mm;
+        part_z[o] = zz;
+    }
+}
+
 // =================================================================================================
 // pass 2: colsum[b,h,key] = sum over the group's G*64 rows of 2^(L2 - a_row), keys < S - W
 // =================================================================================================
@@ -450,6 +591,12 @@ int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m,
     const uint32_t ngb = (a.G + 3) / 4;
     const dim3 grid(nchunk, a.Hkv * ngb, a.B);
     float* clk = kvp_prof_enabled() ? kvp_prof_clock_slot() : nullptr;  // in-kernel clock of pass 1 while profiling is on
+    if (a.G % 4 == 0 && kvp_env_int("KVP_SK_ASM", 1)) {   // hand-scheduled tile loop (KVP_SK_ASM=0: the compiler-scheduled kernel)
+        if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
+        else KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
+        KVP_CHECK_LAUNCH("snapkv_p1_asm");
+        return KVP_OK;
+    }
     const int abl = kvp_env_int("KVP_SK_ABL", 0);  // measurement aid (read per launch)
 #define KVP_P1_ABL(A) case A: KVP_LAUNCH("snapkv_p1_mfma", stream, (snapkv_p1_mfma<KVP_BF16, A><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, clk))); break;
     if (dtype == KVP_BF16) {
@@ -460,6 +607,131 @@ int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m,
 #undef KVP_P1_ABL
     KVP_CHECK_LAUNCH("snapkv_p1_mfma");
     return KVP_OK;
+}
+
+// =================================================================================================
+// pass 2 with the hand-scheduled tile loop (snapkv_asm.inc): MFMA chain of sub-tile s || exp / column sums of s-2
+// =================================================================================================
+// Every lane half of every wave writes its partial column sum of a 32-key sub-tile to its own LDS slot (16 per key); after
+// the barrier that ends the NEXT tile, waves 0-1 add the 16 slots in a fixed order and store the tile's 128 column sums
+// (deterministic; three tiles of slots in flight).  Tiles that reach past S - W, the walk's last tiles when they are ragged,
+// take the C++ path below.  Requires all eight waves active (G % 4 == 0).
+template <int DT>
+__global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_asm(SnapArgs a, uint32_t ngb, const float* __restrict__ rowstat,
+                                                               float* __restrict__ colsum, float* __restrict__ colsum2) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[MF_NBUF * MF_TILEB];
+    __shared__ __attribute__((aligned(16))) unsigned char red3[KVP_P2_RED_BYTES];
+    __shared__ float red[2][MF_WAVES][MF_TILE];
+    const uint32_t chunk = blockIdx.x, b = blockIdx.z;
+    const uint32_t h = blockIdx.y / ngb, gb = blockIdx.y - h * ngb;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t n = lane & 31, kg = lane >> 5;
+    const uint32_t hq = h * a.G + gb * 4 + (wv >> 1);
+    const uint32_t row0 = (wv & 1) * 32;
+    const uint32_t Sm = a.S - a.W;
+
+    const char* kbase = static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2;
+    const KStream ks_(kbase, a.k_ss * 2, a.S);
+    const TileWalk tw(chunk, gridDim.x, Sm);
+    if (tw.ntiles == 0) return;
+    ks_.request_tile(lds, tw.key0(0));
+    ks_.request_tile(lds + MF_TILEB, tw.key0(1));
+    const char* qrow = static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)(row0 + n) * a.q_sw) * 2 + kg * 16;
+    const float* ars = rowstat + (size_t)(b * a.Hq + hq) * a.W + row0;
+    float* cs = (gb == 0 ? colsum : colsum2) + (size_t)(b * a.Hkv + h) * Sm;
+    const float c = a.c;
+
+    uint32_t nfast = 0;   // tiles stored completely (all 128 keys < S - W)
+    while (nfast < tw.ntiles && tw.kbeg + nfast * tw.tstride + MF_TILE <= Sm) ++nfast;
+    const bool last_full = tw.klast + (MF_TILE - 1) <= a.S - 1;
+    const uint32_t nasm = last_full ? nfast : min(nfast, tw.ntiles >= 3 ? tw.ntiles - 3 : 0u);
+
+    if (nasm) {
+        const uint32_t ldsbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+        const uint32_t redbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)red3;
+        uint32_t la[8], vo[4];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) la[ks] = ldsbase + n * MF_ROWB + (((ks * 2 + kg) ^ (n & 15)) << 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vo[i] = (uint32_t)((i * 32 + ks_.lrow) * ks_.k_ssb) + ks_.choff;
+        const uint32_t m0base = __builtin_amdgcn_readfirstlane(ldsbase + wv * 1024);
+        const uint32_t wvs = __builtin_amdgcn_readfirstlane(wv);
+        const char* gnext = kbase + (int64_t)tw.key0(2) * ks_.k_ssb;
+        const uint32_t gstride = (uint32_t)(tw.tstride * ks_.k_ssb);
+        const uint32_t nadv = tw.ntiles >= 3 ? tw.ntiles - 3 : 0;
+        const float* arp = ars + 4 * kg;
+        float* cs0 = cs + tw.kbeg;                               // column sums of this walk's first tile
+        const uint32_t csstride = tw.tstride * 4;
+        const uint32_t redw = redbase + (wv * 2 + kg) * 512 + n * 4;   // this lane's slot for a sub-tile's key n
+        const uint32_t flr = redbase + (threadIdx.x & 127) * 4;        // flush: slot 0 of key threadIdx.x (waves 0, 1)
+        const uint32_t flo = (threadIdx.x & 127) * 4;
+        if (DT == KVP_BF16)
+            asm volatile(KVP_P2_ASM_BF16
+                         :
+                         : "v"(qrow), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(la[0]), "v"(la[1]), "v"(la[2]), "v"(la[3]), "v"(la[4]),
+                           "v"(la[5]), "v"(la[6]), "v"(la[7]), "s"(uni(m0base)), "s"(uni(gnext)), "s"(uni(gstride)), "s"(uni(nasm)), "s"(uni(c)), "s"(uni(nadv)), "s"(uni(wvs)),
+                           "s"(uni(cs0)), "v"(arp), "s"(uni(csstride)), "v"(redw), "v"(flr), "v"(flo)
+                         : KVP_P2_ASM_CLOBBERS);
+        else
+            asm volatile(KVP_P2_ASM_F16
+                         :
+                         : "v"(qrow), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(la[0]), "v"(la[1]), "v"(la[2]), "v"(la[3]), "v"(la[4]),
+                           "v"(la[5]), "v"(la[6]), "v"(la[7]), "s"(uni(m0base)), "s"(uni(gnext)), "s"(uni(gstride)), "s"(uni(nasm)), "s"(uni(c)), "s"(uni(nadv)), "s"(uni(wvs)),
+                           "s"(uni(cs0)), "v"(arp), "s"(uni(csstride)), "v"(redw), "v"(flr), "v"(flo)
+                         : KVP_P2_ASM_CLOBBERS);
+    } else {
+        wait_all_landed();
+        __syncthreads();
+    }
+
+    if (nasm < tw.ntiles) {
+        uint4 qf[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(qrow + ks * 32);
+        float ar[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ar[r] = -ars[(r & 3) + 8 * (r >> 2) + 4 * kg];
+        int bc = nasm % 3;
+        for (uint32_t t = nasm; t < tw.ntiles; ++t) {
+            const unsigned char* buf = lds + bc * MF_TILEB;
+            unsigned char* bufr = lds + ring_prev(bc) * MF_TILEB;
+            const uint32_t key0 = tw.key0(t), keyr = tw.key0(t + 2);
+            const int par = t & 1;
+            for (int sub = 0; sub < MF_SUBS; ++sub) {
+                uint4 kf[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) kf[ks] = kfrag(buf, sub, ks, n, kg);
+                ks_.request(bufr, keyr, sub);
+                f32x16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc = mma32<DT>(qf[ks], kf[ks], acc);
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    s0 += fast_exp2(fmaf(acc[r], c, ar[r]));
+                    s1 += fast_exp2(fmaf(acc[r + 1], c, ar[r + 1]));
+                }
+                float sm = s0 + s1;
+                sm += __shfl_xor(sm, 32);
+                if (kg == 0) red[par][wv][sub * 32 + n] = sm;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            wait_tile_landed();
+            __syncthreads();
+            if (threadIdx.x < MF_TILE) {
+                const uint32_t kk = key0 + threadIdx.x;
+                if (kk < Sm) {
+                    float sm = red[par][0][threadIdx.x];
+                    for (uint32_t w = 1; w < MF_WAVES; ++w) sm += red[par][w][threadIdx.x];
+                    cs[kk] = sm;
+                }
+            }
+            bc = ring_next(bc);
+        }
+    }
+    wait_all_landed();
 }
 
 namespace {
@@ -473,7 +745,10 @@ int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* co
     const uint32_t Sm = a.S - a.W;
     KVP_CHECK_ARG(ngb <= 2 && (ngb == 1 || colsum2), "snapkv_p2_mfma: G = %u needs the second column-sum slab", a.G);
     const dim3 grid(mfma_nchunk_for(a, Sm), a.Hkv * ngb, a.B);
-    if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
+    if (a.G % 4 == 0 && kvp_env_int("KVP_SK_ASM", 1)) {   // hand-scheduled tile loop
+        if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
+        else KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
+    } else if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
     else KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
     KVP_CHECK_LAUNCH("snapkv_p2_mfma");
     if (ngb == 2) {  // colsum += colsum2, always in this order: run-to-run identical scores (float atomics were not)

@@ -16,7 +16,7 @@ Register map (VGPR numbers are fixed inside the asm block and listed as clobbers
   KF0  v[64:95]    K fragments of the sub-tile being multiplied (8 x ds_read_b128)
   KF1  v[96:127]   K fragments of the next sub-tile (loaded while KF0 is multiplied)
   ACC  v[128:175]  three 16-register accumulators: written by the MFMA chain (W), max-reduced (M), exponentiated (X)
-  T    v[176:191]  fma / exp temporaries
+  UB_T    v[176:191]  fma / exp temporaries
   misc v[192:..]   running max m, running sum z, offsets, partial sums
 Pass 1 pipeline per 32-key sub-tile s (one "stage"): MFMA chain of s  ||  row maximum of s-1  ||  exp / sum of s-2.
 """
@@ -24,8 +24,8 @@ import sys
 
 QF, KF0, KF1 = 32, 64, 96
 ACC = [128, 144, 160]
-T = 176
-M_, Z_, OFFX, RX, OFFM, RM, S0, S1, TMAX, MNEW = 192, 193, 194, 195, 196, 197, 198, 199, 200, 201
+UB_T = 176
+UB_M_, UB_Z_, UB_OFFX, UB_RX, UB_OFFM, UB_RM, UB_S0, UB_S1, UB_TMAX, UB_MNEW = 192, 193, 194, 195, 196, 197, 198, 199, 200, 201
 LADDR = 202      # 8 per-lane LDS byte offsets (one per k-step), buffer-relative
 LADDR2 = 210     # the same + 65536 (third ring buffer: ds offset field is 16 bits)
 DMAV = 218       # 4 per-lane global byte offsets (one per request of a tile)
@@ -41,14 +41,14 @@ def mfma(acc, a, b, first, dt="bf16"):
     return f"v_mfma_f32_32x32x16_{dt} {vr(acc, 16)}, {vr(a, 4)}, {vr(b, 4)}, {c}"
 
 
-def p1_valu_x(accx, cs="s20"):
-    """exp / sum part for the sub-tile in accx: uses OFFX (= -c * m_j) and RX (= 2^(c m_{j-1} - c m_j))."""
+def ub_p1_valu_x(accx, cs="s20"):
+    """exp / sum part for the sub-tile in accx: uses UB_OFFX (= -c * m_j) and UB_RX (= 2^(c m_{j-1} - c m_j))."""
     ops = []
-    F = lambda i: f"v_fma_f32 v{T + i}, {cs}, v{accx + i}, v{OFFX}"
-    E = lambda i: f"v_exp_f32 v{T + i}, v{T + i}"
-    A = lambda i: f"v_add_f32 v{S0 if i % 2 == 0 else S1}, v{S0 if i % 2 == 0 else S1}, v{T + i}"
-    # z <- z * RX first (independent of the exps), then the partial sums start from the first two exps
-    ops.append(f"v_mul_f32 v{Z_}, v{Z_}, v{RX}")
+    F = lambda i: f"v_fma_f32 v{UB_T + i}, {cs}, v{accx + i}, v{UB_OFFX}"
+    E = lambda i: f"v_exp_f32 v{UB_T + i}, v{UB_T + i}"
+    A = lambda i: f"v_add_f32 v{UB_S0 if i % 2 == 0 else UB_S1}, v{UB_S0 if i % 2 == 0 else UB_S1}, v{UB_T + i}"
+    # z <- z * UB_RX first (independent of the exps), then the partial sums start from the first two exps
+    ops.append(f"v_mul_f32 v{UB_Z_}, v{UB_Z_}, v{UB_RX}")
     for b in range(4):
         ops += [F(4 * b + i) for i in range(4)]
         ops += [E(4 * b + i) for i in range(4)]
@@ -56,30 +56,30 @@ def p1_valu_x(accx, cs="s20"):
             for i in range(4):
                 j = 4 * (b - 1) + i
                 if j < 2:
-                    ops.append(f"v_mov_b32 v{S0 if j == 0 else S1}, v{T + j}")
+                    ops.append(f"v_mov_b32 v{UB_S0 if j == 0 else UB_S1}, v{UB_T + j}")
                 else:
                     ops.append(A(j))
     ops += [A(12 + i) for i in range(4)]
-    ops.append(f"v_add_f32 v{S0}, v{S0}, v{S1}")
-    ops.append(f"v_add_f32 v{Z_}, v{Z_}, v{S0}")
+    ops.append(f"v_add_f32 v{UB_S0}, v{UB_S0}, v{UB_S1}")
+    ops.append(f"v_add_f32 v{UB_Z_}, v{UB_Z_}, v{UB_S0}")
     return ops
 
 
-def p1_valu_m(accm, cs="s20"):
+def ub_p1_valu_m(accm, cs="s20"):
     """row maximum of the sub-tile in accm -> new running max, the offset and rescale factor its exp part will use."""
-    ops = [f"v_max3_f32 v{TMAX}, v{accm}, v{accm + 1}, v{accm + 2}"]
+    ops = [f"v_max3_f32 v{UB_TMAX}, v{accm}, v{accm + 1}, v{accm + 2}"]
     for i in range(3, 15, 2):
-        ops.append(f"v_max3_f32 v{TMAX}, v{TMAX}, v{accm + i}, v{accm + i + 1}")
-    ops.append(f"v_max3_f32 v{MNEW}, v{M_}, v{TMAX}, v{accm + 15}")
-    ops.append(f"v_mul_f32_e64 v{OFFM}, {cs}, -v{MNEW}")
-    ops.append(f"v_fma_f32 v{RM}, {cs}, v{M_}, v{OFFM}")
-    ops.append(f"v_exp_f32 v{RM}, v{RM}")
-    ops.append(f"v_mov_b32 v{M_}, v{MNEW}")
+        ops.append(f"v_max3_f32 v{UB_TMAX}, v{UB_TMAX}, v{accm + i}, v{accm + i + 1}")
+    ops.append(f"v_max3_f32 v{UB_MNEW}, v{UB_M_}, v{UB_TMAX}, v{accm + 15}")
+    ops.append(f"v_mul_f32_e64 v{UB_OFFM}, {cs}, -v{UB_MNEW}")
+    ops.append(f"v_fma_f32 v{UB_RM}, {cs}, v{UB_M_}, v{UB_OFFM}")
+    ops.append(f"v_exp_f32 v{UB_RM}, v{UB_RM}")
+    ops.append(f"v_mov_b32 v{UB_M_}, v{UB_MNEW}")
     return ops
 
 
-def rotate_m_to_x():
-    return [f"v_mov_b32 v{OFFX}, v{OFFM}", f"v_mov_b32 v{RX}, v{RM}"]
+def ub_rotate_m_to_x():
+    return [f"v_mov_b32 v{UB_OFFX}, v{UB_OFFM}", f"v_mov_b32 v{UB_RX}, v{UB_RM}"]
 
 
 def spread(slots, ops, start=0, end=None):
@@ -113,11 +113,11 @@ def p1_stage(s, opts, lds_imm=None, dma=None):
         reads = []
     valu = []
     if opts.get("softmax", True):
-        x = p1_valu_x(accx)
-        m = p1_valu_m(accm)
+        x = ub_p1_valu_x(accx)
+        m = ub_p1_valu_m(accm)
         # exp part first (its inputs are two stages old), the max chain late (its accumulator finished last stage)
-        valu = x[:len(x) // 2] + m[:4] + x[len(x) // 2:] + m[4:] + rotate_m_to_x()
-        # NB: m reads RX/OFFX? no: it writes OFFM/RM; x reads OFFX/RX -- rotate only after both are done
+        valu = x[:len(x) // 2] + m[:4] + x[len(x) // 2:] + m[4:] + ub_rotate_m_to_x()
+        # NB: m reads UB_RX/UB_OFFX? no: it writes UB_OFFM/UB_RM; x reads UB_OFFX/UB_RX -- rotate only after both are done
     if dma is not None:
         pre += dma
     lines = []
@@ -227,7 +227,7 @@ def ub_init():
     for ks in range(8):  # LDS fragment addresses (operands %4..%11); second set + 64 KiB for the third ring buffer
         L.append(f"v_mov_b32 v{LADDR + ks}, %{4 + ks}")
         L.append(f"v_add_u32 v{LADDR2 + ks}, 0x10000, %{4 + ks}")
-    L.append(f"v_mov_b32 v{M_}, 0xff800000")
+    L.append(f"v_mov_b32 v{UB_M_}, 0xff800000")
     return L
 
 
@@ -325,3 +325,322 @@ if __name__ == "__main__":
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubench_stage.hip")
         open(path, "w").write(gen_ubench())
         print(path)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# production loops (kvpress_amd/csrc/snapkv_asm.inc, included by snapkv_mfma.hip)
+# ------------------------------------------------------------------------------------------------------------------
+# Scalar registers used inside the blocks (all listed as clobbers):
+#   s20 c = log2(e)/sqrt(D)        s21 tiles left for the block       s22 LDS address of this wave's 1 KiB slot in ring buffer 0
+#   s[24:25] global address of the tile the next request group reads (NBUF - 1 tiles ahead, clamped to the walk's last tile)
+#   s26 bytes between a workgroup's tiles      s28 address advances left (clamp)      s29, s30 scratch
+#   pass 2 only: s27 wave index, s[40:41] global address of the column sums of the tile to flush, s42 its stride, s31 tile barriers passed
+import os as _os
+
+SGPR_CLOB = '"s20", "s21", "s22", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s40", "s41", "s42", "scc"'
+GEN_ABL = set(filter(None, _os.environ.get("GEN_ABL", "").split(",")))   # lab builds: nodma, nobar, novalu, nomfma, nolds (results wrong)
+
+
+class Cfg:
+    """Register map and ring geometry of one pass.  QF / KF0 / KF1 as above; nacc accumulators from v128; then T (16 temporaries),
+    pass-specific registers, two sets of 8 LDS fragment addresses (ring buffers 0-1 and 2-3: the ds offset field is 16 bits) and
+    the 4 per-lane global offsets of a tile's requests."""
+
+    def __init__(self, nbuf, nacc, extra):
+        self.nbuf, self.nacc = nbuf, nacc
+        self.acc = [128 + 16 * i for i in range(nacc)]
+        v = 128 + 16 * nacc
+        self.T = v; v += 16
+        self.extra = v; v += extra
+        self.laddr = v; v += 8
+        self.laddr2 = v; v += 8
+        self.dmav = v; v += 4
+        self.last = v
+        per = 4 * nbuf
+        while per % nacc or per % 2:
+            per += 4 * nbuf
+        self.period = per                      # stages after which ring buffer, accumulator roles and fragment parity repeat
+        self.inflight = 4 * (nbuf - 3) + 3     # requests of this wave that may stay in flight at a tile barrier (tiles newer than t + 1)
+
+    def pos(self, p):
+        """pattern position p (stage index mod period) -> (ring buffer of its tile, sub-tile)"""
+        return (p // 4) % self.nbuf, p % 4
+
+
+P1 = Cfg(nbuf=int(_os.environ.get("GEN_P1_NBUF", "4")), nacc=4 if int(_os.environ.get("GEN_P1_NBUF", "4")) == 4 else 3, extra=10)
+P2 = Cfg(nbuf=3, nacc=3, extra=16 + 2 + 5)
+# pass 1 extras: running max m, running sum z, offsets / rescale factors of the X and M parts, partial sums, scratch
+M_, Z_, OFFX, RX, OFFM, RM, S0, S1, TMAX, MNEW = (P1.extra + i for i in range(10))
+# pass 2 extras: 16 row normalisers, 2 partial sums, LDS write address, flush read address / store offset / value / scratch
+AR = P2.extra
+P2_S0, P2_S1, REDW, FLR, FLO, FLV, FLT = (P2.extra + 16 + i for i in range(7))
+RED_BYTES = 3 * 16 * 128 * 4   # three tiles in flight x (8 waves x 2 lane halves) x 128 keys
+
+
+def stage_head(cfg, p, flush=None):
+    """Head of a stage: wait for this stage's K fragments (and LDS writes); at a tile's last sub-tile also for the NEXT tile's
+    LDS-DMA (only the requests of newer tiles may still be in flight) + the workgroup barrier that publishes it and retires the
+    previous tile's buffer; then the request of sub-block `sub` of the tile NBUF - 1 ahead, which lands in the buffer of the
+    previous tile (address clamped to the walk's last tile: s28 counts the advances left)."""
+    buf, sub = cfg.pos(p)
+    L = ["s_waitcnt lgkmcnt(0)"]
+    if sub == 3:
+        L += [f"s_waitcnt vmcnt({cfg.inflight})"] + ([] if "nobar" in GEN_ABL else ["s_barrier"])
+        if flush:
+            L += flush
+    dst = ((buf + cfg.nbuf - 1) % cfg.nbuf) * 32768 + sub * 8192
+    if "nodma" not in GEN_ABL:
+        L += [f"s_add_u32 m0, s22, {dst}", "s_nop 0", f"global_load_lds_dwordx4 v{cfg.dmav + sub}, s[24:25]"]
+    if sub == 3:
+        L += ["s_cmp_lg_u32 s28, 0", "s_cselect_b32 s29, s26, 0", "s_cselect_b32 s30, 1, 0", "s_sub_u32 s28, s28, s30",
+              "s_add_u32 s24, s24, s29", "s_addc_u32 s25, s25, 0"]
+    return L
+
+
+def prefetch_reads(cfg, p, kfl):
+    nbuf, nsub = cfg.pos((p + 1) % cfg.period)
+    base = cfg.laddr2 if nbuf >= 2 else cfg.laddr
+    imm = nsub * 8192 + (nbuf % 2) * 32768
+    return [f"ds_read_b128 {vr(kfl + 4 * ks, 4)}, v{base + ks} offset:{imm}" for ks in range(8)]
+
+
+def interleave(L, mf, reads, slots):
+    if "novalu" in GEN_ABL:
+        slots = [[] for _ in slots]
+    if "nomfma" in GEN_ABL:
+        mf = ["s_nop 0"] * len(mf)
+    if "nolds" in GEN_ABL:
+        reads = []
+    ri = 0
+    for k in range(8):
+        L.append(mf[k])
+        for _ in range(2):
+            if ri < len(reads):
+                L.append(reads[ri])
+                ri += 1
+        L += slots[k]
+    L += reads[ri:]
+    return L
+
+
+# ---- pass 1 -----------------------------------------------------------------------------------------------------------
+def p1_valu_x(accx, cs="s20"):
+    """exp / sum part for the sub-tile in accx: uses OFFX (= -c * m_j) and RX (= 2^(c m_{j-1} - c m_j))."""
+    T = P1.T
+    F = lambda i: f"v_fma_f32 v{T + i}, {cs}, v{accx + i}, v{OFFX}"
+    E = lambda i: f"v_exp_f32 v{T + i}, v{T + i}"
+    def A(i):
+        d = S0 if i % 2 == 0 else S1
+        return f"v_mov_b32 v{d}, v{T + i}" if i < 2 else f"v_add_f32 v{d}, v{d}, v{T + i}"
+    ops = [f"v_mul_f32 v{Z_}, v{Z_}, v{RX}"]
+    for b in range(4):
+        ops += [F(4 * b + i) for i in range(4)]
+        ops += [E(4 * b + i) for i in range(4)]
+        if b >= 1:
+            ops += [A(4 * (b - 1) + i) for i in range(4)]
+    ops += [A(12 + i) for i in range(4)]
+    ops.append(f"v_add_f32 v{S0}, v{S0}, v{S1}")
+    ops.append(f"v_add_f32 v{Z_}, v{Z_}, v{S0}")
+    return ops
+
+
+def p1_valu_m(accm, cs="s20"):
+    """row maximum of the sub-tile in accm -> new running max, the offset and rescale factor its exp part will use."""
+    ops = [f"v_max3_f32 v{TMAX}, v{accm}, v{accm + 1}, v{accm + 2}"]
+    for i in range(3, 15, 2):
+        ops.append(f"v_max3_f32 v{TMAX}, v{TMAX}, v{accm + i}, v{accm + i + 1}")
+    ops.append(f"v_max3_f32 v{MNEW}, v{M_}, v{TMAX}, v{accm + 15}")
+    ops.append(f"v_mul_f32_e64 v{OFFM}, {cs}, -v{MNEW}")
+    ops.append(f"v_fma_f32 v{RM}, {cs}, v{M_}, v{OFFM}")
+    ops.append(f"v_exp_f32 v{RM}, v{RM}")
+    ops.append(f"v_mov_b32 v{M_}, v{MNEW}")
+    return ops
+
+
+def rotate_m_to_x():
+    return [f"v_mov_b32 v{OFFX}, v{OFFM}", f"v_mov_b32 v{RX}, v{RM}"]
+
+
+def p1_prod_stage(p, do_m=True, do_x=True, dt="bf16"):
+    """One pass-1 stage at pattern position p: head, MFMA chain of sub-tile s, and between the MFMAs the fragment reads of s+1,
+    the exp / sum of s-2 and the row maximum of s-1."""
+    n = P1.nacc
+    accw, accm, accx = P1.acc[p % n], P1.acc[(p - 1) % n], P1.acc[(p - 2) % n]
+    kfu, kfl = (KF0, KF1) if p % 2 == 0 else (KF1, KF0)
+    L = stage_head(P1, p)
+    x = p1_valu_x(accx) if do_x else []
+    m = p1_valu_m(accm) if do_m else []
+    slots = [[] for _ in range(8)]
+    if do_x and do_m:
+        spread(slots, x[:len(x) // 2] + m[:4] + x[len(x) // 2:] + m[4:] + rotate_m_to_x())
+    elif do_m:
+        spread(slots, m + rotate_m_to_x(), 3, 8)   # the accumulator being reduced finished at the end of the previous stage: keep clear of it
+    mf = [mfma(accw, kfu + 4 * k, QF + 4 * k, k == 0, dt) for k in range(8)]
+    return interleave(L, mf, prefetch_reads(P1, p, kfl), slots)
+
+
+def p1_drain(p_end):
+    """after the stage at pattern position p_end: exp/sum of the last two sub-tiles, maximum of the last"""
+    a_last, a_prev = P1.acc[p_end % P1.nacc], P1.acc[(p_end - 1) % P1.nacc]
+    return p1_valu_x(a_prev) + p1_valu_m(a_last) + rotate_m_to_x() + p1_valu_x(a_last)
+
+
+def tile_loop(cfg, stage_fn, drain_fn, first_two):
+    """[stage 0][stage 1] LOOP{ stages 2 .. period+1 with an exit check after every tile } + one drain per exit.  s21 = tiles to do (>= 1)."""
+    L = list(first_two)
+    L.append("1:")
+    exits = []
+    for p in range(2, cfg.period + 2):
+        L += stage_fn(p % cfg.period)
+        if p % 4 == 3:
+            L += ["s_sub_u32 s21, s21, 1", "s_cmp_eq_u32 s21, 0", f"s_cbranch_scc1 {100 + p}f"]
+            exits.append(p)
+    L.append("s_branch 1b")
+    for p in exits:
+        L.append(f"{100 + p}:")
+        L += drain_fn(p % cfg.period)
+        if p != exits[-1]:
+            L.append("s_branch 9f")
+    L.append("9:")
+    return L
+
+
+def p1_prod_body(dt):
+    c = P1
+    L = []
+    for ks in range(8):
+        L.append(f"global_load_dwordx4 {vr(QF + 4 * ks, 4)}, %2, off offset:{ks * 32}")
+    for ks in range(8):
+        L.append(f"v_mov_b32 v{c.laddr + ks}, %{7 + ks}")
+        L.append(f"v_add_u32 v{c.laddr2 + ks}, 0x10000, %{7 + ks}")
+    for i in range(4):
+        L.append(f"v_mov_b32 v{c.dmav + i}, %{3 + i}")
+    L += ["s_mov_b32 s22, %15", "s_mov_b64 s[24:25], %16", "s_mov_b32 s26, %17", "s_mov_b32 s21, %18", "s_mov_b32 s20, %19", "s_mov_b32 s28, %20",
+          f"v_mov_b32 v{M_}, 0xff800000", f"v_mov_b32 v{Z_}, 0",
+          "s_waitcnt vmcnt(0)", "s_barrier"]
+    L += [f"ds_read_b128 {vr(KF0 + 4 * ks, 4)}, v{c.laddr + ks}" for ks in range(8)]
+    first = p1_prod_stage(0, do_m=False, do_x=False, dt=dt) + p1_prod_stage(1, do_m=True, do_x=False, dt=dt)
+    L += tile_loop(c, lambda p: p1_prod_stage(p, dt=dt), p1_drain, first)
+    L += [f"v_mov_b32 %0, v{M_}", f"v_mov_b32 %1, v{Z_}"]
+    return L
+
+
+# ---- pass 2 -----------------------------------------------------------------------------------------------------------
+def p2_valu_x(accx, red_imm, cs="s20"):
+    """column sums of P = 2^(c * logit - a_row) over this lane's 16 rows for its key -> LDS slot (wave, lane half)"""
+    T = P2.T
+    F = lambda i: f"v_fma_f32 v{T + i}, {cs}, v{accx + i}, -v{AR + i}"
+    E = lambda i: f"v_exp_f32 v{T + i}, v{T + i}"
+    def A(i):
+        d = P2_S0 if i % 2 == 0 else P2_S1
+        return f"v_mov_b32 v{d}, v{T + i}" if i < 2 else f"v_add_f32 v{d}, v{d}, v{T + i}"
+    ops = []
+    for b in range(4):
+        ops += [F(4 * b + i) for i in range(4)]
+        ops += [E(4 * b + i) for i in range(4)]
+        if b >= 1:
+            ops += [A(4 * (b - 1) + i) for i in range(4)]
+    ops += [A(12 + i) for i in range(4)]
+    ops.append(f"v_add_f32 v{P2_S0}, v{P2_S0}, v{P2_S1}")
+    ops.append(f"ds_write_b32 v{REDW}, v{P2_S0} offset:{red_imm}")
+    return ops
+
+
+def p2_red_imm(p_of_subtile):
+    """LDS offset (relative to the lane's write address) of the column-sum slot of the sub-tile computed at pattern position p"""
+    buf, sub = P2.pos(p_of_subtile % P2.period)
+    return buf * 8192 + sub * 128
+
+
+_label = [50]
+
+
+def new_label():
+    _label[0] += 2
+    return _label[0]
+
+
+def p2_flush(buf):
+    """after a tile barrier: waves 0 and 1 add the 16 partial column sums of a finished tile (red buffer `buf`) in a fixed order
+    and store its 128 column sums; skipped at the first barrier (s31 = barriers passed: nothing finished yet)."""
+    label = new_label()
+    L = ["s_cmp_eq_u32 s31, 0", f"s_cbranch_scc1 {label}f", "s_cmp_gt_u32 s27, 1", f"s_cbranch_scc1 {label + 1}f"]
+    regs = [FLV, FLT] + [P2.T + i for i in range(14)]      # the T registers are free at a stage head
+    for slot in range(16):
+        L.append(f"ds_read_b32 v{regs[slot]}, v{FLR} offset:{buf * 8192 + slot * 512}")
+    L.append("s_waitcnt lgkmcnt(0)")
+    for slot in range(1, 16):
+        L.append(f"v_add_f32 v{FLV}, v{FLV}, v{regs[slot]}")
+    L += [f"global_store_dword v{FLO}, v{FLV}, s[40:41]", f"{label + 1}:", "s_add_u32 s40, s40, s42", "s_addc_u32 s41, s41, 0", f"{label}:", "s_add_u32 s31, s31, 1"]
+    return L
+
+
+def p2_prod_stage(p, do_x=True, dt="bf16"):
+    accw, accx = P2.acc[p % 3], P2.acc[(p - 2) % 3]
+    kfu, kfl = (KF0, KF1) if p % 2 == 0 else (KF1, KF0)
+    buf, sub = P2.pos(p)
+    # at the tile barrier: flush the tile BEFORE this one (its last column sums were written two stages ago)
+    L = stage_head(P2, p, p2_flush((buf + 2) % 3) if sub == 3 else None)
+    slots = [[] for _ in range(8)]
+    if do_x:
+        spread(slots, p2_valu_x(accx, p2_red_imm(p - 2)))
+    mf = [mfma(accw, QF + 4 * k, kfu + 4 * k, k == 0, dt) for k in range(8)]   # C = Q . K^T: a lane owns one key
+    return interleave(L, mf, prefetch_reads(P2, p, kfl), slots)
+
+
+def p2_drain(p_end):
+    a_last, a_prev = P2.acc[p_end % 3], P2.acc[(p_end - 1) % 3]
+    buf, _ = P2.pos(p_end)
+    L = p2_valu_x(a_prev, p2_red_imm(p_end - 1)) + p2_valu_x(a_last, p2_red_imm(p_end))
+    # the last tile's column sums: publish, then flush
+    L += ["s_waitcnt lgkmcnt(0)", "s_barrier", "s_mov_b32 s31, 1"]
+    L += p2_flush(buf)
+    return L
+
+
+def p2_prod_body(dt):
+    c = P2
+    L = []
+    for ks in range(8):
+        L.append(f"global_load_dwordx4 {vr(QF + 4 * ks, 4)}, %0, off offset:{ks * 32}")
+    for j in range(4):   # normalisers of rows (r & 3) + 8 (r >> 2) + 4 kg: four runs of four consecutive rows
+        L.append(f"global_load_dwordx4 {vr(AR + 4 * j, 4)}, %21, off offset:{j * 32}")
+    for ks in range(8):
+        L.append(f"v_mov_b32 v{c.laddr + ks}, %{5 + ks}")
+        L.append(f"v_add_u32 v{c.laddr2 + ks}, 0x10000, %{5 + ks}")
+    for i in range(4):
+        L.append(f"v_mov_b32 v{c.dmav + i}, %{1 + i}")
+    L += ["s_mov_b32 s22, %13", "s_mov_b64 s[24:25], %14", "s_mov_b32 s26, %15", "s_mov_b32 s21, %16", "s_mov_b32 s20, %17", "s_mov_b32 s28, %18",
+          "s_mov_b32 s27, %19", "s_mov_b64 s[40:41], %20", "s_mov_b32 s42, %22", "s_mov_b32 s31, 0",
+          f"v_mov_b32 v{REDW}, %23", f"v_mov_b32 v{FLR}, %24", f"v_mov_b32 v{FLO}, %25",
+          "s_waitcnt vmcnt(0)", "s_barrier"]
+    L += [f"ds_read_b128 {vr(KF0 + 4 * ks, 4)}, v{c.laddr + ks}" for ks in range(8)]
+    first = p2_prod_stage(0, do_x=False, dt=dt) + p2_prod_stage(1, do_x=False, dt=dt)
+    L += tile_loop(c, lambda p: p2_prod_stage(p, dt=dt), p2_drain, first)
+    return L
+
+
+INC_HEAD = """// GENERATED by tools/gen_stage_asm.py kernel -- do not edit (tests/test_capi_symbols.py checks it is up to date).
+// Hand-scheduled steady-state loops of the SnapKV window-attention passes: see tools/gen_stage_asm.py for the register maps
+// and the schedule.
+#pragma once
+#define KVP_P1_ASM_CLOBBERS %(clob1)s, %(sclob)s, "memory"
+#define KVP_P2_ASM_CLOBBERS %(clob2)s, %(sclob)s, "memory"
+#define KVP_P2_RED_BYTES %(red)d
+#define KVP_P1_NBUF %(nbuf1)d
+"""
+
+
+def gen_kernel_inc():
+    out = [INC_HEAD % dict(clob1=clobbers(32, P1.last), clob2=clobbers(32, P2.last), sclob=SGPR_CLOB, red=RED_BYTES, nbuf1=P1.nbuf)]
+    for dt in ("bf16", "f16"):
+        _label[0] = 50
+        for name, body in (("P1", p1_prod_body(dt)), ("P2", p2_prod_body(dt))):
+            out.append(f"#define KVP_{name}_ASM_{dt.upper()} \\\n" + " \\\n".join(f'    "{l}\\n"' for l in body) + "\n")
+    return "\n".join(out)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "kernel":
+    path = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "kvpress_amd", "csrc", "snapkv_asm.inc")
+    open(path, "w").write(gen_kernel_inc())
+    print(path)
