@@ -24,7 +24,9 @@
 // barriers (arrive counter + spin, agent-scope fences = L2 write-back / invalidate on every one of the 8 XCDs) was
 // measured at 51 us (128 workgroups) to 131 us (512 workgroups) against 26-32 us for the three launches: not an option;
 // nor are direct global atomics for the (sparse) second-pass histogram: 260 k of them take 48 us against 14 us for the
-// workgroup-private LDS histograms + flush;
+// workgroup-private LDS histograms + flush; nor is ONE launch with one 1024-thread workgroup per row that streams its row
+// from L2 once per digit and once for the compaction (round 2: 91 us at 8 x 131072, 29 us at 8 x 32768 against 31 / 23 us
+// for the three launches -- a single CU pulls ~25 GB/s through such a dependent walk);
 // the only inter-workgroup traffic inside a launch is atomicAdd into the row histograms.
 //
 // SHORT rows (S <= 16384: decode-time compression, per-chunk / per-block selection, short prompts) are launch-bound in

@@ -367,7 +367,8 @@ class Cfg:
         return (p // 4) % self.nbuf, p % 4
 
 
-P1 = Cfg(nbuf=int(_os.environ.get("GEN_P1_NBUF", "4")), nacc=4 if int(_os.environ.get("GEN_P1_NBUF", "4")) == 4 else 3, extra=10)
+# (a ring of four tiles + four accumulators for pass 1 -- GEN_P1_NBUF=4 -- measured the same as three: 0.2957 vs 0.2969 ms per layer)
+P1 = Cfg(nbuf=int(_os.environ.get("GEN_P1_NBUF", "3")), nacc=4 if int(_os.environ.get("GEN_P1_NBUF", "3")) == 4 else 3, extra=10)
 P2 = Cfg(nbuf=3, nacc=3, extra=16 + 2 + 5)
 # pass 1 extras: running max m, running sum z, offsets / rescale factors of the X and M parts, partial sums, scratch
 M_, Z_, OFFX, RX, OFFM, RM, S0, S1, TMAX, MNEW = (P1.extra + i for i in range(10))
