@@ -9,7 +9,7 @@ WHAT="${*:-tests bench}"
 python __graft_entry__.py > gpurun_out/build.log 2>&1; echo "build rc=$?"
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
 if [[ "$WHAT" == *tests* ]]; then
-  for grp in rownorm rowdot observed lagkv topk gather fused fuzz cur snapkv_kernel snapkv_from snapkv_fused ea_qstats ea_score full_chain keydiff head_mean tova_from random_press press_fp32 press_native; do
+  for grp in rownorm rowdot observed lagkv topk gather fused fuzz cur snapkv_kernel snapkv_from snapkv_fused deterministic ea_qstats ea_score full_chain keydiff head_mean tova_from random_press press_fp32 press_native; do
     timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --no-header -k "$grp" > gpurun_out/test_$grp.log 2>&1
     echo "tests[$grp] rc=$? $(tail -1 gpurun_out/test_$grp.log)"
   done
@@ -21,8 +21,9 @@ if [[ "$WHAT" == *tests* ]]; then
 fi
 if [[ "$WHAT" == *bench* ]]; then
   for wl in knorm32k knorm128k snapkv128k ea128k; do
-    timeout 600 python bench.py --workload $wl --profile-json gpurun_out/kern_$wl.json > gpurun_out/bench_$wl.log 2>&1
-    echo "bench[$wl] rc=$? $(tail -1 gpurun_out/bench_$wl.log | cut -c1-600)"
+    timeout 900 python bench.py --workload $wl --profile-json gpurun_out/r02_kernels_$wl.json > gpurun_out/bench_$wl.log 2>&1
+    echo "bench[$wl] rc=$? $(tail -1 gpurun_out/bench_$wl.log | cut -c1-300)"
+    tail -1 gpurun_out/bench_$wl.log > gpurun_out/r02_bench_$wl.json
   done
 fi
 if [[ "$WHAT" == *ab* ]]; then
@@ -34,27 +35,32 @@ if [[ "$WHAT" == *ab* ]]; then
   done
 fi
 if [[ "$WHAT" == *pmc* ]]; then
-  rocprofv3 -L > gpurun_out/counters_list.txt 2>&1
+  # HBM traffic and issue counters, per MI355X_MICROARCH.md: separate --pmc passes, kernel-trace only (no other tracing domains)
   cd /tmp
-  i=0
-  for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE" \
-             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
-             "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
-    i=$((i+1))
-    timeout 600 rocprofv3 --kernel-trace --pmc $set -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$i" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --workload ${PMC_WL:-snapkv128k} --steps 3 --warmup 1 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$i.log" 2>&1
-    echo "pmc[$i: $set] rc=$?"
+  for wl in ${PMC_WL:-snapkv128k knorm32k}; do
+    i=0
+    for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE" \
+               "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+               "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+      i=$((i+1))
+      timeout 600 rocprofv3 --kernel-trace --pmc $set -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_${wl}_$i" -o pmc -- python "$GRAFT_REPO_ROOT/bench.py" --workload $wl --steps 3 --warmup 1 --prewarm-ms 5 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/pmc_${wl}_$i.log" 2>&1
+      echo "pmc[$wl $i: $set] rc=$?"
+    done
+    ( cd "$GRAFT_REPO_ROOT"; echo "# rocprofv3 --kernel-trace --pmc <set> -- python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline (four separate passes)";
+      echo "# csrc_digest $(python -c 'import bench; print(bench.csrc_digest())')";
+      python scripts/rocpd_pmc.py $(find gpurun_out/pmc_${wl}_[0-9] -name '*.db' | sort) ) > "$GRAFT_REPO_ROOT/gpurun_out/r02_pmc_summary_$wl.txt" 2>&1
+    rm -rf "$GRAFT_REPO_ROOT"/gpurun_out/pmc_${wl}_[0-9]
   done
   cd "$GRAFT_REPO_ROOT"
-  python scripts/rocpd_pmc.py gpurun_out/pmc_*/pmc_results.db > gpurun_out/pmc_summary_${PMC_WL:-snapkv128k}.txt 2>&1
-  rm -rf gpurun_out/pmc_[0-9]*
 fi
 if [[ "$WHAT" == *prof* ]]; then
   cd /tmp
-  for wl in snapkv128k knorm32k; do
+  for wl in ${PROF_WL:-snapkv128k knorm32k knorm128k ea128k}; do
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -o $wl -- python "$GRAFT_REPO_ROOT/bench.py" --workload $wl --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" 2>&1
     echo "prof[$wl] rc=$?"
-    find "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -name "*kernel_trace.csv" -delete 2>/dev/null
-    find "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -name "*.db" -delete 2>/dev/null
+    find "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -name "*kernel_stats.csv" -exec cp {} "$GRAFT_REPO_ROOT/gpurun_out/r02_rocprofv3_kernel_stats_$wl.csv" \;
+    tail -1 "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" > "$GRAFT_REPO_ROOT/gpurun_out/r02_bench_under_rocprof_$wl.json"
+    rm -rf "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl"
   done
   cd "$GRAFT_REPO_ROOT"
 fi
