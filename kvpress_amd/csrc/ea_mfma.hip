@@ -228,6 +228,121 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_qstats_mfma_kernel(QstatArgs
     }
 }
 
+// ---- (1b) query statistics with transposed LDS reads (gfx950 ds_read_b64_tr_b16) -------------------------------------------------
+// The same partials as ea_qstats_mfma_kernel (raw second moments: m0 = 0) at half its matrix-core work and almost none of its
+// VALU work: the row -> column transpose happens in the LDS read.  Within a 16-lane group, lane i supplies the address of an
+// 8-byte piece and lane c receives element c % 4 of pieces c / 4 + {0, 4, 8, 12} (tools/probe_tr.hip): with lane i pointing
+// at X[token t0 + i / 4][dim d0 + 4 (i % 4) ..], lane c gets X[t0 .. t0 + 3][d0 + c] -- four tokens of ONE dimension, which is
+// what both operands of the syrk MFMA want (a lane = one dimension, 8 consecutive tokens of the 16-token k-step: two reads).
+// Q rows (256 B of one head, 8 KiB apart) travel HBM -> LDS by LDS-DMA into a ring of 64-token tiles (ET_NBUF - 1 in flight per
+// workgroup, ET_NBUF - 1 tiles in flight); the 16-byte slots of a row are XOR-swizzled by (token & 3) << 2 on the global side so that the four token rows a
+// transposed read touches sit in different banks.  Per 16-token k-step and wave: 8 transposed reads (fragments of all four
+// 32-dim strips), 4 syrk MFMAs (own strip x every strip) + 1 MFMA against a ones fragment for the column sums.
+// Raw moments cancel when |mean| >> sigma: sum x x^T is accumulated in fp32 over <= 4096 rows per partial, so the relative
+// error of a covariance entry is ~2^-24 (mean / sigma)^2 sqrt(rows / 16): 1e-4 at |mean| = 10 sigma
+// (tests/test_gpu_parity.py::test_ea_qstats_large_mean).  The partials are merged by the same pairwise update.
+template <int DT, int ET_NBUF, int ET_OCC>
+__global__ __launch_bounds__(EM_THREADS, ET_OCC) void ea_qstats_tr_kernel(QstatArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[ET_NBUF * EM_TILEB];
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    const uint32_t hq = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t n = lane & 31, kg = lane >> 5;
+    const uint32_t g = lane >> 4, i16 = lane & 15, t2 = i16 >> 2;
+    const uint32_t bh = b * a.Hq + hq;
+    const char* base = static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh) * 2;
+    const int64_t row_bytes = a.q_ss * 2;
+    const uint32_t rbeg = chunk * a.rows_per_chunk;
+    const uint32_t rend = min(rbeg + a.rows_per_chunk, a.Sq);
+    if (rbeg >= rend) return;
+    const uint32_t ntiles = (rend - rbeg + EM_TILE - 1) / EM_TILE;
+
+    // ---- LDS-DMA: request j (0..3) of a tile moves rows 16 j + 4 wv + g; lane slot i16 fetches chunk i16 ^ (g << 2) (row & 3 == g)
+    const uint32_t ldsbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const uint32_t gch = (i16 ^ (g << 2)) << 4;
+    auto request_tile = [&](uint32_t t, uint32_t buf) {
+        const uint32_t row0 = rbeg + min(t, ntiles - 1) * EM_TILE;   // past the end: re-fetch the last tile (never read)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t row = min(row0 + 16 * j + 4 * wv + g, a.Sq - 1);   // rows past the end are zeroed in LDS below
+            const char* gp = base + (int64_t)row * row_bytes + gch;
+            const uint32_t la = __builtin_amdgcn_readfirstlane(ldsbase + buf * EM_TILEB + (16 * j + 4 * wv) * EM_ROWB);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(gp) : "memory");
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < ET_NBUF - 1; ++p) request_tile(p, p);
+
+    // ---- transposed fragment reads: strip s, k-step ks, half hf -> lds + buf + off0 ^ (s << 6) + ks * 4096 + hf * 1024
+    const uint32_t off0 = (8 * (g >> 1) + t2) * EM_ROWB + (((((g & 1) * 2 + ((i16 & 3) >> 1)) ^ (t2 << 2))) << 4) + (i16 & 1) * 8;
+    uint32_t ones[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ones[e] = one16<DT>() | (one16<DT>() << 16);
+    const uint4 vone = make_uint4(ones[0], ones[1], ones[2], ones[3]);
+
+    f32x16 acc[4], accs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accs[r] = 0.f;
+
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (4 * (ET_NBUF - 2)));   // tile 0 landed (this wave's part)
+    __syncthreads();
+    uint32_t bc = 0;
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        unsigned char* buf = lds + bc * EM_TILEB;
+        request_tile(t + ET_NBUF - 1, (bc + ET_NBUF - 1) % ET_NBUF);   // into the buffer tile t-1 just left
+        const uint32_t valid = rend - (rbeg + t * EM_TILE);            // rows of this tile that exist (>= 1)
+        if (valid < (uint32_t)EM_TILE) {                               // last, ragged tile: zero the rows past the end
+            for (uint32_t e = threadIdx.x; e < (EM_TILE - valid) * 16; e += EM_THREADS)
+                *reinterpret_cast<uint4*>(buf + (valid + (e >> 4)) * EM_ROWB + ((e & 15) << 4)) = make_uint4(0, 0, 0, 0);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 F[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const uint32_t st = (wv + s) & 3;   // F[0] = this wave's own strip
+                const unsigned char* p = buf + (off0 ^ (st << 6)) + ks * 4096;
+                const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(uintptr_t)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)p);
+                const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(uintptr_t)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(p + 1024));
+                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                F[s] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[s] = mma32<DT>(F[0], F[s], acc[s]);   // C[own dim][dim of strip (wv + s) & 3]
+            accs = mma32<DT>(F[0], vone, accs);                                   // C[own dim][*] = sum over the 16 tokens
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070 | (4 * (ET_NBUF - 2)));   // lgkmcnt(0) + tile t+1 landed
+        __syncthreads();
+        bc = (bc + 1) % ET_NBUF;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    float* s2 = a.s2 + ((size_t)bh * a.nchunk + chunk) * 128 * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t jt = (wv + i) & 3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t di = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            s2[(size_t)di * 128 + jt * 32 + n] = acc[i][r];
+        }
+    }
+    if (n == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t di = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            a.dsum[((size_t)bh * a.nchunk + chunk) * 128 + di] = accs[r];
+            a.m0[((size_t)bh * a.nchunk + chunk) * 128 + di] = 0.f;
+        }
+    }
+}
+
 // merge the per-chunk partials: mu[d], cov[i][j]  (Chan et al. pairwise update, all in fp32).
 // grid = (16, B*Hq): workgroup x handles cov elements [x*1024, (x+1)*1024) of one head (and x == 0 also writes mu).
 __global__ __launch_bounds__(256) void ea_qstats_combine(const float* __restrict__ s2, const float* __restrict__ dsum,
@@ -428,7 +543,11 @@ int ea_mfma_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int 
     a.dsum = a.s2 + nbh * a.nchunk * 16384;
     a.m0 = a.dsum + nbh * a.nchunk * 128;
     const dim3 grid((uint32_t)Hq, a.nchunk, (uint32_t)B);
-    if (dtype == KVP_BF16) KVP_LAUNCH("ea_qstats_mfma", stream, ea_qstats_mfma_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a));
+    if (kvp_env_int("KVP_EA_QSTATS_TR", 1)) {   // transposed LDS reads, raw moments (0: the MFMA-transposing, mean-shifted kernel)
+        // ring of three 64-token tiles, three workgroups per CU (measured 211 us at 128k x 32 heads; 4 x 2: 215, 5 x 2: 230, 2 x 4: 213)
+        if (dtype == KVP_BF16) KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_BF16, 3, 3><<<grid, EM_THREADS, 0, stream>>>(a)));
+        else KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_F16, 3, 3><<<grid, EM_THREADS, 0, stream>>>(a)));
+    } else if (dtype == KVP_BF16) KVP_LAUNCH("ea_qstats_mfma", stream, ea_qstats_mfma_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a));
     else KVP_LAUNCH("ea_qstats_mfma", stream, ea_qstats_mfma_kernel<KVP_F16><<<grid, EM_THREADS, 0, stream>>>(a));
     const size_t sm = ((size_t)a.nchunk * 256 + 128) * 4;
     KVP_LAUNCH("ea_qstats_combine", stream, ea_qstats_combine<<<dim3(16, (uint32_t)nbh), 256, sm, stream>>>(a.s2, a.dsum, a.m0, a.Sq, a.nchunk, a.rows_per_chunk, mu, cov));

@@ -592,8 +592,8 @@ int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m,
     const dim3 grid(nchunk, a.Hkv * ngb, a.B);
     float* clk = kvp_prof_enabled() ? kvp_prof_clock_slot() : nullptr;  // in-kernel clock of pass 1 while profiling is on
     if (a.G % 4 == 0 && kvp_env_int("KVP_SK_ASM", 1)) {   // hand-scheduled tile loop (KVP_SK_ASM=0: the compiler-scheduled kernel)
-        if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
-        else KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
+        if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_asm", stream, snapkv_p1_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
+        else KVP_LAUNCH("snapkv_p1_asm", stream, snapkv_p1_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
         KVP_CHECK_LAUNCH("snapkv_p1_asm");
         return KVP_OK;
     }
@@ -746,8 +746,8 @@ int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* co
     KVP_CHECK_ARG(ngb <= 2 && (ngb == 1 || colsum2), "snapkv_p2_mfma: G = %u needs the second column-sum slab", a.G);
     const dim3 grid(mfma_nchunk_for(a, Sm), a.Hkv * ngb, a.B);
     if (a.G % 4 == 0 && kvp_env_int("KVP_SK_ASM", 1)) {   // hand-scheduled tile loop
-        if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
-        else KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
+        if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
+        else KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
     } else if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
     else KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
     KVP_CHECK_LAUNCH("snapkv_p2_mfma");

@@ -251,3 +251,48 @@ def test_config4_expected_attention_128k():
         worst, differ = F.check_against_reference(fx, sc, idx)
         overlap, _ = F.check_against_native(fx, idx, S, NATIVE_ULPS, NATIVE_OVERLAP["full_ea128k"] - 0.01)
         print(f"ea128k vs reference: max rel err {worst:.2e}, {differ} set differences (in band), overlap with bf16 reference {overlap:.4f}")
+
+
+def test_ea_qstats_128k_large_mean_adversarial():
+    """query statistics at 128k tokens with |mean| ~ 10 sigma in a few dominant channels (the regime where raw second
+    moments cancel): mean and covariance against float64, and the FINAL scores through kvp_ea_score within 1e-3 of the float64
+    chain fed with the float64 statistics."""
+    S, Sk = 131072, 16384
+    g = torch.Generator(device=DEV)
+    g.manual_seed(66)
+    sig = torch.exp(0.5 * torch.randn((1, 1, H_Q * D), generator=g, device=DEV))
+    mean = torch.randn((1, 1, H_Q * D), generator=g, device=DEV) * sig
+    dom = torch.arange(H_Q * D, device=DEV) % 17 == 3                      # a few dominant channels per head
+    sig[..., dom] *= 6.0
+    mean[..., dom] = 10.0 * sig[..., dom] * torch.sign(mean[..., dom])     # |mean| = 10 sigma there
+    q = (torch.randn((1, S, H_Q * D), generator=g, device=DEV) * sig + mean).to(torch.bfloat16)
+    qt = q.view(1, S, H_Q, D).transpose(1, 2)                              # the layout q_proj produces
+    mu, cov = _native().ea_qstats(qt, True)
+    mu_r = torch.empty((1, H_Q, D), dtype=torch.float64, device=DEV)
+    cov_r = torch.empty((1, H_Q, D, D), dtype=torch.float64, device=DEV)
+    for h in range(H_Q):
+        x = qt[0, h].double()
+        mu_r[0, h] = x.mean(0)
+        xc = x - mu_r[0, h]
+        cov_r[0, h] = xc.T @ xc / S
+    assert ((mu.double() - mu_r).abs() <= 1e-5 * mu_r.abs().amax() + 1e-6).all()
+    d = cov_r.diagonal(dim1=-2, dim2=-1).sqrt()
+    err = (cov.double() - cov_r).abs() / (d.unsqueeze(-1) * d.unsqueeze(-2))
+    assert err.max() <= 1e-3, f"covariance error {err.max().item():.2e} sigma_i sigma_j"
+    # final scores: float64 chain (expected_attention_press.py:148-160 without the averaged RoPE) with the float64 statistics
+    keys = (torch.randn((1, H_KV, Sk, D), generator=g, device=DEV) * 0.3).to(torch.bfloat16)
+    values = torch.randn((1, H_KV, Sk, D), generator=g, device=DEV).to(torch.bfloat16)
+    sc = _native().ea_score(keys, values, mu, cov, 4, True, 0.0)
+    G = H_Q // H_KV
+    ref = torch.empty((1, H_KV, Sk - 4), dtype=torch.float64, device=DEV)
+    for h in range(H_KV):
+        kh = keys[0, h, 4:].double()
+        acc = 0
+        for gq in range(G):
+            hq = h * G + gq
+            lg = kh @ mu_r[0, hq] / D ** 0.5 + ((kh @ cov_r[0, hq]) * kh).sum(-1) / D / 2
+            acc = acc + torch.softmax(lg, dim=-1)
+        ref[0, h] = acc / G * values[0, h, 4:].double().norm(dim=-1)
+    rel = (sc[..., 4:].double() - ref).abs() / ref.abs().clamp_min(1e-300)
+    assert rel.max() <= 1e-3, f"final scores differ by {rel.max().item():.2e}"
+    print(f"ea qstats 128k adversarial: cov err {err.max().item():.2e} sigma_i sigma_j, final score err {rel.max().item():.2e}")

@@ -262,9 +262,10 @@ def test_ea_qstats_vs_oracle(name):
     if s["use_covariance"]:
         c = cov.cpu().numpy()
         d = np.sqrt(np.einsum("bhii->bhi", cov_w))
-        # Sq >= 4096 with 16-bit D=128 inputs runs on the matrix cores (16-bit shifted products: worst entry ~2e-3)
+        # Sq >= 4096 with 16-bit D=128 inputs runs on the matrix cores (exact products of the 16-bit inputs, fp32 accumulation of raw
+        # second moments: the error grows with (mean / sigma)^2, see ea_mfma.hip)
         mfma = s["dtype"] != "f32" and s["D"] == 128 and q.shape[2] >= 4096
-        tol = (3e-3 if mfma else 1e-4) * d[..., :, None] * d[..., None, :] + 1e-9
+        tol = (1e-3 if mfma else 1e-4) * d[..., :, None] * d[..., None, :] + 1e-9
         assert (np.abs(c - cov_w) <= tol).all(), np.abs(c - cov_w).max()
     else:
         assert cov is None
@@ -626,7 +627,7 @@ def test_snapkv_fused_rope_is_bit_identical_to_torch_rope(name):
 
 def test_ea_qstats_mfma_multichunk():
     """bf16, D=128, 10 000 rows (3 chunks + ragged tail), non-zero mean and a few dominant channels:
-    exercises the shifted-data syrk on the matrix cores and the pairwise combine."""
+    exercises the syrk on the matrix cores (transposed LDS reads) and the pairwise combine."""
     rs = np.random.RandomState(7)
     B, Hq, Sq, D = 1, 3, 10000, 128
     q = rs.standard_normal((B, Hq, Sq, D)).astype(np.float32) * np.exp(0.5 * rs.standard_normal((1, Hq, 1, D))).astype(np.float32)
@@ -639,8 +640,8 @@ def test_ea_qstats_mfma_multichunk():
     assert np.abs(mu.cpu().numpy() - mu_w).max() <= 1e-5 * np.abs(mu_w).max() + 1e-6
     d = np.sqrt(np.einsum("bhii->bhi", cov_w))
     err = np.abs(cov.cpu().numpy() - cov_w) / (d[..., :, None] * d[..., None, :])
-    # 16-bit shifted products on inputs that themselves live on a 16-bit grid: worst entry ~2e-3, mean ~3e-5
-    assert err.max() <= 3e-3 and err.mean() <= 1e-4, (err.max(), err.mean())
+    # exact products of the bf16 inputs, raw moments accumulated in fp32 per chunk: means up to ~10 sigma cost ~1e-4
+    assert err.max() <= 1e-3 and err.mean() <= 1e-4, (err.max(), err.mean())
     mu2, cov2 = native().ea_qstats(qt, False)
     assert cov2 is None and torch.equal(mu, mu2)
 

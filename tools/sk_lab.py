@@ -63,11 +63,11 @@ def main():
             d = (sc[..., :-64] - ref[..., :-64]).abs() / ref[..., :-64].abs().clamp_min(1e-30)
             msg = f"max rel diff vs first cfg {float(d.max()):.2e}" + ("  (bit-identical)" if torch.equal(sc, ref) else "")
 
-        def med(name):
-            v = sorted(t.get(name, [0.0]))
+        def med(*names):
+            v = sorted(sum((t.get(n, []) for n in names), []) or [0.0])
             return v[len(v) // 2]
 
-        print(f"{cfg:44s} p1 {med('snapkv_p1_mfma'):7.1f} us  p2 {med('snapkv_p2_mfma'):7.1f} us  combine {med('softmax_combine_kernel'):5.1f}  "
+        print(f"{cfg:44s} p1 {med('snapkv_p1_mfma', 'snapkv_p1_asm'):7.1f} us  p2 {med('snapkv_p2_mfma', 'snapkv_p2_asm'):7.1f} us  combine {med('softmax_combine_kernel'):5.1f}  "
               f"pool {med('snapkv_pool_kernel'):5.1f}  score call {wall:7.1f} us   {msg}", flush=True)
 
 
