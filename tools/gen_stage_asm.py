@@ -334,10 +334,11 @@ if __name__ == "__main__":
 #   s20 c = log2(e)/sqrt(D)        s21 tiles left for the block       s22 LDS address of this wave's 1 KiB slot in ring buffer 0
 #   s[24:25] global address of the tile the next request group reads (NBUF - 1 tiles ahead, clamped to the walk's last tile)
 #   s26 bytes between a workgroup's tiles      s28 address advances left (clamp)      s29, s30 scratch
+#   s[44:45] c in both halves (packed fma)
 #   pass 2 only: s27 wave index, s[40:41] global address of the column sums of the tile to flush, s42 its stride, s31 tile barriers passed
 import os as _os
 
-SGPR_CLOB = '"s20", "s21", "s22", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s40", "s41", "s42", "scc"'
+SGPR_CLOB = '"s20", "s21", "s22", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s40", "s41", "s42", "s44", "s45", "scc"'
 GEN_ABL = set(filter(None, _os.environ.get("GEN_ABL", "").split(",")))   # lab builds: nodma, nobar, novalu, nomfma, nolds (results wrong)
 
 
@@ -368,13 +369,16 @@ class Cfg:
 
 
 # (a ring of four tiles + four accumulators for pass 1 -- GEN_P1_NBUF=4 -- measured the same as three: 0.2957 vs 0.2969 ms per layer)
-P1 = Cfg(nbuf=int(_os.environ.get("GEN_P1_NBUF", "3")), nacc=4 if int(_os.environ.get("GEN_P1_NBUF", "3")) == 4 else 3, extra=10)
+P1 = Cfg(nbuf=int(_os.environ.get("GEN_P1_NBUF", "3")), nacc=4 if int(_os.environ.get("GEN_P1_NBUF", "3")) == 4 else 3, extra=14)
 P2 = Cfg(nbuf=3, nacc=3, extra=16 + 2 + 5)
 # pass 1 extras: running max m, running sum z, offsets / rescale factors of the X and M parts, partial sums, scratch
-M_, Z_, OFFX, RX, OFFM, RM, S0, S1, TMAX, MNEW = (P1.extra + i for i in range(10))
+# (S0, S1 and the two copies of each offset are even-aligned register pairs for the packed variants)
+S0, S1, OFFX, OFFX2, OFFM, OFFM2, M_, Z_, RX, RM, TMAX, MNEW = (P1.extra + (P1.extra & 1) + i for i in range(12))
+GEN_PK = set(filter(None, _os.environ.get("GEN_PK", "").split(",")))   # packed f32 variants of the exp part: "fma", "add"
 # pass 2 extras: 16 row normalisers, 2 partial sums, LDS write address, flush read address / store offset / value / scratch
 AR = P2.extra
 P2_S0, P2_S1, REDW, FLR, FLO, FLV, FLT = (P2.extra + 16 + i for i in range(7))
+assert AR % 2 == 0 and P2_S0 % 2 == 0 and P1.T % 2 == 0 and P2.T % 2 == 0
 RED_BYTES = 3 * 16 * 128 * 4   # three tiles in flight x (8 waves x 2 lane halves) x 128 keys
 
 
@@ -425,65 +429,94 @@ def interleave(L, mf, reads, slots):
 
 
 # ---- pass 1 -----------------------------------------------------------------------------------------------------------
-def p1_valu_x(accx, cs="s20"):
-    """exp / sum part for the sub-tile in accx: uses OFFX (= -c * m_j) and RX (= 2^(c m_{j-1} - c m_j))."""
-    T = P1.T
-    F = lambda i: f"v_fma_f32 v{T + i}, {cs}, v{accx + i}, v{OFFX}"
-    E = lambda i: f"v_exp_f32 v{T + i}, v{T + i}"
-    def A(i):
-        d = S0 if i % 2 == 0 else S1
-        return f"v_mov_b32 v{d}, v{T + i}" if i < 2 else f"v_add_f32 v{d}, v{d}, v{T + i}"
-    ops = [f"v_mul_f32 v{Z_}, v{Z_}, v{RX}"]
+def exp_sum_ops(T, acc, s0, off1, off2, cs, neg=False):
+    """16 x (fma, exp) into T and the two interleaved partial sums s0 / s0+1 (element i goes to sum i & 1).  off1(i): scalar
+    offset operand of element i, off2: the register PAIR holding the offsets of elements (2i, 2i+1) -- or a callable -- for the
+    packed fma (GEN_PK=fma: half the fma issue slots; GEN_PK=add: v_pk_add_f32 on the sum pair)."""
+    n = "-" if neg else ""
+    def F(i):   # elements 2i, 2i+1
+        if "fma" in GEN_PK:
+            o2 = off2(i) if callable(off2) else off2
+            mod = " neg_lo:[0,0,1] neg_hi:[0,0,1]" if neg else ""
+            return [f"v_pk_fma_f32 v[{T + 2 * i}:{T + 2 * i + 1}], v[{acc + 2 * i}:{acc + 2 * i + 1}], s[44:45], {o2}{mod}"]
+        return [f"v_fma_f32 v{T + 2 * i}, {cs}, v{acc + 2 * i}, {n}{off1(2 * i)}", f"v_fma_f32 v{T + 2 * i + 1}, {cs}, v{acc + 2 * i + 1}, {n}{off1(2 * i + 1)}"]
+    E = lambda i: [f"v_exp_f32 v{T + 2 * i}, v{T + 2 * i}", f"v_exp_f32 v{T + 2 * i + 1}, v{T + 2 * i + 1}"]
+    def A(i):   # pair i
+        if i == 0:
+            return []                                      # folded into the add of pair 1
+        a = f"v[{T}:{T + 1}]" if i == 1 else f"v[{s0}:{s0 + 1}]"
+        if "add" in GEN_PK:
+            return [f"v_pk_add_f32 v[{s0}:{s0 + 1}], {a}, v[{T + 2 * i}:{T + 2 * i + 1}]"]
+        a0, a1 = (f"v{T}", f"v{T + 1}") if i == 1 else (f"v{s0}", f"v{s0 + 1}")
+        return [f"v_add_f32 v{s0}, {a0}, v{T + 2 * i}", f"v_add_f32 v{s0 + 1}, {a1}, v{T + 2 * i + 1}"]
+    ops = []
     for b in range(4):
-        ops += [F(4 * b + i) for i in range(4)]
-        ops += [E(4 * b + i) for i in range(4)]
+        ops += F(2 * b) + F(2 * b + 1) + E(2 * b) + E(2 * b + 1)
         if b >= 1:
-            ops += [A(4 * (b - 1) + i) for i in range(4)]
-    ops += [A(12 + i) for i in range(4)]
-    ops.append(f"v_add_f32 v{S0}, v{S0}, v{S1}")
-    ops.append(f"v_add_f32 v{Z_}, v{Z_}, v{S0}")
+            ops += A(2 * (b - 1)) + A(2 * (b - 1) + 1)
+    ops += A(6) + A(7)
     return ops
 
 
-def p1_valu_m(accm, cs="s20"):
-    """row maximum of the sub-tile in accm -> new running max, the offset and rescale factor its exp part will use."""
+# Offsets / rescale factors / running maxima live in register PAIRS indexed by the parity of the sub-tile they belong to (the
+# pattern period is even): the max part of sub-tile j writes OFF[j & 1], R[j & 1], MX[j & 1] and reads MX[(j - 1) & 1]; the exp
+# part of sub-tile j reads OFF[j & 1], R[j & 1] one stage later.  No register-to-register moves.
+OFF = (OFFX, OFFM)
+R = (RX, RM)
+MX = (M_, MNEW)
+
+
+def p1_valu_x(accx, j, cs="s20"):
+    """exp / sum part for sub-tile j (accumulator accx): z <- z * 2^(c m_{j-1} - c m_j) + sum_k 2^(c l_k - c m_j)"""
+    T = P1.T
+    off, r = OFF[j & 1], R[j & 1]
+    ops = exp_sum_ops(T, accx, S0, lambda i: f"v{off}", f"v[{off}:{off + 1}]", cs)
+    ops.append(f"v_add_f32 v{S0}, v{S0}, v{S1}")
+    ops.append(f"v_fma_f32 v{Z_}, v{Z_}, v{r}, v{S0}")
+    return ops
+
+
+def p1_valu_m(accm, j, cs="s20"):
+    """row maximum of sub-tile j (accumulator accm) -> running max MX[j & 1], offset OFF[j & 1] = -c m_j, rescale factor R[j & 1]"""
+    mprev, mnew = MX[(j - 1) & 1], MX[j & 1]
     ops = [f"v_max3_f32 v{TMAX}, v{accm}, v{accm + 1}, v{accm + 2}"]
     for i in range(3, 15, 2):
         ops.append(f"v_max3_f32 v{TMAX}, v{TMAX}, v{accm + i}, v{accm + i + 1}")
-    ops.append(f"v_max3_f32 v{MNEW}, v{M_}, v{TMAX}, v{accm + 15}")
-    ops.append(f"v_mul_f32_e64 v{OFFM}, {cs}, -v{MNEW}")
-    ops.append(f"v_fma_f32 v{RM}, {cs}, v{M_}, v{OFFM}")
-    ops.append(f"v_exp_f32 v{RM}, v{RM}")
-    ops.append(f"v_mov_b32 v{M_}, v{MNEW}")
+    ops.append(f"v_max3_f32 v{mnew}, v{mprev}, v{TMAX}, v{accm + 15}")
+    ops.append(f"v_mul_f32_e64 v{OFF[j & 1]}, {cs}, -v{mnew}")
+    if "fma" in GEN_PK:
+        ops.append(f"v_mov_b32 v{OFF[j & 1] + 1}, v{OFF[j & 1]}")   # the packed fma wants the offset in both halves of a pair
+    ops.append(f"v_fma_f32 v{R[j & 1]}, {cs}, v{mprev}, v{OFF[j & 1]}")
+    ops.append(f"v_exp_f32 v{R[j & 1]}, v{R[j & 1]}")
     return ops
-
-
-def rotate_m_to_x():
-    return [f"v_mov_b32 v{OFFX}, v{OFFM}", f"v_mov_b32 v{RX}, v{RM}"]
 
 
 def p1_prod_stage(p, do_m=True, do_x=True, dt="bf16"):
     """One pass-1 stage at pattern position p: head, MFMA chain of sub-tile s, and between the MFMAs the fragment reads of s+1,
-    the exp / sum of s-2 and the row maximum of s-1."""
+    the exp / sum of s-2 and the row maximum of s-1 (sub-tile parities = pattern-position parities: the period is even)."""
     n = P1.nacc
     accw, accm, accx = P1.acc[p % n], P1.acc[(p - 1) % n], P1.acc[(p - 2) % n]
     kfu, kfl = (KF0, KF1) if p % 2 == 0 else (KF1, KF0)
     L = stage_head(P1, p)
-    x = p1_valu_x(accx) if do_x else []
-    m = p1_valu_m(accm) if do_m else []
+    x = p1_valu_x(accx, p - 2) if do_x else []
+    m = p1_valu_m(accm, p - 1) if do_m else []
     slots = [[] for _ in range(8)]
     if do_x and do_m:
-        spread(slots, x[:len(x) // 2] + m[:4] + x[len(x) // 2:] + m[4:] + rotate_m_to_x())
+        spread(slots, x[:len(x) // 2] + m[:4] + x[len(x) // 2:] + m[4:])
     elif do_m:
-        spread(slots, m + rotate_m_to_x(), 3, 8)   # the accumulator being reduced finished at the end of the previous stage: keep clear of it
+        spread(slots, m, 3, 8)   # the accumulator being reduced finished at the end of the previous stage: keep clear of it
     mf = [mfma(accw, kfu + 4 * k, QF + 4 * k, k == 0, dt) for k in range(8)]
     return interleave(L, mf, prefetch_reads(P1, p, kfl), slots)
 
 
 def p1_drain(p_end):
-    """after the stage at pattern position p_end: exp/sum of the last two sub-tiles, maximum of the last"""
+    """after the stage at pattern position p_end: exp/sum of the last two sub-tiles, maximum of the last; the final running
+    maximum is left in M_ whatever the parity"""
     a_last, a_prev = P1.acc[p_end % P1.nacc], P1.acc[(p_end - 1) % P1.nacc]
-    return p1_valu_x(a_prev) + p1_valu_m(a_last) + rotate_m_to_x() + p1_valu_x(a_last)
+    L = p1_valu_x(a_prev, p_end - 1) + p1_valu_m(a_last, p_end) + p1_valu_x(a_last, p_end)
+    if MX[p_end & 1] != M_:
+        L.append(f"v_mov_b32 v{M_}, v{MX[p_end & 1]}")
+    return L
 
 
 def tile_loop(cfg, stage_fn, drain_fn, first_two):
@@ -516,8 +549,8 @@ def p1_prod_body(dt):
         L.append(f"v_add_u32 v{c.laddr2 + ks}, 0x10000, %{7 + ks}")
     for i in range(4):
         L.append(f"v_mov_b32 v{c.dmav + i}, %{3 + i}")
-    L += ["s_mov_b32 s22, %15", "s_mov_b64 s[24:25], %16", "s_mov_b32 s26, %17", "s_mov_b32 s21, %18", "s_mov_b32 s20, %19", "s_mov_b32 s28, %20",
-          f"v_mov_b32 v{M_}, 0xff800000", f"v_mov_b32 v{Z_}, 0",
+    L += ["s_mov_b32 s22, %15", "s_mov_b64 s[24:25], %16", "s_mov_b32 s26, %17", "s_mov_b32 s21, %18", "s_mov_b32 s20, %19", "s_mov_b32 s44, %19", "s_mov_b32 s45, %19", "s_mov_b32 s28, %20",
+          f"v_mov_b32 v{MX[1]}, 0xff800000", f"v_mov_b32 v{Z_}, 0",      # the max part of sub-tile 0 reads MX[1]
           "s_waitcnt vmcnt(0)", "s_barrier"]
     L += [f"ds_read_b128 {vr(KF0 + 4 * ks, 4)}, v{c.laddr + ks}" for ks in range(8)]
     first = p1_prod_stage(0, do_m=False, do_x=False, dt=dt) + p1_prod_stage(1, do_m=True, do_x=False, dt=dt)
@@ -529,19 +562,7 @@ def p1_prod_body(dt):
 # ---- pass 2 -----------------------------------------------------------------------------------------------------------
 def p2_valu_x(accx, red_imm, cs="s20"):
     """column sums of P = 2^(c * logit - a_row) over this lane's 16 rows for its key -> LDS slot (wave, lane half)"""
-    T = P2.T
-    F = lambda i: f"v_fma_f32 v{T + i}, {cs}, v{accx + i}, -v{AR + i}"
-    E = lambda i: f"v_exp_f32 v{T + i}, v{T + i}"
-    def A(i):
-        d = P2_S0 if i % 2 == 0 else P2_S1
-        return f"v_mov_b32 v{d}, v{T + i}" if i < 2 else f"v_add_f32 v{d}, v{d}, v{T + i}"
-    ops = []
-    for b in range(4):
-        ops += [F(4 * b + i) for i in range(4)]
-        ops += [E(4 * b + i) for i in range(4)]
-        if b >= 1:
-            ops += [A(4 * (b - 1) + i) for i in range(4)]
-    ops += [A(12 + i) for i in range(4)]
+    ops = exp_sum_ops(P2.T, accx, P2_S0, lambda i: f"v{AR + i}", lambda i: f"v[{AR + 2 * i}:{AR + 2 * i + 1}]", cs, neg=True)
     ops.append(f"v_add_f32 v{P2_S0}, v{P2_S0}, v{P2_S1}")
     ops.append(f"ds_write_b32 v{REDW}, v{P2_S0} offset:{red_imm}")
     return ops
@@ -611,7 +632,7 @@ def p2_prod_body(dt):
         L.append(f"v_add_u32 v{c.laddr2 + ks}, 0x10000, %{5 + ks}")
     for i in range(4):
         L.append(f"v_mov_b32 v{c.dmav + i}, %{1 + i}")
-    L += ["s_mov_b32 s22, %13", "s_mov_b64 s[24:25], %14", "s_mov_b32 s26, %15", "s_mov_b32 s21, %16", "s_mov_b32 s20, %17", "s_mov_b32 s28, %18",
+    L += ["s_mov_b32 s22, %13", "s_mov_b64 s[24:25], %14", "s_mov_b32 s26, %15", "s_mov_b32 s21, %16", "s_mov_b32 s20, %17", "s_mov_b32 s44, %17", "s_mov_b32 s45, %17", "s_mov_b32 s28, %18",
           "s_mov_b32 s27, %19", "s_mov_b64 s[40:41], %20", "s_mov_b32 s42, %22", "s_mov_b32 s31, 0",
           f"v_mov_b32 v{REDW}, %23", f"v_mov_b32 v{FLR}, %24", f"v_mov_b32 v{FLO}, %25",
           "s_waitcnt vmcnt(0)", "s_barrier"]
