@@ -36,7 +36,7 @@ struct ProfRec { std::string name; hipEvent_t e0, e1; };
 thread_local bool g_prof_on = false;
 thread_local std::vector<ProfRec> g_prof;
 void prof_clear() {
-    for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_prof.clear();
 }
 }  // namespace
@@ -45,13 +45,13 @@ bool kvp_prof_enabled() { return g_prof_on; }
 void kvp_prof_begin(const char* name, hipStream_t stream) {
     ProfRec r;
     r.name = name;
-    hipEventCreate(&r.e0);
-    hipEventCreate(&r.e1);
-    hipEventRecord(r.e0, stream);
+    (void)hipEventCreate(&r.e0);
+    (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e0, stream);
     g_prof.push_back(r);
 }
 void kvp_prof_end(hipStream_t stream) {
-    if (!g_prof.empty()) hipEventRecord(g_prof.back().e1, stream);
+    if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().e1, stream);
 }
 
 extern "C" int kvp_prof_enable(int on) {
