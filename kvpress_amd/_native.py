@@ -360,8 +360,10 @@ def snapkv_score_rope(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
 
 
 # The window q_proj can run in the library (qproj.hip), but it is no faster than the model's own GEMM + the RoPE launch
-# (20 vs 17.6 + 5 us for Llama-3.1-8B) and rounds a few queries differently from the GEMM library, so the presses keep the
-# model's q_proj unless this switch is turned on.
+# (round 1: 20 vs 17.6 + 5 us for Llama-3.1-8B in isolation; round 2, inside bench.py's loop where the 32 MiB weight is cold:
+# 21.9 us against 16.4 + 6.3, 0.296 vs 0.287 ms per layer; a split-K variant with a second reduction pass measured 18.4 us
+# against 15.4 us for the one-pass kernel) and rounds 0.01 % of the queries differently from the GEMM library, so the presses
+# keep the model's q_proj unless this switch is turned on.
 USE_LIBRARY_QPROJ = False
 
 

@@ -9,7 +9,7 @@
 //     first S - W columns for n_kept - W entries and the window positions are appended (they are the largest
 //     positions, so the ascending-position order is preserved).  n_kept < W (fewer survivors than window tokens) takes
 //     the unfused sequence.
-//   * short rows (<= 16384 scores, topk_row_eligible): the select is ONE launch (one workgroup per row) and takes no fused
+//   * short rows (<= 32768 scores, topk_row_eligible): the select is ONE launch (one workgroup per row) and takes no fused
 //     histogram; up to 4096 columns SnapKV's pooling + scaling also happen inside that launch's loader
 //     (topk_select_pooled_rows), so neither the pooling launch nor the score round trip exists.
 // Scores and indices live in the caller's workspace and never leave the device.
@@ -85,7 +85,7 @@ extern "C" int kvp_knorm_compress(const void* k, int64_t k_sb, int64_t k_sh, int
     }
     // -||k||, with the first radix histogram accumulated by the same kernel (vector path) -- knorm_press.py:38
     bool hist1_done = false;
-    uint32_t* hist1 = (n_kept < S && !topk_row_eligible(S)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;  // short rows: one-launch select
+    uint32_t* hist1 = (n_kept < S && topk_fused_hist_wanted(S)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;  // short rows: one-launch select with its own digits
     if (int rc = kvp_rownorm_launch(k, dtype, B, H, S, D, k_sb, k_sh, k_ss, -1.0f, w.scores, stream, hist1, &hist1_done)) return rc;
     if (int rc = topk_select_impl(w.scores, R, S, S, n_kept, w.idx, n_kept, 0, 0, w.topk, w.topk_bytes, true, hist1_done, stream)) return rc;
     return kvp_gather_kv(k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, H, S, D, w.idx, n_kept, k_out, v_out, stream_);
@@ -107,7 +107,7 @@ static int snapkv_select_gather(const CompressWs& w, bool fused, const float* co
         rc = topk_select_pooled_rows(colsum, R, S - W, inv, n_kept - W, w.idx, n_kept, (uint32_t)(S - W), (uint32_t)W, stream);
     else if (fused)  // short rows carry no fused histogram: the select is one launch of its own (topk_row_eligible)
         rc = topk_select_impl(w.scores, R, S - W, S, n_kept - W, w.idx, n_kept, (uint32_t)(S - W), (uint32_t)W, w.topk, w.topk_bytes, true,
-                              !topk_row_eligible(S - W), stream);
+                              topk_fused_hist_wanted(S - W), stream);
     else
         rc = topk_select_impl(w.scores, R, S, S, n_kept, w.idx, n_kept, 0, 0, w.topk, w.topk_bytes, true, false, stream);
     if (rc) return rc;
@@ -135,7 +135,7 @@ extern "C" int kvp_snapkv_compress_hidden(const void* hidden_win, int64_t x_sb, 
         return KVP_EHIP;
     }
     const bool fused = n_kept >= W;
-    uint32_t* hist1 = (fused && !topk_row_eligible(S - W)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;
+    uint32_t* hist1 = (fused && topk_fused_hist_wanted(S - W)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;
     const bool pooled = fused && topk_pooled_rows_eligible(S - W, kernel_size);  // short rows: pool + select in one launch
     if (int rc = snapkv_score_hidden_impl(hidden_win, x_sb, x_sw, wq, hidden, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq,
                                           Hkv, S, W, D, kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1,
@@ -164,7 +164,7 @@ extern "C" int kvp_snapkv_compress_rope(const void* q, int64_t q_sb, int64_t q_s
         return KVP_EHIP;
     }
     const bool fused = n_kept >= W;
-    uint32_t* hist1 = (fused && !topk_row_eligible(S - W)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;
+    uint32_t* hist1 = (fused && topk_fused_hist_wanted(S - W)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;
     const bool pooled = fused && topk_pooled_rows_eligible(S - W, kernel_size);  // short rows: pool + select in one launch
     if (int rc = snapkv_score_rope_impl(q, q_sb, q_sh, q_sw, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D,
                                         kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1, false,

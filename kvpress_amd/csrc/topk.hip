@@ -29,7 +29,7 @@
 // for the three launches -- a single CU pulls ~25 GB/s through such a dependent walk);
 // the only inter-workgroup traffic inside a launch is atomicAdd into the row histograms.
 //
-// SHORT rows (S <= 16384: decode-time compression, per-chunk / per-block selection, short prompts) are launch-bound in
+// SHORT rows (S <= 32768: BASELINE config 2, decode-time compression, per-chunk / per-block selection, short prompts) are launch-bound in
 // that scheme (3-4 dependent launches of ~5 us each), so they take ONE launch instead: topk_row_kernel, one 1024-thread
 // workgroup per row, the row's keys in registers, three digit passes (8 + 12 + 12 bits) on an LDS histogram, same tie rule.
 #include "kvp_common.h"
@@ -328,11 +328,17 @@ __device__ __forceinline__ void row_find_bin(const uint32_t* hist, uint32_t k, u
 // PAD >= 0 (fused SnapKV compress): `scores` holds the un-pooled column sums and the score of position p is
 // inv * (x[p-PAD] + ... + x[p+PAD]) with zeros outside the row -- snapkv_pool_kernel's arithmetic, term for term -- so the
 // pooling launch and the score round trip through memory disappear.
-template <int PER, int PAD>
+// HIST1 (fused compress, rows of 16385 .. 32768 scores): the kernel that wrote the scores already accumulated the histogram of
+// the first 12-bit digit (key >> 20) in hist1[row][4096] (topk_internal.h); the digits are then 12 + 12 + 8 bits as in the
+// multi-workgroup passes and only the ~5-10 % of the keys that share the threshold's first digit touch the LDS histogram
+// again (with the kernel's own 8-bit first digit nearly every key of a layer does).  Measured at 8 x 32768 (Knorm, config 2):
+// 19.1 us against 20.7 us with the kernel's own digits and 22.9 us for the three (chunk, row) launches; of the 19 us, ~4 are the
+// launch, ~3.5 the key loads, 2 per digit (block-wide scans over the histogram) and 5.6 the ordered compaction.
+template <int PER, int PAD, bool HIST1 = false>
 __global__ __launch_bounds__(TR_THREADS) void topk_row_kernel(const float* __restrict__ scores, int64_t row_stride, uint32_t S, uint32_t k,
                                                               uint32_t kmask, float inv, int32_t* __restrict__ idx, int64_t idx_stride,
                                                               uint32_t tail_start, uint32_t tail_n, uint32_t nseg, uint32_t seg_len,
-                                                              uint32_t pos_base) {
+                                                              uint32_t pos_base, uint32_t* __restrict__ hist1 = nullptr) {
     // histogram, then the staged output; with PAD >= 0 first the staged input row (one pad word per 16: conflict-free reads)
     __shared__ uint32_t lh[TR_THREADS * PER + (PAD >= 0 ? TR_THREADS * PER / 16 + 1 : 0) > 4096 ? TR_THREADS * PER + (PAD >= 0 ? TR_THREADS * PER / 16 + 1 : 0) : 4096];
     __shared__ uint32_t scr[TR_WAVES + 2];
@@ -396,6 +402,45 @@ __global__ __launch_bounds__(TR_THREADS) void topk_row_kernel(const float* __res
         kmin = min(kmin, keys[j]);
         kmax = max(kmax, keys[j]);
     }
+    uint32_t T, quota;
+    if (HIST1) {
+        // digit 1 (key >> 20) from the score-writing kernel; self-cleaning: the next fused call accumulates into zeros
+        uint32_t* gh = hist1 + (size_t)row * 4096;
+#pragma unroll
+        for (int i = 0; i < 4096 / TR_THREADS; ++i) {
+            lh[threadIdx.x + i * TR_THREADS] = gh[threadIdx.x + i * TR_THREADS];
+            gh[threadIdx.x + i * TR_THREADS] = 0;
+        }
+        __syncthreads();
+        uint32_t b1, k1;
+        row_find_bin<4096>(lh, k, scr, b1, k1);
+        for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
+        __syncthreads();
+        if (full && (kmin >> 8) == (kmax >> 8)) {
+            if ((kmin >> 20) == b1) atomicAdd(&lh[(kmin >> 8) & 0xFFFu], (uint32_t)PER);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if ((keys[j] >> 20) == b1 && keys[j]) atomicAdd(&lh[(keys[j] >> 8) & 0xFFFu], 1u);   // (key 0 = padding past S)
+        }
+        __syncthreads();
+        uint32_t b2, k2;
+        row_find_bin<4096>(lh, k1, scr, b2, k2);
+        const uint32_t prefix = (b1 << 12) | b2;
+        if (threadIdx.x < 256) lh[threadIdx.x] = 0;
+        __syncthreads();
+        if (full && kmin == kmax) {
+            if ((kmin >> 8) == prefix) atomicAdd(&lh[kmin & 0xFFu], (uint32_t)PER);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if ((keys[j] >> 8) == prefix && keys[j]) atomicAdd(&lh[keys[j] & 0xFFu], 1u);
+        }
+        __syncthreads();
+        uint32_t b3;
+        row_find_bin<256>(lh, k2, scr, b3, quota);
+        T = (prefix << 8) | b3;
+    } else {
     if (threadIdx.x < 256) lh[threadIdx.x] = 0;
     __syncthreads();
     {
@@ -443,9 +488,11 @@ __global__ __launch_bounds__(TR_THREADS) void topk_row_kernel(const float* __res
             if ((keys[j] >> 12) == prefix) atomicAdd(&lh[keys[j] & 0xFFFu], 1u);
     }
     __syncthreads();
-    uint32_t b3, quota;
+    uint32_t b3;
     row_find_bin<4096>(lh, k2, scr, b3, quota);
-    const uint32_t T = (prefix << 12) | b3;
+    T = (prefix << 12) | b3;
+
+    }
 
     // ordered compaction: keys > T, and the first `quota` keys == T
     uint32_t cg = 0, ce = 0;
@@ -455,7 +502,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_row_kernel(const float* __res
         ce += keys[j] == T ? 1u : 0u;
     }
     uint32_t tot;
-    const uint32_t ex = row_excl_scan(cg | (ce << 16), scr, &tot);  // S <= 16384: both fields < 65536
+    const uint32_t ex = row_excl_scan(cg | (ce << 16), scr, &tot);  // S <= 32768: both fields < 65536
     uint32_t g = ex & 0xFFFFu, e = ex >> 16;
     int32_t* out = idx + (int64_t)row * idx_stride;
     const uint32_t off = pos_base + (nseg > 1 ? (row % nseg) * seg_len : 0u);
@@ -511,8 +558,13 @@ extern "C" size_t kvp_topk_workspace_bytes(int64_t R, int64_t S, int64_t k) {
 }
 
 // rows this short are selected by one workgroup each (topk_row_kernel); the scorers then skip their fused histogram
+// should the kernel that writes the scores accumulate the first 12-bit histogram?  Not for rows of <= 16384 scores (the plain
+// one-launch select with its own digits is faster there); 16385 .. 32768: one launch that starts from it; longer: the
+// (chunk, row) passes start at their second pass
+bool topk_fused_hist_wanted(int64_t S) { return S > 16384; }
+
 bool topk_row_eligible(int64_t S) {
-    static const int64_t row_max = std::min<int64_t>(16384, kvp_env_int("KVP_TK_ROW_MAX", 16384));  // 1024 threads x 16 keys
+    static const int64_t row_max = std::min<int64_t>(32768, kvp_env_int("KVP_TK_ROW_MAX", 32768));  // 1024 threads x 32 keys
     return S >= 1 && S <= row_max;
 }
 
@@ -537,6 +589,12 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
         KVP_CHECK_LAUNCH("topk(iota)");
         return KVP_OK;
     }
+    if (hist1_ready && S <= 32768 && S > 16384 && ws) {  // one launch from the fused first-digit histogram
+        KVP_LAUNCH("topk_row_kernel", stream, (topk_row_kernel<32, -1, true><<<(uint32_t)R, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w.kmask, 1.f, idx,
+                                                                                                                   idx_stride, tail_start, tail_n, nseg, seg_len, pos_base, w.hist1)));
+        KVP_CHECK_LAUNCH("topk(row, fused digit)");
+        return KVP_OK;
+    }
     if (!hist1_ready && topk_row_eligible(S)) {  // short rows: one launch, no workspace
         const uint32_t km = w.kmask;
 #define KVP_TR_CASE(P)                                                                                                                   \
@@ -546,7 +604,8 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
         else if (S <= 2048) KVP_TR_CASE(2);
         else if (S <= 4096) KVP_TR_CASE(4);
         else if (S <= 8192) KVP_TR_CASE(8);
-        else KVP_TR_CASE(16);
+        else if (S <= 16384) KVP_TR_CASE(16);
+        else KVP_TR_CASE(32);
 #undef KVP_TR_CASE
         KVP_CHECK_LAUNCH("topk(row)");
         return KVP_OK;

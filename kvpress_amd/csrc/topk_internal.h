@@ -80,8 +80,10 @@ __device__ __forceinline__ void topk_hist1_flush(const uint32_t* lds_hist, uint3
 int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, int64_t idx_stride,
                      uint32_t tail_start, uint32_t tail_n, void* ws, size_t ws_bytes, bool ws_clean, bool hist1_ready,
                      hipStream_t stream, uint32_t nseg = 1, uint32_t seg_len = 0, uint32_t pos_base = 0, bool smallest = false);
-// S this short: one launch, one workgroup per row, no workspace and no use for a fused first histogram
+// S this short: one launch, one workgroup per row, no workspace
 bool topk_row_eligible(int64_t S);
+// should a score-writing kernel accumulate the first histogram for a select over S columns?  (S > 16384)
+bool topk_fused_hist_wanted(int64_t S);
 // select from un-pooled SnapKV column sums (kernel_size 5 pooling + scale `inv` inside the loader); rows as above
 bool topk_pooled_rows_eligible(int64_t Sm, int kernel_size);
 int topk_select_pooled_rows(const float* colsum, int64_t R, int64_t Sm, float inv, int64_t k, int32_t* idx, int64_t idx_stride,

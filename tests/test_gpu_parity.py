@@ -146,9 +146,9 @@ def test_topk_heavy_ties_and_edges():
     assert np.array_equal(got, O.topk_select(base[:, 100:20100], 777))
 
 
-@pytest.mark.parametrize("S", [1, 2, 63, 1023, 1024, 1025, 2048, 2049, 4096, 4097, 8191, 8193, 16383, 16384, 16385, 20000])
+@pytest.mark.parametrize("S", [1, 2, 63, 1023, 1024, 1025, 2048, 2049, 4096, 4097, 8191, 8193, 16383, 16384, 16385, 20000, 32767, 32768, 32769, 40000])
 def test_topk_short_rows_one_workgroup(S):
-    """Rows up to 16384 are selected by ONE workgroup per row (topk_row_kernel, every elements-per-thread variant, aligned
+    """Rows up to 32768 are selected by ONE workgroup per row (topk_row_kernel, every elements-per-thread variant, aligned
     and unaligned rows); longer ones by the multi-workgroup passes: same indices either way, bit-exact against the oracle."""
     rs = np.random.RandomState(S)
     N = native()
@@ -690,6 +690,22 @@ def test_fused_knorm_compress_equals_modular(name):
     assert torch.equal(ko, wk) and torch.equal(vo, wv)
 
 
+@pytest.mark.parametrize("S", [16384, 16385, 20000, 32768, 32769])
+def test_fused_knorm_select_variants_equal_modular(S):
+    """Knorm's fused compress across the select's row-length regimes (own digits <= 16384, fused first digit <= 32768, multi-workgroup
+    beyond), heavy ties included (bf16 norms): the modular sequence's bytes, twice through the same self-cleaning workspace."""
+    N = native()
+    g = torch.Generator(device=DEV); g.manual_seed(S)
+    k = torch.randn((1, 8, S, 128), generator=g, device=DEV).to(torch.bfloat16)
+    v = torch.randn((1, 8, S, 128), generator=g, device=DEV).to(torch.bfloat16)
+    k[:, :, ::7] = k[:, :, 3:4]                       # many exactly equal norms
+    sc = N.rownorm_score(k, -1.0)
+    for n in sorted({1, S // 2, (3 * S) // 4, S - 1}) * 2:
+        ko, vo = N.knorm_compress(k, v, n)
+        wk, wv = N.gather_kv(k, v, N.topk_select(sc, n))
+        assert torch.equal(ko, wk) and torch.equal(vo, wv), f"S={S} n={n}"
+
+
 @pytest.mark.parametrize("name", SK + [n for n, c in _inputs.CASES.items() if c["kind"] == "tova"])
 def test_fused_snapkv_compress_equals_modular(name):
     s = _inputs.make_case(name)
@@ -711,10 +727,11 @@ def test_fused_snapkv_compress_equals_modular(name):
         assert torch.equal(ko, wk) and torch.equal(vo, wv), f"{name} n={n}"
 
 
-@pytest.mark.parametrize("S", [70, 1087, 1089, 1500, 2112, 2113, 3000, 4160, 4161, 9000, 16448, 16449])
+@pytest.mark.parametrize("S", [70, 1087, 1089, 1500, 2112, 2113, 3000, 4160, 4161, 9000, 16448, 16449, 20001, 32832, 32833, 40000])
 def test_fused_snapkv_select_variants_equal_modular(S):
     """The fused compress picks its select by row length (pool + select in one launch up to 4096 columns, one-launch select
-    up to 16384, multi-workgroup passes with a fused first histogram beyond): always the modular sequence's bytes."""
+    up to 16384, one launch starting from the fused first-digit histogram up to 32768, multi-workgroup passes beyond): always
+    the modular sequence's bytes."""
     N = native()
     g = torch.Generator(device=DEV); g.manual_seed(S)
     k = torch.randn((2, 2, S, 128), generator=g, device=DEV).to(torch.bfloat16)
