@@ -16,6 +16,10 @@ Parity pin: ``oracle/gen_golden*.py`` run the *real* reference (imported from
 ``tests/_inputs.py`` and commit its outputs under ``tests/golden/``;
 ``tests/test_oracle_golden.py`` (scorers), ``tests/test_wrappers.py``, ``tests/test_finch.py``
 and ``tests/test_think.py`` check this file against those fixtures.
+``oracle/gen_golden_fullsize.py`` does the same at BASELINE.json's full sizes (configs 2-4; CPU-seeded inputs of
+``tests/_fullsize.py``; compact fixtures ``tests/golden/full_*.npz`` checked by ``tests/test_gpu_fullsize.py``), and
+``oracle/torch_path.py`` restates the reference's op sequence in plain PyTorch (pinned bit for bit to the same fixtures by
+``tests/test_oracle_golden.py``): it is what ``bench.py``'s ``cpu_baseline`` leg times on the GPU box's host cores.
 Caveat stated by SURVEY.md §8(c): the reference's own tests hold no score
 values for SnapKV / ExpectedAttention and torch.topk's tie order is
 unspecified, so the pin is "reference executed here", not "reference's own
