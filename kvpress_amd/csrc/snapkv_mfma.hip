@@ -130,9 +130,7 @@ __device__ __forceinline__ int ring_prev(int b) { return b == 0 ? MF_NBUF - 1 : 
 // =================================================================================================
 // pass 1: per (row, chunk) partial max / sum-exp (log2 units)
 // =================================================================================================
-// ABL (measurement aid, tools/sk_lab.py; 0 in production): 1 no softmax update, 2 no MFMA, 4 no K requests inside the tile loop,
-// 8 no per-tile wait + barrier -- timing only, results are wrong
-template <int DT, int ABL>
+template <int DT>
 __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint32_t ngb, uint32_t nchunk,
                                                                 float* __restrict__ part_m, float* __restrict__ part_z,
                                                                 float* __restrict__ clock_mhz) {
@@ -205,21 +203,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) kf[(sub + 1) & 1][ks] = kfrag(buf, sub + 1, ks, n, kg);
             }
-            if (!(ABL & 4)) ks_.request(bufr, keyr, sub);
+            ks_.request(bufr, keyr, sub);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[sub & 1][i] = 0.f;
-            if (ABL & 3) {  // ablations: straight-line, no interleave
-                if (ABL & 2) {
-#pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) { acc[sub & 1][2 * ks] = __uint_as_float(kf[sub & 1][ks].x & 0x3fffffffu); acc[sub & 1][2 * ks + 1] = __uint_as_float(kf[sub & 1][ks].z & 0x3fffffffu); }
-                } else {
-#pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) acc[sub & 1] = mma32<DT>(kf[sub & 1][ks], qf[ks], acc[sub & 1]);
-                }
-                if (ABL & 1) z += acc[sub & 1][0] + acc[sub & 1][15];
-                else { f32x16 t = acc[sub & 1]; softmax16(t, 0, sub, false); }
-            } else if (sub == 0) {
+            if (sub == 0) {
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) acc[0] = mma32<DT>(kf[0][ks], qf[ks], acc[0]);  // C[key][q row]
             } else {
@@ -247,10 +235,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
                 }
             }
         }
-        if (!(ABL & 3)) {
-            f32x16 last = acc[(MF_SUBS - 1) & 1];
-            softmax16(last, 0, MF_SUBS - 1, false);
-        }
+        f32x16 last = acc[(MF_SUBS - 1) & 1];
+        softmax16(last, 0, MF_SUBS - 1, false);
     };
     // the last tiles of a head (causal mask over the window, keys past S): chain, then the masked update, per sub-tile
     auto compute_masked = [&](uint32_t key0, const unsigned char* buf, unsigned char* bufr, uint32_t keyr) {
@@ -280,10 +266,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
             if (active) compute(tw.key0(t), lds + bc * MF_TILEB, bufr, tw.key0(t + 2));
             else ks_.request_tile(bufr, tw.key0(t + 2));
             __builtin_amdgcn_sched_barrier(0);
-            if (!(ABL & 8)) {
-                wait_tile_landed();  // this wave's part of tile t+1 is in LDS ...
-                __syncthreads();     // ... and so is everybody else's; all fragment reads of tile t are done
-            }
+            wait_tile_landed();  // this wave's part of tile t+1 is in LDS ...
+            __syncthreads();     // ... and so is everybody else's; all fragment reads of tile t are done
             bc = ring_next(bc);
         }
         wait_all_landed();
@@ -597,14 +581,8 @@ int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m,
         KVP_CHECK_LAUNCH("snapkv_p1_asm");
         return KVP_OK;
     }
-    const int abl = kvp_env_int("KVP_SK_ABL", 0);  // measurement aid (read per launch)
-#define KVP_P1_ABL(A) case A: KVP_LAUNCH("snapkv_p1_mfma", stream, (snapkv_p1_mfma<KVP_BF16, A><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, clk))); break;
-    if (dtype == KVP_BF16) {
-        switch (abl) { KVP_P1_ABL(1) KVP_P1_ABL(2) KVP_P1_ABL(3) KVP_P1_ABL(4) KVP_P1_ABL(8) KVP_P1_ABL(12) KVP_P1_ABL(13) KVP_P1_ABL(14) KVP_P1_ABL(15) KVP_P1_ABL(5) KVP_P1_ABL(6)
-            default: KVP_LAUNCH("snapkv_p1_mfma", stream, (snapkv_p1_mfma<KVP_BF16, 0><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, clk)));
-        }
-    } else KVP_LAUNCH("snapkv_p1_mfma", stream, (snapkv_p1_mfma<KVP_F16, 0><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, clk)));
-#undef KVP_P1_ABL
+    if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, clk));
+    else KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, clk));
     KVP_CHECK_LAUNCH("snapkv_p1_mfma");
     return KVP_OK;
 }

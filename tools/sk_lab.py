@@ -3,7 +3,8 @@
 stream, kvp_prof_*) under environment-selected variants on the BASELINE shape (B=1, H_q=32, H_kv=8, S=131072, D=128,
 W=64, bf16, random data) and checks every variant's scores against variant 0.
 
-    python tools/sk_lab.py "KVP_SK_ABL=0" "KVP_SK_ABL=1" "KVP_SK_P1_VAR=1 KVP_SK_P2_VAR=1" ...
+    python tools/sk_lab.py "KVP_SK_ASM=1" "KVP_SK_ASM=0" ...
+    KVPRESS_HIP_LIB=kvpress_amd/lib/variants/nodma.so python tools/sk_lab.py      (ablated builds: tools/build_variants.sh)
 
 Each argument is one configuration: space-separated NAME=VALUE pairs put into the environment for that run (the
 library reads these measurement knobs per launch).  Measurement aid, not part of the product path.
@@ -20,7 +21,7 @@ from kvpress_amd import _native  # noqa: E402
 
 
 def main():
-    cfgs = sys.argv[1:] or ["KVP_SK_ABL=0"]
+    cfgs = sys.argv[1:] or ["KVP_SK_ASM=1"]
     S = int(os.environ.get("SK_LAB_S", 131072))
     reps = int(os.environ.get("SK_LAB_REPS", 12))
     dev = torch.device("cuda", 0)
