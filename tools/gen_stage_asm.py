@@ -8,17 +8,22 @@ VALU work runs in the shadow of an MFMA).  hipcc's scheduler does not produce th
 loop is emitted here as ONE inline-asm block with fixed registers.
 
 This file emits
-  * tools/ubench_stage.hip  (`python tools/gen_stage_asm.py ubench`): the stage in isolation, ingredient by ingredient,
-  * kvpress_amd/csrc/snapkv_asm_p1.inc / snapkv_asm_p2.inc (`... kernel`): the production loops included by snapkv_mfma.hip.
+  * tools/ubench_stage.hip  (`python tools/gen_stage_asm.py ubench`): the stage in isolation, ingredient by ingredient
+    (first part of this file, names prefixed UB_ / ub_: the micro-benchmark's own fixed register map),
+  * kvpress_amd/csrc/snapkv_asm.inc (`python tools/gen_stage_asm.py kernel`): the production loops of both passes, included by
+    snapkv_mfma.hip (second part: class Cfg holds the register map and ring geometry of a pass).
+    GEN_ABL=nodma,nobar,novalu,nomfma,nolds / GEN_P1_NBUF=4 / GEN_PK=fma,add produce the lab variants of DESIGN.md section 6
+    (tools/build_variants.sh); tests/test_capi_symbols.py checks that the committed .inc is what the default settings emit.
 
 Register map (VGPR numbers are fixed inside the asm block and listed as clobbers):
   QF   v[32:63]    Q fragments, 8 k-steps x 4 dwords (B operand in pass 1, A operand in pass 2)
   KF0  v[64:95]    K fragments of the sub-tile being multiplied (8 x ds_read_b128)
   KF1  v[96:127]   K fragments of the next sub-tile (loaded while KF0 is multiplied)
   ACC  v[128:175]  three 16-register accumulators: written by the MFMA chain (W), max-reduced (M), exponentiated (X)
-  UB_T    v[176:191]  fma / exp temporaries
-  misc v[192:..]   running max m, running sum z, offsets, partial sums
+  T    v[176:191]  fma / exp temporaries
+  misc v[192:..]   running max m, running sum z, offsets, partial sums, LDS / global addresses
 Pass 1 pipeline per 32-key sub-tile s (one "stage"): MFMA chain of s  ||  row maximum of s-1  ||  exp / sum of s-2.
+Pass 2: MFMA chain of s  ||  exp / column sums of s-2 (-> LDS slots, flushed one tile later).
 """
 import sys
 
