@@ -180,7 +180,9 @@ int kvp_topk_select(const float* scores, int64_t R, int64_t S, int64_t row_strid
                     int32_t* idx, void* ws, size_t ws_bytes, kvp_stream_t stream);
 
 /* kvp_gather_kv: k_out[b,h,j,:] = k[b,h,idx[b*H+h, j],:], same for v (scorer_press.py:96-100).
- * Outputs are contiguous [B,H,n,D] in the input dtype; inputs are not modified. */
+ * Outputs are contiguous [B,H,n,D] in the input dtype; inputs are not modified.  When K + V exceed the memory-side cache
+ * (192 MiB) the rows are moved with non-temporal loads / stores: the copy then neither displaces what the next kernels
+ * re-read nor leaves its output behind as dirty cache lines. */
 int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
                   const void* v, int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype,
                   int64_t B, int64_t H, int64_t S, int64_t D,
