@@ -223,6 +223,71 @@ __global__ __launch_bounds__(SK_THREADS) void snapkv_pool_kernel(const float* __
     }
 }
 
+// The same for kernel_size 5 with four consecutive scores per thread and iteration: 8-byte loads of the 8 inputs they share, one
+// 16-byte store, term-for-term the additions of the kernel above (same scores, same histogram).  Needs S - W even and S % 4 == 0
+// (alignment of the row starts); the row's first and last group take the guarded loads.
+template <bool HIST>
+__global__ __launch_bounds__(SK_THREADS) void snapkv_pool5_vec_kernel(const float* __restrict__ colsum, uint32_t S, uint32_t W, float inv,
+                                                                      float* __restrict__ scores, float* __restrict__ bmax,
+                                                                      uint32_t* __restrict__ hist1) {
+    __shared__ float scr[4];
+    __shared__ uint32_t lh[HIST ? 4096 : 1];
+    if (HIST) {
+        for (uint32_t i = threadIdx.x; i < 4096; i += SK_THREADS) lh[i] = 0;
+        __syncthreads();
+    }
+    const uint32_t Sm = S - W, bh = blockIdx.y;
+    const float* __restrict__ row = colsum + (size_t)bh * Sm;
+    float* __restrict__ out = scores + (size_t)bh * S;
+    float vmax = KVP_NEG_INF;
+    const uint32_t ngrp = (Sm + 3) / 4, ngrpw = (ngrp + 63) & ~63u;   // whole waves: the histogram's aggregation wants converged lanes
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngrpw; g += gridDim.x * blockDim.x) {
+        const uint32_t c0 = 4 * g;
+        float x[8], s[4];
+        if (c0 >= 2 && c0 + 5 < Sm) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float2 v = *reinterpret_cast<const float2*>(row + c0 - 2 + 2 * i);
+                x[2 * i] = v.x; x[2 * i + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int cc = (int)c0 - 2 + i;
+                x[i] = (cc >= 0 && cc < (int)Sm) ? row[cc] : 0.f;   // (adding the zero of a position outside the row changes nothing: sums are >= +0)
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) t += x[i + j];
+            s[i] = t * inv;
+        }
+        if (c0 + 3 < Sm) {
+            *reinterpret_cast<float4*>(out + c0) = make_float4(s[0], s[1], s[2], s[3]);
+            vmax = fmaxf(fmaxf(vmax, fmaxf(s[0], s[1])), fmaxf(s[2], s[3]));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (c0 + i < Sm) {
+                    out[c0 + i] = s[i];
+                    vmax = fmaxf(vmax, s[i]);
+                }
+        }
+        if (HIST) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) topk_hist1_add(lh, s[i], c0 + i < Sm);
+        }
+    }
+    if (HIST) {
+        __syncthreads();
+        topk_hist1_flush(lh, hist1 + (size_t)bh * 4096);
+    } else {
+        block_store_max(vmax, scr, bmax, blockIdx.y * gridDim.x + blockIdx.x);
+    }
+}
+
 struct SnapWs {
     float* part_m;
     float* part_z;
@@ -270,18 +335,27 @@ int finish_scores(const SnapWs& w, int64_t B, int64_t Hq, int64_t Hkv, int64_t S
     const int64_t G = Hq / Hkv;
     const float inv = snapkv_pool_scale(Hq, Hkv, W, kernel_size);
     (void)G;
+    // four scores per thread (kernel_size 5, aligned rows, long rows only: short ones are launch-bound either way)
+    const bool vec = kernel_size == 5 && (S - W) % 2 == 0 && S % 4 == 0 && ((uintptr_t)scores % 16) == 0 && S - W >= 8192 && kvp_env_int("KVP_SK_POOL_VEC", 1);
+    uint32_t bxv = bx;
+    if (vec) {
+        const uint64_t per_row4 = ((uint64_t)(S - W) + 4 * SK_THREADS - 1) / (4 * SK_THREADS);
+        bxv = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per_row4, std::max<uint64_t>(1, (uint64_t)kvp_env_int("KVP_SK_POOL_WGS", 1024) / BH)));
+    }
     if (hist1) {
-        KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<true><<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.bmax, hist1));
+        if (vec) KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool5_vec_kernel<true><<<dim3(bxv, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, inv, scores, w.bmax, hist1));
+        else KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<true><<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.bmax, hist1));
         KVP_CHECK_LAUNCH("snapkv(pool+hist)");
         return KVP_OK;
     }
-    KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<false><<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.bmax, nullptr));
+    if (vec) KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool5_vec_kernel<false><<<dim3(bxv, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, inv, scores, w.bmax, nullptr));
+    else KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<false><<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.bmax, nullptr));
     if (skip_pad) {
         KVP_CHECK_LAUNCH("snapkv(pool)");
         return KVP_OK;
     }
     const uint32_t nfill = BH * (uint32_t)W;
-    KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, (uint32_t)(S - W), (uint32_t)W, w.bmax, bx * BH));
+    KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, (uint32_t)(S - W), (uint32_t)W, w.bmax, (vec ? bxv : bx) * BH));
     KVP_CHECK_LAUNCH("snapkv(pool/fill)");
     return KVP_OK;
 }

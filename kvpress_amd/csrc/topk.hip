@@ -324,6 +324,45 @@ __device__ __forceinline__ void row_find_bin(const uint32_t* hist, uint32_t k, u
     __syncthreads();
 }
 
+// ---- K2 with wide workgroups --------------------------------------------------------------------------------------
+// The second 12-bit histogram only counts the keys of the threshold's first-digit bin.  Flat score rows (SnapKV averages
+// over 256 window rows x 5 pooled keys: half of a row sits in that bin) spread those candidates evenly over the 4096 second
+// digits, so a 2048-key workgroup flushes ~900 different bins with one global atomic each (~460 k atomics at 8 x 131072: most
+// of the pass's 15.6 us).  1024 threads x PER keys aggregate PER / 2 times as many candidates per bin before the flush.
+template <int PER>
+__global__ __launch_bounds__(TR_THREADS) void topk_hist12_wide_kernel(const float* __restrict__ scores, int64_t row_stride, uint32_t S,
+                                                                      uint32_t k, TopkWs w) {
+    __shared__ uint32_t lh[4096];
+    __shared__ uint32_t scr[TR_WAVES + 2];
+    const uint32_t row = blockIdx.y, base = blockIdx.x * (TR_THREADS * PER);
+    const float* rp = scores + (int64_t)row * row_stride;
+    uint32_t keys[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t i = base + j * TR_THREADS + threadIdx.x;
+        keys[j] = i < S ? (float_to_key(rp[i]) ^ w.kmask) : 0u;
+    }
+    for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < 256) w.hist3[(size_t)row * 256 + threadIdx.x] = 0;  // self-cleaning: filled by K3, read by K4
+    uint32_t b1, k1;
+    row_find_bin<4096>(w.hist1 + (size_t)row * 4096, k, scr, b1, k1);   // (its barriers also publish the zeroed histogram)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        w.sel[row * 4 + 0] = b1;
+        w.sel[row * 4 + 1] = k1;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const bool valid = base + j * TR_THREADS + threadIdx.x < S;
+        if (valid && (keys[j] >> 20) == b1) atomicAdd(&lh[(keys[j] >> 8) & 0xFFFu], 1u);
+    }
+    __syncthreads();
+    uint32_t* gh = w.hist2 + (size_t)row * 4096;
+    for (int i = threadIdx.x; i < 4096; i += TR_THREADS) {
+        const uint32_t c = lh[i];
+        if (c) atomicAdd(&gh[i], c);
+    }
+}
+
 // thread t owns the PER consecutive positions t * PER ..: S <= 1024 * PER.
 // PAD >= 0 (fused SnapKV compress): `scores` holds the un-pooled column sums and the score of position p is
 // inv * (x[p-PAD] + ... + x[p+PAD]) with zeros outside the row -- snapkv_pool_kernel's arithmetic, term for term -- so the
@@ -624,6 +663,16 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
     const dim3 grid((uint32_t)nchunks, (uint32_t)R);
     if (!hist1_ready)
         KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<1><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
+    // keys per thread of the wide second pass (0: the 2048-key workgroups).  Measured at 8 x 131072, flat SnapKV scores / Knorm:
+    // 15.4-15.8 us -> 11.3-11.9 with 16 (the next pass gets 1.3 us slower: 0.2971 -> 0.292-0.2945 ms per SnapKV layer, 0.1549 ->
+    // 0.1522 per Knorm layer), 17.0-17.7 with 32 (too few workgroups).
+    const int wide = kvp_env_int("KVP_TK_H2_WIDE", 16);
+    if (wide == 16 || wide == 32) {
+        const uint32_t per_wg = (uint32_t)TR_THREADS * (uint32_t)wide;
+        const dim3 gw((uint32_t)((S + per_wg - 1) / per_wg), (uint32_t)R);
+        if (wide == 16) KVP_LAUNCH("topk_hist12_wide_kernel", stream, topk_hist12_wide_kernel<16><<<gw, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
+        else KVP_LAUNCH("topk_hist12_wide_kernel", stream, topk_hist12_wide_kernel<32><<<gw, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
+    } else
     KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<2><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
     KVP_LAUNCH("topk_hist8_kernel", stream, topk_hist8_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)nchunks, w));
     KVP_LAUNCH("topk_write_kernel", stream, topk_write_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, (uint32_t)nchunks, w, idx, idx_stride, tail_start, tail_n, nseg, seg_len, pos_base));

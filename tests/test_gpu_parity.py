@@ -146,6 +146,28 @@ def test_topk_heavy_ties_and_edges():
     assert np.array_equal(got, O.topk_select(base[:, 100:20100], 777))
 
 
+@pytest.mark.parametrize("S", [32769, 49153, 65536, 100003, 131072])
+def test_topk_second_pass_variants(S, monkeypatch):
+    """Rows beyond 32768 take the multi-workgroup passes; their second 12-bit histogram runs in 16384-key workgroups by default
+    (KVP_TK_H2_WIDE=16), 32768-key or the original 2048-key ones on request: the oracle's indices every time, on wide, flat
+    (one exponent, heavy ties: half the row in the threshold's first-digit bin) and constant rows, k smallest included."""
+    rs = np.random.RandomState(S)
+    N = native()
+    wide = rs.standard_normal((3, S)).astype(np.float32)
+    flat = (2.0 ** -17 * (1 + 0.05 * rs.standard_normal((3, S)))).astype(np.float32)   # pooled-attention-like: +-5 % around one value
+    ties = _inputs.round_to(-np.sqrt(rs.chisquare(64, size=(3, S))).astype(np.float32), "bf16")
+    const = np.full((2, S), 0.25, np.float32)
+    for variant in ("16", "32", "0"):
+        monkeypatch.setenv("KVP_TK_H2_WIDE", variant)
+        for sc_np in (wide, flat, ties, const):
+            t = torch.from_numpy(sc_np).to(DEV)
+            for k in sorted({1, S // 3, S // 2, S - 1}):
+                got = N.topk_select(t, k).cpu().numpy()
+                assert np.array_equal(got, O.topk_select(sc_np, k)), f"variant {variant} S={S} k={k}"
+        got = N.topk_select(torch.from_numpy(flat).to(DEV), S // 2, N.ORDER_POSITION | N.TOPK_SMALLEST).cpu().numpy()
+        assert np.array_equal(got, O.topk_select(-flat, S // 2)), f"variant {variant} S={S} smallest"
+
+
 @pytest.mark.parametrize("S", [1, 2, 63, 1023, 1024, 1025, 2048, 2049, 4096, 4097, 8191, 8193, 16383, 16384, 16385, 20000, 32767, 32768, 32769, 40000])
 def test_topk_short_rows_one_workgroup(S):
     """Rows up to 32768 are selected by ONE workgroup per row (topk_row_kernel, every elements-per-thread variant, aligned
@@ -1001,3 +1023,27 @@ def test_snapkv_mfma_group_blocks_are_deterministic(G):
     ref = O.snapkv_score(q.float().cpu().numpy(), keys.float().cpu().numpy(), 5)
     got = a.cpu().numpy()
     np.testing.assert_allclose(got[..., :-64], ref[..., :-64], rtol=1e-3)
+
+
+@pytest.mark.parametrize("S", [8256, 8260, 12288 + 64, 20000, 40000, 65600])
+def test_snapkv_pool_variants_identical(S, monkeypatch):
+    """Long rows with kernel_size 5 are pooled four scores per thread (8-byte loads, one 16-byte store; aligned rows only): the
+    same additions in the same order as the one-score-per-thread kernel, so scores (pad value included), fused histogram and
+    the compressed cache are bit-identical with KVP_SK_POOL_VEC=0, and the scores match the oracle."""
+    g = torch.Generator().manual_seed(S)
+    keys = torch.randn((1, 2, S, 128), generator=g).to(torch.bfloat16).to(DEV)
+    vals = torch.randn((1, 2, S, 128), generator=g).to(torch.bfloat16).to(DEV)
+    q = (torch.randn((1, 8, 64, 128), generator=g) * 1.2).to(torch.bfloat16).to(DEV)
+    cos = torch.ones((1, 64, 128), dtype=torch.bfloat16, device=DEV)
+    sin = torch.zeros((1, 64, 128), dtype=torch.bfloat16, device=DEV)
+    N = native()
+    out = {}
+    for variant in ("1", "0"):
+        monkeypatch.setenv("KVP_SK_POOL_VEC", variant)
+        sc = N.snapkv_score(q, keys, 5)
+        ko, vo = N.snapkv_compress_rope(q, cos, sin, keys, vals, 5, S // 2)
+        out[variant] = (sc, ko, vo)
+    for a, b in zip(out["1"], out["0"]):
+        assert torch.equal(a, b)
+    ref = O.snapkv_score(q.float().cpu().numpy(), keys.float().cpu().numpy(), 5)
+    np.testing.assert_allclose(out["1"][0].cpu().numpy()[..., :-64], ref[..., :-64], rtol=1e-3)
