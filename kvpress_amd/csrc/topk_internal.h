@@ -5,10 +5,13 @@
 
 constexpr int TK_THREADS = 256;
 #ifndef KVP_TK_PER
-#define KVP_TK_PER 8
+#define KVP_TK_PER 4
 #endif
 constexpr int TK_PER = KVP_TK_PER;
-constexpr int TK_CHUNK = TK_THREADS * TK_PER;  // 2048 scores per workgroup
+// 1024 scores per workgroup: the passes are chains of dependent steps (loads, histogram scan, block scans), so many small
+// workgroups beat few large ones (8 x 131072, last two passes: 8.2 + 7.6 us with 4 scores per thread, 9.6 + 8.2 with 8,
+// 11.0 + 9.1 with 16)
+constexpr int TK_CHUNK = TK_THREADS * TK_PER;
 
 struct TopkWs {
     uint32_t* hist1;       // [R][4096]
