@@ -598,8 +598,8 @@ extern "C" size_t kvp_topk_workspace_bytes(int64_t R, int64_t S, int64_t k) {
 
 // rows this short are selected by one workgroup each (topk_row_kernel); the scorers then skip their fused histogram
 // should the kernel that writes the scores accumulate the first 12-bit histogram?  Not for rows of <= 16384 scores (the plain
-// one-launch select with its own digits is faster there); 16385 .. 32768: one launch that starts from it; longer: the
-// (chunk, row) passes start at their second pass
+// one-launch select with its own digits is faster there); longer: the (chunk, row) passes start at their second pass
+// (KVP_TK_ROW_FUSED=1: one launch that starts from it up to 32768)
 bool topk_fused_hist_wanted(int64_t S) { return S > 16384; }
 
 bool topk_row_eligible(int64_t S) {
@@ -628,7 +628,9 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
         KVP_CHECK_LAUNCH("topk(iota)");
         return KVP_OK;
     }
-    if (hist1_ready && S <= 32768 && S > 16384 && ws) {  // one launch from the fused first-digit histogram
+    // One launch from the fused first-digit histogram: KVP_TK_ROW_FUSED=1 only.  With 1024-score chunks and the wide second pass
+    // the three (chunk, row) launches are faster even at 8 x 32768 (Knorm config 2: 0.0525 against 0.0538 ms per layer).
+    if (hist1_ready && S <= 32768 && S > 16384 && ws && kvp_env_int("KVP_TK_ROW_FUSED", 0)) {
         KVP_LAUNCH("topk_row_kernel", stream, (topk_row_kernel<32, -1, true><<<(uint32_t)R, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w.kmask, 1.f, idx,
                                                                                                                    idx_stride, tail_start, tail_n, nseg, seg_len, pos_base, w.hist1)));
         KVP_CHECK_LAUNCH("topk(row, fused digit)");

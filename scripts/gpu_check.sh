@@ -59,7 +59,7 @@ if [[ "$WHAT" == *prof* ]]; then
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -o $wl -- python "$GRAFT_REPO_ROOT/bench.py" --workload $wl --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" 2>&1
     echo "prof[$wl] rc=$?"
     find "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -name "*kernel_stats.csv" -exec cp {} "$GRAFT_REPO_ROOT/gpurun_out/r02_rocprofv3_kernel_stats_$wl.csv" \;
-    tail -1 "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" > "$GRAFT_REPO_ROOT/gpurun_out/r02_bench_under_rocprof_$wl.json"
+    grep "^{" "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" | tail -1 > "$GRAFT_REPO_ROOT/gpurun_out/r02_bench_under_rocprof_$wl.json"
     rm -rf "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl"
   done
   cd "$GRAFT_REPO_ROOT"

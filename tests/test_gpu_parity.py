@@ -712,10 +712,13 @@ def test_fused_knorm_compress_equals_modular(name):
     assert torch.equal(ko, wk) and torch.equal(vo, wv)
 
 
+@pytest.mark.parametrize("row_fused", ["0", "1"])
 @pytest.mark.parametrize("S", [16384, 16385, 20000, 32768, 32769])
-def test_fused_knorm_select_variants_equal_modular(S):
-    """Knorm's fused compress across the select's row-length regimes (own digits <= 16384, fused first digit <= 32768, multi-workgroup
-    beyond), heavy ties included (bf16 norms): the modular sequence's bytes, twice through the same self-cleaning workspace."""
+def test_fused_knorm_select_variants_equal_modular(S, row_fused, monkeypatch):
+    """Knorm's fused compress across the select's row-length regimes (own digits <= 16384, multi-workgroup passes from the fused
+    first-digit histogram beyond; KVP_TK_ROW_FUSED=1: one launch from that histogram up to 32768), heavy ties included (bf16
+    norms): the modular sequence's bytes, twice through the same self-cleaning workspace."""
+    monkeypatch.setenv("KVP_TK_ROW_FUSED", row_fused)
     N = native()
     g = torch.Generator(device=DEV); g.manual_seed(S)
     k = torch.randn((1, 8, S, 128), generator=g, device=DEV).to(torch.bfloat16)
@@ -752,8 +755,8 @@ def test_fused_snapkv_compress_equals_modular(name):
 @pytest.mark.parametrize("S", [70, 1087, 1089, 1500, 2112, 2113, 3000, 4160, 4161, 9000, 16448, 16449, 20001, 32832, 32833, 40000])
 def test_fused_snapkv_select_variants_equal_modular(S):
     """The fused compress picks its select by row length (pool + select in one launch up to 4096 columns, one-launch select
-    up to 16384, one launch starting from the fused first-digit histogram up to 32768, multi-workgroup passes beyond): always
-    the modular sequence's bytes."""
+    up to 16384, multi-workgroup passes starting from the fused first-digit histogram beyond): always the modular sequence's
+    bytes."""
     N = native()
     g = torch.Generator(device=DEV); g.manual_seed(S)
     k = torch.randn((2, 2, S, 128), generator=g, device=DEV).to(torch.bfloat16)
