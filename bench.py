@@ -96,6 +96,8 @@ def kernel_flops(name: str, S: int) -> float:
     """Algorithmic matrix-core flops of ONE launch (B=1; SURVEY §8d: 2 * H_q * W * S * D per QK^T pass)."""
     if name.startswith(("snapkv_p1", "snapkv_p2")):
         return 2.0 * H_Q * WINDOW * S * D
+    if name.startswith("ea_logits"):
+        return 2.0 * H_Q * S * D * D  # k^T Sigma k per key and query head (the kernel's hi + lo split of Sigma executes twice that)
     return 0.0
 
 
@@ -402,6 +404,10 @@ def main():
                     "kernels_sum_us": round(sum(a * c for a, c in avg.values()) * 1e3, 2),
                 },
             }
+            m = roofline["mfma"]
+            if m and m["frac"] > roofline["frac"]:   # the matrix-core roof is the nearer one (ExpectedAttention's quadratic form)
+                roofline["hbm"] = {k: roofline[k] for k in ("achieved", "peak", "unit", "frac")}
+                roofline.update(bound="mfma", achieved=m["achieved"], peak=m["peak"], unit=m["unit"], frac=m["frac"])
         if args.profile_json:
             with open(args.profile_json, "w") as f:
                 json.dump({"workload": args.workload, "ms_per_step": t_step * 1e3,

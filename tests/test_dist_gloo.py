@@ -55,6 +55,9 @@ def test_algorithmic_bytes_match_survey():
     assert bench.algorithmic_bytes("knorm", 32768, 0.5)["total"] == 201326592       # config 2
     assert bench.algorithmic_bytes("ea", 131072, 0.7)["total"] == 1932730368        # config 4
     assert bench.algorithmic_bytes("ea", 131072, 0.7)["n_kept"] == 39321
+    assert bench.kernel_flops("snapkv_p1_asm", 131072) == 2 * 32 * 64 * 131072 * 128       # 68.7 GFLOP per QK^T pass
+    assert bench.kernel_flops("ea_logits_mfma", 131072) == 2 * 32 * 131072 * 128 * 128    # k^T Sigma k: 137 GFLOP
+    assert bench.kernel_bytes("ea_logits_mfma", "ea", 131072, 0.7) == 131072 * 8 * 128 * 2
 
 
 def _run_bench(cmd):
