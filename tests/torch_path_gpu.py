@@ -4,9 +4,10 @@
 
 The reference itself cannot travel to the GPU box, so the op sequence of its three scorers and of ``ScorerPress.compress``
 is restated here with torch calls, one line per reference line (cited) -- same intermediates, same dtypes, same rounding
-points, nothing fused.  Measurement aid only: nothing in the package, the tests or bench.py imports this file.
+points, nothing fused.  Measurement aid (under tests/ because it runs the oracle's torch restatement): nothing in the package, the test suite or
+bench.py imports this file, and pytest does not collect it.
 
-    python tools/torch_path_gpu.py [--workload snapkv128k|knorm32k|knorm128k|ea128k] [--reps 10]
+    python tests/torch_path_gpu.py [--workload snapkv128k|knorm32k|knorm128k|ea128k] [--reps 10]
 
 Prints one JSON line per workload: ms/layer of the torch path and of the HIP path (CUDA events on the current stream,
 3 warm-up calls), the peak extra memory of each, and the overlap of the two retained sets.
