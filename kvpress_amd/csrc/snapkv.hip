@@ -330,32 +330,28 @@ int finish_scores(const SnapWs& w, int64_t B, int64_t Hq, int64_t Hkv, int64_t S
     if (finish == SNAP_FINISH_COLSUM) return KVP_OK;
     const bool skip_pad = finish != SNAP_FINISH_FULL;
     const uint32_t BH = (uint32_t)(B * Hkv);
-    const uint64_t per_row = ((uint64_t)(S - W) + SK_THREADS - 1) / SK_THREADS;
-    const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per_row, std::max<uint64_t>(1, 2048 / BH)));
-    const int64_t G = Hq / Hkv;
     const float inv = snapkv_pool_scale(Hq, Hkv, W, kernel_size);
-    (void)G;
-    // four scores per thread (kernel_size 5, aligned rows, long rows only: short ones are launch-bound either way)
+    // four scores per thread: kernel_size 5, aligned row starts, long rows (short ones are launch-bound either way)
     const bool vec = kernel_size == 5 && (S - W) % 2 == 0 && S % 4 == 0 && ((uintptr_t)scores % 16) == 0 && S - W >= 8192 && kvp_env_int("KVP_SK_POOL_VEC", 1);
-    uint32_t bxv = bx;
-    if (vec) {
-        const uint64_t per_row4 = ((uint64_t)(S - W) + 4 * SK_THREADS - 1) / (4 * SK_THREADS);
-        bxv = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per_row4, std::max<uint64_t>(1, (uint64_t)kvp_env_int("KVP_SK_POOL_WGS", 1024) / BH)));
-    }
+    const uint64_t per_wg = (uint64_t)SK_THREADS * (vec ? 4 : 1);
+    const uint64_t wg_cap = vec ? (uint64_t)std::max(1, kvp_env_int("KVP_SK_POOL_WGS", 1024)) : 2048;   // <= 4096: the size of w.bmax
+    const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)(S - W) + per_wg - 1) / per_wg, std::max<uint64_t>(1, std::min<uint64_t>(wg_cap, 4096) / BH)));
+    const dim3 grid(bx, BH);
+    const int pad = kernel_size / 2;
     if (hist1) {
-        if (vec) KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool5_vec_kernel<true><<<dim3(bxv, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, inv, scores, w.bmax, hist1));
-        else KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<true><<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.bmax, hist1));
+        if (vec) KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool5_vec_kernel<true><<<grid, SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, inv, scores, w.bmax, hist1));
+        else KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<true><<<grid, SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, pad, inv, scores, w.bmax, hist1));
         KVP_CHECK_LAUNCH("snapkv(pool+hist)");
         return KVP_OK;
     }
-    if (vec) KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool5_vec_kernel<false><<<dim3(bxv, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, inv, scores, w.bmax, nullptr));
-    else KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<false><<<dim3(bx, BH), SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, kernel_size / 2, inv, scores, w.bmax, nullptr));
+    if (vec) KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool5_vec_kernel<false><<<grid, SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, inv, scores, w.bmax, nullptr));
+    else KVP_LAUNCH("snapkv_pool_kernel", stream, snapkv_pool_kernel<false><<<grid, SK_THREADS, 0, stream>>>(w.colsum, (uint32_t)S, (uint32_t)W, pad, inv, scores, w.bmax, nullptr));
     if (skip_pad) {
         KVP_CHECK_LAUNCH("snapkv(pool)");
         return KVP_OK;
     }
     const uint32_t nfill = BH * (uint32_t)W;
-    KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, (uint32_t)(S - W), (uint32_t)W, w.bmax, (vec ? bxv : bx) * BH));
+    KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, (uint32_t)(S - W), (uint32_t)W, w.bmax, bx * BH));
     KVP_CHECK_LAUNCH("snapkv(pool/fill)");
     return KVP_OK;
 }

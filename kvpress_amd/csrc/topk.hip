@@ -665,19 +665,20 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
     const dim3 grid((uint32_t)nchunks, (uint32_t)R);
     if (!hist1_ready)
         KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<1><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
-    // keys per thread of the wide second pass (0: the 2048-key workgroups).  Measured at 8 x 131072, flat SnapKV scores / Knorm:
-    // 15.4-15.8 us -> 11.3-11.9 with 16 (the next pass gets 1.3 us slower: 0.2971 -> 0.292-0.2945 ms per SnapKV layer, 0.1549 ->
-    // 0.1522 per Knorm layer), 17.0-17.7 with 32 (too few workgroups).
+    // Second pass: 1024-thread workgroups of KVP_TK_H2_WIDE scores per thread (default 8; 0 = the narrow kernel with this pass's
+    // own (chunk, row) grid).  Measured at 8 x 131072 on flat SnapKV scores / Knorm norms: narrow 15.4-15.8 us, 4: 9.3-9.8,
+    // 8: 9.2-9.6, 16: 11.3-11.9, 32: 17.0-17.7 (too few workgroups).
     const int wide = kvp_env_int("KVP_TK_H2_WIDE", 8);
-    if (wide == 4 || wide == 8 || wide == 16 || wide == 32) {
-        const uint32_t per_wg = (uint32_t)TR_THREADS * (uint32_t)wide;
-        const dim3 gw((uint32_t)((S + per_wg - 1) / per_wg), (uint32_t)R);
-        if (wide == 4) KVP_LAUNCH("topk_hist12_wide_kernel", stream, topk_hist12_wide_kernel<4><<<gw, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
-        else if (wide == 8) KVP_LAUNCH("topk_hist12_wide_kernel", stream, topk_hist12_wide_kernel<8><<<gw, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
-        else if (wide == 16) KVP_LAUNCH("topk_hist12_wide_kernel", stream, topk_hist12_wide_kernel<16><<<gw, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
-        else KVP_LAUNCH("topk_hist12_wide_kernel", stream, topk_hist12_wide_kernel<32><<<gw, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
-    } else
-    KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<2><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
+    const dim3 gw((uint32_t)((S + (int64_t)TR_THREADS * std::max(wide, 1) - 1) / ((int64_t)TR_THREADS * std::max(wide, 1))), (uint32_t)R);
+#define KVP_TK_WIDE(P) KVP_LAUNCH("topk_hist12_wide_kernel", stream, topk_hist12_wide_kernel<P><<<gw, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w))
+    switch (wide) {
+        case 4: KVP_TK_WIDE(4); break;
+        case 8: KVP_TK_WIDE(8); break;
+        case 16: KVP_TK_WIDE(16); break;
+        case 32: KVP_TK_WIDE(32); break;
+        default: KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<2><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
+    }
+#undef KVP_TK_WIDE
     KVP_LAUNCH("topk_hist8_kernel", stream, topk_hist8_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)nchunks, w));
     KVP_LAUNCH("topk_write_kernel", stream, topk_write_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, (uint32_t)nchunks, w, idx, idx_stride, tail_start, tail_n, nseg, seg_len, pos_base));
     KVP_CHECK_LAUNCH("topk");
