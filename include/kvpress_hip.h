@@ -290,6 +290,10 @@ int kvp_prof_kernel_clock(float* mhz);
  * memory) it saw: s_memtime ticks per 100 MHz s_memrealtime tick.  Enqueued right behind a kernel it shows the clock that
  * kernel ran at (the governor is slow compared with a kernel). */
 int kvp_clock_probe(float* mhz_out, int spin_us, kvp_stream_t stream);
+/* kvp_tuning_reload: the library's tuning knobs (KVP_* environment variables: launch geometries and kernel-variant switches
+ * for A/B runs) are read from the environment once, at first use, and cached; this drops the cache so that the next use of
+ * every knob re-reads the environment.  Not needed in production; tests and lab scripts call it after changing a variable. */
+int kvp_tuning_reload(void);
 
 #ifdef __cplusplus
 }

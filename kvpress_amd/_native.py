@@ -88,6 +88,7 @@ SIGNATURES = {
     "kvp_prof_count": (c_int, []),
     "kvp_prof_get": (c_int, [c_int, ctypes.POINTER(c_char_p), ctypes.POINTER(c_float)]),
     "kvp_clock_probe": (c_int, [c_void_p, c_int, c_void_p]),
+    "kvp_tuning_reload": (c_int, []),
     "kvp_prof_kernel_clock": (c_int, [ctypes.POINTER(c_float)]),
 }
 
@@ -727,3 +728,8 @@ def prof_records():
         _check(lib().kvp_prof_get(i, ctypes.byref(name), ctypes.byref(ms)), "kvp_prof_get")
         out.append((name.value.decode(), float(ms.value)))
     return out
+
+
+def tuning_reload() -> None:
+    """Make the library re-read its KVP_* tuning variables (they are read from the environment once and cached)."""
+    _check(lib().kvp_tuning_reload(), "kvp_tuning_reload")

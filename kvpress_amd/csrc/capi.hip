@@ -16,9 +16,30 @@ void kvp_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// Tuning knobs (KVP_* environment variables, used for A/B runs on hardware): every variable is read from the environment
+// ONCE -- at its first use -- and then served from this table, so the launch path never calls getenv (a data race in glibc
+// if another host thread calls setenv concurrently) and the launch geometry cannot change silently in the middle of a run.
+// kvp_tuning_reload() drops the table: the next use of every knob re-reads the environment (tests, lab scripts).
+#include <mutex>
+#include <vector>
+namespace {
+struct Knob { const char* name; bool set; int value; };
+std::mutex g_knob_mu;
+std::vector<Knob> g_knobs;
+}  // namespace
 int kvp_env_int(const char* name, int dflt) {
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    for (const Knob& k : g_knobs)
+        if (k.name == name || strcmp(k.name, name) == 0) return k.set ? k.value : dflt;
     const char* s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
+    const Knob k{name, s && *s, (s && *s) ? atoi(s) : 0};
+    g_knobs.push_back(k);
+    return k.set ? k.value : dflt;
+}
+extern "C" int kvp_tuning_reload(void) {
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    g_knobs.clear();
+    return KVP_OK;
 }
 
 extern "C" int kvp_version(void) { return KVP_VERSION; }

@@ -83,6 +83,16 @@ extern "C" int kvp_knorm_compress(const void* k, int64_t k_sb, int64_t k_sh, int
         kvp_set_error("knorm_compress: hipMemsetAsync failed");
         return KVP_EHIP;
     }
+    // long rows of 256-byte keys (Llama: D = 128, bf16 / f16): norms, select digits and compaction in ONE launch, the scores stay
+    // in registers (topk_cluster.hip); KVP_TK_CLUSTER_KNORM=0 / other shapes / a device that cannot hold the grid: the sequence below
+    if (n_kept < S && topk_cluster_eligible(R, S) && (dtype == KVP_BF16 || dtype == KVP_F16) && D == 128 && ((uintptr_t)k % 16) == 0 &&
+        (k_sb * 2) % 16 == 0 && (k_sh * 2) % 16 == 0 && (k_ss * 2) % 16 == 0 && kvp_env_int("KVP_TK_CLUSTER_KNORM", 1)) {
+        TopkWs tw = topk_carve_ws(w.topk, R, (S + TK_CHUNK - 1) / TK_CHUNK);
+        const int rc = topk_cluster_select(TOPK_CLUSTER_KNORM, nullptr, 0, 1.f, k, dtype, k_sb, k_sh, k_ss, H, -1.0f, R, S, n_kept, w.idx, n_kept, 0, 0, tw,
+                                           false, stream);
+        if (rc < 0) return rc;
+        if (rc == 0) return kvp_gather_kv(k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, H, S, D, w.idx, n_kept, k_out, v_out, stream_);
+    }
     // -||k||, with the first radix histogram accumulated by the same kernel (vector path) -- knorm_press.py:38
     bool hist1_done = false;
     uint32_t* hist1 = (n_kept < S && topk_fused_hist_wanted(S)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;  // short rows: one-launch select with its own digits
@@ -97,13 +107,26 @@ extern "C" size_t kvp_snapkv_compress_workspace_bytes(int64_t B, int64_t Hq, int
     return carve(nullptr, B * Hkv, std::max<int64_t>(1, S - W), S, n_kept, kvp_snapkv_workspace_bytes(B, Hq, Hkv, S, W, D)).total_bytes;
 }
 
+// long rows, kernel_size 5: the cluster select pools SnapKV's column sums in its loader (no pooling launch, no score round trip)
+static bool snapkv_cluster_pooled(int64_t R, int64_t Sm, int kernel_size) {
+    return kernel_size == 5 && topk_cluster_eligible(R, Sm) && topk_cluster_launchable() && kvp_env_int("KVP_TK_CLUSTER_POOL", 1);
+}
+
 // select + gather after a SnapKV scorer has run (fused: hist1 holds the first pass over the S - W non-window columns)
 static int snapkv_select_gather(const CompressWs& w, bool fused, const float* colsum, float inv, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, const void* v,
                                 int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype, int64_t B, int64_t Hkv, int64_t S, int64_t W, int64_t D,
                                 int64_t n_kept, void* k_out, void* v_out, hipStream_t stream) {
     const int64_t R = B * Hkv;
     int rc;
-    if (fused && colsum)  // short rows, kernel_size 5: pooling happens inside the select's loader
+    if (fused && colsum && !topk_pooled_rows_eligible(S - W, 5)) {  // long rows, kernel_size 5: pooling inside the cluster select's loader
+        TopkWs tw = topk_carve_ws(w.topk, R, (S - W + TK_CHUNK - 1) / TK_CHUNK);
+        if (n_kept - W == 0 || n_kept == S)   // only the window / everything is kept: no selection
+            rc = topk_select_impl(colsum, R, S - W, S - W, n_kept - W, w.idx, n_kept, (uint32_t)(S - W), (uint32_t)W, w.topk, w.topk_bytes, true, false, stream);
+        else
+            rc = topk_cluster_select(TOPK_CLUSTER_POOL5, colsum, S - W, inv, nullptr, 0, 0, 0, 0, 1, 0.f, R, S - W, n_kept - W, w.idx, n_kept, (uint32_t)(S - W),
+                                     (uint32_t)W, tw, false, stream);
+        KVP_CHECK_ARG(rc != 1, "snapkv_compress: cluster select not launchable");   // (snapkv_cluster_pooled() asked the same question before the scorer ran)
+    } else if (fused && colsum)  // short rows, kernel_size 5: pooling happens inside the select's loader
         rc = topk_select_pooled_rows(colsum, R, S - W, inv, n_kept - W, w.idx, n_kept, (uint32_t)(S - W), (uint32_t)W, stream);
     else if (fused)  // short rows carry no fused histogram: the select is one launch of its own (topk_row_eligible)
         rc = topk_select_impl(w.scores, R, S - W, S, n_kept - W, w.idx, n_kept, (uint32_t)(S - W), (uint32_t)W, w.topk, w.topk_bytes, true,
@@ -136,7 +159,7 @@ extern "C" int kvp_snapkv_compress_hidden(const void* hidden_win, int64_t x_sb, 
     }
     const bool fused = n_kept >= W;
     uint32_t* hist1 = (fused && topk_fused_hist_wanted(S - W)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;
-    const bool pooled = fused && topk_pooled_rows_eligible(S - W, kernel_size);  // short rows: pool + select in one launch
+    const bool pooled = fused && (topk_pooled_rows_eligible(S - W, kernel_size) || snapkv_cluster_pooled(R, S - W, kernel_size));  // pool + select in one launch
     if (int rc = snapkv_score_hidden_impl(hidden_win, x_sb, x_sw, wq, hidden, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq,
                                           Hkv, S, W, D, kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1,
                                           pooled ? SNAP_FINISH_COLSUM : fused ? SNAP_FINISH_NO_PAD : SNAP_FINISH_FULL))
@@ -165,7 +188,7 @@ extern "C" int kvp_snapkv_compress_rope(const void* q, int64_t q_sb, int64_t q_s
     }
     const bool fused = n_kept >= W;
     uint32_t* hist1 = (fused && topk_fused_hist_wanted(S - W)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;
-    const bool pooled = fused && topk_pooled_rows_eligible(S - W, kernel_size);  // short rows: pool + select in one launch
+    const bool pooled = fused && (topk_pooled_rows_eligible(S - W, kernel_size) || snapkv_cluster_pooled(R, S - W, kernel_size));  // pool + select in one launch
     if (int rc = snapkv_score_rope_impl(q, q_sb, q_sh, q_sw, cosp, sinp, cs_sb, cs_sw, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D,
                                         kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1, false,
                                         pooled ? SNAP_FINISH_COLSUM : fused ? SNAP_FINISH_NO_PAD : SNAP_FINISH_FULL))

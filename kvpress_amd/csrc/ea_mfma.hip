@@ -522,7 +522,7 @@ bool aligned8(int64_t x) { return x % 8 == 0; }
 
 // ---- host ---------------------------------------------------------------------------------------
 bool ea_mfma_qstats_eligible(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int dtype, int64_t Sq, int64_t D) {
-    static const int off = kvp_env_int("KVP_EA_GENERIC", 0);
+    const int off = kvp_env_int("KVP_EA_GENERIC", 0);
     if (off) return false;
     // 16-bit rounding of the shifted products: relative covariance error ~ 4.6e-3 / sqrt(Sq) (1 sigma); shorter
     // sequences take the exact fp32 generic kernels
@@ -562,7 +562,7 @@ int ea_mfma_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int 
 }
 
 bool ea_mfma_logits_eligible(const EaArgs& a, int dtype) {
-    static const int off = kvp_env_int("KVP_EA_GENERIC", 0);
+    const int off = kvp_env_int("KVP_EA_GENERIC", 0);
     if (off) return false;
     return (dtype == KVP_BF16 || dtype == KVP_F16) && a.D == 128 && a.Sp >= 64 && (uintptr_t)a.k % 16 == 0 && aligned8(a.k_sb) &&
            aligned8(a.k_sh) && aligned8(a.k_ss) && a.G <= 65535;

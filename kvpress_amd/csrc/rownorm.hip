@@ -128,7 +128,7 @@ int launch_rownorm(const void* x, PlaneMap map, uint32_t BH, uint32_t D, float s
     const uint64_t bx_full = (groups_needed + gpb - 1) / gpb;
     const uint64_t bx_cap = std::max<uint64_t>(1, (256 * 8 + BH - 1) / BH);  // ~8 workgroups per CU in total
     const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap));
-    static const bool nt = kvp_env_int("KVP_RN_NT", 0) != 0;
+    const bool nt = kvp_env_int("KVP_RN_NT", 0) != 0;
 #define KVP_RN_CASE(L)                                                                                     \
     case L:                                                                                                \
         if (hist1) KVP_LAUNCH("rownorm_vec_kernel", stream, rownorm_vec_kernel<DT, L, false, true><<<dim3(bx, BH), RN_THREADS, 0, stream>>>(xp, map, chunks, scale, out, hist1)); \

@@ -34,6 +34,7 @@
 // workgroup per row, the row's keys in registers, three digit passes (8 + 12 + 12 bits) on an LDS histogram, same tie rule.
 #include "kvp_common.h"
 #include "topk_internal.h"
+#include "topk_block.h"
 
 namespace {
 
@@ -266,63 +267,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_write_kernel(const float* __r
     }
 }
 
-// ---- one workgroup per row (short rows) ------------------------------------------------------------
-constexpr int TR_THREADS = 1024;
-constexpr int TR_WAVES = TR_THREADS / 64;
-
-// exclusive prefix sum over the 1024 threads of the block; lds: >= TR_WAVES words
-__device__ __forceinline__ uint32_t row_excl_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
-    if (lane == 63) lds[w] = inc;
-    __syncthreads();
-    uint32_t woff = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < TR_WAVES; ++i) {
-        const uint32_t x = lds[i];
-        if (i < w) woff += x;
-        tot += x;
-    }
-    __syncthreads();
-    *total = tot;
-    return woff + inc - v;
-}
-
-// find_bin for the 1024-thread block: thread 0 owns the highest bins.  lds: >= TR_WAVES + 2 words.
-template <int NB>
-__device__ __forceinline__ void row_find_bin(const uint32_t* hist, uint32_t k, uint32_t* lds, uint32_t& bin, uint32_t& krem) {
-    constexpr int PERB = NB >= TR_THREADS ? NB / TR_THREADS : 1;
-    const bool owner = NB >= TR_THREADS || threadIdx.x < NB;
-    const uint32_t rg = (NB >= TR_THREADS ? TR_THREADS : NB) - 1 - threadIdx.x;
-    uint32_t loc[PERB], sum = 0;
-#pragma unroll
-    for (int i = 0; i < PERB; ++i) {
-        loc[i] = owner ? hist[rg * PERB + i] : 0u;
-        sum += loc[i];
-    }
-    uint32_t total;
-    const uint32_t excl = row_excl_scan(sum, lds, &total);
-    if (owner && excl < k && k <= excl + sum) {
-        uint32_t c = excl;
-#pragma unroll
-        for (int i = PERB - 1; i >= 0; --i) {
-            if (k > c && k <= c + loc[i]) {
-                lds[TR_WAVES] = rg * PERB + i;
-                lds[TR_WAVES + 1] = k - c;
-            }
-            c += loc[i];
-        }
-    }
-    __syncthreads();
-    bin = lds[TR_WAVES];
-    krem = lds[TR_WAVES + 1];
-    __syncthreads();
-}
+// ---- one workgroup per row (short rows): block scan / digit search in topk_block.h ----------------------------
 
 // ---- K2 with wide workgroups --------------------------------------------------------------------------------------
 // The second 12-bit histogram only counts the keys of the threshold's first-digit bin.  Flat score rows (SnapKV averages
@@ -603,7 +548,7 @@ extern "C" size_t kvp_topk_workspace_bytes(int64_t R, int64_t S, int64_t k) {
 bool topk_fused_hist_wanted(int64_t S) { return S > 16384; }
 
 bool topk_row_eligible(int64_t S) {
-    static const int64_t row_max = std::min<int64_t>(32768, kvp_env_int("KVP_TK_ROW_MAX", 32768));  // 1024 threads x 32 keys
+    const int64_t row_max = std::min<int64_t>(32768, kvp_env_int("KVP_TK_ROW_MAX", 32768));  // 1024 threads x 32 keys
     return S >= 1 && S <= row_max;
 }
 
@@ -661,6 +606,12 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
             kvp_set_error("topk: hipMemsetAsync failed");
             return KVP_EHIP;
         }
+    }
+    // long rows: the whole select in one launch (topk_cluster.hip); rc 1 = the device cannot hold its grid -> the passes below
+    if (topk_cluster_eligible(R, S)) {
+        const int rc = topk_cluster_select(TOPK_CLUSTER_SCORES, scores, row_stride, 1.f, nullptr, 0, 0, 0, 0, 1, 0.f, R, S, k, idx, idx_stride, tail_start,
+                                           tail_n, w, hist1_ready, stream, nseg, seg_len, pos_base);
+        if (rc != 1) return rc;
     }
     const dim3 grid((uint32_t)nchunks, (uint32_t)R);
     if (!hist1_ready)

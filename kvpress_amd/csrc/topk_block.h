@@ -1,0 +1,80 @@
+// Block-wide scan / digit search shared by the one-workgroup-per-row select (topk.hip) and the cluster select
+// (topk_cluster.hip): 1024-thread workgroups, thread 0 owns the HIGHEST bins of a histogram.
+#pragma once
+#include "kvp_common.h"
+
+constexpr int TR_THREADS = 1024;
+constexpr int TR_WAVES = TR_THREADS / 64;
+
+// exclusive prefix sum over the 1024 threads of the block; lds: >= TR_WAVES words.
+// The wave index is wave-uniform (readfirstlane) and the second level -- the scan over the 16 wave totals -- runs in the lanes
+// (every 16-lane group scans the same 16 values; the wave picks its offset with v_readlane): no per-wave comparison masks, which
+// the compiler would otherwise keep alive in 2 x 15 scalar registers across every scan of a kernel.
+__device__ __forceinline__ uint32_t row_excl_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    uint32_t x = lds[lane & (TR_WAVES - 1)];
+#pragma unroll
+    for (int o = 1; o < TR_WAVES; o <<= 1) {
+        const uint32_t t = __shfl_up(x, o);
+        if ((lane & (TR_WAVES - 1)) >= o) x += t;
+    }
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)x, TR_WAVES - 1);
+    const uint32_t below = (uint32_t)__builtin_amdgcn_readlane((int)x, w > 0 ? w - 1 : 0);
+    const uint32_t woff = w > 0 ? below : 0u;
+    __syncthreads();
+    *total = tot;
+    return woff + inc - v;
+}
+
+// Digit search on bin counts held in registers: thread t (< nowners) holds the PERB consecutive bins
+// (nowners - 1 - t) * PERB + i in loc[i] (thread 0 the highest ones), every other thread zeros.  Finds the bin that holds
+// the k-th largest element (k >= 1): count(d > bin) < k <= count(d >= bin); krem = k - count(d > bin).
+// lds: >= TR_WAVES + 2 words.
+template <int PERB>
+__device__ __forceinline__ void row_find_bin_regs(const uint32_t (&loc)[PERB], uint32_t nowners, uint32_t k, uint32_t* lds, uint32_t& bin,
+                                                  uint32_t& krem) {
+    const bool owner = threadIdx.x < nowners;
+    const uint32_t rg = nowners - 1 - threadIdx.x;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < PERB; ++i) sum += loc[i];
+    uint32_t total;
+    const uint32_t excl = row_excl_scan(sum, lds, &total);
+    if (owner && excl < k && k <= excl + sum) {
+        uint32_t c = excl;
+#pragma unroll
+        for (int i = PERB - 1; i >= 0; --i) {
+            if (k > c && k <= c + loc[i]) {
+                lds[TR_WAVES] = rg * PERB + i;
+                lds[TR_WAVES + 1] = k - c;
+            }
+            c += loc[i];
+        }
+    }
+    __syncthreads();
+    bin = lds[TR_WAVES];
+    krem = lds[TR_WAVES + 1];
+    __syncthreads();
+}
+
+// the same on a histogram in (LDS or global) memory
+template <int NB>
+__device__ __forceinline__ void row_find_bin(const uint32_t* hist, uint32_t k, uint32_t* lds, uint32_t& bin, uint32_t& krem) {
+    constexpr int PERB = NB >= TR_THREADS ? NB / TR_THREADS : 1;
+    constexpr uint32_t NOWN = NB >= TR_THREADS ? TR_THREADS : NB;
+    const bool owner = threadIdx.x < NOWN;
+    const uint32_t rg = NOWN - 1 - threadIdx.x;
+    uint32_t loc[PERB];
+#pragma unroll
+    for (int i = 0; i < PERB; ++i) loc[i] = owner ? hist[rg * PERB + i] : 0u;
+    row_find_bin_regs<PERB>(loc, NOWN, k, lds, bin, krem);
+}

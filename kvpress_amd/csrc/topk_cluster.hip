@@ -1,0 +1,398 @@
+// Cluster select: the whole radix select of long score rows (16384 < S <= 262144) in ONE launch.
+// Replaces `scores.topk(n_kept, dim=-1).indices` (kvpress/presses/scorer_press.py:95); same digits (12 + 12 + 8 bits of the
+// order-preserving key), same tie rule (lowest position first) and therefore the same indices as the (chunk, row) passes of
+// topk.hip, which stay as the fallback (other devices, rows beyond 262144 scores, more than 16 rows, KVP_TK_CLUSTER=0).
+//
+// Structure.  The (chunk, row) passes are chains of dependent launches over an L2-resident row: load the keys, count a digit,
+// flush, kernel boundary, load the keys again ...  (4 launches of 5-7 us for ~2 us of work each).  Here a row belongs to a
+// CLUSTER of TC_SLOTS = 32 workgroups of 1024 threads; a workgroup keeps its 1024 * PER keys in registers from the first
+// load to the compaction, and the three digit steps are separated by cluster barriers (one monotonic arrival counter per
+// cluster, 32 arrivals) instead of kernel boundaries.  256 workgroups = 8 clusters, one per XCD when the dispatcher places
+// block b on XCD b % 8 (observed; MI355X_MICROARCH.md "Workgroup dispatch"): a speed assumption only.  Correctness is
+// placement-independent: every word another workgroup reads -- the row histograms, the per-slot suffix tables, the
+// counter -- is written AND read with agent-scope (sc1) atomics / loads / stores, every wave drains its vector-memory
+// counter before the arrival, no fences, nothing relies on two workgroups sharing an L2 (cdna_hip_programming.md
+// Guideline 16, the "agent atomics on both sides" form).  One launch selects 8 rows (up to 16 rows take this path).
+// The barrier spins are bounded (give-up code in the workspace) so that a grid that is not fully resident cannot hang the GPU;
+// the host launches this kernel only on a device with at least 256 CUs (one workgroup each).
+//
+// Key sources (MODE):  SCORES  the row is read from memory (kvp_topk_select, every scorer);
+//                      POOL5   SnapKV's un-pooled column sums: avg_pool1d(kernel 5) + scale in the loader, term for term the
+//                              arithmetic of snapkv_pool_kernel (snapkv_press.py:96) -- no pooling launch, no score round trip;
+//                      KNORM   the keys are -||k||_2 of the workgroup's own 1024 * PER rows of K, computed with the lanes /
+//                              shuffles / rounding of rownorm_vec_kernel (knorm_press.py:38) -- the fused Knorm compress
+//                              never writes its scores.
+// HIST1: the kernel that wrote the scores already accumulated the first digit's histogram (topk_internal.h): the first
+// step and its barrier are skipped.
+#include "kvp_common.h"
+#include "topk_block.h"
+#include "topk_internal.h"
+
+namespace {
+
+#define TC_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ uint32_t tc_ld(const uint32_t* p) { return __hip_atomic_load(p, TC_RLX); }
+__device__ __forceinline__ void tc_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, TC_RLX); }
+__device__ __forceinline__ void tc_add(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, TC_RLX); }
+
+constexpr uint32_t TC_TIMEOUT_TICKS = 20000000u;  // 0.2 s of the 100 MHz real-time counter
+
+// Arrive at / wait for the cluster's next barrier.  Every wave first drains its own agent-scope stores and atomics
+// (they are what the other workgroups read after the barrier).
+__device__ __forceinline__ void cluster_barrier(uint32_t* ctr, uint32_t* give_up, uint32_t code) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t old = __hip_atomic_fetch_add(ctr, 1u, TC_RLX);
+        const uint32_t target = (old & ~(uint32_t)(TC_SLOTS - 1)) + TC_SLOTS;
+        if ((int32_t)(tc_ld(ctr) - target) < 0) {
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            while ((int32_t)(tc_ld(ctr) - target) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > TC_TIMEOUT_TICKS) {  // not all workgroups resident: give up (results invalid)
+                    tc_st(give_up, code);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+struct ClusterArgs {
+    const float* scores;   // SCORES: [R][row_stride]; POOL5: colsum [R][row_stride] (un-pooled column sums)
+    int64_t row_stride;
+    uint32_t R, row_base, S, k, kmask;
+    float inv;             // POOL5: 1 / (G * W * kernel_size)
+    int32_t* idx;
+    int64_t idx_stride;
+    uint32_t tail_start, tail_n, nseg, seg_len, pos_base;
+    TopkWs w;
+    // KNORM
+    const void* x;         // [B,H,S,D], 256-byte rows
+    int64_t x_sb, x_sh, x_ss;  // element strides
+    uint32_t H;
+    float scale;
+};
+
+enum { TC_SCORES = 0, TC_POOL5 = 1, TC_KNORM_BF16 = 2, TC_KNORM_F16 = 3 };
+
+template <int DT>
+__device__ __forceinline__ float tc_sumsq16(const uint4& v) {   // = rownorm.hip's sumsq16 (same fma chain)
+    float f[Elem<DT>::PER16];
+    unpack16<DT>(v, f);
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < Elem<DT>::PER16; ++i) a = fmaf(f[i], f[i], a);
+    return a;
+}
+
+// out-of-range positions carry key 0; real keys are >= 1 (as in topk_row_kernel)
+__device__ __forceinline__ uint32_t tc_key(float f, uint32_t kmask) { return max(float_to_key(f) ^ kmask, 1u); }
+
+template <int PER, int MODE, bool HIST1>
+__global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a) {
+    constexpr uint32_t L = TR_THREADS * PER;   // keys per workgroup
+    __shared__ __attribute__((aligned(16))) uint32_t lh[L > 4096 ? L : 4096];   // histogram; KNORM: first the staged scores; last the staged output
+    __shared__ uint32_t scr[TR_WAVES + 2];
+    const uint32_t cluster = blockIdx.x % TC_CLUSTERS, slot = blockIdx.x / TC_CLUSTERS;
+    uint32_t* bar = a.w.bar + cluster * 32;
+    uint32_t* give_up = a.w.bar + TC_CLUSTERS * 32;
+    const uint32_t S = a.S, k = a.k, kmask = a.kmask;
+    const uint32_t p0 = slot * L + threadIdx.x * PER;   // this thread's PER consecutive positions
+
+    // (one row per cluster and launch: a row loop in here makes the compiler hoist every thread-index comparison of the body
+    // into lane masks that overflow the scalar register file; the host launches once per 8 rows instead)
+    const uint32_t row = a.row_base + cluster;
+    if (row >= a.R) return;
+    {
+        // ---- keys ------------------------------------------------------------------------------------------------
+        uint32_t keys[PER];
+        if (MODE == TC_SCORES) {
+            const float* rp = a.scores + (int64_t)row * a.row_stride;
+            if (PER % 4 == 0 && p0 + PER <= S && ((((uintptr_t)(rp + p0)) & 15u) == 0)) {
+#pragma unroll
+                for (int q = 0; q < PER / 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(rp + p0 + 4 * q);
+                    keys[4 * q + 0] = tc_key(v.x, kmask); keys[4 * q + 1] = tc_key(v.y, kmask);
+                    keys[4 * q + 2] = tc_key(v.z, kmask); keys[4 * q + 3] = tc_key(v.w, kmask);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    const uint32_t inside = (uint32_t)((int32_t)(p0 + j - S) >> 31);  // all ones iff p0 + j < S
+                    keys[j] = tc_key(rp[min(p0 + j, S - 1)], kmask) & inside;
+                }
+            }
+        } else if (MODE == TC_POOL5) {
+            const float* rp = a.scores + (int64_t)row * a.row_stride;
+            constexpr int NIN = PER + 4;
+            float in[NIN];
+            if (PER % 2 == 0 && p0 >= 2 && p0 + PER + 2 <= S && ((((uintptr_t)(rp + p0 - 2)) & 7u) == 0)) {
+#pragma unroll
+                for (int i = 0; i < NIN / 2; ++i) {
+                    const float2 v = *reinterpret_cast<const float2*>(rp + p0 - 2 + 2 * i);
+                    in[2 * i] = v.x; in[2 * i + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NIN; ++i) {
+                    const int32_t pos = (int32_t)p0 + i - 2;
+                    const uint32_t inside = (uint32_t)(((pos - (int32_t)S) >> 31) & ~(pos >> 31));   // all ones iff 0 <= pos < S
+                    in[i] = __uint_as_float(__float_as_uint(rp[min(max(pos, 0), (int32_t)S - 1)]) & inside);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                float sum = 0.f;
+#pragma unroll
+                for (int d = 0; d < 5; ++d) sum += in[j + d];
+                sum *= a.inv;
+                const uint32_t inside = (uint32_t)((int32_t)(p0 + j - S) >> 31);
+                keys[j] = tc_key(sum, kmask) & inside;
+            }
+        } else {
+            // -||k||: 16 lanes per 256-byte row, 64 rows per step of the workgroup, four steps in flight (rownorm_vec_kernel's
+            // loads, fma chain, xor-shuffle order and rounding); the scores go through LDS to their owning threads
+            constexpr int DT = MODE == TC_KNORM_BF16 ? KVP_BF16 : KVP_F16;
+            using T = typename Elem<DT>::T;
+            const uint32_t b = row / a.H, h = row - b * a.H;
+            const T* __restrict__ base = static_cast<const T*>(a.x) + (int64_t)b * a.x_sb + (int64_t)h * a.x_sh;
+            float* st = reinterpret_cast<float*>(lh);
+            const uint32_t lir = threadIdx.x & 15u, g = threadIdx.x >> 4;
+            const uint32_t r0 = slot * L;
+#pragma unroll 1
+            for (uint32_t it = 0; it < L; it += 256) {
+                uint4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t s = r0 + it + u * 64 + g;
+                    v[u] = make_uint4(0, 0, 0, 0);
+                    if (s < S) v[u] = *reinterpret_cast<const uint4*>(base + (int64_t)s * a.x_ss + (size_t)lir * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float acc = tc_sumsq16<DT>(v[u]);
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+                    if (lir == 0) st[it + u * 64 + g] = a.scale * sqrtf(acc);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const uint32_t inside = (uint32_t)((int32_t)(p0 + j - S) >> 31);
+                keys[j] = tc_key(st[threadIdx.x * PER + j], kmask) & inside;
+            }
+            __syncthreads();  // lh becomes the histogram
+        }
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            kmin = min(kmin, keys[j]);
+            kmax = max(kmax, keys[j]);
+        }
+        const bool full = kmin != 0u;   // all PER positions inside the row
+
+        uint32_t* h1 = a.w.hist1 + (size_t)row * 4096;
+        uint32_t* h2 = a.w.hist2 + (size_t)row * 4096;
+        uint32_t* h3 = a.w.hist3 + (size_t)row * 256;
+        // ---- digit 1: key >> 20 ----------------------------------------------------------------------------------
+        if (!HIST1) {
+            for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PER; ++j) topk_hist_add_bin(lh, keys[j] >> 20, keys[j] != 0u);
+            __syncthreads();
+            for (int i = threadIdx.x; i < 4096; i += TR_THREADS) {
+                const uint32_t c = lh[i];
+                if (c) tc_add(&h1[i], c);
+            }
+            cluster_barrier(bar, give_up, 1);
+        }
+        uint32_t b1, k1;
+        {
+            uint32_t loc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) loc[i] = tc_ld(&h1[(TR_THREADS - 1 - threadIdx.x) * 4 + i]);
+            row_find_bin_regs<4>(loc, TR_THREADS, k, scr, b1, k1);
+        }
+        // ---- digit 2: (key >> 8) & 0xFFF among key >> 20 == b1 -----------------------------------------------------
+        if (slot == 0 && threadIdx.x < 256) tc_st(&h3[threadIdx.x], 0u);   // self-cleaning: filled below, read after the last barrier
+        for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
+        __syncthreads();
+        if (full && (kmin >> 8) == (kmax >> 8)) {   // all of this thread's keys in one bin (rows of equal scores): one weighted add
+            if ((kmin >> 20) == b1) atomicAdd(&lh[(kmin >> 8) & 0xFFFu], (uint32_t)PER);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if ((keys[j] >> 20) == b1 && keys[j]) atomicAdd(&lh[(keys[j] >> 8) & 0xFFFu], 1u);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4096; i += TR_THREADS) {
+            const uint32_t c = lh[i];
+            if (c) tc_add(&h2[i], c);
+        }
+        cluster_barrier(bar, give_up, 2);
+        uint32_t b2, k2;
+        {
+            uint32_t loc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) loc[i] = tc_ld(&h2[(TR_THREADS - 1 - threadIdx.x) * 4 + i]);
+            row_find_bin_regs<4>(loc, TR_THREADS, k1, scr, b2, k2);
+        }
+        const uint32_t prefix = (b1 << 12) | b2;
+        // ---- digit 3: key & 0xFF among key >> 8 == prefix; per-slot suffix table + count of larger prefixes ------------
+        if (threadIdx.x < 256) lh[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t ngt = 0;
+        if (full && kmin == kmax) {
+            if ((kmin >> 8) == prefix) atomicAdd(&lh[kmin & 0xFFu], (uint32_t)PER);
+            ngt = (kmin >> 8) > prefix ? (uint32_t)PER : 0u;
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const uint32_t p = keys[j] >> 8;
+                ngt += (keys[j] && p > prefix) ? 1u : 0u;
+                if (keys[j] && p == prefix) atomicAdd(&lh[keys[j] & 0xFFu], 1u);
+            }
+        }
+        uint32_t ngt_tot;
+        row_excl_scan(ngt, scr, &ngt_tot);   // (its barriers also cover the LDS atomics)
+        {
+            // thread t < 256 owns bin 255 - t: the exclusive scan over threads counts the keys in HIGHER bins
+            const uint32_t d = 255u - threadIdx.x;
+            const uint32_t c = threadIdx.x < 256 ? lh[d & 255u] : 0u;
+            uint32_t tot2;
+            const uint32_t above = row_excl_scan(c, scr, &tot2);
+            uint32_t* tab = a.w.chunk_hist + ((size_t)row * TC_SLOTS + slot) * 257;
+            if (threadIdx.x < 256) {
+                tc_st(&tab[d], above + c);   // suffix[d] = #(digit >= d)
+                if (c) tc_add(&h3[d], c);
+            }
+            if (threadIdx.x == 0) {
+                tc_st(&tab[256], 0u);
+                tc_st(&a.w.chunk_gt[(size_t)row * TC_SLOTS + slot], ngt_tot);
+            }
+        }
+        cluster_barrier(bar, give_up, 3);
+        uint32_t b3, quota;
+        {
+            uint32_t loc[1];
+            loc[0] = threadIdx.x < 256 ? tc_ld(&h3[255u - threadIdx.x]) : 0u;
+            row_find_bin_regs<1>(loc, 256, k2, scr, b3, quota);
+        }
+        const uint32_t T = (prefix << 8) | b3;
+        // kept elements in the slots before this one
+        uint32_t gt_part = 0, eq_part = 0;
+        if (threadIdx.x < slot) {
+            const uint32_t* sf = a.w.chunk_hist + ((size_t)row * TC_SLOTS + threadIdx.x) * 257;
+            const uint32_t ge = tc_ld(&sf[b3]), gt = tc_ld(&sf[b3 + 1]);
+            gt_part = tc_ld(&a.w.chunk_gt[(size_t)row * TC_SLOTS + threadIdx.x]) + gt;
+            eq_part = ge - gt;
+        }
+        uint32_t gt_before, eq_before;
+        row_excl_scan(gt_part, scr, &gt_before);
+        row_excl_scan(eq_part, scr, &eq_before);
+        // self-cleaning: this row's hist1 / hist2 are dead (every workgroup read them before the last barrier)
+        for (uint32_t i = slot * TR_THREADS + threadIdx.x; i < 4096; i += TC_SLOTS * TR_THREADS) {
+            tc_st(&h1[i], 0u);
+            tc_st(&h2[i], 0u);
+        }
+        // ---- ordered compaction: keys > T, and the first `quota` keys == T ---------------------------------------------
+        uint32_t cg = 0, ce = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            cg += keys[j] > T ? 1u : 0u;
+            ce += keys[j] == T ? 1u : 0u;
+        }
+        uint32_t tot;
+        const uint32_t ex = row_excl_scan(cg | (ce << 16), scr, &tot);   // L <= 8192: both fields < 65536
+        uint32_t g = gt_before + (ex & 0xFFFFu), e = eq_before + (ex >> 16);
+        // ranks of this workgroup: [rank0, rank0 + nmine)
+        const uint32_t rank0 = gt_before + min(eq_before, quota);
+        const uint32_t nmine = (tot & 0xFFFFu) + (min(eq_before + (tot >> 16), quota) - min(eq_before, quota));
+        int32_t* out = a.idx + (int64_t)row * a.idx_stride;
+        const uint32_t off = a.pos_base + (a.nseg > 1 ? (row % a.nseg) * a.seg_len : 0u);
+        if (slot == 0)
+            for (uint32_t j = threadIdx.x; j < a.tail_n; j += TR_THREADS) out[k + j] = (int32_t)(off + a.tail_start + j);
+        int32_t* ob = reinterpret_cast<int32_t*>(lh);   // staged: the ranks of one thread are consecutive, the stores below coalesced
+        const uint32_t Ts = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const bool isg = keys[j] > Ts;
+            const bool ise = keys[j] == Ts;
+            if (isg || (ise && e < quota)) {
+                const uint32_t rank = g + (e < quota ? e : quota);
+                if (rank < k) ob[rank - rank0] = (int32_t)(off + p0 + j);
+            }
+            g += isg ? 1u : 0u;
+            e += ise ? 1u : 0u;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nmine; i += TR_THREADS)
+            if (rank0 + i < k) out[rank0 + i] = ob[i];
+    }
+}
+
+template <int PER, int MODE, bool HIST1>
+int launch_one(const ClusterArgs& a, hipStream_t stream) {
+    if (!topk_cluster_launchable()) return 1;
+    ClusterArgs b = a;
+    for (b.row_base = 0; b.row_base < b.R; b.row_base += TC_CLUSTERS)
+        KVP_LAUNCH("topk_cluster_kernel", stream, (topk_cluster_kernel<PER, MODE, HIST1><<<TC_CLUSTERS * TC_SLOTS, TR_THREADS, 0, stream>>>(b)));
+    return 0;
+}
+
+template <int MODE, bool HIST1>
+int launch_per(const ClusterArgs& a, hipStream_t stream) {
+    const int64_t per = ((int64_t)a.S + (int64_t)TC_SLOTS * TR_THREADS - 1) / ((int64_t)TC_SLOTS * TR_THREADS);
+    if (per <= 1) return launch_one<1, MODE, HIST1>(a, stream);
+    if (per <= 2) return launch_one<2, MODE, HIST1>(a, stream);
+    if (per <= 4) return launch_one<4, MODE, HIST1>(a, stream);
+    return launch_one<8, MODE, HIST1>(a, stream);   // (16 keys per thread spill scalar registers: rows beyond 262144 take the passes)
+}
+
+}  // namespace
+
+// All TC_CLUSTERS * TC_SLOTS workgroups must be resident at once (the barriers spin).  Every instantiation fits an empty CU
+// (1024 threads, <= 128 VGPRs, <= 66 KB of LDS), so the question is whether the current device has that many CUs.
+bool topk_cluster_launchable() {
+    static int ok[64] = {0};   // per device: 0 unknown, 1 yes, -1 no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (ok[dev] == 0) {
+        int cus = 0;
+        ok[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= TC_CLUSTERS * TC_SLOTS) ? 1 : -1;
+    }
+    return ok[dev] > 0;
+}
+
+// (few long rows: the structure buys latency, not throughput -- one launch per 8 rows; many rows fill the chip with the
+// (chunk, row) passes)
+bool topk_cluster_eligible(int64_t R, int64_t S) {
+    return R <= 2 * TC_CLUSTERS && S > 16384 && S <= (int64_t)TC_SLOTS * TR_THREADS * 8 && kvp_env_int("KVP_TK_CLUSTER", 1) != 0;
+}
+
+// returns KVP_OK, an error, or 1 = "not launched" (the device cannot hold the grid: the caller takes the (chunk, row) passes)
+int topk_cluster_select(int mode, const float* scores, int64_t row_stride, float inv, const void* x, int dtype, int64_t x_sb, int64_t x_sh,
+                        int64_t x_ss, int64_t H, float scale, int64_t R, int64_t S, int64_t k, int32_t* idx, int64_t idx_stride,
+                        uint32_t tail_start, uint32_t tail_n, const TopkWs& w, bool hist1_ready, hipStream_t stream, uint32_t nseg,
+                        uint32_t seg_len, uint32_t pos_base) {
+    ClusterArgs a;
+    a.scores = scores; a.row_stride = row_stride;
+    a.R = (uint32_t)R; a.S = (uint32_t)S; a.k = (uint32_t)k; a.kmask = w.kmask;
+    a.inv = inv;
+    a.idx = idx; a.idx_stride = idx_stride;
+    a.tail_start = tail_start; a.tail_n = tail_n; a.nseg = nseg; a.seg_len = seg_len; a.pos_base = pos_base;
+    a.w = w;
+    a.x = x; a.x_sb = x_sb; a.x_sh = x_sh; a.x_ss = x_ss; a.H = (uint32_t)std::max<int64_t>(1, H); a.scale = scale;
+    int rc;
+    switch (mode) {
+        case TOPK_CLUSTER_POOL5: rc = launch_per<TC_POOL5, false>(a, stream); break;
+        case TOPK_CLUSTER_KNORM: rc = dtype == KVP_BF16 ? launch_per<TC_KNORM_BF16, false>(a, stream) : launch_per<TC_KNORM_F16, false>(a, stream); break;
+        default: rc = hist1_ready ? launch_per<TC_SCORES, true>(a, stream) : launch_per<TC_SCORES, false>(a, stream); break;
+    }
+    if (rc == 0) KVP_CHECK_LAUNCH("topk(cluster)");
+    return rc;
+}

@@ -12,11 +12,16 @@ constexpr int TK_PER = KVP_TK_PER;
 // workgroups beat few large ones (8 x 131072, last two passes: 8.2 + 7.6 us with 4 scores per thread, 9.6 + 8.2 with 8,
 // 11.0 + 9.1 with 16)
 constexpr int TK_CHUNK = TK_THREADS * TK_PER;
+// cluster select (topk_cluster.hip): TC_CLUSTERS row clusters of TC_SLOTS workgroups each, one launch per select
+constexpr int TC_CLUSTERS = 8;
+constexpr int TC_SLOTS = 32;
 
 struct TopkWs {
     uint32_t* hist1;       // [R][4096]
     uint32_t* hist2;       // [R][4096]
     uint32_t* hist3;       // [R][256]
+    uint32_t* bar;         // [TC_CLUSTERS][32] cluster select: one monotonic arrival counter per row cluster (own 128-byte line);
+                           // [TC_CLUSTERS * 32] = give-up code of a barrier that timed out (0 = none)
     uint32_t* sel;         // [R][4] : b1, k1, b2, k2
     uint32_t* chunk_hist;  // [R][nchunks][257] suffix counts of the last digit: [d] = #(digit >= d), [256] = 0
     uint32_t* chunk_gt;    // [R][nchunks]
@@ -37,10 +42,13 @@ inline TopkWs topk_carve_ws(void* ws, int64_t R, int64_t nchunks) {
     w.hist1 = (uint32_t*)take((size_t)R * 4096 * 4);
     w.hist2 = (uint32_t*)take((size_t)R * 4096 * 4);
     w.hist3 = (uint32_t*)take((size_t)R * 256 * 4);
+    w.bar = (uint32_t*)take((size_t)(TC_CLUSTERS * 32 + 32) * 4);
     w.zero_bytes = off;
     w.sel = (uint32_t*)take((size_t)R * 4 * 4);
-    w.chunk_hist = (uint32_t*)take((size_t)R * nchunks * 257 * 4);
-    w.chunk_gt = (uint32_t*)take((size_t)R * nchunks * 4);
+    // per-chunk tables: the (chunk, row) passes index them by 1024-score chunk, the cluster select by its TC_SLOTS slots
+    const int64_t ntab = std::max<int64_t>(nchunks, TC_SLOTS);
+    w.chunk_hist = (uint32_t*)take((size_t)R * ntab * 257 * 4);
+    w.chunk_gt = (uint32_t*)take((size_t)R * ntab * 4);
     w.total_bytes = off;
     w.kmask = 0;
     return w;
@@ -85,6 +93,17 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
                      hipStream_t stream, uint32_t nseg = 1, uint32_t seg_len = 0, uint32_t pos_base = 0, bool smallest = false);
 // S this short: one launch, one workgroup per row, no workspace
 bool topk_row_eligible(int64_t S);
+// Cluster select (topk_cluster.hip): the whole select of up to 16 rows of 16385 .. 262144 scores in ONE launch.  mode: where the keys
+// come from -- the score rows, SnapKV's un-pooled column sums (avg_pool1d of width 5 + scale `inv` in the loader), or
+// -||x[b,h,s,:]|| computed from 256-byte rows of a 2-byte dtype (fused Knorm compress).  Returns KVP_OK, an error code, or
+// 1 = not launched (the device cannot hold the 256 workgroups at once): the caller falls back to the (chunk, row) passes.
+enum { TOPK_CLUSTER_SCORES = 0, TOPK_CLUSTER_POOL5 = 1, TOPK_CLUSTER_KNORM = 2 };
+bool topk_cluster_eligible(int64_t R, int64_t S);
+bool topk_cluster_launchable();   // the current device can hold the cluster kernel's 256 workgroups at once
+int topk_cluster_select(int mode, const float* scores, int64_t row_stride, float inv, const void* x, int dtype, int64_t x_sb, int64_t x_sh,
+                        int64_t x_ss, int64_t H, float scale, int64_t R, int64_t S, int64_t k, int32_t* idx, int64_t idx_stride,
+                        uint32_t tail_start, uint32_t tail_n, const TopkWs& w, bool hist1_ready, hipStream_t stream, uint32_t nseg = 1,
+                        uint32_t seg_len = 0, uint32_t pos_base = 0);
 // should a score-writing kernel accumulate the first histogram for a select over S columns?  (S > 16384)
 bool topk_fused_hist_wanted(int64_t S);
 // select from un-pooled SnapKV column sums (kernel_size 5 pooling + scale `inv` inside the loader); rows as above

@@ -37,6 +37,25 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture
+def knobs(monkeypatch):
+    """knobs(KVP_X=1, KVP_Y=None, ...): set / unset KVP_* tuning variables and make the library re-read them (it reads the
+    environment once and caches the values: kvp_tuning_reload); everything is restored and re-read when the test ends."""
+    from kvpress_amd import _native
+
+    def set_(**kv):
+        for k, v in kv.items():
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, str(v))
+        _native.tuning_reload()
+
+    yield set_
+    monkeypatch.undo()
+    _native.tuning_reload()
+
+
 # ---- CPU stand-in for the HIP entry points (tests of the HOST logic only) ---------------------------------------
 # The HIP kernels cannot run in the build container, so host-logic tests swap kvpress_amd._native's entry points for
 # oracle-backed fakes.  Test infrastructure only: the product has no such switch and fails loudly without the library.

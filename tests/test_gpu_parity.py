@@ -112,9 +112,13 @@ def test_topk_order_score_matches_torch_topk(name):
         t = torch.from_numpy(ref).topk(n, dim=-1)
         vals = np.take_along_axis(ref, got.astype(np.int64), axis=-1)
         assert np.array_equal(vals, t.values.numpy())          # same score sequence as torch.topk(sorted=True)
-        distinct = np.diff(vals, axis=-1) != 0
-        same = got[..., 1:] == t.indices.numpy()[..., 1:]
-        assert np.all(same | ~distinct | ~np.roll(distinct, 1, axis=-1) | True)  # (indices may differ only inside tie runs)
+        # a position whose score differs from both neighbours' is in no tie run: there the index must be torch's too
+        ti = t.indices.numpy()
+        pad = np.ones(vals.shape[:-1] + (1,), bool)
+        dl = np.concatenate([pad, np.diff(vals, axis=-1) != 0], axis=-1)      # differs from the left neighbour
+        dr = np.concatenate([np.diff(vals, axis=-1) != 0, pad], axis=-1)      # ... from the right one
+        alone = dl & dr
+        assert alone.any() and np.array_equal(got[alone], ti[alone]), f"{name} r={r}: index order differs outside tie runs"
     # smallest-first variant
     n = s["S"] // 3
     got = N.topk_select(sc, n, N.ORDER_SCORE | N.TOPK_SMALLEST).cpu().numpy()
@@ -147,18 +151,20 @@ def test_topk_heavy_ties_and_edges():
 
 
 @pytest.mark.parametrize("S", [32769, 49153, 65536, 100003, 131072])
-def test_topk_second_pass_variants(S, monkeypatch):
-    """Rows beyond 32768 take the multi-workgroup passes; their second 12-bit histogram runs in 16384-key workgroups by default
-    (KVP_TK_H2_WIDE=16), 32768-key or the original 2048-key ones on request: the oracle's indices every time, on wide, flat
-    (one exponent, heavy ties: half the row in the threshold's first-digit bin) and constant rows, k smallest included."""
+def test_topk_second_pass_variants(S, knobs):
+    """Rows beyond 32768: the cluster select (one launch; default) and, with KVP_TK_CLUSTER=0, the (chunk, row) passes whose second
+    12-bit histogram runs in 1024-thread workgroups of KVP_TK_H2_WIDE scores per thread (default 8; 4 / 16 / 32 compiled too) or in
+    the original 2048-key ones (0): the oracle's indices every time, on wide, flat (one exponent, heavy ties: half the row in
+    the threshold's first-digit bin) and constant rows, k smallest included."""
     rs = np.random.RandomState(S)
     N = native()
     wide = rs.standard_normal((3, S)).astype(np.float32)
     flat = (2.0 ** -17 * (1 + 0.05 * rs.standard_normal((3, S)))).astype(np.float32)   # pooled-attention-like: +-5 % around one value
     ties = _inputs.round_to(-np.sqrt(rs.chisquare(64, size=(3, S))).astype(np.float32), "bf16")
     const = np.full((2, S), 0.25, np.float32)
-    for variant in ("16", "32", "0"):
-        monkeypatch.setenv("KVP_TK_H2_WIDE", variant)
+    variants = [dict(KVP_TK_CLUSTER=None, KVP_TK_H2_WIDE=None)] + [dict(KVP_TK_CLUSTER=0, KVP_TK_H2_WIDE=w) for w in (None, 4, 16, 32, 0)]
+    for variant in variants:
+        knobs(**variant)
         for sc_np in (wide, flat, ties, const):
             t = torch.from_numpy(sc_np).to(DEV)
             for k in sorted({1, S // 3, S // 2, S - 1}):
@@ -166,6 +172,40 @@ def test_topk_second_pass_variants(S, monkeypatch):
                 assert np.array_equal(got, O.topk_select(sc_np, k)), f"variant {variant} S={S} k={k}"
         got = N.topk_select(torch.from_numpy(flat).to(DEV), S // 2, N.ORDER_POSITION | N.TOPK_SMALLEST).cpu().numpy()
         assert np.array_equal(got, O.topk_select(-flat, S // 2)), f"variant {variant} S={S} smallest"
+
+
+@pytest.mark.parametrize("R,S", [(1, 16385), (3, 20000), (8, 32768), (9, 32769), (16, 40000), (17, 40000), (8, 131008), (2, 131073), (5, 262144), (2, 262145)])
+def test_topk_cluster_select_rows_and_lengths(R, S, knobs):
+    """The cluster select (topk_cluster.hip: 32 workgroups per row, keys in registers, cluster barriers between the digit steps)
+    over its whole range of row lengths (every keys-per-thread instantiation, partially filled last slots, unaligned rows), with
+    fewer and more rows than clusters (one launch per 8 rows), twice through the same self-cleaning workspace, k smallest, score
+    order; 17 rows or 262145 scores are past its range and take the (chunk, row) passes.  Against the oracle AND bit-identical
+    to KVP_TK_CLUSTER=0."""
+    rs = np.random.RandomState(R * 1000003 + S)
+    N = native()
+    flat = (2.0 ** -17 * (1 + 0.05 * rs.standard_normal((R, S)))).astype(np.float32)
+    ties = _inputs.round_to(rs.standard_normal((R, S)).astype(np.float32), "bf16")
+    for sc_np in (flat, ties):
+        t = torch.from_numpy(sc_np).to(DEV)
+        for k in sorted({1, S // 2, S - 1}) * 2:
+            knobs(KVP_TK_CLUSTER=None)
+            got = N.topk_select(t, k)
+            knobs(KVP_TK_CLUSTER=0)
+            legacy = N.topk_select(t, k)
+            assert torch.equal(got, legacy), f"R={R} S={S} k={k}: cluster != passes"
+            if R * S <= 8 * 131072:
+                assert np.array_equal(got.cpu().numpy(), O.topk_select(sc_np, k)), f"R={R} S={S} k={k}"
+    knobs(KVP_TK_CLUSTER=None)
+    t = torch.from_numpy(flat).to(DEV)
+    if R * S <= 8 * 131072:
+        got = N.topk_select(t, S // 3, N.ORDER_POSITION | N.TOPK_SMALLEST).cpu().numpy()
+        assert np.array_equal(got, O.topk_select(-flat, S // 3))
+        got = N.topk_select(t, S // 3, N.ORDER_SCORE).cpu().numpy()
+        assert np.array_equal(got, O.topk_select_by_score(flat, S // 3))
+    view = t[:, 3:S - 2]                                   # unaligned, strided rows
+    got = N.topk_select(view, (S - 5) // 2)
+    knobs(KVP_TK_CLUSTER=0)
+    assert torch.equal(got, N.topk_select(view, (S - 5) // 2))
 
 
 @pytest.mark.parametrize("S", [1, 2, 63, 1023, 1024, 1025, 2048, 2049, 4096, 4097, 8191, 8193, 16383, 16384, 16385, 20000, 32767, 32768, 32769, 40000])
@@ -712,13 +752,16 @@ def test_fused_knorm_compress_equals_modular(name):
     assert torch.equal(ko, wk) and torch.equal(vo, wv)
 
 
-@pytest.mark.parametrize("row_fused", ["0", "1"])
-@pytest.mark.parametrize("S", [16384, 16385, 20000, 32768, 32769])
-def test_fused_knorm_select_variants_equal_modular(S, row_fused, monkeypatch):
-    """Knorm's fused compress across the select's row-length regimes (own digits <= 16384, multi-workgroup passes from the fused
-    first-digit histogram beyond; KVP_TK_ROW_FUSED=1: one launch from that histogram up to 32768), heavy ties included (bf16
-    norms): the modular sequence's bytes, twice through the same self-cleaning workspace."""
-    monkeypatch.setenv("KVP_TK_ROW_FUSED", row_fused)
+@pytest.mark.parametrize("variant", ["cluster_knorm", "cluster", "passes", "row_fused"])
+@pytest.mark.parametrize("S", [16384, 16385, 20000, 32768, 32769, 70001])
+def test_fused_knorm_select_variants_equal_modular(S, variant, knobs):
+    """Knorm's fused compress across the select's row-length regimes and variants: own digits <= 16384; beyond, norms + select in
+    ONE cluster launch (default), the cluster select after the norm kernel with its fused first-digit histogram
+    (KVP_TK_CLUSTER_KNORM=0), the (chunk, row) passes (KVP_TK_CLUSTER=0), one launch from that histogram up to 32768
+    (KVP_TK_ROW_FUSED=1); heavy ties included (bf16 norms): the modular sequence's bytes, twice through the same self-cleaning
+    workspace."""
+    knobs(**{"cluster_knorm": {}, "cluster": dict(KVP_TK_CLUSTER_KNORM=0), "passes": dict(KVP_TK_CLUSTER=0),
+             "row_fused": dict(KVP_TK_CLUSTER=0, KVP_TK_ROW_FUSED=1)}[variant])
     N = native()
     g = torch.Generator(device=DEV); g.manual_seed(S)
     k = torch.randn((1, 8, S, 128), generator=g, device=DEV).to(torch.bfloat16)
@@ -729,6 +772,12 @@ def test_fused_knorm_select_variants_equal_modular(S, row_fused, monkeypatch):
         ko, vo = N.knorm_compress(k, v, n)
         wk, wv = N.gather_kv(k, v, N.topk_select(sc, n))
         assert torch.equal(ko, wk) and torch.equal(vo, wv), f"S={S} n={n}"
+    if S > 16384:   # two batch elements, float16, a strided view of the cache: rows 0..7 and 8..15 share clusters
+        k2 = torch.randn((2, 8, S + 5, 128), generator=g, device=DEV).to(torch.float16)[:, :, 5:]
+        v2 = torch.randn((2, 8, S + 5, 128), generator=g, device=DEV).to(torch.float16)[:, :, 5:]
+        ko, vo = N.knorm_compress(k2, v2, S // 2)
+        wk, wv = N.gather_kv(k2, v2, N.topk_select(N.rownorm_score(k2, -1.0), S // 2))
+        assert torch.equal(ko, wk) and torch.equal(vo, wv), f"S={S} (B=2, f16, view)"
 
 
 @pytest.mark.parametrize("name", SK + [n for n, c in _inputs.CASES.items() if c["kind"] == "tova"])
@@ -752,11 +801,16 @@ def test_fused_snapkv_compress_equals_modular(name):
         assert torch.equal(ko, wk) and torch.equal(vo, wv), f"{name} n={n}"
 
 
-@pytest.mark.parametrize("S", [70, 1087, 1089, 1500, 2112, 2113, 3000, 4160, 4161, 9000, 16448, 16449, 20001, 32832, 32833, 40000])
-def test_fused_snapkv_select_variants_equal_modular(S):
+@pytest.mark.parametrize("variant", ["default", "cluster_hist1", "passes"])
+@pytest.mark.parametrize("S", [70, 1087, 1089, 1500, 2112, 2113, 3000, 4160, 4161, 9000, 16448, 16449, 20001, 32832, 32833, 40000, 70003])
+def test_fused_snapkv_select_variants_equal_modular(S, variant, knobs):
     """The fused compress picks its select by row length (pool + select in one launch up to 4096 columns, one-launch select
-    up to 16384, multi-workgroup passes starting from the fused first-digit histogram beyond): always the modular sequence's
-    bytes."""
+    up to 16384; beyond: pooling inside the cluster select's loader (default), the pooling kernel with its fused first-digit
+    histogram + the cluster select (KVP_TK_CLUSTER_POOL=0) or + the (chunk, row) passes (KVP_TK_CLUSTER=0)): always the modular
+    sequence's bytes."""
+    if variant != "default" and S - 64 <= 16384:
+        pytest.skip("the variants differ only for rows beyond 16384 columns")
+    knobs(**{"default": {}, "cluster_hist1": dict(KVP_TK_CLUSTER_POOL=0), "passes": dict(KVP_TK_CLUSTER=0)}[variant])
     N = native()
     g = torch.Generator(device=DEV); g.manual_seed(S)
     k = torch.randn((2, 2, S, 128), generator=g, device=DEV).to(torch.bfloat16)
@@ -765,7 +819,7 @@ def test_fused_snapkv_select_variants_equal_modular(S):
     ang = torch.rand((1, 64, 128), generator=g, device=DEV)
     c, si = torch.cos(ang).to(torch.bfloat16), torch.sin(ang).to(torch.bfloat16)
     sc = N.snapkv_score_rope(q, c, si, k, 5)
-    for n in sorted({64, 65, S // 2, (3 * S) // 4, S - 1}):
+    for n in sorted({64, 65, S // 2, (3 * S) // 4, S - 1}) * 2:
         ko, vo = N.snapkv_compress_rope(q, c, si, k, v, 5, n)
         wk, wv = N.gather_kv(k, v, N.topk_select(sc, n))
         assert torch.equal(ko, wk) and torch.equal(vo, wv), f"S={S} n={n}"
@@ -1029,7 +1083,7 @@ def test_snapkv_mfma_group_blocks_are_deterministic(G):
 
 
 @pytest.mark.parametrize("S,W", [(8256, 64), (8260, 64), (12288 + 64, 64), (20000, 64), (40000, 64), (65600, 64), (8228, 30), (9000, 2)])
-def test_snapkv_pool_variants_identical(S, W, monkeypatch):
+def test_snapkv_pool_variants_identical(S, W, knobs):
     """Long rows with kernel_size 5 are pooled four scores per thread (8-byte loads, one 16-byte store; aligned rows only): the
     same additions in the same order as the one-score-per-thread kernel, so scores (pad value included), fused histogram and
     the compressed cache are bit-identical with KVP_SK_POOL_VEC=0, and the scores match the oracle.  (Windows other than 64
@@ -1043,7 +1097,7 @@ def test_snapkv_pool_variants_identical(S, W, monkeypatch):
     N = native()
     out = {}
     for variant in ("1", "0"):
-        monkeypatch.setenv("KVP_SK_POOL_VEC", variant)
+        knobs(KVP_SK_POOL_VEC=variant, KVP_TK_CLUSTER_POOL=0)   # (the fused compress through the pooling kernel, not the cluster select's loader)
         sc = N.snapkv_score(q, keys, 5)
         ko, vo = N.snapkv_compress_rope(q, cos, sin, keys, vals, 5, S // 2)
         out[variant] = (sc, ko, vo)

@@ -458,7 +458,8 @@ def test_topk_segmented_vs_oracle():
     from kvpress_amd import _native
 
     rs = np.random.RandomState(9)
-    for R, nseg, L, k, base in ((4, 7, 100, 33, 0), (2, 3, 2048, 1024, 5), (8, 128, 1024, 512, 0), (3, 1, 77, 77, 1000), (1, 5, 64, 1, 0)):
+    for R, nseg, L, k, base in ((4, 7, 100, 33, 0), (2, 3, 2048, 1024, 5), (8, 128, 1024, 512, 0), (3, 1, 77, 77, 1000), (1, 5, 64, 1, 0),
+                                (2, 5, 20000, 7000, 3), (3, 2, 40001, 20000, 0)):   # (long segments: the cluster select with segment offsets)
         sc = rs.standard_normal((R, nseg * L)).astype(np.float32)
         sc[:, ::7] = 0.25  # ties inside every chunk
         got = _native.topk_select_segmented(torch.from_numpy(sc).to(DEV), L, k, pos_base=base).cpu().numpy()
