@@ -12,7 +12,7 @@
 // placement-independent: every word another workgroup reads -- the row histograms, the per-slot suffix tables, the
 // counter -- is written AND read with agent-scope (sc1) atomics / loads / stores, every wave drains its vector-memory
 // counter before the arrival, no fences, nothing relies on two workgroups sharing an L2 (cdna_hip_programming.md
-// Guideline 16, the "agent atomics on both sides" form).  One launch selects 8 rows (up to 16 rows take this path).
+// Guideline 16, the "agent atomics on both sides" form).  One launch selects up to 8 rows; more rows take the (chunk, row) passes.
 // The barrier spins are bounded (give-up code in the workspace) so that a grid that is not fully resident cannot hang the GPU;
 // the host launches this kernel only on a device with at least 256 CUs (one workgroup each).
 //
@@ -30,10 +30,20 @@
 
 namespace {
 
+#ifndef KVP_TC_L2LOCAL
 #define TC_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 __device__ __forceinline__ uint32_t tc_ld(const uint32_t* p) { return __hip_atomic_load(p, TC_RLX); }
 __device__ __forceinline__ void tc_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, TC_RLX); }
 __device__ __forceinline__ void tc_add(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, TC_RLX); }
+#else
+// LAB ONLY (tools/build_variants.sh tc_l2): the same protocol on XCD-local traffic -- atomics executed in the XCD's L2 (no sc1),
+// loads that bypass the L1 but are served by the L2 (nt), plain write-through stores.  Correct only while the 32 workgroups of
+// a cluster really share an XCD (block b on XCD b % 8): a measurement of what placement-DEPENDENT traffic would buy.
+#define TC_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP
+__device__ __forceinline__ uint32_t tc_ld(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void tc_st(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
+__device__ __forceinline__ void tc_add(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, TC_RLX); }
+#endif
 
 constexpr uint32_t TC_TIMEOUT_TICKS = 20000000u;  // 0.2 s of the 100 MHz real-time counter
 
@@ -105,6 +115,12 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
     // into lane masks that overflow the scalar register file; the host launches once per 8 rows instead)
     const uint32_t row = a.row_base + cluster;
     if (row >= a.R) return;
+#ifdef KVP_TC_TIMING   // lab build (tools/select_lab.py --stamps): 10 ns time stamps of cluster 0's workgroups at the phase boundaries
+#define TC_STAMP(i) do { if (threadIdx.x == 0 && cluster == 0) a.w.bar[TC_CLUSTERS * 32 + 32 + slot * 16 + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TC_STAMP(i) do { } while (0)
+#endif
+    TC_STAMP(0);
     {
         // ---- keys ------------------------------------------------------------------------------------------------
         uint32_t keys[PER];
@@ -192,6 +208,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             kmin = min(kmin, keys[j]);
             kmax = max(kmax, keys[j]);
         }
+        TC_STAMP(1);   // keys loaded
         const bool full = kmin != 0u;   // all PER positions inside the row
 
         uint32_t* h1 = a.w.hist1 + (size_t)row * 4096;
@@ -208,7 +225,9 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
                 const uint32_t c = lh[i];
                 if (c) tc_add(&h1[i], c);
             }
+            TC_STAMP(2);   // first histogram flushed
             cluster_barrier(bar, give_up, 1);
+            TC_STAMP(3);
         }
         uint32_t b1, k1;
         {
@@ -217,6 +236,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             for (int i = 0; i < 4; ++i) loc[i] = tc_ld(&h1[(TR_THREADS - 1 - threadIdx.x) * 4 + i]);
             row_find_bin_regs<4>(loc, TR_THREADS, k, scr, b1, k1);
         }
+        TC_STAMP(4);   // first digit found
         // ---- digit 2: (key >> 8) & 0xFFF among key >> 20 == b1 -----------------------------------------------------
         if (slot == 0 && threadIdx.x < 256) tc_st(&h3[threadIdx.x], 0u);   // self-cleaning: filled below, read after the last barrier
         for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
@@ -233,7 +253,9 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             const uint32_t c = lh[i];
             if (c) tc_add(&h2[i], c);
         }
+        TC_STAMP(5);   // second histogram flushed
         cluster_barrier(bar, give_up, 2);
+        TC_STAMP(6);
         uint32_t b2, k2;
         {
             uint32_t loc[4];
@@ -242,6 +264,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             row_find_bin_regs<4>(loc, TR_THREADS, k1, scr, b2, k2);
         }
         const uint32_t prefix = (b1 << 12) | b2;
+        TC_STAMP(7);   // second digit found
         // ---- digit 3: key & 0xFF among key >> 8 == prefix; per-slot suffix table + count of larger prefixes ------------
         if (threadIdx.x < 256) lh[threadIdx.x] = 0;
         __syncthreads();
@@ -275,7 +298,9 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
                 tc_st(&a.w.chunk_gt[(size_t)row * TC_SLOTS + slot], ngt_tot);
             }
         }
+        TC_STAMP(8);   // third histogram + suffix table
         cluster_barrier(bar, give_up, 3);
+        TC_STAMP(9);
         uint32_t b3, quota;
         {
             uint32_t loc[1];
@@ -283,6 +308,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             row_find_bin_regs<1>(loc, 256, k2, scr, b3, quota);
         }
         const uint32_t T = (prefix << 8) | b3;
+        TC_STAMP(10);  // threshold known
         // kept elements in the slots before this one
         uint32_t gt_part = 0, eq_part = 0;
         if (threadIdx.x < slot) {
@@ -299,6 +325,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             tc_st(&h1[i], 0u);
             tc_st(&h2[i], 0u);
         }
+        TC_STAMP(11);  // offsets of the earlier slots, histograms zeroed
         // ---- ordered compaction: keys > T, and the first `quota` keys == T ---------------------------------------------
         uint32_t cg = 0, ce = 0;
 #pragma unroll
@@ -332,6 +359,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < nmine; i += TR_THREADS)
             if (rank0 + i < k) out[rank0 + i] = ob[i];
+        TC_STAMP(12);
     }
 }
 
@@ -368,10 +396,11 @@ bool topk_cluster_launchable() {
     return ok[dev] > 0;
 }
 
-// (few long rows: the structure buys latency, not throughput -- one launch per 8 rows; many rows fill the chip with the
-// (chunk, row) passes)
+// (few long rows: the structure buys latency, not throughput.  Measured on MI355X, profiles/r03_select_cluster_lab.txt: 8 x 131008
+// flat scores 22.5 us = the four (chunk, row) launches; 1 row 18 against 24 us; 16 rows (two launches) 44 against 29 us -- so up to
+// 8 rows.  What it saves is SnapKV's pooling launch (POOL5 loader: -3 us per compress) and Knorm's score round trip.)
 bool topk_cluster_eligible(int64_t R, int64_t S) {
-    return R <= 2 * TC_CLUSTERS && S > 16384 && S <= (int64_t)TC_SLOTS * TR_THREADS * 8 && kvp_env_int("KVP_TK_CLUSTER", 1) != 0;
+    return R <= TC_CLUSTERS && S > 16384 && S <= (int64_t)TC_SLOTS * TR_THREADS * 8 && kvp_env_int("KVP_TK_CLUSTER", 1) != 0;
 }
 
 // returns KVP_OK, an error, or 1 = "not launched" (the device cannot hold the grid: the caller takes the (chunk, row) passes)

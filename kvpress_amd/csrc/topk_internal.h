@@ -42,7 +42,7 @@ inline TopkWs topk_carve_ws(void* ws, int64_t R, int64_t nchunks) {
     w.hist1 = (uint32_t*)take((size_t)R * 4096 * 4);
     w.hist2 = (uint32_t*)take((size_t)R * 4096 * 4);
     w.hist3 = (uint32_t*)take((size_t)R * 256 * 4);
-    w.bar = (uint32_t*)take((size_t)(TC_CLUSTERS * 32 + 32) * 4);
+    w.bar = (uint32_t*)take((size_t)(TC_CLUSTERS * 32 + 32 + TC_SLOTS * 16) * 4);   // (+ phase time stamps of the KVP_TC_TIMING lab build)
     w.zero_bytes = off;
     w.sel = (uint32_t*)take((size_t)R * 4 * 4);
     // per-chunk tables: the (chunk, row) passes index them by 1024-score chunk, the cluster select by its TC_SLOTS slots
@@ -93,7 +93,7 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
                      hipStream_t stream, uint32_t nseg = 1, uint32_t seg_len = 0, uint32_t pos_base = 0, bool smallest = false);
 // S this short: one launch, one workgroup per row, no workspace
 bool topk_row_eligible(int64_t S);
-// Cluster select (topk_cluster.hip): the whole select of up to 16 rows of 16385 .. 262144 scores in ONE launch.  mode: where the keys
+// Cluster select (topk_cluster.hip): the whole select of up to 8 rows of 16385 .. 262144 scores in ONE launch.  mode: where the keys
 // come from -- the score rows, SnapKV's un-pooled column sums (avg_pool1d of width 5 + scale `inv` in the loader), or
 // -||x[b,h,s,:]|| computed from 256-byte rows of a 2-byte dtype (fused Knorm compress).  Returns KVP_OK, an error code, or
 // 1 = not launched (the device cannot hold the 256 workgroups at once): the caller falls back to the (chunk, row) passes.

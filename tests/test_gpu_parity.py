@@ -118,7 +118,8 @@ def test_topk_order_score_matches_torch_topk(name):
         dl = np.concatenate([pad, np.diff(vals, axis=-1) != 0], axis=-1)      # differs from the left neighbour
         dr = np.concatenate([np.diff(vals, axis=-1) != 0, pad], axis=-1)      # ... from the right one
         alone = dl & dr
-        assert alone.any() and np.array_equal(got[alone], ti[alone]), f"{name} r={r}: index order differs outside tie runs"
+        assert np.array_equal(got[alone], ti[alone]), f"{name} r={r}: index order differs outside tie runs"
+        assert alone.any() or name == "st_tiny"           # (StreamingLLM's 0 / 1 scores are one tie run; every other case has distinct scores)
     # smallest-first variant
     n = s["S"] // 3
     got = N.topk_select(sc, n, N.ORDER_SCORE | N.TOPK_SMALLEST).cpu().numpy()
@@ -174,12 +175,12 @@ def test_topk_second_pass_variants(S, knobs):
         assert np.array_equal(got, O.topk_select(-flat, S // 2)), f"variant {variant} S={S} smallest"
 
 
-@pytest.mark.parametrize("R,S", [(1, 16385), (3, 20000), (8, 32768), (9, 32769), (16, 40000), (17, 40000), (8, 131008), (2, 131073), (5, 262144), (2, 262145)])
+@pytest.mark.parametrize("R,S", [(1, 16385), (3, 20000), (8, 32769), (7, 40000), (9, 40000), (8, 131008), (2, 131073), (5, 262144), (2, 262145)])
 def test_topk_cluster_select_rows_and_lengths(R, S, knobs):
     """The cluster select (topk_cluster.hip: 32 workgroups per row, keys in registers, cluster barriers between the digit steps)
     over its whole range of row lengths (every keys-per-thread instantiation, partially filled last slots, unaligned rows), with
-    fewer and more rows than clusters (one launch per 8 rows), twice through the same self-cleaning workspace, k smallest, score
-    order; 17 rows or 262145 scores are past its range and take the (chunk, row) passes.  Against the oracle AND bit-identical
+    fewer rows than clusters, twice through the same self-cleaning workspace, k smallest, score
+    order; 9 rows or 262145 scores are past its range and take the (chunk, row) passes.  Against the oracle AND bit-identical
     to KVP_TK_CLUSTER=0."""
     rs = np.random.RandomState(R * 1000003 + S)
     N = native()
@@ -772,9 +773,9 @@ def test_fused_knorm_select_variants_equal_modular(S, variant, knobs):
         ko, vo = N.knorm_compress(k, v, n)
         wk, wv = N.gather_kv(k, v, N.topk_select(sc, n))
         assert torch.equal(ko, wk) and torch.equal(vo, wv), f"S={S} n={n}"
-    if S > 16384:   # two batch elements, float16, a strided view of the cache: rows 0..7 and 8..15 share clusters
-        k2 = torch.randn((2, 8, S + 5, 128), generator=g, device=DEV).to(torch.float16)[:, :, 5:]
-        v2 = torch.randn((2, 8, S + 5, 128), generator=g, device=DEV).to(torch.float16)[:, :, 5:]
+    if S > 16384:   # two batch elements x four heads (row = b * H + h), float16, a strided view of the cache
+        k2 = torch.randn((2, 4, S + 5, 128), generator=g, device=DEV).to(torch.float16)[:, :, 5:]
+        v2 = torch.randn((2, 4, S + 5, 128), generator=g, device=DEV).to(torch.float16)[:, :, 5:]
         ko, vo = N.knorm_compress(k2, v2, S // 2)
         wk, wv = N.gather_kv(k2, v2, N.topk_select(N.rownorm_score(k2, -1.0), S // 2))
         assert torch.equal(ko, wk) and torch.equal(vo, wv), f"S={S} (B=2, f16, view)"

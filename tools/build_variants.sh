@@ -5,6 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p kvpress_amd/lib/variants
 for spec in "$@"; do
+  [[ "$spec" == tc_* ]] && continue
   name=${spec%%=*}; abl=${spec#*=}
   env $abl python tools/gen_stage_asm.py kernel > /dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form -c kvpress_amd/csrc/snapkv_mfma.hip -o /tmp/snapkv_mfma_$name.o 2>/dev/null
@@ -13,3 +14,20 @@ for spec in "$@"; do
   echo "built $name ($abl)"
 done
 python tools/gen_stage_asm.py kernel > /dev/null   # restore the production loops
+# tc_timing: the cluster select with phase time stamps (tools/select_lab.py --stamps)
+if [[ " $* " == *" tc_timing "* ]]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DKVP_TC_TIMING -c kvpress_amd/csrc/topk_cluster.hip -o /tmp/topk_cluster_timing.o
+  objs=$(ls kvpress_amd/build/*.o | grep -v topk_cluster.o)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o kvpress_amd/lib/variants/tc_timing.so $objs /tmp/topk_cluster_timing.o
+  echo "built tc_timing"
+fi
+# tc_l2 / tc_l2_timing: the cluster select on XCD-local (placement-dependent) traffic -- lab measurement only
+for v in tc_l2 tc_l2_timing; do
+  if [[ " $* " == *" $v "* ]]; then
+    fl="-DKVP_TC_L2LOCAL"; [[ $v == *timing ]] && fl="$fl -DKVP_TC_TIMING"
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $fl -c kvpress_amd/csrc/topk_cluster.hip -o /tmp/topk_cluster_$v.o
+    objs=$(ls kvpress_amd/build/*.o | grep -v topk_cluster.o)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o kvpress_amd/lib/variants/$v.so $objs /tmp/topk_cluster_$v.o
+    echo "built $v"
+  fi
+done

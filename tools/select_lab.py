@@ -43,10 +43,48 @@ def timeit(fn, reps):
     return best * 1e6
 
 
+def stamps(R, S, flat=True):
+    """Phase time stamps of the cluster kernel (lab build with -DKVP_TC_TIMING, see tools/build_variants.sh tc_timing):
+    run with KVPRESS_HIP_LIB=kvpress_amd/lib/variants/tc_timing.so."""
+    import ctypes
+
+    import numpy as np
+
+    g = torch.Generator(device=DEV)
+    g.manual_seed(1)
+    sc = (2.0 ** -17 * (1 + 0.05 * torch.randn((R, S), generator=g, device=DEV))).float() if flat else torch.randn((R, S), generator=g, device=DEV)
+    L = N.lib()
+    nws = L.kvp_topk_workspace_bytes(R, S, S // 2)
+    ws = torch.zeros(nws, dtype=torch.uint8, device=DEV)
+    idx = torch.empty((R, S // 2), dtype=torch.int32, device=DEV)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    al = lambda x: (x + 255) // 256 * 256
+    bar_off = (2 * al(R * 4096 * 4) + al(R * 256 * 4)) // 4 + 8 * 32 + 32
+    names = ["start", "keys", "h1 flushed", "B1", "digit1", "h2 flushed", "B2", "digit2", "h3+table", "B3", "T", "offsets", "end"]
+    for it in range(6):
+        rc = L.kvp_topk_select(P(sc), R, S, S, S // 2, N.TOPK_WS_CLEAN, P(idx), P(ws), nws, st)
+        assert rc == 0, L.kvp_last_error()
+        torch.cuda.synchronize()
+    w = ws.view(torch.int32).cpu().numpy().astype(np.int64)[bar_off:bar_off + 32 * 16].reshape(32, 16)[:, :13]
+    t0 = w[:, 0].min()
+    rel = (w - t0) * 0.01   # us
+    print(f"cluster kernel phase stamps, R={R} S={S} {'flat' if flat else 'wide'} (us since the first workgroup of cluster 0 started; min / median / max over its 32 slots)")
+    for i, n in enumerate(names):
+        col = rel[:, i]
+        print(f"  {n:12s} {col.min():7.2f} {np.median(col):7.2f} {col.max():7.2f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=300)
+    ap.add_argument("--stamps", action="store_true")
     args = ap.parse_args()
+    if args.stamps:
+        stamps(8, 131008, True)
+        stamps(8, 131008, False)
+        stamps(8, 40000, True)
+        return
     g = torch.Generator(device=DEV)
     g.manual_seed(0)
     ALL = dict(KVP_TK_CLUSTER=None, KVP_TK_CLUSTER_KNORM=None, KVP_TK_CLUSTER_POOL=None)
