@@ -35,14 +35,21 @@ SUPPORTED_MODEL_NAMES = (
 )
 
 
-def is_prefilling(kv_len: int, q_len: int, kwargs: dict | None = None) -> bool:
-    """True for the initial prefill.  When the model passes ``cache_position`` (transformers < 5.3) the reference's own rule
-    applies, ``cache_position[-1] + 1 == q_len`` (base_press.py:37-40): it is right whatever the cache layer stores (a
-    pre-allocated static cache, a sliding-window layer).  transformers >= 5.3 no longer passes it; then the
-    tensor shapes decide without a device sync: the cache held nothing before this forward, i.e. after the layer's update it
-    holds the q_len tokens of this forward -- or fewer, when an earlier press of a ComposedPress has already pruned them (a
-    continuation or decoding step leaves kv_len = past + q_len > q_len).  That shape rule needs a cache whose stored length is
-    its logical length (DynamicCache / QuantizedCache)."""
+# cache layers whose stored length IS their logical length: the tensor shapes alone tell a prefill from a later step
+_SHAPE_DECIDES = frozenset({"DynamicLayer", "QuantizedLayer", "QuantoQuantizedLayer", "HQQQuantizedLayer"})
+
+
+def is_prefilling(kv_len: int, q_len: int, kwargs: dict | None = None, cache_layer=None) -> bool:
+    """True for the initial prefill.
+    * ``cache_layer`` is a DynamicCache / QuantizedCache layer: the shapes decide, without a device sync -- the cache held
+      nothing before this forward, i.e. after the layer's update it holds the q_len tokens of this forward, or fewer when an
+      earlier press of a ComposedPress has already pruned them (a continuation or decoding step leaves kv_len = past + q_len >
+      q_len).  This is the path of every decoded token under a DecodingPress: no ``.item()`` per layer and token.
+    * any other layer (pre-allocated static cache, sliding window, unknown) with ``cache_position`` passed by the model
+      (transformers < 5.3): the reference's own rule, ``cache_position[-1] + 1 == q_len`` (base_press.py:37-40; one sync).
+    * otherwise (transformers >= 5.3 passes no cache_position): the shape rule."""
+    if cache_layer is not None and type(cache_layer).__name__ in _SHAPE_DECIDES:
+        return int(kv_len) <= int(q_len)
     cache_position = None if kwargs is None else kwargs.get("cache_position")
     if cache_position is not None:
         return int(cache_position[-1]) + 1 == int(q_len)
@@ -81,7 +88,7 @@ class BasePress:
 
         # Don't compress after pre-filling
         kv_len = cache.get_seq_length(module.layer_idx) if _is_quantized(cache) else cache_layer.keys.shape[2]
-        if not is_prefilling(kv_len, q_len, kwargs):
+        if not is_prefilling(kv_len, q_len, kwargs, cache_layer):
             return output
 
         keys, values = extract_keys_and_values(cache, module.layer_idx)

@@ -6,6 +6,33 @@ from dataclasses import dataclass
 from kvpress_amd.presses.base_press import BasePress
 
 
+def _inner_presses(press):
+    out = []
+    for name in ("press", "prefill_press", "decoding_press", "base_press"):
+        p = getattr(press, name, None)
+        if isinstance(p, BasePress):
+            out.append(p)
+    out += [p for p in getattr(press, "presses", None) or [] if isinstance(p, BasePress)]
+    return out
+
+
+def _masks_keys(press) -> bool:
+    """press (or a press it wraps) records module.masked_key_indices"""
+    from kvpress_amd.presses.adakv_press import AdaKVPress
+    from kvpress_amd.presses.criticalkv_press import CriticalAdaKVPress
+    from kvpress_amd.presses.dms_press import DMSPress
+    from kvpress_amd.presses.duo_attention_press import DuoAttentionPress
+
+    return isinstance(press, (AdaKVPress, CriticalAdaKVPress, DMSPress, DuoAttentionPress)) or any(_masks_keys(p) for p in _inner_presses(press))
+
+
+def _prunes_positions(press) -> bool:
+    """press removes or reorders cache positions (everything but the channel-pruning ThinKPress and other masking presses)"""
+    from kvpress_amd.presses.think_press import ThinKPress
+
+    return not isinstance(press, ThinKPress) and not (_masks_keys(press) and not _inner_presses(press))
+
+
 @dataclass
 class ComposedPress(BasePress):
     """Chain compression methods: each press's forward hook runs on the cache the previous one left; the overall
@@ -20,16 +47,20 @@ class ComposedPress(BasePress):
 
     def __post_init__(self):
         self.compression_ratio = None
-        # composed_press.py:31-34 forbids AdaKVPress / KVzipPress here.  The same holds for every press that records
-        # ``module.masked_key_indices`` relative to the cache it saw: a later pruning press would silently invalidate them.
         from kvpress_amd.presses.adakv_press import AdaKVPress
-        from kvpress_amd.presses.criticalkv_press import CriticalAdaKVPress
-        from kvpress_amd.presses.dms_press import DMSPress
-        from kvpress_amd.presses.duo_attention_press import DuoAttentionPress
 
-        masking = (AdaKVPress, CriticalAdaKVPress, DMSPress, DuoAttentionPress)
-        assert not any(isinstance(press, masking) for press in self.presses), \
-            "ComposedPress cannot contain presses that mask keys through module.masked_key_indices (AdaKVPress, CriticalAdaKVPress, DMSPress, DuoAttentionPress)"
+        # the reference's own rule (composed_press.py:47-50; KVzipPress is not part of this package)
+        assert not any(isinstance(press, AdaKVPress) for press in self.presses), "ComposedPress cannot contains AdaKVPress or KVzipPress"
+        # Beyond the reference: presses that record ``module.masked_key_indices`` relative to the cache they saw (CriticalAdaKVPress,
+        # DMSPress, DuoAttentionPress, also nested inside a wrapper) are fine on their own, in last position, or followed only by a
+        # channel-pruning ThinKPress -- the reference's test suite composes a lone DuoAttentionPress -- but a later press that
+        # removes or reorders positions silently invalidates those indices: warn about exactly that case.
+        for i, press in enumerate(self.presses):
+            if _masks_keys(press) and any(_prunes_positions(later) for later in self.presses[i + 1:]):
+                import warnings
+
+                warnings.warn(f"ComposedPress: {type(press).__name__} masks keys through module.masked_key_indices, but a later press "
+                              f"prunes positions: the masked indices will no longer refer to the same tokens", stacklevel=2)
 
     def post_init_from_model(self, model):
         for press in self.presses:

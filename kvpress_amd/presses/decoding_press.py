@@ -102,7 +102,7 @@ class DecodingPress(BasePress):
         cache = kwargs["past_key_values"]
         q_len = hidden_states.shape[1]
         layer_idx = module.layer_idx
-        if is_prefilling(_kv_len(cache, layer_idx), q_len, kwargs):
+        if is_prefilling(_kv_len(cache, layer_idx), q_len, kwargs, cache.layers[layer_idx]):
             return output                                   # still pre-filling: nothing to do
 
         self.hidden_states_buffer[layer_idx].append(hidden_states.detach().clone())

@@ -63,7 +63,7 @@ class DMSPress(BasePress):
         layer_idx = module.layer_idx
         # tokens in the cache after this forward (the reference reads cache_position[-1] + 1, :85)
         cache_len = cache.get_seq_length(layer_idx) if _is_quantized(cache) else cache.layers[layer_idx].keys.shape[2]
-        prefilling = is_prefilling(cache_len, q_len, kwargs)
+        prefilling = is_prefilling(cache_len, q_len, kwargs, cache.layers[layer_idx])
         if prefilling and layer_idx == 0:
             self.scores_buffer.clear()
             self.compression_ratios.clear()

@@ -148,16 +148,44 @@ def test_prefill_detection_prefers_cache_position():
     assert not is_prefilling(257, 1, {"cache_position": torch.tensor([256])})
     # no cache_position: DynamicCache shapes
     assert is_prefilling(100, 100, {}) and is_prefilling(60, 100) and not is_prefilling(101, 1, {})
+    # a DynamicCache layer decides by shape even when cache_position is there -- no device sync per layer and decoded token
+    from transformers import DynamicCache
+
+    class Boom:   # a cache_position that must not be read
+        def __getitem__(self, i):
+            raise AssertionError("cache_position read (device sync) although the layer's shapes decide")
+
+    cache = DynamicCache()
+    cache.update(torch.zeros(1, 1, 4, 2), torch.zeros(1, 1, 4, 2), 0)
+    layer = cache.layers[0]
+    assert not is_prefilling(257, 1, {"cache_position": Boom()}, layer)
+    assert is_prefilling(100, 100, {"cache_position": Boom()}, layer) and is_prefilling(60, 100, {"cache_position": Boom()}, layer)
+    # a layer of another kind (static, sliding window) still takes the reference's rule
+    assert is_prefilling(4096, 100, {"cache_position": torch.arange(0, 100)}, object())
 
 
-def test_composed_press_rejects_masking_presses():
-    """composed_press.py:31-34 forbids AdaKVPress inside a ComposedPress; here every press that writes masked_key_indices is."""
+def test_composed_press_masking_presses():
+    """composed_press.py:47-50 forbids AdaKVPress (and KVzipPress) inside a ComposedPress: the same hard error here.  The other
+    presses that write masked_key_indices compose as in the reference (its test_presses_run builds ComposedPress([DuoAttentionPress])):
+    alone, last, or followed by the channel-pruning ThinKPress silently; followed by a press that prunes positions with a warning."""
+    import warnings
+
     import kvpress_amd as P
 
     P.ComposedPress([P.KnormPress(0.2), P.SnapKVPress(0.3)])
-    for bad in (P.AdaKVPress(P.KnormPress(0.2)), P.DMSPress(P.KnormPress(), threshold=0.0)):
-        with pytest.raises(AssertionError):
-            P.ComposedPress([P.KnormPress(0.2), bad])
+    with pytest.raises(AssertionError):
+        P.ComposedPress([P.KnormPress(0.2), P.AdaKVPress(P.KnormPress(0.2))])
+    dms = lambda: P.DMSPress(P.KnormPress(), threshold=0.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        P.ComposedPress([dms()])                                       # alone
+        P.ComposedPress([P.KnormPress(0.2), dms()])                    # last
+        P.ComposedPress([dms(), P.ThinKPress(key_channel_compression_ratio=0.5)])   # followed by channel pruning only
+        P.ComposedPress([P.DuoAttentionPress(head_compression_ratio=0.5)])
+    with pytest.warns(UserWarning, match="masked_key_indices"):
+        P.ComposedPress([dms(), P.KnormPress(0.2)])
+    with pytest.warns(UserWarning, match="masked_key_indices"):
+        P.ComposedPress([P.ComposedPress([dms()]), P.KnormPress(0.2)])   # nested inside a wrapper
 
 
 def test_kept_order_switch(fake_native):
