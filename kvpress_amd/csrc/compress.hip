@@ -9,9 +9,11 @@
 //     first S - W columns for n_kept - W entries and the window positions are appended (they are the largest
 //     positions, so the ascending-position order is preserved).  n_kept < W (fewer survivors than window tokens) takes
 //     the unfused sequence.
-//   * short rows (<= 32768 scores, topk_row_eligible): the select is ONE launch (one workgroup per row) and takes no fused
-//     histogram; up to 4096 columns SnapKV's pooling + scaling also happen inside that launch's loader
-//     (topk_select_pooled_rows), so neither the pooling launch nor the score round trip exists.
+//   * the select by row length: <= 16384 scores ONE launch with one workgroup per row and its own digits (topk_row_kernel; SnapKV up
+//     to 4096 columns also pools + scales inside that launch's loader, topk_select_pooled_rows); 16385 .. 262144 scores of <= 8 rows
+//     ONE launch of the cluster select (topk_cluster.hip) whose loader pools SnapKV's column sums (no pooling launch, no score
+//     round trip) or computes Knorm's norms (the scores never reach memory); everything else -- more rows, longer rows, other
+//     devices -- the (chunk, row) passes starting from the first-digit histogram that the score-writing kernel accumulated.
 // Scores and indices live in the caller's workspace and never leave the device.
 #include "kvp_common.h"
 #include "snapkv_internal.h"

@@ -145,7 +145,8 @@ extern "C" int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t 
     const int wg_per_cu = kvp_env_int("KVP_GA_WG_PER_CU", 8);
     const uint64_t bx_cap = std::max<uint64_t>(1, ((uint64_t)256 * wg_per_cu + BH - 1) / BH);
     const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap));
-    // Streaming (non-temporal) loads / stores when K + V do not fit the 256 MiB memory-side cache anyway: the copy must not
+    // Streaming (non-temporal) loads / stores when K + V do not fit the memory-side cache anyway (the cache is 256 MiB; the cutoff
+    // chosen by measurement is 192 MiB of K + V): the copy must not
     // displace what the next kernels re-read nor leave its output behind as dirty lines -- at 128k tokens the following
     // window-attention pass pays for both (measured: its cold K stream 79 -> 50 us).  Smaller caches stay cached: there the
     // rows just scored are still resident (32k tokens: gather 23 us cached vs 26 us streaming).  KVP_GA_NT=0/1 forces either.
