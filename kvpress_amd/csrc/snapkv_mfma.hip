@@ -353,13 +353,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_asm(SnapArgs a, uint3
             asm volatile(KVP_P1_ASM_BF16
                          : "=&v"(m), "=&v"(z)
                          : "v"(qrow), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(la[0]), "v"(la[1]), "v"(la[2]), "v"(la[3]), "v"(la[4]),
-                           "v"(la[5]), "v"(la[6]), "v"(la[7]), "s"(uni(m0base)), "s"(uni(gnext)), "s"(uni(gstride)), "s"(uni(nasm)), "s"(uni(c)), "s"(uni(nadv))
+                           "v"(la[5]), "v"(la[6]), "v"(la[7]), "s"(uni(m0base)), "s"(uni(gnext)), "s"(uni(gstride)), "s"(uni(nasm)), "s"(uni(c)), "s"(uni(nadv)), "s"(uni(wv))
                          : KVP_P1_ASM_CLOBBERS);
         else
             asm volatile(KVP_P1_ASM_F16
                          : "=&v"(m), "=&v"(z)
                          : "v"(qrow), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(la[0]), "v"(la[1]), "v"(la[2]), "v"(la[3]), "v"(la[4]),
-                           "v"(la[5]), "v"(la[6]), "v"(la[7]), "s"(uni(m0base)), "s"(uni(gnext)), "s"(uni(gstride)), "s"(uni(nasm)), "s"(uni(c)), "s"(uni(nadv))
+                           "v"(la[5]), "v"(la[6]), "v"(la[7]), "s"(uni(m0base)), "s"(uni(gnext)), "s"(uni(gstride)), "s"(uni(nasm)), "s"(uni(c)), "s"(uni(nadv)), "s"(uni(wv))
                          : KVP_P1_ASM_CLOBBERS);
     } else if (tw.ntiles > 0) {
         wait_all_landed();

@@ -345,6 +345,13 @@ import os as _os
 
 SGPR_CLOB = '"s20", "s21", "s22", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s40", "s41", "s42", "s44", "s45", "scc"'
 GEN_ABL = set(filter(None, _os.environ.get("GEN_ABL", "").split(",")))   # lab builds: nodma, nobar, novalu, nomfma, nolds (results wrong)
+# schedule labs (results unchanged): GEN_DMA_AT=k issues a stage's LDS-DMA request after its k-th MFMA instead of at the head;
+# GEN_RPS fragment reads per MFMA slot (default 2: slots 0-3), GEN_READ_FROM first slot that carries reads; GEN_PRIO=1 raises
+# the priority of waves 4-7 (the younger wave of every SIMD) once, before the loop
+GEN_DMA_AT = int(_os.environ["GEN_DMA_AT"]) if _os.environ.get("GEN_DMA_AT", "") != "" else None
+GEN_RPS = int(_os.environ.get("GEN_RPS", "2"))
+GEN_READ_FROM = int(_os.environ.get("GEN_READ_FROM", "0"))
+GEN_PRIO = int(_os.environ.get("GEN_PRIO", "0"))
 
 
 class Cfg:
@@ -399,12 +406,15 @@ def stage_head(cfg, p, flush=None):
         if flush:
             L += flush
     dst = ((buf + cfg.nbuf - 1) % cfg.nbuf) * 32768 + sub * 8192
+    D = []
     if "nodma" not in GEN_ABL:
-        L += [f"s_add_u32 m0, s22, {dst}", "s_nop 0", f"global_load_lds_dwordx4 v{cfg.dmav + sub}, s[24:25]"]
+        D += [f"s_add_u32 m0, s22, {dst}", "s_nop 0", f"global_load_lds_dwordx4 v{cfg.dmav + sub}, s[24:25]"]
     if sub == 3:
-        L += ["s_cmp_lg_u32 s28, 0", "s_cselect_b32 s29, s26, 0", "s_cselect_b32 s30, 1, 0", "s_sub_u32 s28, s28, s30",
+        D += ["s_cmp_lg_u32 s28, 0", "s_cselect_b32 s29, s26, 0", "s_cselect_b32 s30, 1, 0", "s_sub_u32 s28, s28, s30",
               "s_add_u32 s24, s24, s29", "s_addc_u32 s25, s25, 0"]
-    return L
+    if GEN_DMA_AT is None:
+        return L + D, []
+    return L, D     # lab: the request is issued after MFMA GEN_DMA_AT of the stage instead of at its head
 
 
 def prefetch_reads(cfg, p, kfl):
@@ -414,7 +424,8 @@ def prefetch_reads(cfg, p, kfl):
     return [f"ds_read_b128 {vr(kfl + 4 * ks, 4)}, v{base + ks} offset:{imm}" for ks in range(8)]
 
 
-def interleave(L, mf, reads, slots):
+def interleave(L, mf, reads, slots, dma=()):
+    L, dma = (L[0], L[1]) if isinstance(L, tuple) else (L, list(dma))
     if "novalu" in GEN_ABL:
         slots = [[] for _ in slots]
     if "nomfma" in GEN_ABL:
@@ -424,8 +435,10 @@ def interleave(L, mf, reads, slots):
     ri = 0
     for k in range(8):
         L.append(mf[k])
-        for _ in range(2):
-            if ri < len(reads):
+        if dma and k == GEN_DMA_AT:
+            L += dma
+        for _ in range(GEN_RPS):
+            if ri < len(reads) and k >= GEN_READ_FROM:
                 L.append(reads[ri])
                 ri += 1
         L += slots[k]
@@ -544,6 +557,13 @@ def tile_loop(cfg, stage_fn, drain_fn, first_two):
     return L
 
 
+def prio_lines():
+    """GEN_PRIO: waves 4-7 (s27 = wave index) get priority 1 for the whole loop; reset at the end of the block"""
+    if not GEN_PRIO:
+        return []
+    return ["s_cmp_lt_u32 s27, 4", "s_cbranch_scc1 48f", "s_setprio 1", "48:"]
+
+
 def p1_prod_body(dt):
     c = P1
     L = []
@@ -556,11 +576,12 @@ def p1_prod_body(dt):
         L.append(f"v_mov_b32 v{c.dmav + i}, %{3 + i}")
     L += ["s_mov_b32 s22, %15", "s_mov_b64 s[24:25], %16", "s_mov_b32 s26, %17", "s_mov_b32 s21, %18", "s_mov_b32 s20, %19", "s_mov_b32 s44, %19", "s_mov_b32 s45, %19", "s_mov_b32 s28, %20",
           f"v_mov_b32 v{MX[1]}, 0xff800000", f"v_mov_b32 v{Z_}, 0",      # the max part of sub-tile 0 reads MX[1]
+          "s_mov_b32 s27, %21"] + prio_lines() + [
           "s_waitcnt vmcnt(0)", "s_barrier"]
     L += [f"ds_read_b128 {vr(KF0 + 4 * ks, 4)}, v{c.laddr + ks}" for ks in range(8)]
     first = p1_prod_stage(0, do_m=False, do_x=False, dt=dt) + p1_prod_stage(1, do_m=True, do_x=False, dt=dt)
     L += tile_loop(c, lambda p: p1_prod_stage(p, dt=dt), p1_drain, first)
-    L += [f"v_mov_b32 %0, v{M_}", f"v_mov_b32 %1, v{Z_}"]
+    L += (["s_setprio 0"] if GEN_PRIO else []) + [f"v_mov_b32 %0, v{M_}", f"v_mov_b32 %1, v{Z_}"]
     return L
 
 
@@ -639,12 +660,12 @@ def p2_prod_body(dt):
         L.append(f"v_mov_b32 v{c.dmav + i}, %{1 + i}")
     L += ["s_mov_b32 s22, %13", "s_mov_b64 s[24:25], %14", "s_mov_b32 s26, %15", "s_mov_b32 s21, %16", "s_mov_b32 s20, %17", "s_mov_b32 s44, %17", "s_mov_b32 s45, %17", "s_mov_b32 s28, %18",
           "s_mov_b32 s27, %19", "s_mov_b64 s[40:41], %20", "s_mov_b32 s42, %22", "s_mov_b32 s31, 0",
-          f"v_mov_b32 v{REDW}, %23", f"v_mov_b32 v{FLR}, %24", f"v_mov_b32 v{FLO}, %25",
+          f"v_mov_b32 v{REDW}, %23", f"v_mov_b32 v{FLR}, %24", f"v_mov_b32 v{FLO}, %25"] + prio_lines() + [
           "s_waitcnt vmcnt(0)", "s_barrier"]
     L += [f"ds_read_b128 {vr(KF0 + 4 * ks, 4)}, v{c.laddr + ks}" for ks in range(8)]
     first = p2_prod_stage(0, do_x=False, dt=dt) + p2_prod_stage(1, do_x=False, dt=dt)
     L += tile_loop(c, lambda p: p2_prod_stage(p, dt=dt), p2_drain, first)
-    return L
+    return L + (["s_setprio 0"] if GEN_PRIO else [])
 
 
 INC_HEAD = """// GENERATED by tools/gen_stage_asm.py kernel -- do not edit (tests/test_capi_symbols.py checks it is up to date).
