@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- the kvpress score -> top-k -> gather hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload snapkv128k|knorm32k|knorm128k|ea128k]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload snapkv128k|knorm32k|knorm128k|ea128k|<f-row workload>]
 
 A "step" is ONE pass of the hot path over one batch of synthetic input: one layer's
 ``press.compress()`` (score + top-k + gather) for B=1 per GPU, Llama-3.1-8B attention geometry
@@ -11,13 +11,17 @@ Default workload = BASELINE.json's metric configuration (configs[2]): SnapKVPres
 metric  : press ms/layer (``ms_per_step``) and press-only prefill tok/s (``value`` =
           n_gpus * S / (32 layers * t_layer)), as BASELINE.json / SURVEY.md §8(d) define them.
 roofline: the dominant library kernel (largest average duration, HIP events on its launch
-          stream via kvp_prof_*), its algorithmic bytes / duration vs the 8 TB/s HBM peak;
-          ``path`` holds the same for the whole compress() against SURVEY §8(d)'s
-          algorithmic bytes per layer.
-cpu_baseline: the reference's own op sequence in plain PyTorch (oracle/torch_path.py, pinned bit for bit to the
-          real reference by tests/test_oracle_golden.py) timed on this box's host cores on the same workload, bf16
-          (as users run it) and float32, torch.get_num_threads() threads (N=1, rank 0 only); the numpy oracle's time
-          is kept as a secondary field.
+          stream via kvp_prof_*), its algorithmic bytes / duration vs the 8 TB/s HBM peak -- and, at the same level,
+          ``path_frac`` (the whole compress() against SURVEY §8(d)'s algorithmic bytes per layer: THE number the
+          north-star target of 0.70 is about), the window-attention passes' own fractions (``p1_frac``, ``p2_frac``) and
+          ``path_model_us`` / ``path_frac_of_model``: the floor of this kernel chain from measured ceilings (per kernel
+          max(bytes / 6.29 TB/s copy ceiling, matrix-core flops / 1.46 PFLOP/s sustained on random operands, one
+          1.7 us dependent-launch boundary), summed -- path_model()).  ``path`` holds the details.
+cpu_baseline: the REFERENCE ITSELF (``kind: "reference"``: NVIDIA/kvpress's press.compress(), imported from oracle/_ref, a
+          build-time copy made by oracle/build_ref.py where /root/reference exists) timed on this box's host cores on the
+          same workload, bf16 (as users run it) and float32, torch.get_num_threads() threads (N=1, rank 0 only), and
+          cross-checked bit for bit against oracle/torch_path.py, the op-for-op restatement (pinned to the real reference by
+          tests/test_oracle_golden.py) that is the fallback (``kind: "port"``) where the copy is absent.
 Multi-GPU: one process per GPU, batch sharded one element per GPU, no collective on the data path; only
           the timing is max-reduced over ranks.  `python bench.py --gpus N` launches the N ranks itself (it re-executes
           under torch.distributed.run on 127.0.0.1 when WORLD_SIZE is not set); under an external launcher it reads
@@ -37,15 +41,28 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 LAYERS = 32  # Llama-3.1-8B
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md); with real operands the chip power-limits to ~1.44 GHz
+# measured ceilings the path model is built from:
+COPY_CEILING_GBS = 6290.0       # float4 copy ceiling, MI355X_MICROARCH.md "HBM": what a pure streaming kernel reaches
+MFMA_SUSTAINED_TFLOPS = 1459.0  # v_mfma_f32_32x32x16_bf16 back to back on all 256 CUs with RANDOM operands: 367.9 ns per 524 288-flop
+                                # SIMD stage (profiles/r02_ubench_stage.txt, "mfma_only", 256 workgroups) -- the chip power-limits to ~1.4 GHz
+BOUNDARY_US = 1.7               # one dependent kernel boundary / all-to-all hop (MI355X_MICROARCH.md price list "boundary"; the cluster
+                                # select's in-launch hops measure ~2 us each, profiles/r03_select_cluster_lab.txt)
 
+H_Q, H_KV, D, HIDDEN, WINDOW = 32, 8, 128, 4096, 64
 WORKLOADS = {
-    # name: (press kind, S, ratio)
+    # name: (press kind, S, ratio)            BASELINE.json configs 2-4 + Knorm at 128k
     "snapkv128k": ("snapkv", 131072, 0.5),
     "knorm32k": ("knorm", 32768, 0.5),
     "knorm128k": ("knorm", 131072, 0.5),
     "ea128k": ("ea", 131072, 0.7),
+    # SURVEY §8(f) rows on the same tensors: the scorers / wrappers that reuse the path's kernels
+    "keydiff128k": ("keydiff", 131072, 0.5),             # keydiff_press.py:45-46
+    "cur128k": ("cur", 131072, 0.5),                     # cur_press.py:42-65 (kv_product leverage, local windows of 16)
+    "finch128k": ("finch", 131072, 0.5),                 # finch_press.py:56-83 (window 64, normalised, kept keys re-rotated)
+    "chunk_snapkv128k": ("chunk_snapkv", 131072, 0.5),   # chunk_press.py:67-85: SnapKV per 1024-token chunk, segmented select
+    "rerotate128k": ("rerotate", 131072, 0.5),           # key_rerotation_press.py:101-152 around KnormPress
+    "decode_snapkv2k": ("snapkv", 2048, 0.5),            # decoding_press.py:113-179's regime: a 2k-token cache, latency-bound
 }
-H_Q, H_KV, D, HIDDEN, WINDOW = 32, 8, 128, 4096, 64
 
 
 def shard_batch(global_batch: int, world: int, rank: int):
@@ -68,14 +85,25 @@ def aggregate_time(local_seconds: float, world: int) -> float:
     return float(t.item())
 
 
+def n_kept_of(kind: str, S: int, ratio: float) -> int:
+    if kind == "chunk_snapkv":   # chunk_press.py:79: per 1024-token chunk
+        return (S // 1024) * max(1, int(1024 * (1 - ratio))) + (max(1, int((S % 1024) * (1 - ratio))) if S % 1024 else 0)
+    return int(S * (1 - ratio))
+
+
 def algorithmic_bytes(kind: str, S: int, ratio: float, B: int = 1) -> dict:
-    """bytes per layer the path must move (e = 2 bytes)."""
-    n_kept = int(S * (1 - ratio))
+    """bytes per layer the path must move (e = 2 bytes): K read once for scoring (+ what else the scorer
+    must read) + kept K, V rows read + K', V' written (+ the in-place re-rotation of K' where the press does it)."""
+    n_kept = n_kept_of(kind, S, ratio)
     kread = B * S * H_KV * D * 2
     gather = B * 4 * n_kept * H_KV * D * 2  # read kept K,V rows + write K',V'
     extra = 0
     if kind == "ea":
         extra = B * (S * H_KV * D * 2 + S * H_Q * D * 2)  # V for ||v||, Q for the statistics
+    if kind == "cur":
+        extra = B * S * H_KV * D * 2                      # V for its leverage scores
+    if kind in ("finch", "rerotate"):
+        extra = B * 2 * n_kept * H_KV * D * 2             # K' read + written once more by the re-rotation
     return {"n_kept": n_kept, "score_read": kread + extra, "gather": gather, "total": kread + extra + gather}
 
 
@@ -85,10 +113,14 @@ def kernel_bytes(name: str, kind: str, S: int, ratio: float) -> float:
     kbytes = S * H_KV * D * 2
     if name.startswith("gather"):
         return ab["gather"]
-    if name.startswith(("snapkv_p1", "snapkv_p2", "rownorm", "ea_logits")):
-        return kbytes
+    if name.startswith(("snapkv_p1", "snapkv_p2", "rownorm", "ea_logits", "keydiff_anchor_kernel", "keydiff_score", "colsumsq", "rowdot")):
+        return kbytes   # one pass over K (or V)
     if name.startswith("ea_qstats_mfma"):
         return S * H_Q * D * 2  # Q [B, S, H_q * D] read once for the statistics
+    if name.startswith("rerotate"):
+        return 2 * ab["n_kept"] * H_KV * D * 2
+    if name.startswith("topk_cluster") and kind == "knorm":
+        return kbytes   # fused Knorm compress: the cluster select computes the norms itself (one pass over K)
     return 0.0
 
 
@@ -98,7 +130,32 @@ def kernel_flops(name: str, S: int) -> float:
         return 2.0 * H_Q * WINDOW * S * D
     if name.startswith("ea_logits"):
         return 2.0 * H_Q * S * D * D  # k^T Sigma k per key and query head (the kernel's hi + lo split of Sigma executes twice that)
+    if name.startswith("ea_qstats_mfma"):
+        return 2.0 * H_Q * S * D * D  # covariance (syrk executes half of it)
     return 0.0
+
+
+def path_model(kernels: dict, kind: str, S: int, ratio: float, B: int = 1) -> dict:
+    """Floor of THIS kernel chain from measured ceilings: per launch max(algorithmic bytes / copy ceiling, matrix-core flops /
+    sustained rate on random operands, one dependent-launch boundary), summed over the launches of a step; the cluster select
+    counts its four digit / compaction steps as four boundaries (they are all-to-all hops of ~2 us each whether they are
+    kernel boundaries or in-launch barriers).  Host-side torch ops that the library does not launch (the window q_proj of the
+    SnapKV-type presses: 32 MiB of weight; ExpectedAttention's full-sequence q_proj: 2 * S * hidden^2 flops) are added as
+    ``torch_ops``.  `kernels`: {name: (avg ms per launch, launches per step)}."""
+    per = {}
+    for name, (_, count) in kernels.items():
+        t_bytes = kernel_bytes(name, kind, S, ratio) * B / (COPY_CEILING_GBS * 1e3)     # us
+        t_flops = kernel_flops(name, S) * B / (MFMA_SUSTAINED_TFLOPS * 1e6)             # us
+        hops = 4 if name.startswith("topk_cluster") else 1
+        per[name] = round(max(t_bytes, t_flops, hops * BOUNDARY_US) * count, 2)
+    torch_ops = 0.0
+    if kind in ("snapkv", "finch", "chunk_snapkv"):
+        torch_ops = max(HIDDEN * H_Q * D * 2 / (COPY_CEILING_GBS * 1e3), BOUNDARY_US)
+    if kind == "ea":
+        torch_ops = 2.0 * B * S * HIDDEN * H_Q * D / (MFMA_SUSTAINED_TFLOPS * 1e6)
+    total = sum(per.values()) + torch_ops
+    return {"per_kernel_us": per, "torch_ops_us": round(torch_ops, 2), "total_us": round(total, 2),
+            "ceilings": {"copy_GBs": COPY_CEILING_GBS, "mfma_sustained_TFLOPs": MFMA_SUSTAINED_TFLOPS, "boundary_us": BOUNDARY_US}}
 
 
 def csrc_digest() -> str:
@@ -117,10 +174,10 @@ def csrc_digest() -> str:
 def pmc_traffic(kernel_name: str, workload: str):
     """(HBM bytes per launch of `kernel_name`, provenance).  The counters cannot be read from inside this process: they come
     from the rocprofv3 --pmc passes of this same command (`scripts/gpu_check.sh pmc`, separate passes, no tracing), whose
-    summary is committed as profiles/r02_pmc_summary_<workload>.txt together with the digest of the kernel sources it was
+    summary is committed as profiles/r03_pmc_summary_<workload>.txt together with the digest of the kernel sources it was
     measured on.  A summary of a different build is NOT quoted (traffic = null).  MI355X_MICROARCH.md §HBM: FETCH_SIZE and
     WRITE_SIZE are in KiB and on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads -> doubled."""
-    rel = os.path.join("profiles", f"r02_pmc_summary_{workload}.txt")
+    rel = os.path.join("profiles", f"r03_pmc_summary_{workload}.txt")
     path = os.path.join(ROOT, rel)
     if not os.path.exists(path):
         return None, f"{rel} missing"
@@ -165,13 +222,28 @@ def build_module(device):
     return att, rot
 
 
-def make_press(kind, ratio):
-    import kvpress_amd as P
+def make_press(kind, ratio, P=None):
+    """The press of a workload from package `P` (kvpress_amd by default; the reference package for the CPU baseline: same
+    class names, same constructor arguments)."""
+    if P is None:
+        import kvpress_amd as P
 
     if kind == "snapkv":
         return P.SnapKVPress(compression_ratio=ratio, window_size=WINDOW, kernel_size=5)
     if kind == "knorm":
         return P.KnormPress(compression_ratio=ratio)
+    if kind == "keydiff":
+        return P.KeyDiffPress(compression_ratio=ratio)
+    if kind == "cur":
+        return P.CURPress(compression_ratio=ratio)
+    if kind == "finch":
+        press = P.FinchPress(compression_ratio=ratio)
+        press.window_size = WINDOW   # (set by the embedding hook in a model run: the question's length)
+        return press
+    if kind == "chunk_snapkv":
+        return P.ChunkPress(press=P.SnapKVPress(compression_ratio=ratio, window_size=WINDOW, kernel_size=5), chunk_length=1024)
+    if kind == "rerotate":
+        return P.KeyRerotationPress(press=P.KnormPress(compression_ratio=ratio))
     return P.ExpectedAttentionPress(compression_ratio=ratio)
 
 
@@ -214,13 +286,32 @@ def result_line(args, world: int, B: int, S: int, t_step: float, config: dict, r
             "dtype": dtype, "data": "synthetic", "config": config, "roofline": roofline, "cpu_baseline": cpu}
 
 
+def reference_package():
+    """NVIDIA/kvpress itself: oracle/_ref/kvpress, the build-time copy oracle/build_ref.py makes where /root/reference exists (it
+    travels to the GPU box with the tree but is never committed), with stand-ins for its two missing dependencies.  None if absent."""
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    if not os.path.isfile(os.path.join(ref, "kvpress", "__init__.py")):
+        return None
+    if ref not in sys.path:
+        sys.path.insert(0, ref)
+    try:
+        import kvpress
+
+        return kvpress
+    except Exception as e:  # a broken copy must not take the bench line down: fall back to the restatement
+        print(f"[bench] oracle/_ref/kvpress not importable ({e!r}): using oracle/torch_path.py", file=sys.stderr)
+        return None
+
+
 def cpu_baseline(workload, press, att, rot, hidden, keys, values, kwargs, n_kept):
-    """The reference's pure-PyTorch path on the host CPU cores of THIS box, same run, same tensors (north_star):
-    oracle/torch_path.py = ScorerPress.compress (scorer_press.py:76-102) + the scorer, restated op for op and pinned bit for
-    bit to the real reference (tests/test_oracle_golden.py).  bf16 as users run it and float32 ("O32"); 1 warm-up + timed
-    runs, median; threads = torch.get_num_threads().  ExpectedAttention's 4.4-TFLOP q_proj makes one run ~10 s: one timed
-    run per dtype there.  The numpy float32 port (oracle/kvpress_oracle.py) is timed once as a secondary figure, and the GPU
-    path's retained set is checked against the float32 CPU scores while they are at hand."""
+    """The reference's pure-PyTorch path on the host CPU cores of THIS box, same run, same tensors (north_star).
+    kind "reference": the reference's own ``press.compress()`` (scorer_press.py:76-102 + the scorer; wrappers likewise) from
+    oracle/_ref; its output is compared bit for bit with oracle/torch_path.py -- the same op sequence restated line by line and
+    pinned to the real reference by tests/test_oracle_golden.py -- which is what is timed instead (kind "port") where the copy
+    of the reference is absent.  bf16 as users run it and float32 ("O32"); 1 warm-up + timed runs, median; threads =
+    torch.get_num_threads().  ExpectedAttention's 4.4-TFLOP q_proj makes one run ~10 s: one timed run per dtype there.  The
+    numpy float32 port (oracle/kvpress_oracle.py) is timed once as a secondary figure, and the GPU path's retained set is
+    checked against the float32 CPU scores while they are at hand."""
     import numpy as np
     import torch
 
@@ -229,36 +320,48 @@ def cpu_baseline(workload, press, att, rot, hidden, keys, values, kwargs, n_kept
     from oracle import torch_path as TP
 
     kind, S, ratio = WORKLOADS[workload]
+    ref = reference_package()
+    restated = kind in TP.SCORERS
+    if ref is None and not restated:
+        return None   # an f-row workload without the reference at hand: nothing honest to time
     threads = torch.get_num_threads()
-    n_timed = 1 if kind == "ea" else 3
+    n_timed = 1 if kind in ("ea", "chunk_snapkv") else 3
     att_cpu = {torch.bfloat16: build_module(torch.device("cpu"))[0]}
     att_cpu[torch.float32] = build_module(torch.device("cpu"))[0].float()
     rot_cpu = build_module(torch.device("cpu"))[1]
-    res, sc32 = {}, None
+    res, sc32, identical = {}, None, None
     with torch.no_grad():
         for dt in (torch.bfloat16, torch.float32):
             m = att_cpu[dt]
             m.rotary_emb = rot_cpu
             h, k, v = hidden.cpu().to(dt), keys.cpu().to(dt), values.cpu().to(dt)
             kw = {"position_embeddings": tuple(t.cpu().to(dt) for t in kwargs["position_embeddings"])}
+            ref_press = make_press(kind, ratio, ref) if ref is not None else None
             times = []
             for i in range(1 + n_timed):
                 t0 = time.perf_counter()
-                ko, vo, idx = TP.torch_compress(TP.SCORERS[kind], ratio, m, h, k, v, kw)
+                if ref_press is not None:
+                    ko, vo = ref_press.compress(m, h, k, v, None, kw)
+                else:
+                    ko, vo, _ = TP.torch_compress(TP.SCORERS[kind], ratio, m, h, k, v, kw)
                 if i:
                     times.append(time.perf_counter() - t0)
-            assert tuple(ko.shape) == (k.shape[0], H_KV, n_kept, D)
+            assert tuple(ko.shape) == (k.shape[0], H_KV, n_kept, D), (tuple(ko.shape), n_kept)
             res[dt] = sorted(times)[len(times) // 2]
-            if dt == torch.float32:
+            if ref_press is not None and restated and dt == torch.bfloat16 and kind != "ea":   # the restatement IS the reference: same bytes
+                k2, v2, _ = TP.torch_compress(TP.SCORERS[kind], ratio, m, h, k, v, kw)
+                identical = bool(torch.equal(k2, ko) and torch.equal(v2, vo))
+            if dt == torch.float32 and restated:
                 sc32 = TP.SCORERS[kind](m, h, k, v, kw).numpy()
             del h, k, v, ko, vo
-    # GPU retained set vs the float32 CPU scores (tie-tolerant, 1e-3 band)
-    gsc = press.score(att, hidden, keys, values, None, kwargs)
-    gidx = _native.topk_select(gsc, n_kept).cpu().numpy()
-    ok, _ = O.topk_is_valid(sc32, gidx, n_kept, rel_band=1e-3)
+    ok = None
+    if sc32 is not None:   # GPU retained set vs the float32 CPU scores (tie-tolerant, 1e-3 band)
+        gsc = press.score(att, hidden, keys, values, None, kwargs)
+        gidx = _native.topk_select(gsc, n_kept).cpu().numpy()
+        ok = bool(O.topk_is_valid(sc32, gidx, n_kept, rel_band=1e-3)[0])
     # secondary: the numpy float32 port of the same algorithm (the round-1 baseline)
     port_ms = None
-    if kind != "ea":
+    if kind in ("snapkv", "knorm") and S > 4096:
         k_np, v_np = keys.float().cpu().numpy(), values.float().cpu().numpy()
         if kind == "snapkv":
             with torch.no_grad():
@@ -268,12 +371,15 @@ def cpu_baseline(workload, press, att, rot, hidden, keys, values, kwargs, n_kept
         O.compress(sc, k_np, v_np, ratio)
         port_ms = round((time.perf_counter() - t0) * 1e3, 1)
     t = res[torch.bfloat16]
-    return {"value": round(S / (LAYERS * t), 1), "unit": "tok/s", "cores": threads, "kind": "torch-restatement",
-            "sample": f"one full {workload} layer (B=1, H_kv={H_KV}, S={S}) per run: score + topk + gather of the reference in plain PyTorch "
-                      f"(oracle/torch_path.py), bf16 module and tensors, 1 warm-up + {n_timed} timed run(s), median; "
-                      f"torch.get_num_threads() = {threads}, os.cpu_count() = {os.cpu_count()}; tok/s extrapolates one layer x {LAYERS}",
+    what = ("NVIDIA/kvpress's own press.compress() (oracle/_ref/kvpress, copied from the reference tree at build time)" if ref is not None
+            else "score + topk + gather of the reference restated op for op in plain PyTorch (oracle/torch_path.py)")
+    return {"value": round(S / (LAYERS * t), 1), "unit": "tok/s", "cores": threads, "kind": "reference" if ref is not None else "port",
+            "sample": f"one full {workload} layer (B=1, H_kv={H_KV}, S={S}) per run: {what}, bf16 module and tensors, 1 warm-up + "
+                      f"{n_timed} timed run(s), median; torch.get_num_threads() = {threads}, os.cpu_count() = {os.cpu_count()}; "
+                      f"tok/s extrapolates one layer x {LAYERS}",
             "ms_per_layer": round(t * 1e3, 1), "ms_per_layer_fp32": round(res[torch.float32] * 1e3, 1),
-            "numpy_port_ms_per_layer": port_ms, "gpu_topk_valid_vs_cpu_fp32_scores": bool(ok)}
+            "restatement_bit_identical_to_reference": identical,
+            "numpy_port_ms_per_layer": port_ms, "gpu_topk_valid_vs_cpu_fp32_scores": ok}
 
 
 def stub_main(args, world: int, rank: int):
@@ -323,17 +429,28 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU"
     stub = args.stub_step is not None
+    device = None
+    if not stub:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+        # KVP_BENCH_SHARE_GPU=1 (tests only, gloo backend): every rank uses GPU 0, so that the N-rank path -- real kernels, real
+        # sharding, barrier-bracketed timing, MAX over ranks -- can run on a one-GPU box.  Never set it for a measurement.
+        share = os.environ.get("KVP_BENCH_SHARE_GPU") == "1"
+        assert not (share and args.backend == "nccl"), "KVP_BENCH_SHARE_GPU needs --backend gloo (RCCL refuses two ranks on one GPU)"
+        dev_index = 0 if share else local_rank
+        assert torch.cuda.device_count() > dev_index, f"rank {rank}: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible on this node"
+        device = torch.device("cuda", dev_index)
+        torch.cuda.set_device(device)   # before the process group: the RCCL communicator binds this rank's GPU (device_id) at init,
+                                        # so the first barrier does not have to guess a device
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        if args.backend == "nccl" and not stub:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     if stub:
         return stub_main(args, world, rank)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
-    assert torch.cuda.device_count() > local_rank, f"rank {rank}: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible on this node"
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
 
     from kvpress_amd import _native
 
@@ -366,7 +483,7 @@ def main():
     out = step()
     total = aggregate_time(local, world)
     t_step = total / args.steps
-    n_kept = int(S * (1 - ratio))
+    n_kept = n_kept_of(kind, S, ratio)
     assert tuple(out[0].shape) == (B, H_KV, n_kept, D), out[0].shape
 
     # ---- per-kernel HIP-event timing (profiling on: separate from the timed region) -------------
@@ -387,11 +504,21 @@ def main():
             dom = max(cand, key=cand.get)
             kb = kernel_bytes(dom, kind, S, ratio) * B
             ach = kb / (cand[dom] * 1e-3) / 1e9
+            model = path_model(avg, kind, S, ratio, B)
+            path_frac = ab["total"] * B / t_step / 1e9 / HBM_PEAK_GBS
+
+            def kfrac(prefix):   # HBM fraction of one kernel family (None if the workload does not launch it)
+                ks = [k for k in avg if k.startswith(prefix)]
+                return round(kernel_bytes(ks[0], kind, S, ratio) * B / (avg[ks[0]][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ks else None
+
+            traffic, traffic_source = pmc_traffic(dom, args.workload)
             roofline = {
                 "kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args.workload)[0],
-                "traffic_source": pmc_traffic(dom, args.workload)[1],
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": kb, "avg_launch_us": round(cand[dom] * 1e3, 2),
+                # the whole path and its slowest members, at the same level as the dominant kernel's own figure:
+                "path_frac": round(path_frac, 4), "p1_frac": kfrac("snapkv_p1"), "p2_frac": kfrac("snapkv_p2"),
+                "path_model_us": model["total_us"], "path_frac_of_model": round(model["total_us"] * 1e-6 / t_step, 4),
                 # secondary bound of the same kernel: the window-attention passes are matrix-core / VALU work
                 "mfma": ({"achieved": round(kernel_flops(dom, S) * B / (cand[dom] * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS,
                           "unit": "TFLOP/s", "frac": round(kernel_flops(dom, S) * B / (cand[dom] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
@@ -399,9 +526,10 @@ def main():
                 "path": {
                     "algorithmic_bytes_per_layer": ab["total"] * B,
                     "achieved": round(ab["total"] * B / t_step / 1e9, 1),
-                    "frac": round(ab["total"] * B / t_step / 1e9 / HBM_PEAK_GBS, 4),
+                    "frac": round(path_frac, 4),
                     "kernels_us": {k: round(a * 1e3 * c, 2) for k, (a, c) in sorted(avg.items())},
                     "kernels_sum_us": round(sum(a * c for a, c in avg.values()) * 1e3, 2),
+                    "model": model,
                 },
             }
             m = roofline["mfma"]

@@ -2,6 +2,7 @@
 kvp_ea_qstats / kvp_ea_score."""
 from __future__ import annotations
 
+import weakref
 from dataclasses import dataclass
 
 import torch
@@ -53,21 +54,37 @@ class ExpectedAttentionPress(ScorerPress):
         mu, cov = _native.ea_qstats(query_states, self.use_covariance)
         return self.apply_avg_rope(module, mu, cov, q_len)
 
+    def _avg_rope_matrix(self, module: nn.Module, q_len: int, device, dtype) -> torch.Tensor:
+        """R = mean over positions q_len .. q_len + n_future_positions - 1 of the RoPE matrix (expected_attention_press.py:110-120).
+        It depends on the rotary embedding (shared by all layers), q_len and n_future_positions only, so the 32 layers of a
+        forward pass share ONE computation (the reference rebuilds it per layer: ~10 small launches each): cached per press
+        instance, a handful of 64 KiB matrices at most."""
+        key = (id(module.rotary_emb), int(q_len), int(self.n_future_positions), int(module.head_dim), str(device), dtype)
+        cache = self.__dict__.setdefault("_rope_cache", {})
+        hit = cache.get(key)
+        R = hit[1] if hit is not None and hit[0]() is module.rotary_emb else None   # (the id of a dead module may be reused)
+        if R is None:
+            position_ids = torch.arange(q_len, q_len + self.n_future_positions, device=device).unsqueeze(0)
+            head_dim = module.head_dim
+            cos, sin = module.rotary_emb(torch.empty(0, dtype=dtype, device=device), position_ids)
+            cos, sin = cos[0].to(dtype), sin[0].to(dtype)
+            half = head_dim // 2
+            eye_h = torch.eye(half, device=device, dtype=dtype)
+            P = torch.zeros((head_dim, head_dim), device=device, dtype=dtype)
+            P[half:, :half] = eye_h
+            P[:half, half:] = -eye_h
+            # mean_p (diag(cos_p) + P * sin_p[:, None]) == diag(mean cos) + P * mean(sin)[:, None]
+            R = torch.diag(cos.mean(dim=0)) + sin.mean(dim=0).unsqueeze(1) * P
+            if len(cache) >= 8:
+                cache.clear()
+            cache[key] = (weakref.ref(module.rotary_emb), R)
+        return R
+
     def apply_avg_rope(self, module: nn.Module, mu: torch.Tensor, cov: torch.Tensor, q_len: int):
         """mu <- mu R^T, cov <- R cov R^T with R the RoPE matrix averaged over positions
         q_len .. q_len + n_future_positions - 1 (expected_attention_press.py:88-124).
         D x D host-side math in float32 on the device of mu."""
-        position_ids = torch.arange(q_len, q_len + self.n_future_positions, device=mu.device).unsqueeze(0)
-        head_dim = module.head_dim
-        cos, sin = module.rotary_emb(mu, position_ids)
-        cos, sin = cos[0].to(mu.dtype), sin[0].to(mu.dtype)
-        half = head_dim // 2
-        eye_h = torch.eye(half, device=mu.device, dtype=mu.dtype)
-        P = torch.zeros((head_dim, head_dim), device=mu.device, dtype=mu.dtype)
-        P[half:, :half] = eye_h
-        P[:half, half:] = -eye_h
-        # mean_p (diag(cos_p) + P * sin_p[:, None]) == diag(mean cos) + P * mean(sin)[:, None]
-        R = torch.diag(cos.mean(dim=0)) + sin.mean(dim=0).unsqueeze(1) * P
+        R = self._avg_rope_matrix(module, q_len, mu.device, mu.dtype)
         mu = torch.matmul(mu, R.T)
         if cov is not None:
             cov = torch.matmul(R, torch.matmul(cov, R.T))

@@ -58,6 +58,30 @@ def test_algorithmic_bytes_match_survey():
     assert bench.kernel_flops("snapkv_p1_asm", 131072) == 2 * 32 * 64 * 131072 * 128       # 68.7 GFLOP per QK^T pass
     assert bench.kernel_flops("ea_logits_mfma", 131072) == 2 * 32 * 131072 * 128 * 128    # k^T Sigma k: 137 GFLOP
     assert bench.kernel_bytes("ea_logits_mfma", "ea", 131072, 0.7) == 131072 * 8 * 128 * 2
+    # f-row workloads: K once (+ V for CUR's leverage, + K' re-rotated in place) + the gather
+    kb = 131072 * 8 * 128 * 2
+    assert bench.algorithmic_bytes("keydiff", 131072, 0.5)["total"] == 3 * kb
+    assert bench.algorithmic_bytes("cur", 131072, 0.5)["total"] == 4 * kb
+    assert bench.algorithmic_bytes("rerotate", 131072, 0.5)["total"] == 3 * kb + kb
+    assert bench.n_kept_of("chunk_snapkv", 131072, 0.5) == 65536 and bench.n_kept_of("chunk_snapkv", 1024 + 100, 0.5) == 512 + 50
+
+
+def test_path_model_is_the_sum_of_measured_ceilings():
+    """roofline.path_model_us: per launch max(bytes / 6.29 TB/s, flops / 1.459 PFLOP/s, one 1.7 us boundary), the
+    cluster select as four boundaries, + the torch-side window q_proj (32 MiB of weight)."""
+    import bench
+
+    kernels = {"snapkv_rope_kernel": (0.004, 1), "snapkv_p1_asm": (0.076, 1), "softmax_combine_kernel": (0.004, 1), "snapkv_p2_asm": (0.072, 1),
+               "topk_cluster_kernel": (0.015, 1), "gather_vec_kernel": (0.085, 1)}
+    m = bench.path_model(kernels, "snapkv", 131072, 0.5)
+    kb, fl = 131072 * 8 * 128 * 2, 2 * 32 * 64 * 131072 * 128
+    p_pass = max(kb / 6290e3, fl / 1459e6)                       # us: the matrix cores' sustained rate is the nearer ceiling
+    assert abs(p_pass - 47.1) < 0.2 and m["per_kernel_us"]["snapkv_p1_asm"] == round(p_pass, 2)
+    assert m["per_kernel_us"]["gather_vec_kernel"] == round(2 * kb / 6290e3, 2)
+    assert m["per_kernel_us"]["topk_cluster_kernel"] == 6.8 and m["per_kernel_us"]["snapkv_rope_kernel"] == 1.7
+    assert m["torch_ops_us"] == round(4096 * 4096 * 2 / 6290e3, 2)
+    assert abs(m["total_us"] - (2 * round(p_pass, 2) + round(2 * kb / 6290e3, 2) + 6.8 + 2 * 1.7 + m["torch_ops_us"])) < 0.02
+    assert 190 < m["total_us"] < 200                             # vs 100.7 us for the bytes alone at 8 TB/s and ~270 us measured
 
 
 def _run_bench(cmd):

@@ -296,3 +296,29 @@ def test_ea_qstats_128k_large_mean_adversarial():
     rel = (sc[..., 4:].double() - ref).abs() / ref.abs().clamp_min(1e-300)
     assert rel.max() <= 1e-3, f"final scores differ by {rel.max().item():.2e}"
     print(f"ea qstats 128k adversarial: cov err {err.max().item():.2e} sigma_i sigma_j, final score err {rel.max().item():.2e}")
+
+
+def test_bench_two_ranks_real_kernels_on_one_gpu():
+    """The N > 1 path of bench.py with the REAL kernels: `python bench.py --gpus 2` launches two ranks (one process per
+    "GPU"); KVP_BENCH_SHARE_GPU=1 lets both use GPU 0 of this one-GPU box (gloo for the timing reduction: RCCL refuses two ranks on one
+    device).  Real sharding (one batch element per rank), barrier-bracketed timing, MAX over ranks, one JSON line with n_gpus = 2; the
+    two ranks share one GPU, so the aggregate rate is about the N = 1 rate."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KVP_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "knorm32k", "--steps", "5",
+                        "--warmup", "2", "--prewarm-ms", "5", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["scaling"] == "weak" and line["config"]["batch_per_gpu"] == 1
+    assert 0.02 < line["ms_per_step"] < 5.0, line["ms_per_step"]
+    assert abs(line["value"] - 2 * 32768 / (32 * line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
+    assert line["roofline"] is not None and line["roofline"]["path_frac"] > 0
