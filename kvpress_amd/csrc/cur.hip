@@ -15,6 +15,7 @@ namespace {
 
 constexpr int CU_THREADS = 256;
 constexpr int CU_MAXBLK = 256;  // workgroups per row in the combine pass (their partial sums are added in a fixed order)
+static_assert(CU_MAXBLK <= CU_THREADS, "cur_normalize_kernel reads one partial per thread");
 
 __device__ __forceinline__ float combine(int type, float a, float b) {
     switch (type) {
@@ -60,8 +61,14 @@ __global__ __launch_bounds__(CU_THREADS) void cur_combine_kernel(const float* __
 // pass 2: divide by the row total (the partials added in block order), sinks = 1
 __global__ __launch_bounds__(CU_THREADS) void cur_normalize_kernel(float* __restrict__ scores, const float* __restrict__ partial, uint32_t nblk, uint32_t S,
                                                                    uint32_t num_sinks) {
-    float tot = 0.f;
-    for (uint32_t i = 0; i < nblk; ++i) tot += partial[(size_t)blockIdx.y * nblk + i];
+    // row total: the nblk <= CU_MAXBLK = CU_THREADS partials, one per thread, added in a fixed (tree) order -- every workgroup of
+    // the row computes the same value (a serial loop over 256 dependent loads per thread was 25 of this kernel's 27 us)
+    __shared__ float red[CU_THREADS / 64];
+    float t = threadIdx.x < nblk ? partial[(size_t)blockIdx.y * nblk + threadIdx.x] : 0.f;
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
     float* out = scores + (size_t)blockIdx.y * S;
     for (uint32_t s = blockIdx.x * CU_THREADS + threadIdx.x; s < S; s += gridDim.x * CU_THREADS) out[s] = s < num_sinks ? 1.0f : out[s] / tot;
 }

@@ -373,16 +373,35 @@ __global__ __launch_bounds__(256) void ea_qstats_combine(const float* __restrict
     }
     __syncthreads();
     if (!cov) return;
-    for (uint32_t e = blockIdx.x * 1024 + threadIdx.x; e < (blockIdx.x + 1) * 1024; e += 256) {
-        const uint32_t i = e >> 7, j = e & 127;
-        float s = 0.f;
-        for (uint32_t c = 0; c < nchunk; ++c) {
-            const float nc = (float)(min((c + 1) * rows_per_chunk, Sq) - c * rows_per_chunk);
-            const float ai = muc[c * 128 + i] - mug[i], aj = muc[c * 128 + j] - mug[j];
-            s += s2[((size_t)bh * nchunk + c) * 16384 + e] + nc * (ai * aj - del[c * 128 + i] * del[c * 128 + j]);
+    // The 67 MB of raw second moments (32 heads x <= 32 chunks x 64 KiB) are this kernel's whole cost: every thread keeps its four
+    // elements' loads of several chunks in flight (4 x 8 independent 4-byte loads; one dependent load per iteration ran at 2 TB/s).
+    const uint32_t e0 = blockIdx.x * 1024 + threadIdx.x;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* sp = s2 + (size_t)bh * nchunk * 16384 + e0;
+    for (uint32_t c0 = 0; c0 < nchunk; c0 += 8) {
+        float v[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t c = min(c0 + u, nchunk - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[u][q] = sp[(size_t)c * 16384 + q * 256];
         }
-        cov[(size_t)bh * 16384 + e] = s * invN;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t c = c0 + u;
+            if (c < nchunk) {
+                const float nc = (float)(min((c + 1) * rows_per_chunk, Sq) - c * rows_per_chunk);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t e = e0 + q * 256, i = e >> 7, j = e & 127;
+                    const float ai = muc[c * 128 + i] - mug[i], aj = muc[c * 128 + j] - mug[j];
+                    s[q] += v[u][q] + nc * (ai * aj - del[c * 128 + i] * del[c * 128 + j]);   // (chunk order as before: same sums)
+                }
+            }
+        }
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cov[(size_t)bh * 16384 + e0 + q * 256] = s[q] * invN;
 }
 
 void qstats_plan(int64_t Sq, uint32_t& nchunk, uint32_t& rows) {

@@ -109,29 +109,50 @@ __global__ __launch_bounds__(KD_THREADS) void keydiff_anchor_scalar_kernel(const
     }
 }
 
-// anchor[bh][d] = (sum over workgroups of partial) / S, then scaled to unit length (cosine_similarity's y / max(||y||, eps))
-__global__ __launch_bounds__(KD_THREADS) void keydiff_anchor_reduce_kernel(const float* __restrict__ partial, uint32_t nwg, uint32_t D,
-                                                                           uint32_t S, float* __restrict__ anchor) {
-    __shared__ float wsum[KD_THREADS / 64];
+// anchor[bh][d] = (sum over workgroups of partial) / S, then scaled to unit length (cosine_similarity's y / max(||y||, eps)).
+// 1024 threads per (b, h): `stripes` threads share a dimension and add interleaved subsets of the nwg partial rows
+// (independent loads in flight), the stripes are then added in a fixed order -- deterministic.  (One thread per dimension
+// walking all 256 partial rows one dependent load after the other took 64 us at 8 x 131072: more than a pass over K.)
+constexpr int KD_RED_THREADS = 1024;
+__global__ __launch_bounds__(KD_RED_THREADS) void keydiff_anchor_reduce_kernel(const float* __restrict__ partial, uint32_t nwg, uint32_t D,
+                                                                               uint32_t S, float* __restrict__ anchor) {
+    __shared__ float red[KD_RED_THREADS];
+    __shared__ float wsum[KD_RED_THREADS / 64];
     const uint32_t bh = blockIdx.x;
     const float* p = partial + (size_t)bh * nwg * D;
     float* a = anchor + (size_t)bh * D;
+    uint32_t DB = 1;                                   // dimensions per sweep: the power of two >= min(D, 1024)
+    while (DB < D && DB < KD_RED_THREADS) DB <<= 1;
+    const uint32_t stripes = KD_RED_THREADS / DB;
+    const uint32_t dl = threadIdx.x % DB, st = threadIdx.x / DB;
     float ss = 0.f;
-    for (uint32_t d = threadIdx.x; d < D; d += KD_THREADS) {
+    for (uint32_t db = 0; db < D; db += DB) {
+        const uint32_t d = db + dl;
         float s = 0.f;
-        for (uint32_t w = 0; w < nwg; ++w) s += p[(size_t)w * D + d];
-        s /= (float)S;
-        a[d] = s;
-        ss = fmaf(s, s, ss);
+        if (d < D) {
+#pragma unroll 8
+            for (uint32_t w = st; w < nwg; w += stripes) s += p[(size_t)w * D + d];
+        }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (st == 0 && d < D) {
+            float tot = 0.f;
+            for (uint32_t i = 0; i < stripes; ++i) tot += red[i * DB + dl];
+            tot /= (float)S;
+            a[d] = tot;
+            ss = fmaf(tot, tot, ss);
+        }
+        __syncthreads();
     }
     ss = wave_sum(ss);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ss;
     __syncthreads();
     float tot = 0.f;
 #pragma unroll
-    for (int i = 0; i < KD_THREADS / 64; ++i) tot += wsum[i];
+    for (int i = 0; i < KD_RED_THREADS / 64; ++i) tot += wsum[i];
     const float inv = 1.f / fmaxf(sqrtf(tot), KD_EPS_COS);
-    for (uint32_t d = threadIdx.x; d < D; d += KD_THREADS) a[d] *= inv;  // same thread wrote a[d]
+    if (st == 0)
+        for (uint32_t d = dl; d < D; d += DB) a[d] *= inv;  // the same thread wrote a[d]
 }
 
 // ---- pass B -------------------------------------------------------------------------------------
@@ -249,7 +270,7 @@ int launch_keydiff(const void* x, KdMap map, uint32_t BH, uint32_t D, float* sco
         const uint32_t rows_per_wg = (map.S + p.nwg - 1) / p.nwg;
         KVP_LAUNCH("keydiff_anchor_kernel", stream, keydiff_anchor_scalar_kernel<DT><<<grid, KD_THREADS, 0, stream>>>(xp, map, D, rows_per_wg, partial));
     }
-    KVP_LAUNCH("keydiff_anchor_reduce_kernel", stream, keydiff_anchor_reduce_kernel<<<BH, KD_THREADS, 0, stream>>>(partial, p.nwg, D, map.S, anchor));
+    KVP_LAUNCH("keydiff_anchor_reduce_kernel", stream, keydiff_anchor_reduce_kernel<<<BH, KD_RED_THREADS, 0, stream>>>(partial, p.nwg, D, map.S, anchor));
     if (p.vec) {
 #define KVP_KD_CASE(L)                                                                                                                      \
     case L:                                                                                                                                 \

@@ -13,6 +13,20 @@ template <> __device__ __forceinline__ void st_elem<KVP_F32>(float* p, float x) 
 template <> __device__ __forceinline__ void st_elem<KVP_F16>(_Float16* p, float x) { *p = (_Float16)x; }
 template <> __device__ __forceinline__ void st_elem<KVP_BF16>(uint16_t* p, float x) { *p = (uint16_t)(__float_as_uint(round_dt<KVP_BF16>(x)) >> 16); }
 
+// cos / sin of a float32 angle (torch: `freqs.cos()`, `.sin()` of the float32 product delta * inv_freq).  The angles reach ~1e5 rad,
+// where cosf and sinf each run their slow argument reduction (140 of the kernel's 150 us at 8 x 65536 rows).  Instead: ONE
+// reduction to [-pi, pi] in double (exact to ~1e-16 of a revolution), the reduced angle split into a float32 head and tail, one
+// sincosf of the head on its short path and a first-order correction by the tail: accurate to ~1 ulp like cosf / sinf themselves.
+__device__ __forceinline__ void sincos_f32_angle(float angle, float& s, float& c) {
+    const double rev = (double)angle * 0.15915494309189535;   // 1 / (2 pi)
+    const double x = (rev - rint(rev)) * 6.283185307179586;
+    const float xh = (float)x, xl = (float)(x - (double)xh);
+    float sh, ch;
+    sincosf(xh, &sh, &ch);
+    c = fmaf(-sh, xl, ch);
+    s = fmaf(ch, xl, sh);
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void rerotate_kernel(typename Elem<DT>::T* __restrict__ k, const int32_t* __restrict__ idx,
                                                        const float* __restrict__ inv_freq, uint32_t n, uint32_t D) {
@@ -25,11 +39,56 @@ __global__ __launch_bounds__(256) void rerotate_kernel(typename Elem<DT>::T* __r
         const uint32_t j = i / half, d = i - j * half;
         const float delta = (float)((int32_t)j - ib[j]);
         const float freq = __fmul_rn(delta, inv_freq[d]);
-        const float c = round_dt<DT>(cosf(freq)), s = round_dt<DT>(sinf(freq));  // same angle for d and d + half
+        float sv, cv;
+        sincos_f32_angle(freq, sv, cv);
+        const float c = round_dt<DT>(cv), s = round_dt<DT>(sv);  // same angle for d and d + half
         typename Elem<DT>::T* row = kb + (size_t)j * D;
         const float k0 = Elem<DT>::ld(row + d), k1 = Elem<DT>::ld(row + d + half);
         st_elem<DT>(row + d, rope_elem<DT>(k0, c, -k1, s));
         st_elem<DT>(row + d + half, rope_elem<DT>(k1, c, k0, s));
+    }
+}
+
+// 2-byte dtypes, D % 16 == 0, 16-byte aligned rows: a thread owns 8 consecutive dims d0 .. d0+7 of the first half and the matching 8 of
+// the second half: two 16-byte loads, 8 angles, two 16-byte stores (the scalar kernel above moves 2 bytes per lane and instruction).
+template <int DT> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<KVP_BF16>(float lo, float hi) {
+    return (__float_as_uint(round_dt<KVP_BF16>(lo)) >> 16) | (__float_as_uint(round_dt<KVP_BF16>(hi)) & 0xFFFF0000u);
+}
+template <> __device__ __forceinline__ uint32_t pack2<KVP_F16>(float lo, float hi) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+template <int DT>
+__global__ __launch_bounds__(256) void rerotate_vec_kernel(typename Elem<DT>::T* __restrict__ k, const int32_t* __restrict__ idx,
+                                                           const float* __restrict__ inv_freq, uint32_t n, uint32_t D) {
+    const uint32_t half = D / 2, tpr = half / 8;   // threads per row
+    const uint32_t bh = blockIdx.y;
+    typename Elem<DT>::T* kb = k + (size_t)bh * n * D;
+    const int32_t* ib = idx + (size_t)bh * n;
+    const uint32_t total = n * tpr;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t j = i / tpr, d0 = (i - j * tpr) * 8;
+        const float delta = (float)((int32_t)j - ib[j]);
+        typename Elem<DT>::T* row = kb + (size_t)j * D;
+        const uint4 a = *reinterpret_cast<const uint4*>(row + d0), b = *reinterpret_cast<const uint4*>(row + d0 + half);
+        float k0[8], k1[8], o0[8], o1[8];
+        unpack16<DT>(a, k0);
+        unpack16<DT>(b, k1);
+        const float4 f0 = *reinterpret_cast<const float4*>(inv_freq + d0), f1 = *reinterpret_cast<const float4*>(inv_freq + d0 + 4);
+        const float fr[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float freq = __fmul_rn(delta, fr[e]);
+            float sv, cv;
+            sincos_f32_angle(freq, sv, cv);
+            const float c = round_dt<DT>(cv), s = round_dt<DT>(sv);
+            o0[e] = rope_elem<DT>(k0[e], c, -k1[e], s);
+            o1[e] = rope_elem<DT>(k1[e], c, k0[e], s);
+        }
+        *reinterpret_cast<uint4*>(row + d0) = make_uint4(pack2<DT>(o0[0], o0[1]), pack2<DT>(o0[2], o0[3]), pack2<DT>(o0[4], o0[5]), pack2<DT>(o0[6], o0[7]));
+        *reinterpret_cast<uint4*>(row + d0 + half) = make_uint4(pack2<DT>(o1[0], o1[1]), pack2<DT>(o1[2], o1[3]), pack2<DT>(o1[4], o1[5]), pack2<DT>(o1[6], o1[7]));
     }
 }
 
@@ -47,6 +106,14 @@ extern "C" int kvp_rerotate_keys(void* k, int dtype, int64_t B, int64_t H, int64
     const uint32_t total = (uint32_t)(n * (D / 2));
     const uint32_t BH = (uint32_t)(B * H);
     const uint32_t bx = std::max<uint32_t>(1, std::min<uint32_t>((total + 255) / 256, std::max<uint32_t>(1, 4096 / BH)));
+    if (dtype != KVP_F32 && D % 16 == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)inv_freq % 16) == 0) {
+        const uint32_t tv = (uint32_t)(n * (D / 16));
+        const uint32_t bv = std::max<uint32_t>(1, std::min<uint32_t>((tv + 255) / 256, std::max<uint32_t>(1, 4096 / BH)));
+        if (dtype == KVP_F16) KVP_LAUNCH("rerotate_kernel", stream, rerotate_vec_kernel<KVP_F16><<<dim3(bv, BH), 256, 0, stream>>>(static_cast<_Float16*>(k), idx, inv_freq, (uint32_t)n, (uint32_t)D));
+        else KVP_LAUNCH("rerotate_kernel", stream, rerotate_vec_kernel<KVP_BF16><<<dim3(bv, BH), 256, 0, stream>>>(static_cast<uint16_t*>(k), idx, inv_freq, (uint32_t)n, (uint32_t)D));
+        KVP_CHECK_LAUNCH("rerotate");
+        return KVP_OK;
+    }
     switch (dtype) {
         case KVP_F32: KVP_LAUNCH("rerotate_kernel", stream, rerotate_kernel<KVP_F32><<<dim3(bx, BH), 256, 0, stream>>>(static_cast<float*>(k), idx, inv_freq, (uint32_t)n, (uint32_t)D)); break;
         case KVP_F16: KVP_LAUNCH("rerotate_kernel", stream, rerotate_kernel<KVP_F16><<<dim3(bx, BH), 256, 0, stream>>>(static_cast<_Float16*>(k), idx, inv_freq, (uint32_t)n, (uint32_t)D)); break;

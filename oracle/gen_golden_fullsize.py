@@ -104,5 +104,63 @@ def main(argv):
               f"band entries {len(out['band_pos'])}; O32-vs-Obf overlap {overlap:.4f}, worst ulps above/below threshold {worst_drop:.1f}/{worst_keep:.1f}", flush=True)
 
 
+def gen_batch_case(name):
+    """BATCH_CASES (tests/_fullsize.py): the reference's float32 run over a batch of B different elements in ONE call -- its pad
+    constant is the maximum over the whole batch (snapkv_press.py:103).  As in the single-element SnapKV cases the float32 run
+    consumes the bf16 model's own window queries (snapkv_press.py:53-58 in bf16, through a q_proj hook + identity rotary tables)."""
+    from gen_golden import _install_shims
+
+    _install_shims()
+    import numpy as np
+    import torch
+    from kvpress import SnapKVPress  # the reference
+    from kvpress.utils import get_prerope_query_states
+    from transformers.models.llama.modeling_llama import rotate_half
+
+    import _fullsize as F
+    import bench
+
+    spec = F.BATCH_CASES[name]
+    assert spec["kind"] == "snapkv"
+    S, ratio, B, W = spec["S"], spec["ratio"], len(spec["elements"]), F.WINDOW
+    n_kept = int(S * (1 - ratio))
+    kv = [F.make_kv(F.element_spec(spec, b)) for b in range(B)]
+    keys, values = torch.cat([k for k, _ in kv]), torch.cat([v for _, v in kv])
+    hidden = torch.cat([F.make_hidden(F.element_spec(spec, b)) for b in range(B)])
+    att, rot = bench.build_module(torch.device("cpu"))
+    att.rotary_emb = rot
+    press = SnapKVPress(compression_ratio=ratio, window_size=W, kernel_size=5)
+    with torch.no_grad():
+        pe_bf = rot(hidden[:1], torch.arange(S)[None])
+        q = get_prerope_query_states(att, hidden[:, -W:])                                              # snapkv_press.py:53 (bf16 model)
+        cos, sin = pe_bf[0][:, -W:], pe_bf[1][:, -W:]
+        q_rot = (q * cos.unsqueeze(1)) + (rotate_half(q) * sin.unsqueeze(1))                           # :56-58 (bf16)
+        att32 = att.float()
+        handle = att32.q_proj.register_forward_hook(lambda m, i, o: q_rot.float().transpose(1, 2).reshape(B, W, F.H_Q * F.D))
+        pe_id = (torch.ones((1, S, F.D)), torch.zeros((1, S, F.D)))
+        t0 = time.perf_counter()
+        sc32 = press.score(att32, hidden.float(), keys.float(), values.float(), None, {"position_embeddings": pe_id})   # :61-105 in float32, B = 2
+        dt = time.perf_counter() - t0
+        handle.remove()
+    assert tuple(sc32.shape) == (B, F.H_KV, S)
+    pad_value = float(sc32[..., -1].max())
+    assert bool((sc32[..., S - W:] == pad_value).all()), "one pad constant for the whole batch"
+    out = {"B": np.int64(B), "pad_value": np.float32(pad_value), "elem_max": sc32[..., :S - W].amax(dim=(1, 2)).numpy().astype(np.float32)}
+    for b in range(B):
+        for k, v in F.pack_reference(sc32[b:b + 1], n_kept, S - W, S, subsample=F.BATCH_SUBSAMPLE).items():
+            out[f"{k}__b{b}"] = v
+    path = os.path.join(REPO, "tests", "golden", f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path)} bytes; reference {dt:.1f} s (float32, B = {B}); pad constant {pad_value:.6g}, per-element maxima {out['elem_max']}", flush=True)
+
+
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    import _fullsize as _F
+
+    args = sys.argv[1:]
+    single = [a for a in args if a in _F.FULL_CASES] if args else list(_F.FULL_CASES)
+    batch = [a for a in args if a in _F.BATCH_CASES] if args else list(_F.BATCH_CASES)
+    if single:
+        main(single)
+    for name in batch:
+        gen_batch_case(name)

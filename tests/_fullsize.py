@@ -19,6 +19,14 @@ FULL_CASES = {
     "full_snapkv128k_B": dict(kind="snapkv", S=131072 - 1000 + 37, ratio=0.5, data="B", seed=113),  # ragged length, structured keys
     "full_ea128k": dict(kind="ea", S=131072, ratio=0.7, data="B", seed=104),                       # BASELINE config 4
 }
+# BASELINE config 5's shard shape: ONE reference run over a batch of two different elements (flat data, then structured data with
+# ~100x larger score maxima), i.e. with the reference's pad constant `scores.max().item() + 1` taken over BOTH (snapkv_press.py:103).
+# The kernels are then run per element (one shard per GPU: each shard only sees its own maximum) and on the whole batch: the
+# retained sets must be the reference's either way.  Stored per element with pack_reference (float32 "O32" run only).
+BATCH_CASES = {
+    "full_snapkv128k_B2": dict(kind="snapkv", S=131072, ratio=0.5, elements=[dict(data="A", seed=103), dict(data="B", seed=213)]),
+}
+BATCH_SUBSAMPLE = 32   # (the dense per-element comparison is full_snapkv128k's job: these fixtures keep every 32nd score + the band)
 SUBSAMPLE = 8      # the fixtures keep every 8th score (offset 5) + everything near the selection threshold
 SUB_OFFSET = 5
 BAND = 4e-3        # relative half-width of the stored threshold band (4x the 1e-3 score tolerance)
@@ -53,7 +61,12 @@ def make_hidden(spec: dict):
     return h
 
 
-def pack_reference(scores: torch.Tensor, n_kept: int, pad_lo: int, pad_hi: int) -> dict:
+def element_spec(spec: dict, b: int) -> dict:
+    """the single-element spec of element b of a BATCH_CASES entry (for make_kv / make_hidden)"""
+    return dict(kind=spec["kind"], S=spec["S"], ratio=spec["ratio"], **spec["elements"][b])
+
+
+def pack_reference(scores: torch.Tensor, n_kept: int, pad_lo: int, pad_hi: int, subsample: int = SUBSAMPLE) -> dict:
     """Fixture arrays from reference float32 scores [1, H, S]: every SUBSAMPLE-th score, the top-k membership bitmask, the
     threshold per row and every score within BAND of it.  Columns [pad_lo, pad_hi) hold the reference's pad constant
     (max + 1: kept by construction) and are excluded from the numeric comparison."""
@@ -64,7 +77,7 @@ def pack_reference(scores: torch.Tensor, n_kept: int, pad_lo: int, pad_hi: int) 
     kept.scatter_(1, idx, True)
     t = sc.gather(1, idx).amin(-1)
     out = {
-        "sub": sc[:, SUB_OFFSET::SUBSAMPLE].numpy().astype(np.float32),
+        "sub": sc[:, SUB_OFFSET::subsample].numpy().astype(np.float32), "subsample": np.int64(subsample),
         "kept_bits": np.packbits(kept.numpy(), axis=-1),
         "threshold": t.numpy().astype(np.float32),
         "n_kept": np.int64(n_kept), "pad": np.asarray([pad_lo, pad_hi], dtype=np.int64),
@@ -90,7 +103,7 @@ def check_against_reference(fx, scores: torch.Tensor, idx: torch.Tensor, rtol: f
     pad_lo, pad_hi = (int(x) for x in fx["pad"])
     assert idx.shape[-1] == n
     sub = torch.from_numpy(fx["sub"])
-    cols = torch.arange(SUB_OFFSET, S, SUBSAMPLE)
+    cols = torch.arange(SUB_OFFSET, S, int(fx["subsample"]) if "subsample" in fx else SUBSAMPLE)
     numeric = (cols < pad_lo) | (cols >= pad_hi)
     got = sc[:, cols]
     rel = ((got - sub).abs() / sub.abs().clamp_min(1e-30))[:, numeric]
@@ -99,7 +112,8 @@ def check_against_reference(fx, scores: torch.Tensor, idx: torch.Tensor, rtol: f
     if "sub_pure" in fx:   # all-float32 reference run (queries never rounded to bf16): differs by the model's bf16 q / cos / sin
         pure = torch.from_numpy(fx["sub_pure"])
         rel_pure = ((got - pure).abs() / pure.abs().clamp_min(1e-30))[:, numeric]
-        assert rel_pure.max() <= 2e-2, f"scores differ from the all-float32 reference by {float(rel_pure.max()):.3e}"
+        # measured when the fixtures were made: 3.0e-4 (flat data) / 4.5e-3 (structured keys) -- the bound leaves a third of headroom
+        assert rel_pure.max() <= 6e-3, f"scores differ from the all-float32 reference by {float(rel_pure.max()):.3e}"
     kept_ref = torch.from_numpy(np.unpackbits(fx["kept_bits"], axis=-1)[:, :S].astype(bool))
     kept = torch.zeros((H, S), dtype=torch.bool)
     kept.scatter_(1, idx[0].long().cpu(), True)

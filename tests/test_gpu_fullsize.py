@@ -150,6 +150,50 @@ def test_config3_snapkv_128k(name):
         assert torch.equal(ko, keys.gather(2, e)) and torch.equal(vo, values.gather(2, e))
 
 
+def test_config5_shards_keep_what_the_batched_reference_keeps():
+    """BASELINE config 5 (batch sharded over the GPUs) pinned by the reference: tests/golden/full_snapkv128k_B2.npz is ONE
+    float32 run of NVIDIA/kvpress over a batch of two elements whose score maxima differ by ~3000x, with ITS pad constant (the maximum
+    over the whole batch + 1, snapkv_press.py:103).  (a) every element on its own, as a shard of `bench.py --gpus N` sees it (pad = its own
+    maximum + 1), and (b) the whole batch in one call (pad = the batch maximum + 1, the reference's value): scores within 1e-3 of the
+    reference's, retained sets the reference's up to the tolerance band, and (a) == (b) exactly."""
+    import os
+
+    import _fullsize as F
+    import kvpress_amd as P
+
+    name = "full_snapkv128k_B2"
+    spec = F.BATCH_CASES[name]
+    fxa = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{name}.npz"))
+    S, Bn = spec["S"], len(spec["elements"])
+    n = int(S * 0.5)
+    kv = [F.make_kv(F.element_spec(spec, b)) for b in range(Bn)]
+    keys, values = torch.cat([k for k, _ in kv]).to(DEV), torch.cat([v for _, v in kv]).to(DEV)
+    hidden = torch.cat([F.make_hidden(F.element_spec(spec, b)) for b in range(Bn)]).to(DEV)
+    att, rot = llama_module()
+    press = P.SnapKVPress(0.5)
+    with torch.no_grad():
+        pe = rot(hidden[:1], torch.arange(S, device=DEV)[None])
+        kwargs = {"position_embeddings": pe}
+        scB = press.score(att, hidden, keys, values, None, kwargs)
+        idxB = _native().topk_select(scB, n)
+        koB, voB = press.compress(att, hidden, keys, values, None, kwargs)
+        pad = float(fxa["pad_value"])
+        assert abs(float(scB[..., -64:].max()) - pad) <= 1e-3 * pad and (scB[..., -64:] == scB[..., -64:].max()).all(), "batched call: the reference's pad constant"
+        for b in range(Bn):
+            fx = {k[:-len(f"__b{b}")]: fxa[k] for k in fxa.files if k.endswith(f"__b{b}")}
+            sc = press.score(att, hidden[b:b + 1], keys[b:b + 1], values[b:b + 1], None, kwargs)
+            idx = _native().topk_select(sc, n)
+            worst, differ = F.check_against_reference(fx, sc, idx)                       # (a) the shard
+            worstB, differB = F.check_against_reference(fx, scB[b:b + 1], idxB[b:b + 1])  # (b) the batch
+            own = sc[..., :-64].max() + 1
+            assert (sc[..., -64:] == own).all() and float(own) <= pad * (1 + 1e-3)
+            assert torch.equal(idx, idxB[b:b + 1]), "a shard keeps exactly what the batched call keeps"
+            assert torch.equal(sc[..., :-64], scB[b:b + 1, :, :-64])
+            ko, vo = press.compress(att, hidden[b:b + 1], keys[b:b + 1], values[b:b + 1], None, kwargs)
+            assert torch.equal(ko, koB[b:b + 1]) and torch.equal(vo, voB[b:b + 1])
+            print(f"{name}[{b}] vs the batched reference run: max rel err {worst:.2e} (shard) / {worstB:.2e} (batch), {differ} set differences (in band)")
+
+
 def test_config1_opt125m_plumbing():
     """BASELINE config 1: OPT-125m geometry (12 heads, D=64, fp32, 2k tokens), KnormPress(0.5) under the
     hook; [1,12,2048,64] -> [1,12,1024,64].  (The reference's __call__ cannot attach to OPT.)"""
