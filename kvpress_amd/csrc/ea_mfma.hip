@@ -415,12 +415,35 @@ void qstats_plan(int64_t Sq, uint32_t& nchunk, uint32_t& rows) {
 // (2) logits
 // =================================================================================================
 constexpr int EL_CHUNK = 4096;  // keys per workgroup
+constexpr int EL_TILE = 128;    // keys per LDS tile: ONE workgroup barrier per 128 keys (64-key tiles: a third of the wave cycles parked at it)
+constexpr int EL_SUBS = EL_TILE / 32;
+constexpr int EL_TILEB = EL_TILE * EM_ROWB;
 
-template <int DT>
+struct StageL { uint4 v[8]; };   // a 128-key tile in flight: 8 x 16 bytes per thread
+__device__ __forceinline__ StageL stagel_load(const char* __restrict__ base, int64_t row_bytes, uint32_t row0, uint32_t nrows) {
+    const uint32_t r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
+    StageL st;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t r = min(row0 + r0 + 16 * i, nrows - 1);  // unconditional loads; rows past the end are masked later
+        st.v[i] = *reinterpret_cast<const uint4*>(base + (int64_t)r * row_bytes + ch * 16);
+    }
+    return st;
+}
+__device__ __forceinline__ void stagel_store(const StageL st, unsigned char* buf) {   // (by value: a by-reference struct ends up in scratch)
+    const uint32_t r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t row = r0 + 16 * i;
+        *reinterpret_cast<uint4*>(buf + row * EM_ROWB + ((ch ^ (row & 15)) << 4)) = st.v[i];
+    }
+}
+
+template <int DT, bool HAS_COV>
 __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk,
                                                                         float* __restrict__ part_m, float* __restrict__ part_z) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * EM_TILEB];
-    __shared__ float red[2][4][EM_TILE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * EL_TILEB];
+    __shared__ float red[2][4][EL_TILE];
     // XCD-aware order: workgroups go round-robin over the 8 XCDs (linear id % 8), each with its own L2.  The G query heads of a
     // (kv-head, key chunk) unit read the same K chunk, so they take CONSECUTIVE slots of ONE XCD: the chunk enters that L2 once
     // instead of G times through G different XCDs (measured at 128k: L2 fetch traffic 1.09 GB -> see DESIGN section 5).
@@ -437,7 +460,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
 
     // this wave's 32-row strip of cov (rows j = 32 wv + n), split hi + lo: A fragments for all 8 k-steps
     uint4 chi[8], clo[8];
-    const bool has_cov = a.cov != nullptr;
+    constexpr bool has_cov = HAS_COV;
     {
         const float* crow = has_cov ? a.cov + ((size_t)bhq * 128 + wv * 32 + n) * 128 : nullptr;
 #pragma unroll
@@ -468,70 +491,100 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
 
     const uint32_t kbeg = chunk * EL_CHUNK;
     const uint32_t kend = min(kbeg + EL_CHUNK, a.Sp);
-    const uint32_t ntiles = (kend - kbeg + EM_TILE - 1) / EM_TILE;
+    const uint32_t ntiles = (kend - kbeg + EL_TILE - 1) / EL_TILE;
     float* lrow = logits + (size_t)bhq * a.Sp;
-    float m_run = KVP_NEG_INF, z_run = 0.f;  // threads 0..63: running softmax partial of the keys they own
+    float m_run = KVP_NEG_INF, z_run = 0.f;  // threads 0..127: running softmax partial of the keys they own
+
+    // K fragments of 32-key sub-tile `sub`: all eight k-steps requested together, one sub-tile AHEAD of their use (the compiler's
+    // own schedule requested two fragments at a time right in front of the MFMAs that consume them: one LDS round trip per four
+    // MFMAs, which -- not the matrix pipe, the barrier or the K stream -- is what the round-2 kernel's 290 us were made of)
+    auto frags = [&](const unsigned char* buf, int sub, uint4 (&kf)[8]) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) kf[ks] = frag16(buf, sub, ks * 2 + kg, n);
+    };
+    // the MFMA chains of a sub-tile (cov strip x K sub-tile, hi and lo part of cov)
+    auto chains = [&](const uint4 (&kf)[8], f32x16& ah, f32x16& al) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ah[i] = 0.f; al[i] = 0.f; }
+        if (has_cov) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                ah = mma32<DT>(chi[ks], kf[ks], ah);  // C[cov row][key]
+                al = mma32<DT>(clo[ks], kf[ks], al);
+            }
+        }
+    };
+    // row-dot of sub-tile `sub`: K in the C layout: key = sub*32 + n, dims 32 wv + 8 q + 4 kg + {0..3}: 8 bytes of 16-byte column 4 wv + q
+    auto rowdot = [&](const unsigned char* buf, int sub, const f32x16& ah, const f32x16& al, float* redrow) {
+        float val = 0.f;
+        const uint32_t row = sub * 32 + n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint2 kk = *reinterpret_cast<const uint2*>(buf + row * EM_ROWB + (((wv * 4 + q) ^ (row & 15)) << 4) + kg * 8);
+            const float k0 = lo16<DT>(kk.x), k1 = hi16<DT>(kk.x), k2 = lo16<DT>(kk.y), k3 = hi16<DT>(kk.y);
+            val = fmaf(k0, fmaf(ah[4 * q + 0] + al[4 * q + 0], a.inv_2d, muv[4 * q + 0]), val);
+            val = fmaf(k1, fmaf(ah[4 * q + 1] + al[4 * q + 1], a.inv_2d, muv[4 * q + 1]), val);
+            val = fmaf(k2, fmaf(ah[4 * q + 2] + al[4 * q + 2], a.inv_2d, muv[4 * q + 2]), val);
+            val = fmaf(k3, fmaf(ah[4 * q + 3] + al[4 * q + 3], a.inv_2d, muv[4 * q + 3]), val);
+        }
+        val += __shfl_xor(val, 32);
+        if (kg == 0) redrow[sub * 32 + n] = val;
+    };
 
     unsigned char* bufc = lds;
-    unsigned char* bufn = lds + EM_TILEB;
-    stage_store(stage_load(kb, row_bytes, kbeg, a.Sp), bufc);
+    unsigned char* bufn = lds + EL_TILEB;
+    stagel_store(stagel_load(kb, row_bytes, kbeg, a.Sp), bufc);
     __syncthreads();
     for (uint32_t t = 0; t < ntiles; ++t) {
-        const uint32_t key0 = kbeg + t * EM_TILE;
-        const Stage st = stage_load(kb, row_bytes, min(key0 + EM_TILE, kend - 1), a.Sp);
+        const uint32_t key0 = kbeg + t * EL_TILE;
+        const StageL st = stagel_load(kb, row_bytes, min(key0 + EL_TILE, kend - 1), a.Sp);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            f32x16 ah, al;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { ah[i] = 0.f; al[i] = 0.f; }
-            if (has_cov) {
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    const uint4 kf = frag16(bufc, sub, ks * 2 + kg, n);
-                    ah = mma32<DT>(chi[ks], kf, ah);  // C[cov row][key]
-                    al = mma32<DT>(clo[ks], kf, al);
-                }
-            }
-            // K in the C layout: key = sub*32 + n, dims 32 wv + 8 q + 4 kg + {0..3}: 8 bytes of 16-byte column 4 wv + q
-            float val = 0.f;
-            const uint32_t row = sub * 32 + n;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint2 kk = *reinterpret_cast<const uint2*>(bufc + row * EM_ROWB + (((wv * 4 + q) ^ (row & 15)) << 4) + kg * 8);
-                const float k0 = lo16<DT>(kk.x), k1 = hi16<DT>(kk.x), k2 = lo16<DT>(kk.y), k3 = hi16<DT>(kk.y);
-                val = fmaf(k0, fmaf(ah[4 * q + 0] + al[4 * q + 0], a.inv_2d, muv[4 * q + 0]), val);
-                val = fmaf(k1, fmaf(ah[4 * q + 1] + al[4 * q + 1], a.inv_2d, muv[4 * q + 1]), val);
-                val = fmaf(k2, fmaf(ah[4 * q + 2] + al[4 * q + 2], a.inv_2d, muv[4 * q + 2]), val);
-                val = fmaf(k3, fmaf(ah[4 * q + 3] + al[4 * q + 3], a.inv_2d, muv[4 * q + 3]), val);
-            }
-            val += __shfl_xor(val, 32);
-            if (kg == 0) red[t & 1][wv][sub * 32 + n] = val;
-        }
+        // software pipeline over the four sub-tiles: the chains of sub-tile s next to the row-dot of sub-tile s - 1 (two accumulator
+        // pairs), so that the row-dot does not read a register file the matrix pipe is still writing
+        f32x16 ah, al;
+        float* redw = red[t & 1][wv];
+        uint4 kfa[8], kfb[8];
+        static_assert(EL_SUBS == 4, "the pipeline below is written out for four sub-tiles");
+        if (has_cov) frags(bufc, 0, kfa);
+        if (has_cov) frags(bufc, 1, kfb);
+        chains(kfa, ah, al);
+        rowdot(bufc, 0, ah, al, redw);
+        if (has_cov) frags(bufc, 2, kfa);
+        chains(kfb, ah, al);
+        rowdot(bufc, 1, ah, al, redw);
+        if (has_cov) frags(bufc, 3, kfb);
+        chains(kfa, ah, al);
+        rowdot(bufc, 2, ah, al, redw);
+        chains(kfb, ah, al);
+        rowdot(bufc, 3, ah, al, redw);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < ntiles) stage_store(st, bufn);
+        if (t + 1 < ntiles) stagel_store(st, bufn);
         __syncthreads();
-        if (threadIdx.x < EM_TILE) {
+        if (threadIdx.x < EL_TILE) {
             const uint32_t kk = key0 + threadIdx.x;
             if (kk < kend) {
                 const float* rr = &red[t & 1][0][threadIdx.x];
-                const float l2 = (rr[0] + rr[EM_TILE] + rr[2 * EM_TILE] + rr[3 * EM_TILE]) * KVP_LOG2E;
+                const float l2 = (rr[0] + rr[EL_TILE] + rr[2 * EL_TILE] + rr[3 * EL_TILE]) * KVP_LOG2E;
                 lrow[kk] = l2;
                 softmax_merge(m_run, z_run, l2, 1.0f);
             }
         }
         unsigned char* tmp = bufc; bufc = bufn; bufn = tmp;
     }
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < EL_TILE) {   // two waves own keys: merge inside each wave, then across the two through LDS
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float m2 = __shfl_xor(m_run, o), z2 = __shfl_xor(z_run, o);
             softmax_merge(m_run, z_run, m2, z2);
         }
-        if (threadIdx.x == 0) {
-            part_m[(size_t)bhq * nblk + chunk] = m_run;
-            part_z[(size_t)bhq * nblk + chunk] = z_run;
-        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 64) { red[0][0][0] = m_run; red[0][0][1] = z_run; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        softmax_merge(m_run, z_run, red[0][0][0], red[0][0][1]);
+        part_m[(size_t)bhq * nblk + chunk] = m_run;
+        part_z[(size_t)bhq * nblk + chunk] = z_run;
     }
 }
 
@@ -593,8 +646,10 @@ int ea_mfma_logits(const EaArgs& a, int dtype, float* logits, uint32_t nblk, flo
     const uint64_t units = (uint64_t)nblk * a.B * a.Hkv;
     KVP_CHECK_ARG((units + 7) / 8 * 8 * a.G < ((uint64_t)1 << 31), "ea_logits_mfma: grid too large");
     const dim3 grid((uint32_t)((units + 7) / 8 * 8 * a.G));   // (unit, head-in-group) -> linear id: see the kernel
-    if (dtype == KVP_BF16) KVP_LAUNCH("ea_logits_mfma", stream, ea_logits_mfma_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z));
-    else KVP_LAUNCH("ea_logits_mfma", stream, ea_logits_mfma_kernel<KVP_F16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z));
+#define KVP_EL_LAUNCH(DTV, COV) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_kernel<DTV, COV><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)))
+    if (dtype == KVP_BF16) { if (a.cov) KVP_EL_LAUNCH(KVP_BF16, true); else KVP_EL_LAUNCH(KVP_BF16, false); }
+    else { if (a.cov) KVP_EL_LAUNCH(KVP_F16, true); else KVP_EL_LAUNCH(KVP_F16, false); }
+#undef KVP_EL_LAUNCH
     KVP_CHECK_LAUNCH("ea_logits_mfma");
     return KVP_OK;
 }
