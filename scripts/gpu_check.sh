@@ -9,21 +9,23 @@ WHAT="${*:-tests bench}"
 python __graft_entry__.py > gpurun_out/build.log 2>&1; echo "build rc=$?"
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
 if [[ "$WHAT" == *tests* ]]; then
-  for grp in rownorm rowdot observed lagkv topk gather fused fuzz cur snapkv_kernel snapkv_from snapkv_fused deterministic ea_qstats ea_score full_chain keydiff head_mean tova_from random_press press_fp32 press_native; do
-    timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --no-header -k "$grp" > gpurun_out/test_$grp.log 2>&1
-    echo "tests[$grp] rc=$? $(tail -1 gpurun_out/test_$grp.log)"
-  done
-  timeout 600 python -m pytest tests/test_pipeline.py tests/test_wrappers.py tests/test_finch.py tests/test_decoding_compression.py tests/test_reference_suite.py tests/test_think.py tests/test_simlayer.py -m gpu -q --no-header > gpurun_out/test_pipeline.log 2>&1
-  echo "tests[pipeline+wrappers+finch] rc=$? $(tail -1 gpurun_out/test_pipeline.log)"
-  timeout 1200 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --no-header > gpurun_out/test_fullsize.log 2>&1
-  echo "tests[fullsize] rc=$? $(tail -1 gpurun_out/test_fullsize.log)"
+  timeout 2400 python -m pytest tests -m gpu -q --no-header > gpurun_out/r03_gpu_tests.log 2>&1
+  echo "tests rc=$? $(tail -1 gpurun_out/r03_gpu_tests.log)"
   timeout 300 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$? $(tail -1 gpurun_out/smoke.log)"
 fi
 if [[ "$WHAT" == *bench* ]]; then
-  for wl in knorm32k knorm128k snapkv128k ea128k; do
-    timeout 900 python bench.py --workload $wl --profile-json gpurun_out/r02_kernels_$wl.json > gpurun_out/bench_$wl.log 2>&1
+  for wl in ${BENCH_WL:-knorm32k knorm128k snapkv128k ea128k}; do
+    timeout 900 python bench.py --workload $wl --profile-json gpurun_out/r03_kernels_$wl.json > gpurun_out/bench_$wl.log 2>&1
     echo "bench[$wl] rc=$? $(tail -1 gpurun_out/bench_$wl.log | cut -c1-300)"
-    tail -1 gpurun_out/bench_$wl.log > gpurun_out/r02_bench_$wl.json
+    tail -1 gpurun_out/bench_$wl.log > gpurun_out/r03_bench_$wl.json
+  done
+fi
+if [[ "$WHAT" == *frows* ]]; then
+  # SURVEY section 8(f) workloads (no CPU baseline: the four BASELINE configs above carry it)
+  for wl in keydiff128k cur128k finch128k chunk_snapkv128k rerotate128k decode_snapkv2k; do
+    timeout 600 python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/bench_$wl.log 2>&1
+    echo "bench[$wl] rc=$? $(tail -1 gpurun_out/bench_$wl.log | cut -c1-200)"
+    tail -1 gpurun_out/bench_$wl.log > gpurun_out/r03_bench_$wl.json
   done
 fi
 if [[ "$WHAT" == *ab* ]]; then
@@ -48,8 +50,18 @@ if [[ "$WHAT" == *pmc* ]]; then
     done
     ( cd "$GRAFT_REPO_ROOT"; echo "# rocprofv3 --kernel-trace --pmc <set> -- python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline (four separate passes)";
       echo "# csrc_digest $(python -c 'import bench; print(bench.csrc_digest())')";
-      python scripts/rocpd_pmc.py $(find gpurun_out/pmc_${wl}_[0-9] -name '*.db' | sort) ) > "$GRAFT_REPO_ROOT/gpurun_out/r02_pmc_summary_$wl.txt" 2>&1
+      python scripts/rocpd_pmc.py $(find gpurun_out/pmc_${wl}_[0-9] -name '*.db' | sort) ) > "$GRAFT_REPO_ROOT/gpurun_out/r03_pmc_summary_$wl.txt" 2>&1
     rm -rf "$GRAFT_REPO_ROOT"/gpurun_out/pmc_${wl}_[0-9]
+  done
+  cd "$GRAFT_REPO_ROOT"
+fi
+if [[ "$WHAT" == *timeline* ]]; then
+  cd /tmp
+  for wl in ${TL_WL:-snapkv128k knorm32k}; do
+    timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/tl_$wl" -o t -- python "$GRAFT_REPO_ROOT/bench.py" --workload $wl --steps 6 --warmup 2 --prewarm-ms 5 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/tl_$wl.log" 2>&1
+    python "$GRAFT_REPO_ROOT/scripts/timeline.py" "$GRAFT_REPO_ROOT/gpurun_out/tl_$wl" > "$GRAFT_REPO_ROOT/gpurun_out/r03_timeline_$wl.txt" 2>&1
+    echo "timeline[$wl] rc=$?"
+    rm -rf "$GRAFT_REPO_ROOT/gpurun_out/tl_$wl"
   done
   cd "$GRAFT_REPO_ROOT"
 fi
@@ -58,8 +70,8 @@ if [[ "$WHAT" == *prof* ]]; then
   for wl in ${PROF_WL:-snapkv128k knorm32k knorm128k ea128k}; do
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -o $wl -- python "$GRAFT_REPO_ROOT/bench.py" --workload $wl --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" 2>&1
     echo "prof[$wl] rc=$?"
-    find "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -name "*kernel_stats.csv" -exec cp {} "$GRAFT_REPO_ROOT/gpurun_out/r02_rocprofv3_kernel_stats_$wl.csv" \;
-    grep "^{" "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" | tail -1 > "$GRAFT_REPO_ROOT/gpurun_out/r02_bench_under_rocprof_$wl.json"
+    find "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -name "*kernel_stats.csv" -exec cp {} "$GRAFT_REPO_ROOT/gpurun_out/r03_rocprofv3_kernel_stats_$wl.csv" \;
+    grep "^{" "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" | tail -1 > "$GRAFT_REPO_ROOT/gpurun_out/r03_bench_under_rocprof_$wl.json"
     rm -rf "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl"
   done
   cd "$GRAFT_REPO_ROOT"
