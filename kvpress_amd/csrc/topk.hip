@@ -41,12 +41,7 @@ namespace {
 // exclusive prefix sum over the 256 threads of the block (4 waves); lds: >= 4 words
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
+    const uint32_t inc = wave_incl_scan(v);   // DPP row shifts / broadcasts (topk_block.h)
     if (lane == 63) lds[w] = inc;
     __syncthreads();
     uint32_t woff = 0, tot = 0;

@@ -6,27 +6,35 @@
 constexpr int TR_THREADS = 1024;
 constexpr int TR_WAVES = TR_THREADS / 64;
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / row broadcasts (the classic gfx9 sequence: three row_shr
+// of the input, row_shr:4 / :8 with bank masks, row_bcast:15 / :31 with row masks): 7 VALU-speed steps instead of the 6 dependent
+// ds_bpermute round trips of a __shfl_up ladder (~100+ cycles each) -- the scans are on the critical path of the latency-bound
+// select kernels.  update_dpp(old = 0, ...) yields 0 for lanes that the masks disable or whose source lies outside the row.
+#define KVP_DPP0(v, ctrl, row_mask, bank_mask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (row_mask), (bank_mask), false))
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+    uint32_t v = x;
+    v += KVP_DPP0(x, 0x111, 0xf, 0xf);   // row_shr:1
+    v += KVP_DPP0(x, 0x112, 0xf, 0xf);   // row_shr:2
+    v += KVP_DPP0(x, 0x113, 0xf, 0xf);   // row_shr:3   -> sum of a lane and its three predecessors inside the 16-lane row
+    v += KVP_DPP0(v, 0x114, 0xf, 0xe);   // row_shr:4 into lanes 4..15 of every row
+    v += KVP_DPP0(v, 0x118, 0xf, 0xc);   // row_shr:8 into lanes 8..15              -> inclusive scan of every row
+    v += KVP_DPP0(v, 0x142, 0xa, 0xf);   // row_bcast:15 into rows 1 and 3
+    v += KVP_DPP0(v, 0x143, 0xc, 0xf);   // row_bcast:31 into rows 2 and 3          -> inclusive scan of the wave
+    return v;
+}
+#undef KVP_DPP0
+
 // exclusive prefix sum over the 1024 threads of the block; lds: >= TR_WAVES words.
 // The wave index is wave-uniform (readfirstlane) and the second level -- the scan over the 16 wave totals -- runs in the lanes
-// (every 16-lane group scans the same 16 values; the wave picks its offset with v_readlane): no per-wave comparison masks, which
+// (every 16-lane row scans the same 16 values; the wave picks its offset with v_readlane): no per-wave comparison masks, which
 // the compiler would otherwise keep alive in 2 x 15 scalar registers across every scan of a kernel.
 __device__ __forceinline__ uint32_t row_excl_scan(uint32_t v, uint32_t* lds, uint32_t* total) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
+    const uint32_t inc = wave_incl_scan(v);
     if (lane == 63) lds[w] = inc;
     __syncthreads();
-    uint32_t x = lds[lane & (TR_WAVES - 1)];
-#pragma unroll
-    for (int o = 1; o < TR_WAVES; o <<= 1) {
-        const uint32_t t = __shfl_up(x, o);
-        if ((lane & (TR_WAVES - 1)) >= o) x += t;
-    }
+    const uint32_t x = wave_incl_scan(lds[lane & (TR_WAVES - 1)]);   // lanes 0..15 (row 0): the inclusive scan of the 16 wave totals
     const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)x, TR_WAVES - 1);
     const uint32_t below = (uint32_t)__builtin_amdgcn_readlane((int)x, w > 0 ? w - 1 : 0);
     const uint32_t woff = w > 0 ? below : 0u;
