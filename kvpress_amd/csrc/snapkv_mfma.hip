@@ -419,6 +419,14 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_asm(SnapArgs a, uint3
     }
     wait_all_landed();
 
+#ifdef KVP_SK_STAMP   // lab build (tools/gen_stage_asm.py GEN_STAMP=1): the asm block returned cycle counters instead of statistics
+    if (kg == 0) {
+        const size_t o = ((size_t)(b * a.Hq + hq) * a.W + row0 + n) * nchunk + chunk;
+        part_m[o] = m;
+        part_z[o] = z;
+    }
+    return;
+#endif
     float mm = m == KVP_NEG_INF ? KVP_NEG_INF : m * c, zz = z;
     const float m2 = __shfl_xor(mm, 32), z2 = __shfl_xor(zz, 32);
     softmax_merge(mm, zz, m2, z2);

@@ -8,7 +8,7 @@ for spec in "$@"; do
   [[ "$spec" == tc_* ]] && continue
   name=${spec%%=*}; abl=${spec#*=}
   env $abl python tools/gen_stage_asm.py kernel > /dev/null
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form -c kvpress_amd/csrc/snapkv_mfma.hip -o /tmp/snapkv_mfma_$name.o 2>/tmp/snapkv_mfma_$name.err || { cat /tmp/snapkv_mfma_$name.err; exit 1; }
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form $(env $abl bash -c 'echo ${KVP_VARIANT_CFLAGS:-}') -c kvpress_amd/csrc/snapkv_mfma.hip -o /tmp/snapkv_mfma_$name.o 2>/tmp/snapkv_mfma_$name.err || { cat /tmp/snapkv_mfma_$name.err; exit 1; }
   objs=$(ls kvpress_amd/build/*.o | grep -v snapkv_mfma.o)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o kvpress_amd/lib/variants/$name.so $objs /tmp/snapkv_mfma_$name.o
   echo "built $name ($abl)"

@@ -343,7 +343,8 @@ if __name__ == "__main__":
 #   pass 2 only: s27 wave index, s[40:41] global address of the column sums of the tile to flush, s42 its stride, s31 tile barriers passed
 import os as _os
 
-SGPR_CLOB = '"s20", "s21", "s22", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s40", "s41", "s42", "s44", "s45", "s46", "vcc", "scc"'
+SGPR_CLOB = '"s20", "s21", "s22", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s40", "s41", "s42", "s44", "s45", "s46", "vcc", "scc"' + (
+    ', "s50", "s51", "s52", "s54", "s55", "s56", "s57", "s58", "s59", "s60"' if int(_os.environ.get("GEN_STAMP", "0")) else "")
 GEN_ABL = set(filter(None, _os.environ.get("GEN_ABL", "").split(",")))   # lab builds: nodma, nobar, novalu, nomfma, nolds (results wrong)
 # schedule labs (results unchanged): GEN_DMA_AT=k issues a stage's LDS-DMA request after its k-th MFMA instead of at the head;
 # GEN_RPS fragment reads per MFMA slot (default 2: slots 0-3), GEN_READ_FROM first slot that carries reads; GEN_PRIO=1 raises
@@ -352,6 +353,10 @@ GEN_DMA_AT = int(_os.environ["GEN_DMA_AT"]) if _os.environ.get("GEN_DMA_AT", "")
 GEN_RPS = int(_os.environ.get("GEN_RPS", "2"))
 GEN_READ_FROM = int(_os.environ.get("GEN_READ_FROM", "0"))
 GEN_PRIO = int(_os.environ.get("GEN_PRIO", "0"))
+# GEN_STAMP=1 (with -DKVP_SK_STAMP for snapkv_mfma.hip, tools/build_variants.sh "stamp=..."): pass 1 returns, instead of its statistics,
+# the cycles a wave spent in the whole loop / waiting for K fragments (even / odd window rows of part_m) and waiting for the K stream /
+# at the tile barrier (even / odd rows of part_z): tools/sk_lab.py --stamps prints the breakdown
+GEN_STAMP = int(_os.environ.get("GEN_STAMP", "0"))
 
 
 class Cfg:
@@ -402,11 +407,21 @@ def stage_head(cfg, p, flush=None):
     previous tile's buffer; then the request of sub-block `sub` of the tile NBUF - 1 ahead, which lands in the buffer of the
     previous tile (address clamped to the walk's last tile: s28 counts the advances left)."""
     buf, sub = cfg.pos(p)
-    L = ["s_waitcnt lgkmcnt(0)"]
-    if sub == 3:
-        L += [f"s_waitcnt vmcnt({cfg.inflight})"] + ([] if "nobar" in GEN_ABL else ["s_barrier"])
-        if flush:
-            L += flush
+    if GEN_STAMP:
+        # lab: where a wave's cycles go.  s_memtime before / after each wait of the head; s50 += fragment (lgkmcnt) wait, s51 += K stream
+        # (vmcnt) wait, s52 += barrier wait.  Every stamp is an SMEM round trip itself (~50-100 cycles, included in the sums).
+        L = ["s_memtime s[56:57]", "s_waitcnt lgkmcnt(0)", "s_memtime s[58:59]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s60, s58, s56", "s_add_u32 s50, s50, s60"]
+        if sub == 3:
+            L += [f"s_waitcnt vmcnt({cfg.inflight})", "s_memtime s[56:57]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s60, s56, s58", "s_add_u32 s51, s51, s60",
+                  "s_barrier", "s_memtime s[58:59]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s60, s58, s56", "s_add_u32 s52, s52, s60"]
+            if flush:
+                L += flush
+    else:
+        L = ["s_waitcnt lgkmcnt(0)"]
+        if sub == 3:
+            L += [f"s_waitcnt vmcnt({cfg.inflight})"] + ([] if "nobar" in GEN_ABL else ["s_barrier"])
+            if flush:
+                L += flush
     dst = ((buf + cfg.nbuf - 1) % cfg.nbuf) * 32768 + sub * 8192
     D = []
     if "nodma" not in GEN_ABL:
@@ -639,6 +654,8 @@ def p1l_body(dt):
           f"v_mov_b32 v{MREF}, 0xff800000", f"v_mov_b32 v{OFFL}, 0x7f800000", f"v_mov_b32 v{Z_}, 0",   # m_ref = -inf, OFF = +inf
           "s_mov_b32 s27, %21"] + prio_lines() + [
           "s_waitcnt vmcnt(0)", "s_barrier"]
+    if GEN_STAMP:
+        L += ["s_mov_b32 s50, 0", "s_mov_b32 s51, 0", "s_mov_b32 s52, 0", "s_memtime s[54:55]", "s_waitcnt lgkmcnt(0)"]
     L += [f"ds_read_b128 {vr(KF0 + 4 * ks, 4)}, v{c.laddr + ks}" for ks in range(8)]
     slow = []
     # stages 0, 1: chains only; stage 2: first exp part (no check pending yet); from stage 3 on: check + exp part
@@ -667,7 +684,14 @@ def p1l_body(dt):
     for b in slow:
         L += b
     L.append("9:")
-    L += (["s_setprio 0"] if GEN_PRIO else []) + [f"v_mov_b32 %0, v{MREF}", f"v_mov_b32 %1, v{Z_}"]
+    if GEN_STAMP:
+        T = P1.T
+        L += ["s_memtime s[56:57]", "s_waitcnt lgkmcnt(0)", "s_sub_u32 s60, s56, s54",
+              f"v_mbcnt_lo_u32_b32 v{T}, -1, 0", f"v_and_b32 v{T}, 1, v{T}", f"v_cmp_eq_u32 vcc, 1, v{T}",
+              f"v_mov_b32 v{T + 1}, s60", f"v_mov_b32 v{T + 2}, s50", f"v_cndmask_b32 v{T + 1}, v{T + 1}, v{T + 2}, vcc", f"v_cvt_f32_u32 %0, v{T + 1}",
+              f"v_mov_b32 v{T + 1}, s51", f"v_mov_b32 v{T + 2}, s52", f"v_cndmask_b32 v{T + 1}, v{T + 1}, v{T + 2}, vcc", f"v_cvt_f32_u32 %1, v{T + 1}"]
+    else:
+        L += (["s_setprio 0"] if GEN_PRIO else []) + [f"v_mov_b32 %0, v{MREF}", f"v_mov_b32 %1, v{Z_}"]
     # the first check (position 2 of the first pass) must find S0 = 0 and vcc = 0
     i = L.index("1:")
     L[i:i] = [f"v_mov_b32 v{S0}, 0", "s_mov_b64 vcc, 0"]
