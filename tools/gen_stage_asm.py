@@ -163,6 +163,47 @@ def p1_stage(s, opts, lds_imm=None, dma=None):
     return [l for l in lines if l]
 
 
+# ---- one wave per SIMD (4-wave workgroup): a wave owns a whole q-head (both 32-row halves of the window) -------------------------
+# K fragments in AGPRs a[0:31] / a[32:63] (MFMA A operands may be AGPRs; ds_read may target them), the second half's accumulators in
+# the VGPRs the fragments freed.  Per stage: 16 MFMAs (two chains sharing their K fragments), the softmax pieces of both halves, 8
+# fragment reads, two LDS-DMA pieces.
+ACCB = [64, 80, 96]
+
+
+def w1_stage(s, opts, lds_imm=None, dma=None):
+    A = (ACC[s % 3], ACC[(s - 1) % 3], ACC[(s - 2) % 3])
+    B = (ACCB[s % 3], ACCB[(s - 1) % 3], ACCB[(s - 2) % 3])
+    kfu, kfl = (0, 32) if s % 2 == 0 else (32, 0)
+    lines = []
+    reads = []
+    if opts.get("lds"):
+        buf, sub = lds_imm
+        base = LADDR2 if buf == 2 else LADDR
+        imm = (buf % 2) * 32768 + sub * 8192 if buf < 2 else sub * 8192
+        reads = [f"ds_read_b128 a[{kfl + 4 * ks}:{kfl + 4 * ks + 3}], v{base + ks} offset:{imm}" for ks in range(8)]
+        lines.append("s_waitcnt lgkmcnt(0)")
+    if dma is not None:
+        lines += dma
+    valu = []
+    if opts.get("softmax", True):
+        for acc in (A, B):
+            x, m = ub_p1_valu_x(acc[2]), ub_p1_valu_m(acc[1])
+            valu += x[:len(x) // 2] + m[:4] + x[len(x) // 2:] + m[4:] + ub_rotate_m_to_x()
+    slots = [[] for _ in range(16)]
+    spread(slots, valu)
+    ri = 0
+    for k in range(8):
+        for h, acc in enumerate((A, B)):
+            if opts.get("mfma", True):
+                c = "0" if k == 0 else vr(acc[0], 16)
+                lines.append(f"v_mfma_f32_32x32x16_bf16 {vr(acc[0], 16)}, a[{kfu + 4 * k}:{kfu + 4 * k + 3}], {vr(QF + 4 * k, 4)}, {c}")
+            if h == 0 and ri < len(reads):
+                lines.append(reads[ri]); ri += 1
+            lines += slots[2 * k + h]
+    lines += reads[ri:]
+    return [l for l in lines if l]
+
+
 def clobbers(lo=32, hi=LAST_V):
     return ", ".join(f'"v{i}"' for i in range(lo, hi))
 
@@ -183,10 +224,10 @@ UB_HEAD = r'''// GENERATED by tools/gen_stage_asm.py ubench -- do not edit.
 '''
 
 UB_KERNEL = r'''
-__global__ __launch_bounds__(512, 1) void k_%(name)s(unsigned long long* cyc, float* sink, const uint32_t* in, const char* kglob) {
+__global__ __launch_bounds__(%(threads)d, 1) void k_%(name)s(unsigned long long* cyc, float* sink, const uint32_t* in, const char* kglob) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const uint32_t lane = threadIdx.x & 63, n = lane & 31, kg = lane >> 5;
-    for (uint32_t i = threadIdx.x; i < 98304 / 4; i += 512) reinterpret_cast<uint32_t*>(lds)[i] = in[i & 511];
+    for (uint32_t i = threadIdx.x; i < 98304 / 4; i += %(threads)d) reinterpret_cast<uint32_t*>(lds)[i] = in[i & 511];
     __syncthreads();
     const uint32_t ldsbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     uint32_t la[8];
@@ -207,7 +248,7 @@ __global__ __launch_bounds__(512, 1) void k_%(name)s(unsigned long long* cyc, fl
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
         "s_nop 15\n"
         :: "v"(in + lane * 8), "v"(voff), "s"(m0base), "s"(g), "v"(la[0]), "v"(la[1]), "v"(la[2]), "v"(la[3]), "v"(la[4]), "v"(la[5]), "v"(la[6]), "v"(la[7])
-        : CLOB, "s20", "s21", "s22", "s23", "s24", "s25", "m0", "scc", "memory");
+        : CLOB%(aclob)s, "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "m0", "scc", "memory");
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float r;
     asm volatile("v_add_f32 %%0, v193, v192" : "=v"(r));
@@ -258,9 +299,36 @@ def gen_ubench():
         "m16_math_lds_bar_dma": dict(m16=True, lds=True, bar=True, dma=True),
         "valu_lds": dict(mfma=False, lds=True),
     }
+    for n_, o_ in (("w1_mfma_only", dict(softmax=False)), ("w1_valu_only", dict(mfma=False)), ("w1_math", dict()), ("w1_math_lds", dict(lds=True)),
+                   ("w1_math_lds_bar", dict(lds=True, bar=True)), ("w1_math_lds_bar_dma", dict(lds=True, bar=True, dma=True))):
+        variants[n_] = dict(o_, w1=True)
     out = [UB_HEAD % dict(clob=clobbers())]
     for name, o in variants.items():
         body = []
+        if o.get("w1"):
+            for s_ in range(12):
+                tile, sub = divmod(s_, 4)
+                nxt_tile, nxt_sub = divmod((s_ + 1) % 12, 4)
+                dma = None
+                if o.get("dma"):   # two 1 KiB pieces per wave and stage (4 waves move the stage's 8 KiB)
+                    dst = ((tile + 2) % 3) * 32768 + sub * 8192
+                    dma = [f"s_add_u32 m0, s22, {dst}", "s_nop 0", f"global_load_lds_dwordx4 v{DMAV + sub}, s[24:25]",
+                           f"s_add_u32 m0, s22, {dst + 4096}", "s_nop 0", f"global_load_lds_dwordx4 v{DMAV + sub}, s[26:27]"]
+                    if sub == 3:
+                        dma += ["s_add_u32 s24, s24, 0x8000", "s_addc_u32 s25, s25, 0", "s_add_u32 s26, s26, 0x8000", "s_addc_u32 s27, s27, 0"]
+                body += w1_stage(s_, o, lds_imm=(nxt_tile, nxt_sub), dma=dma)
+                if sub == 3 and o.get("bar"):
+                    if o.get("dma"):
+                        body.append("s_waitcnt vmcnt(8)")
+                    body.append("s_barrier")
+            init = [l for l in ub_init() if not any(f"v_mov_b32 v{i}," in l for i in range(64, 128))]
+            init += [f"v_accvgpr_write_b32 a{i}, v{32 + (i % 8)}" for i in range(64)] + [f"v_mov_b32 v{i}, 0" for i in range(64, 112)]
+            if o.get("dma"):
+                init += ["s_mov_b32 s22, %2", "s_mov_b64 s[24:25], %3", "s_add_u32 s26, s24, 0x1000", "s_addc_u32 s27, s25, 0"]
+                init += [f"v_add_u32 v{DMAV + i}, {i * 8192}, %1" for i in range(4)]
+            out.append(UB_KERNEL % dict(name=name, init=fmt(init), body=fmt(body), iters=400, threads=256,
+                                        aclob=", " + ", ".join(f'"a{i}"' for i in range(64))))
+            continue
         # 12 stages = 3 tiles (ring of three buffers), accumulators rotate with period 3, fragments with period 2
         for s in range(12):
             tile, sub = divmod(s, 4)
@@ -282,23 +350,24 @@ def gen_ubench():
             # s22 = LDS base + 1 KiB * wave (this wave's block inside a sub-block), s[24:25] = global base of this workgroup's stream
             init += ["s_mov_b32 s22, %2", "s_mov_b64 s[24:25], %3"]
             init += [f"v_add_u32 v{DMAV + i}, {i * 8192}, %1" for i in range(4)]
-        out.append(UB_KERNEL % dict(name=name, init=fmt(init), body=fmt(body), iters=400 // 1))
+        out.append(UB_KERNEL % dict(name=name, init=fmt(init), body=fmt(body), iters=400 // 1, threads=512, aclob=""))
     # host
     out.append(r'''
-template <typename K> void run(const char* name, K kern, int blocks, const uint32_t* in, const char* kglob, unsigned long long* d_cyc, float* sink) {
+template <typename K> void run(const char* name, K kern, int blocks, const uint32_t* in, const char* kglob, unsigned long long* d_cyc, float* sink, int threads = 512) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    kern<<<blocks, 512, 98304>>>(d_cyc, sink, in, kglob);
+    hipMemset(d_cyc, 0, 4096 * 8);
+    kern<<<blocks, threads, 98304>>>(d_cyc, sink, in, kglob);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    kern<<<blocks, 512, 98304>>>(d_cyc, sink, in, kglob);
+    kern<<<blocks, threads, 98304>>>(d_cyc, sink, in, kglob);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> h(blocks * 8);
     hipMemcpy(h.data(), d_cyc, h.size() * 8, hipMemcpyDeviceToHost);
-    double a = 0; for (auto x : h) a += (double)x;
+    double a = 0; int nz = 0; for (auto x : h) if (x) { a += (double)x; ++nz; }
     const double stages = 400.0 * 12.0;
-    printf("%-22s blocks %3d: %7.1f ns per stage (2 waves/SIMD)   %7.1f s_memtime ticks per stage   kernel %.1f us\n", name, blocks, ms * 1e6 / stages, a / h.size() / stages, ms * 1e3);
+    printf("%-22s blocks %3d: %7.1f ns per stage (%d wave%s/SIMD)   %7.1f s_memtime ticks per stage   kernel %.1f us\n", name, blocks, ms * 1e6 / stages, threads / 256, threads == 512 ? "s" : "", a / (nz ? nz : 1) / stages, ms * 1e3);
 }
 int main() {
     unsigned long long* d_cyc; float* sink; uint32_t* in_rand; uint32_t* in_const; char* kglob;
@@ -317,8 +386,8 @@ int main() {
         const uint32_t* in = mode ? in_rand : in_const;
         printf("== %s\n", mode ? "256 workgroups, random operands" : "8 workgroups, constant operands");
 ''')
-    for name in variants:
-        out.append(f'        run("{name}", k_{name}, blocks, in, kglob, d_cyc, sink);\n')
+    for name, o in variants.items():
+        out.append(f'        run("{name}", k_{name}, blocks, in, kglob, d_cyc, sink, {256 if o.get("w1") else 512});\n')
     out.append("    }\n    return 0;\n}\n")
     return "".join(out)
 
