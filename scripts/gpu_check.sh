@@ -55,6 +55,12 @@ if [[ "$WHAT" == *pmc* ]]; then
   done
   cd "$GRAFT_REPO_ROOT"
 fi
+if [[ "$WHAT" == *e2e* ]]; then
+  # random-init Llama-3.1-8B body, prefill with / without the press (tools/e2e_prefill.py)
+  : > gpurun_out/r03_e2e_prefill.jsonl
+  timeout 900 python tools/e2e_prefill.py --seq-len 131072 --press snapkv --reps 3 2> gpurun_out/e2e.err | tail -1 >> gpurun_out/r03_e2e_prefill.jsonl; echo "e2e[128k snapkv] rc=$?"
+  timeout 600 python tools/e2e_prefill.py --seq-len 32768 --press knorm --reps 5 2>> gpurun_out/e2e.err | tail -1 >> gpurun_out/r03_e2e_prefill.jsonl; echo "e2e[32k knorm] rc=$?"
+fi
 if [[ "$WHAT" == *timeline* ]]; then
   cd /tmp
   for wl in ${TL_WL:-snapkv128k knorm32k}; do

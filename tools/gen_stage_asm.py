@@ -426,6 +426,8 @@ GEN_PRIO = int(_os.environ.get("GEN_PRIO", "0"))
 # the cycles a wave spent in the whole loop / waiting for K fragments (even / odd window rows of part_m) and waiting for the K stream /
 # at the tile barrier (even / odd rows of part_z): tools/sk_lab.py --stamps prints the breakdown
 GEN_STAMP = int(_os.environ.get("GEN_STAMP", "0"))
+# GEN_DMA_NT: non-temporal hint on the K stream's LDS-DMA requests: 1 = pass 1 only, 3 = pass 2 only, 2 = both
+GEN_DMA_NT = int(_os.environ.get("GEN_DMA_NT", "0"))
 
 
 class Cfg:
@@ -494,7 +496,8 @@ def stage_head(cfg, p, flush=None):
     dst = ((buf + cfg.nbuf - 1) % cfg.nbuf) * 32768 + sub * 8192
     D = []
     if "nodma" not in GEN_ABL:
-        D += [f"s_add_u32 m0, s22, {dst}", "s_nop 0", f"global_load_lds_dwordx4 v{cfg.dmav + sub}, s[24:25]"]
+        nt = " nt" if (GEN_DMA_NT == 2 or (GEN_DMA_NT == 1 and cfg is P1) or (GEN_DMA_NT == 3 and cfg is P2)) else ""
+        D += [f"s_add_u32 m0, s22, {dst}", "s_nop 0", f"global_load_lds_dwordx4 v{cfg.dmav + sub}, s[24:25]{nt}"]
     if sub == 3:
         D += ["s_cmp_lg_u32 s28, 0", "s_cselect_b32 s29, s26, 0", "s_cselect_b32 s30, 1, 0", "s_sub_u32 s28, s28, s30",
               "s_add_u32 s24, s24, s29", "s_addc_u32 s25, s25, 0"]
