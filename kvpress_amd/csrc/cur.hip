@@ -1,5 +1,5 @@
 // kvp_cur_score: CURPress.score (kvpress/presses/cur_press.py:32-66), approximate leverage scores of keys and values.
-//   k2 = sum_d k^2, v2 = sum_d v^2                                   (:40-41)   two streaming passes (rownorm.hip, squared)
+//   k2 = sum_d k^2, v2 = sum_d v^2                                   (:40-41)   one launch over both tensors (rownorm.hip, squared)
 //   local approximation: each is divided by its sum over windows of `w` consecutive tokens (zero-padded tail)   (:43-48)
 //   combined by leverage type: key | value | (k2 + v2) / 2 | k2 * v2                                              (:50-59)
 //   normalised by the row sum, first `num_sinks` positions set to 1                                               (:61-62)
@@ -8,8 +8,8 @@
 // deterministic), fp32 throughout.  (One workgroup per row, as first written, took 400 us of the 490 us at 8 x 131072.)
 #include "kvp_common.h"
 
-int kvp_rowsumsq_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh, int64_t ss,
-                        float* out, hipStream_t stream);
+int kvp_rowsumsq2_launch(const void* k, const void* v, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t k_sb, int64_t k_sh, int64_t k_ss,
+                         int64_t v_sb, int64_t v_sh, int64_t v_ss, float* out_k, float* out_v, hipStream_t stream);
 
 namespace {
 
@@ -97,8 +97,7 @@ extern "C" int kvp_cur_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t 
     }
     float* k2 = static_cast<float*>(ws);
     float* v2 = reinterpret_cast<float*>(static_cast<char*>(ws) + half);
-    if (int rc = kvp_rowsumsq_launch(k, dtype, B, H, S, D, k_sb, k_sh, k_ss, k2, stream)) return rc;
-    if (int rc = kvp_rowsumsq_launch(v, dtype, B, H, S, D, v_sb, v_sh, v_ss, v2, stream)) return rc;
+    if (int rc = kvp_rowsumsq2_launch(k, v, dtype, B, H, S, D, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, k2, v2, stream)) return rc;
     float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + 2 * half);
     const uint32_t R = (uint32_t)(B * H);
     const uint32_t nblk = (uint32_t)std::max<int64_t>(1, std::min<int64_t>({(S + CU_THREADS - 1) / CU_THREADS, (int64_t)CU_MAXBLK, std::max<int64_t>(1, 2048 / R)}));

@@ -14,17 +14,21 @@ template <> __device__ __forceinline__ void st_elem<KVP_F16>(_Float16* p, float 
 template <> __device__ __forceinline__ void st_elem<KVP_BF16>(uint16_t* p, float x) { *p = (uint16_t)(__float_as_uint(round_dt<KVP_BF16>(x)) >> 16); }
 
 // cos / sin of a float32 angle (torch: `freqs.cos()`, `.sin()` of the float32 product delta * inv_freq).  The angles reach ~1e5 rad,
-// where cosf and sinf each run their slow argument reduction (140 of the kernel's 150 us at 8 x 65536 rows).  Instead: ONE
-// reduction to [-pi, pi] in double (exact to ~1e-16 of a revolution), the reduced angle split into a float32 head and tail, one
-// sincosf of the head on its short path and a first-order correction by the tail: accurate to ~1 ulp like cosf / sinf themselves.
+// where cosf and sinf each run their slow argument reduction (140 of the kernel's 150 us at 8 x 65536 rows).  Instead: ONE reduction
+// in double -- k = rint(angle * 2/pi), r = (angle * 2/pi - k) * pi/2 in [-pi/4, pi/4], exact to ~1e-16 of a quarter turn -- then the
+// two minimax polynomials of that interval in float32 (Cephes sinf / cosf coefficients, |error| < 1.2e-7 = the accuracy class of
+// cosf / sinf themselves) and the quadrant's swap / signs.
 __device__ __forceinline__ void sincos_f32_angle(float angle, float& s, float& c) {
-    const double rev = (double)angle * 0.15915494309189535;   // 1 / (2 pi)
-    const double x = (rev - rint(rev)) * 6.283185307179586;
-    const float xh = (float)x, xl = (float)(x - (double)xh);
-    float sh, ch;
-    sincosf(xh, &sh, &ch);
-    c = fmaf(-sh, xl, ch);
-    s = fmaf(ch, xl, sh);
+    const double t = (double)angle * 0.6366197723675814;       // 2 / pi
+    const double kq = rint(t);
+    const float r = (float)((t - kq) * 1.5707963267948966);     // pi / 2
+    const int q = (int)kq;
+    const float z = r * r;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z, fmaf(-0.5f, z, 1.0f));
+    const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
 }
 
 template <int DT>

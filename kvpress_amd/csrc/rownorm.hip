@@ -88,6 +88,45 @@ __global__ __launch_bounds__(RN_THREADS) void rownorm_vec_kernel(
     }
 }
 
+// Two tensors of the same shape in ONE launch (CURPress: sum of squares of the keys' and of the values' rows, cur_press.py:40-41):
+// blockIdx.z selects the tensor, so both streams are in flight together (two launches ran 118 us for 537 MB at 8 x 131072; one
+// boundary and one ramp less, and the second stream starts while the first one drains).
+template <int DT, int LPR>
+__global__ __launch_bounds__(RN_THREADS) void rowsumsq2_vec_kernel(const typename Elem<DT>::T* __restrict__ x0, const typename Elem<DT>::T* __restrict__ x1,
+                                                                   PlaneMap map0, PlaneMap map1, uint32_t chunks, float* __restrict__ out0,
+                                                                   float* __restrict__ out1) {
+    using T = typename Elem<DT>::T;
+    constexpr int PER16 = Elem<DT>::PER16;
+    constexpr int GPB = RN_THREADS / LPR;
+    const bool second = blockIdx.z != 0;
+    const PlaneMap map = second ? map1 : map0;
+    const uint32_t bh = blockIdx.y;
+    const uint32_t b = bh / map.H, h = bh - b * map.H;
+    const T* __restrict__ base = (second ? x1 : x0) + (int64_t)b * map.sb + (int64_t)h * map.sh;
+    float* __restrict__ ob = (second ? out1 : out0) + (size_t)bh * map.S;
+    const uint32_t lir = threadIdx.x % LPR;
+    const uint32_t g = blockIdx.x * GPB + threadIdx.x / LPR;
+    const uint32_t TG = gridDim.x * GPB;
+    const uint32_t S = map.S;
+    for (uint32_t s0 = g; s0 < S; s0 += TG * RN_UNROLL) {
+        uint4 v[RN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RN_UNROLL; ++u) {
+            const uint32_t s = s0 + u * TG;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (s < S && lir < chunks) v[u] = *reinterpret_cast<const uint4*>(base + (int64_t)s * map.ss + (size_t)lir * PER16);
+        }
+#pragma unroll
+        for (int u = 0; u < RN_UNROLL; ++u) {
+            const uint32_t s = s0 + u * TG;
+            float acc = sumsq16<DT>(v[u]);   // (same lanes, fma chain and shuffle order as rownorm_vec_kernel: same bits)
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lir == 0 && s < S) ob[s] = acc;
+        }
+    }
+}
+
 // Any D / alignment: one thread per row, scalar loads (tiny test shapes such as head_dim 6).
 template <int DT>
 __global__ __launch_bounds__(RN_THREADS) void rownorm_scalar_kernel(
@@ -182,6 +221,34 @@ int kvp_rownorm_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S
 int kvp_rowsumsq_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh, int64_t ss,
                         float* out, hipStream_t stream) {
     return rownorm_launch_impl(x, dtype, B, H, S, D, sb, sh, ss, 1.0f, out, stream, nullptr, nullptr, true);
+}
+
+// out_k[b,h,s] = sum_d k^2 and out_v likewise in one launch when both tensors take the 16-lanes-per-256-byte-row vector path (else two
+// launches of the general kernel).  Same values as kvp_rowsumsq_launch.
+int kvp_rowsumsq2_launch(const void* k, const void* v, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t k_sb, int64_t k_sh, int64_t k_ss,
+                         int64_t v_sb, int64_t v_sh, int64_t v_ss, float* out_k, float* out_v, hipStream_t stream) {
+    const int64_t es = kvp_elem_size(dtype);
+    auto al = [&](const void* p, int64_t sb, int64_t sh, int64_t ss) {
+        return ((uintptr_t)p % 16) == 0 && (sb * es) % 16 == 0 && (sh * es) % 16 == 0 && (ss * es) % 16 == 0;
+    };
+    const bool fast = (dtype == KVP_BF16 || dtype == KVP_F16) && D * es == 256 && B * H >= 1 && B * H <= 65535 && S >= 1 && S < ((int64_t)1 << 31) &&
+                      al(k, k_sb, k_sh, k_ss) && al(v, v_sb, v_sh, v_ss) && k && v && out_k && out_v;
+    if (!fast) {
+        if (int rc = kvp_rowsumsq_launch(k, dtype, B, H, S, D, k_sb, k_sh, k_ss, out_k, stream)) return rc;
+        return kvp_rowsumsq_launch(v, dtype, B, H, S, D, v_sb, v_sh, v_ss, out_v, stream);
+    }
+    PlaneMap mk{(uint32_t)H, (uint32_t)S, k_sb, k_sh, k_ss, true}, mv{(uint32_t)H, (uint32_t)S, v_sb, v_sh, v_ss, true};
+    const uint32_t BH = (uint32_t)(B * H);
+    constexpr uint32_t gpb = RN_THREADS / 16;
+    const uint64_t bx_full = (((uint64_t)S + RN_UNROLL - 1) / RN_UNROLL + gpb - 1) / gpb;
+    const uint64_t bx_cap = std::max<uint64_t>(1, (256 * 4 + BH - 1) / BH);   // ~8 workgroups per CU over the two tensors
+    const dim3 grid((uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap)), BH, 2);
+    if (dtype == KVP_BF16)
+        KVP_LAUNCH("rownorm_vec_kernel", stream, (rowsumsq2_vec_kernel<KVP_BF16, 16><<<grid, RN_THREADS, 0, stream>>>(static_cast<const uint16_t*>(k), static_cast<const uint16_t*>(v), mk, mv, 16, out_k, out_v)));
+    else
+        KVP_LAUNCH("rownorm_vec_kernel", stream, (rowsumsq2_vec_kernel<KVP_F16, 16><<<grid, RN_THREADS, 0, stream>>>(static_cast<const _Float16*>(k), static_cast<const _Float16*>(v), mk, mv, 16, out_k, out_v)));
+    KVP_CHECK_LAUNCH("rowsumsq2");
+    return KVP_OK;
 }
 
 extern "C" int kvp_rownorm_score(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb,

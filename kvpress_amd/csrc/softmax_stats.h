@@ -45,6 +45,27 @@ static __global__ __launch_bounds__(256) void softmax_combine_kernel(const float
     if (lane == 0) a[row] = m + log2f(z) - (norm_base ? log2f((float)(norm_base + row % W)) : 0.f);
 }
 
+// The same with one THREAD per row, for many rows with few partials each (ChunkPress scores every 1024-token chunk as a batch
+// element: 262 144 window rows with one partial each at 128k tokens -- a wave per row spent 55 us on them).  Same merge order for
+// nchunk <= 2 (a wave's lanes 0 and 1), hence the same bits there; used for nchunk <= 2 only.
+static __global__ __launch_bounds__(256) void softmax_combine_rows_kernel(const float* __restrict__ part_m, const float* __restrict__ part_z,
+                                                                           uint32_t nrows, uint32_t nchunk, float* __restrict__ a, uint32_t W = 0,
+                                                                           uint32_t norm_base = 0) {
+    const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= nrows) return;
+    float m = KVP_NEG_INF, z = 0.f;
+    for (uint32_t j = 0; j < nchunk; ++j) softmax_merge(m, z, part_m[(size_t)row * nchunk + j], part_z[(size_t)row * nchunk + j]);
+    a[row] = m + log2f(z) - (norm_base ? log2f((float)(norm_base + row % W)) : 0.f);
+}
+// launch helper: picks the row-per-thread form for many rows with <= 2 partials
+#define KVP_SOFTMAX_COMBINE(stream, part_m, part_z, nrows, nchunk, a, ...)                                                                  \
+    do {                                                                                                                                 \
+        if ((nchunk) <= 2 && (nrows) >= 4096)                                                                                            \
+            KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_rows_kernel<<<((nrows) + 255) / 256, 256, 0, stream>>>(part_m, part_z, nrows, nchunk, a, ##__VA_ARGS__)); \
+        else                                                                                                                             \
+            KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_kernel<<<((nrows) + 3) / 4, 256, 0, stream>>>(part_m, part_z, nrows, nchunk, a, ##__VA_ARGS__));       \
+    } while (0)
+
 // Global max without same-address atomics (2048 atomicMax on one word cost ~12 ns each = 25 us):
 // every workgroup stores its maximum to bmax[its linear id]; the (tiny) pad-fill kernel reduces them.
 // lds >= 4 words.
