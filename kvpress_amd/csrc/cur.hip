@@ -89,6 +89,8 @@ __global__ __launch_bounds__(CU_THREADS) void cur_combine_win_kernel(const float
     if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// (Round 3: one THREAD per window -- its two sums once, then its w scores -- was measured at 82 us against this kernel's 12: sixteen
+// dependent 4-byte loads per lane, 64 bytes apart across the wave, is the worst shape for the vector memory path.)
 // pass 2: divide by the row total (the partials added in block order), sinks = 1
 __global__ __launch_bounds__(CU_THREADS) void cur_normalize_kernel(float* __restrict__ scores, const float* __restrict__ partial, uint32_t nblk, uint32_t S,
                                                                    uint32_t num_sinks) {
