@@ -93,7 +93,8 @@ def n_kept_of(kind: str, S: int, ratio: float) -> int:
 
 def algorithmic_bytes(kind: str, S: int, ratio: float, B: int = 1) -> dict:
     """bytes per layer the path must move (e = 2 bytes): K read once for scoring (+ what else the scorer
-    must read) + kept K, V rows read + K', V' written (+ the in-place re-rotation of K' where the press does it)."""
+    must read) + kept K, V rows read + K', V' written (the re-rotating presses rotate the kept keys on their way through the
+    gather: no extra pass)."""
     n_kept = n_kept_of(kind, S, ratio)
     kread = B * S * H_KV * D * 2
     gather = B * 4 * n_kept * H_KV * D * 2  # read kept K,V rows + write K',V'
@@ -102,8 +103,6 @@ def algorithmic_bytes(kind: str, S: int, ratio: float, B: int = 1) -> dict:
         extra = B * (S * H_KV * D * 2 + S * H_Q * D * 2)  # V for ||v||, Q for the statistics
     if kind == "cur":
         extra = B * S * H_KV * D * 2                      # V for its leverage scores
-    if kind in ("finch", "rerotate"):
-        extra = B * 2 * n_kept * H_KV * D * 2             # K' read + written once more by the re-rotation
     return {"n_kept": n_kept, "score_read": kread + extra, "gather": gather, "total": kread + extra + gather}
 
 

@@ -168,6 +168,13 @@ int kvp_topk_select_segmented(const float* scores, int64_t R, int64_t nseg, int6
  * module.rotary_emb.inv_freq), cos/sin cast to the key dtype and every op rounded in it, as torch does. */
 int kvp_rerotate_keys(void* k, int dtype, int64_t B, int64_t H, int64_t n, int64_t D, const int32_t* idx,
                       const float* inv_freq, kvp_stream_t stream);
+/* The gather and the re-rotation above in one pass (key_rerotation_press.py:157-160 + :107-128; finch_press.py:111-119): same
+ * arguments as kvp_gather_kv + inv_freq, same bits as kvp_gather_kv followed by kvp_rerotate_keys on k_out; the gathered keys are
+ * written once instead of written, read and written again.  2-byte dtypes with D % 16 == 0 and 16-byte aligned rows take the
+ * one-pass kernel, everything else runs the two kernels it replaces. */
+int kvp_gather_kv_rerotate(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, const void* v, int64_t v_sb, int64_t v_sh,
+                           int64_t v_ss, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, const int32_t* idx, int64_t n,
+                           const float* inv_freq, void* k_out, void* v_out, kvp_stream_t stream);
 
 /* ---- fused ScorerPress.compress (scorer_press.py:76-102 with the scorer inlined) ---------------------------------
  * One call = score -> select n_kept -> gather into caller-allocated contiguous k_out / v_out [B,H,n_kept,D].  Same

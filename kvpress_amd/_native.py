@@ -84,6 +84,8 @@ SIGNATURES = {
     "kvp_rerotate_keys": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, c_void_p, c_void_p, c_void_p]),
     "kvp_gather_kv": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64,
                               c_void_p, _I64, c_void_p, c_void_p, c_void_p]),
+    "kvp_gather_kv_rerotate": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64,
+                                       c_void_p, _I64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "kvp_prof_enable": (c_int, [c_int]),
     "kvp_prof_count": (c_int, []),
     "kvp_prof_get": (c_int, [c_int, ctypes.POINTER(c_char_p), ctypes.POINTER(c_float)]),
@@ -694,6 +696,28 @@ def gather_kv(keys: torch.Tensor, values: torch.Tensor, idx: torch.Tensor):
             _check(lib().kvp_gather_kv(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2),
                                        _p(values), _st(values, 0), _st(values, 1), _st(values, 2), _DTYPES[keys.dtype],
                                        B, H, S, D, _p(idx), n, _p(ko), _p(vo), _stream(keys)), "kvp_gather_kv")
+    return ko, vo
+
+
+def gather_kv_rerotate(keys: torch.Tensor, values: torch.Tensor, idx: torch.Tensor, inv_freq: torch.Tensor):
+    """gather_kv + rerotate_keys_ in one pass: K'[b,h,j] = K[b,h,idx[b,h,j]] re-rotated from position idx[b,h,j] to position j, V' the
+    plain gather (same bits as the two calls)."""
+    keys = _rows_last_contig(_dev(keys))
+    values = _rows_last_contig(_dev(values))
+    assert keys.dtype == values.dtype and keys.shape == values.shape
+    B, H, S, D = keys.shape
+    idx = idx.to(torch.int32).contiguous()
+    n = idx.shape[-1]
+    assert idx.shape == (B, H, n)
+    inv = inv_freq.to(device=keys.device, dtype=torch.float32).contiguous()
+    assert inv.numel() == D // 2
+    ko = torch.empty((B, H, n, D), dtype=keys.dtype, device=keys.device)
+    vo = torch.empty((B, H, n, D), dtype=values.dtype, device=values.device)
+    if B * H * n:
+        with torch.cuda.device(keys.device):
+            _check(lib().kvp_gather_kv_rerotate(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2),
+                                                _p(values), _st(values, 0), _st(values, 1), _st(values, 2), _DTYPES[keys.dtype],
+                                                B, H, S, D, _p(idx), n, _p(inv), _p(ko), _p(vo), _stream(keys)), "kvp_gather_kv_rerotate")
     return ko, vo
 
 

@@ -101,6 +101,7 @@ struct QstatArgs {
     float* s2;    // [B*Hq][nchunk][128][128]
     float* dsum;  // [B*Hq][nchunk][128]   sum over the chunk's rows of (x - m0)
     float* m0;    // [B*Hq][nchunk][128]
+    uint32_t nt;  // non-temporal Q stream (read once)
 };
 
 // transpose the 32 rows x 32 dims block (sub, ct) of the tile into the C layout: lane (dim j = lane & 31, kg),
@@ -238,9 +239,9 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_qstats_mfma_kernel(QstatArgs
 // workgroup, ET_NBUF - 1 tiles in flight); the 16-byte slots of a row are XOR-swizzled by (token & 3) << 2 on the global side so that the four token rows a
 // transposed read touches sit in different banks.  Per 16-token k-step and wave: 8 transposed reads (fragments of all four
 // 32-dim strips), 4 syrk MFMAs (own strip x every strip) + 1 MFMA against a ones fragment for the column sums.
-// Raw moments cancel when |mean| >> sigma: sum x x^T is accumulated in fp32 over <= 4096 rows per partial, so the relative
-// error of a covariance entry is ~2^-24 (mean / sigma)^2 sqrt(rows / 16): 1e-4 at |mean| = 10 sigma
-// (tests/test_gpu_parity.py::test_ea_qstats_large_mean).  The partials are merged by the same pairwise update.
+// Raw moments cancel when |mean| >> sigma: sum x x^T is accumulated in fp32 over the rows of one partial (4096 .. 16384 at 128k tokens,
+// qstats_plan), so the relative error of a covariance entry is ~2^-24 (mean / sigma)^2 sqrt(rows / 16): 1e-4 .. 2e-4 at |mean| = 10 sigma
+// (tests/test_gpu_fullsize.py::test_ea_qstats_128k_large_mean_adversarial, bound 1e-3).  The partials are merged by the same pairwise update.
 template <int DT, int ET_NBUF, int ET_OCC>
 __global__ __launch_bounds__(EM_THREADS, ET_OCC) void ea_qstats_tr_kernel(QstatArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[ET_NBUF * EM_TILEB];
@@ -267,7 +268,8 @@ __global__ __launch_bounds__(EM_THREADS, ET_OCC) void ea_qstats_tr_kernel(QstatA
             const uint32_t row = min(row0 + 16 * j + 4 * wv + g, a.Sq - 1);   // rows past the end are zeroed in LDS below
             const char* gp = base + (int64_t)row * row_bytes + gch;
             const uint32_t la = __builtin_amdgcn_readfirstlane(ldsbase + buf * EM_TILEB + (16 * j + 4 * wv) * EM_ROWB);
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(gp) : "memory");
+            if (a.nt) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(la), "v"(gp) : "memory");
+            else asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(gp) : "memory");
         }
     };
 #pragma unroll
@@ -404,8 +406,14 @@ __global__ __launch_bounds__(256) void ea_qstats_combine(const float* __restrict
     for (int q = 0; q < 4; ++q) cov[(size_t)bh * 16384 + e0 + q * 256] = s[q] * invN;
 }
 
-void qstats_plan(int64_t Sq, uint32_t& nchunk, uint32_t& rows) {
-    int64_t nc = std::min<int64_t>(32, std::max<int64_t>(1, (Sq + 4095) / 4096));
+// Partials per head: about one workgroup per CU over all heads (32 heads: 8 chunks of 16384 rows), at least 4096 rows each.  Measured
+// at 32 heads x 131072 rows (tools/stream_lab.py, statistics + combine): 32 chunks per head 273 us, 16: 230, 8: 219 (8 with the
+// streaming loads below: 194), 4: 446 -- fewer partials are less to write, re-read and merge (67 MB -> 17 MB), and a workgroup
+// that walks 16384 consecutive rows keeps its ring full for longer.  KVP_EA_QCHUNKS caps the count.
+void qstats_plan(int64_t Sq, int64_t nbh, uint32_t& nchunk, uint32_t& rows) {
+    const int64_t target = std::max<int64_t>(1, 256 / std::max<int64_t>(1, nbh));
+    const int64_t cap = std::min<int64_t>(32, std::max(1, kvp_env_int("KVP_EA_QCHUNKS", (int)std::min<int64_t>(32, target))));
+    int64_t nc = std::min<int64_t>(cap, std::max<int64_t>(1, (Sq + 4095) / 4096));
     int64_t r = ((Sq + nc - 1) / nc + EM_TILE - 1) / EM_TILE * EM_TILE;
     nchunk = (uint32_t)((Sq + r - 1) / r);
     rows = (uint32_t)r;
@@ -605,7 +613,7 @@ bool ea_mfma_qstats_eligible(const void* q, int64_t q_sb, int64_t q_sh, int64_t 
 size_t ea_mfma_qstats_ws_bytes(int64_t B, int64_t Hq, int64_t Sq, int64_t D) {
     if (D != 128) return 0;
     uint32_t nchunk, rows;
-    qstats_plan(Sq, nchunk, rows);
+    qstats_plan(Sq, B * Hq, nchunk, rows);
     return (size_t)B * Hq * nchunk * (128 * 128 + 256) * 4 + 1024;
 }
 
@@ -615,7 +623,9 @@ int ea_mfma_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int 
     QstatArgs a;
     a.q = q; a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss;
     a.B = (uint32_t)B; a.Hq = (uint32_t)Hq; a.Sq = (uint32_t)Sq;
-    qstats_plan(Sq, a.nchunk, a.rows_per_chunk);
+    qstats_plan(Sq, B * Hq, a.nchunk, a.rows_per_chunk);
+    const int nt_env = kvp_env_int("KVP_EA_QNT", -1);   // streaming Q loads when Q cannot stay in the memory-side cache anyway (as kvp_gather_kv)
+    a.nt = nt_env >= 0 ? nt_env != 0 : (uint64_t)B * Hq * Sq * 256 > (192ull << 20);
     const size_t nbh = (size_t)B * Hq;
     a.s2 = static_cast<float*>(ws);
     a.dsum = a.s2 + nbh * a.nchunk * 16384;
@@ -623,7 +633,11 @@ int ea_mfma_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int 
     const dim3 grid((uint32_t)Hq, a.nchunk, (uint32_t)B);
     if (kvp_env_int("KVP_EA_QSTATS_TR", 1)) {   // transposed LDS reads, raw moments (0: the MFMA-transposing, mean-shifted kernel)
         // ring of three 64-token tiles, three workgroups per CU (measured 211 us at 128k x 32 heads; 4 x 2: 215, 5 x 2: 230, 2 x 4: 213)
-        if (dtype == KVP_BF16) KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_BF16, 3, 3><<<grid, EM_THREADS, 0, stream>>>(a)));
+        const int ring = kvp_env_int("KVP_EA_QRING", 3);
+        if (ring >= 6) {
+            if (dtype == KVP_BF16) KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_BF16, 6, 1><<<grid, EM_THREADS, 0, stream>>>(a)));
+            else KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_F16, 6, 1><<<grid, EM_THREADS, 0, stream>>>(a)));
+        } else if (dtype == KVP_BF16) KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_BF16, 3, 3><<<grid, EM_THREADS, 0, stream>>>(a)));
         else KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_F16, 3, 3><<<grid, EM_THREADS, 0, stream>>>(a)));
     } else if (dtype == KVP_BF16) KVP_LAUNCH("ea_qstats_mfma", stream, ea_qstats_mfma_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a));
     else KVP_LAUNCH("ea_qstats_mfma", stream, ea_qstats_mfma_kernel<KVP_F16><<<grid, EM_THREADS, 0, stream>>>(a));

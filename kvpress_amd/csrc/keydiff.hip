@@ -23,20 +23,22 @@ struct KdMap {
 };
 
 // ---- pass A (vector path) ---------------------------------------------------------------------
-template <int DT, int LPR>
-__global__ __launch_bounds__(KD_THREADS) void keydiff_anchor_vec_kernel(const typename Elem<DT>::T* __restrict__ x, KdMap map,
-                                                                        uint32_t chunks, float* __restrict__ partial) {
+// rows_per_wg == 0: the workgroups interleave (row group g, then g + all groups, ...); > 0: every workgroup streams ONE contiguous
+// range of rows (the walk of topk_cluster.hip's Knorm mode).
+template <int DT, int LPR, int THREADS, bool NT>
+__global__ __launch_bounds__(THREADS) void keydiff_anchor_vec_kernel(const typename Elem<DT>::T* __restrict__ x, KdMap map,
+                                                                     uint32_t chunks, float* __restrict__ partial, uint32_t rows_per_wg) {
     using T = typename Elem<DT>::T;
     constexpr int PER16 = Elem<DT>::PER16;
-    constexpr int GPB = KD_THREADS / LPR;
+    constexpr int GPB = THREADS / LPR;
     __shared__ float red[GPB][LPR * PER16 + 1];
     const uint32_t bh = blockIdx.y;
     const uint32_t b = bh / map.H, h = bh - b * map.H;
     const T* __restrict__ base = x + (int64_t)b * map.sb + (int64_t)h * map.sh;
     const uint32_t lir = threadIdx.x % LPR, grp = threadIdx.x / LPR;
-    const uint32_t g = blockIdx.x * GPB + grp;
-    const uint32_t TG = gridDim.x * GPB;
-    const uint32_t S = map.S;
+    const uint32_t g = rows_per_wg ? blockIdx.x * rows_per_wg + grp : blockIdx.x * GPB + grp;
+    const uint32_t TG = rows_per_wg ? GPB : gridDim.x * GPB;
+    const uint32_t S = rows_per_wg ? min(map.S, (blockIdx.x + 1) * rows_per_wg) : map.S;
 
     float acc[PER16];
 #pragma unroll
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(KD_THREADS) void keydiff_anchor_vec_kernel(const ty
         for (int u = 0; u < KD_UNROLL; ++u) {
             const uint32_t s = s0 + u * TG;
             v[u] = make_uint4(0, 0, 0, 0);
-            if (s < S && lir < chunks) v[u] = ld16<false>(base + (int64_t)s * map.ss + (size_t)lir * PER16);
+            if (s < S && lir < chunks) v[u] = ld16<NT>(base + (int64_t)s * map.ss + (size_t)lir * PER16);
         }
 #pragma unroll
         for (int u = 0; u < KD_UNROLL; ++u) {
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(KD_THREADS) void keydiff_anchor_vec_kernel(const ty
     __syncthreads();
     const uint32_t D = chunks * PER16;
     float* __restrict__ out = partial + ((size_t)bh * gridDim.x + blockIdx.x) * D;
-    for (uint32_t d = threadIdx.x; d < D; d += KD_THREADS) {
+    for (uint32_t d = threadIdx.x; d < D; d += THREADS) {
         float s = 0.f;
 #pragma unroll 4
         for (int r = 0; r < GPB; ++r) s += red[r][d];
@@ -156,21 +158,21 @@ __global__ __launch_bounds__(KD_RED_THREADS) void keydiff_anchor_reduce_kernel(c
 }
 
 // ---- pass B -------------------------------------------------------------------------------------
-template <int DT, int LPR>
-__global__ __launch_bounds__(KD_THREADS) void keydiff_score_vec_kernel(const typename Elem<DT>::T* __restrict__ x, KdMap map,
-                                                                       uint32_t chunks, const float* __restrict__ anchor,
-                                                                       float* __restrict__ out) {
+template <int DT, int LPR, int THREADS, bool NT>
+__global__ __launch_bounds__(THREADS) void keydiff_score_vec_kernel(const typename Elem<DT>::T* __restrict__ x, KdMap map,
+                                                                    uint32_t chunks, const float* __restrict__ anchor,
+                                                                    float* __restrict__ out, uint32_t rows_per_wg) {
     using T = typename Elem<DT>::T;
     constexpr int PER16 = Elem<DT>::PER16;
-    constexpr int GPB = KD_THREADS / LPR;
+    constexpr int GPB = THREADS / LPR;
     const uint32_t bh = blockIdx.y;
     const uint32_t b = bh / map.H, h = bh - b * map.H;
     const T* __restrict__ base = x + (int64_t)b * map.sb + (int64_t)h * map.sh;
     float* __restrict__ ob = out + (size_t)bh * map.S;
     const uint32_t lir = threadIdx.x % LPR;
-    const uint32_t g = blockIdx.x * GPB + threadIdx.x / LPR;
-    const uint32_t TG = gridDim.x * GPB;
-    const uint32_t S = map.S;
+    const uint32_t g = (rows_per_wg ? blockIdx.x * rows_per_wg : blockIdx.x * GPB) + threadIdx.x / LPR;
+    const uint32_t TG = rows_per_wg ? GPB : gridDim.x * GPB;
+    const uint32_t S = rows_per_wg ? min(map.S, (blockIdx.x + 1) * rows_per_wg) : map.S;
     float an[PER16];
 #pragma unroll
     for (int j = 0; j < PER16; ++j) an[j] = lir < chunks ? anchor[(size_t)bh * chunks * PER16 + lir * PER16 + j] : 0.f;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(KD_THREADS) void keydiff_score_vec_kernel(const typ
         for (int u = 0; u < KD_UNROLL; ++u) {
             const uint32_t s = s0 + u * TG;
             v[u] = make_uint4(0, 0, 0, 0);
-            if (s < S && lir < chunks) v[u] = ld16<false>(base + (int64_t)s * map.ss + (size_t)lir * PER16);
+            if (s < S && lir < chunks) v[u] = ld16<NT>(base + (int64_t)s * map.ss + (size_t)lir * PER16);
         }
 #pragma unroll
         for (int u = 0; u < KD_UNROLL; ++u) {
@@ -228,6 +230,7 @@ struct KdPlan {
     bool vec;
     uint32_t chunks, nwg;
     int lpr;
+    uint32_t threads, rows_per_wg;   // rows_per_wg > 0: slot walk with `threads`-wide workgroups
 };
 
 template <int DT>
@@ -246,6 +249,17 @@ KdPlan plan_for(const void* x, const KdMap& map, uint32_t BH, uint32_t D) {
         const uint64_t full = (groups_needed + gpb - 1) / gpb;
         const uint64_t cap = std::max<uint64_t>(1, (256 * 8 + BH - 1) / BH);  // ~8 workgroups per CU in total
         p.nwg = (uint32_t)std::max<uint64_t>(1, std::min(full, cap));
+        p.threads = KD_THREADS;
+        if (kvp_env_int("KVP_KD_SLOT", 1) != 0 && map.S >= 4096) {
+            p.threads = kvp_env_int("KVP_KD_THREADS", 1024) >= 1024 ? 1024 : 256;
+            const uint32_t per_cu = (uint32_t)std::min(8, std::max(1, kvp_env_int("KVP_KD_WGS", p.threads >= 1024 ? 1 : 8)));
+            const uint64_t want = std::max<uint64_t>(1, ((uint64_t)256 * per_cu + BH - 1) / BH);
+            const uint32_t step = p.threads / p.lpr * KD_UNROLL;
+            uint64_t rows = ((uint64_t)map.S + want - 1) / want;
+            rows = (rows + step - 1) / step * step;
+            p.rows_per_wg = (uint32_t)rows;
+            p.nwg = (uint32_t)(((uint64_t)map.S + rows - 1) / rows);
+        }
     } else {
         p.nwg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)map.S + 1023) / 1024, 256));
     }
@@ -259,10 +273,18 @@ int launch_keydiff(const void* x, KdMap map, uint32_t BH, uint32_t D, float* sco
     const T* xp = static_cast<const T*>(x);
     const KdPlan p = plan_for<DT>(x, map, BH, D);
     const dim3 grid(p.nwg, BH);
+    // streaming loads in both passes when K cannot stay in the memory-side cache between them anyway (rownorm.hip: rn_streaming);
+    // KVP_KD_NT: bit 0 = anchor pass, bit 1 = score pass.  8 x 131072 x 128 bf16 after a 512 MB copy: 128 -> 109 us, with the slot walk 97.
+    const int nte = kvp_env_int("KVP_KD_NT", -1);
+    const int ntk = nte >= 0 ? nte : ((uint64_t)BH * map.S * D * sizeof(T) > (192ull << 20) ? 3 : 0);
+    const bool nta = (ntk & 1) != 0, ntb = (ntk & 2) != 0;
     if (p.vec) {
 #define KVP_KD_CASE(L)                                                                                                                 \
     case L:                                                                                                                            \
-        KVP_LAUNCH("keydiff_anchor_kernel", stream, keydiff_anchor_vec_kernel<DT, L><<<grid, KD_THREADS, 0, stream>>>(xp, map, p.chunks, partial)); \
+        if (p.threads == 1024 && nta) KVP_LAUNCH("keydiff_anchor_kernel", stream, (keydiff_anchor_vec_kernel<DT, L, 1024, true><<<grid, 1024, 0, stream>>>(xp, map, p.chunks, partial, p.rows_per_wg))); \
+        else if (p.threads == 1024) KVP_LAUNCH("keydiff_anchor_kernel", stream, (keydiff_anchor_vec_kernel<DT, L, 1024, false><<<grid, 1024, 0, stream>>>(xp, map, p.chunks, partial, p.rows_per_wg))); \
+        else if (nta) KVP_LAUNCH("keydiff_anchor_kernel", stream, (keydiff_anchor_vec_kernel<DT, L, KD_THREADS, true><<<grid, KD_THREADS, 0, stream>>>(xp, map, p.chunks, partial, p.rows_per_wg))); \
+        else KVP_LAUNCH("keydiff_anchor_kernel", stream, (keydiff_anchor_vec_kernel<DT, L, KD_THREADS, false><<<grid, KD_THREADS, 0, stream>>>(xp, map, p.chunks, partial, p.rows_per_wg))); \
         break;
         switch (p.lpr) { KVP_KD_CASE(1) KVP_KD_CASE(2) KVP_KD_CASE(4) KVP_KD_CASE(8) KVP_KD_CASE(16) KVP_KD_CASE(32) KVP_KD_CASE(64) }
 #undef KVP_KD_CASE
@@ -274,7 +296,10 @@ int launch_keydiff(const void* x, KdMap map, uint32_t BH, uint32_t D, float* sco
     if (p.vec) {
 #define KVP_KD_CASE(L)                                                                                                                      \
     case L:                                                                                                                                 \
-        KVP_LAUNCH("keydiff_score_kernel", stream, keydiff_score_vec_kernel<DT, L><<<grid, KD_THREADS, 0, stream>>>(xp, map, p.chunks, anchor, scores)); \
+        if (p.threads == 1024 && ntb) KVP_LAUNCH("keydiff_score_kernel", stream, (keydiff_score_vec_kernel<DT, L, 1024, true><<<grid, 1024, 0, stream>>>(xp, map, p.chunks, anchor, scores, p.rows_per_wg))); \
+        else if (p.threads == 1024) KVP_LAUNCH("keydiff_score_kernel", stream, (keydiff_score_vec_kernel<DT, L, 1024, false><<<grid, 1024, 0, stream>>>(xp, map, p.chunks, anchor, scores, p.rows_per_wg))); \
+        else if (ntb) KVP_LAUNCH("keydiff_score_kernel", stream, (keydiff_score_vec_kernel<DT, L, KD_THREADS, true><<<grid, KD_THREADS, 0, stream>>>(xp, map, p.chunks, anchor, scores, p.rows_per_wg))); \
+        else KVP_LAUNCH("keydiff_score_kernel", stream, (keydiff_score_vec_kernel<DT, L, KD_THREADS, false><<<grid, KD_THREADS, 0, stream>>>(xp, map, p.chunks, anchor, scores, p.rows_per_wg))); \
         break;
         switch (p.lpr) { KVP_KD_CASE(1) KVP_KD_CASE(2) KVP_KD_CASE(4) KVP_KD_CASE(8) KVP_KD_CASE(16) KVP_KD_CASE(32) KVP_KD_CASE(64) }
 #undef KVP_KD_CASE

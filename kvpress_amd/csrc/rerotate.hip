@@ -64,6 +64,27 @@ template <> __device__ __forceinline__ uint32_t pack2<KVP_F16>(float lo, float h
     h2 v = {(_Float16)lo, (_Float16)hi};
     return __builtin_bit_cast(uint32_t, v);
 }
+// dims d0 .. d0+7 of the first half (a) and of the second half (b) of one row, rotated by delta * inv_freq[d0 .. d0+7]
+template <int DT>
+__device__ __forceinline__ void rotate8(const uint4& a, const uint4& b, float delta, const float* __restrict__ invf, uint4& out0, uint4& out1) {
+    float k0[8], k1[8], o0[8], o1[8];
+    unpack16<DT>(a, k0);
+    unpack16<DT>(b, k1);
+    const float4 f0 = *reinterpret_cast<const float4*>(invf), f1 = *reinterpret_cast<const float4*>(invf + 4);
+    const float fr[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float freq = __fmul_rn(delta, fr[e]);
+        float sv, cv;
+        sincos_f32_angle(freq, sv, cv);
+        const float c = round_dt<DT>(cv), s = round_dt<DT>(sv);
+        o0[e] = rope_elem<DT>(k0[e], c, -k1[e], s);
+        o1[e] = rope_elem<DT>(k1[e], c, k0[e], s);
+    }
+    out0 = make_uint4(pack2<DT>(o0[0], o0[1]), pack2<DT>(o0[2], o0[3]), pack2<DT>(o0[4], o0[5]), pack2<DT>(o0[6], o0[7]));
+    out1 = make_uint4(pack2<DT>(o1[0], o1[1]), pack2<DT>(o1[2], o1[3]), pack2<DT>(o1[4], o1[5]), pack2<DT>(o1[6], o1[7]));
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void rerotate_vec_kernel(typename Elem<DT>::T* __restrict__ k, const int32_t* __restrict__ idx,
                                                            const float* __restrict__ inv_freq, uint32_t n, uint32_t D) {
@@ -77,22 +98,76 @@ __global__ __launch_bounds__(256) void rerotate_vec_kernel(typename Elem<DT>::T*
         const float delta = (float)((int32_t)j - ib[j]);
         typename Elem<DT>::T* row = kb + (size_t)j * D;
         const uint4 a = *reinterpret_cast<const uint4*>(row + d0), b = *reinterpret_cast<const uint4*>(row + d0 + half);
-        float k0[8], k1[8], o0[8], o1[8];
-        unpack16<DT>(a, k0);
-        unpack16<DT>(b, k1);
-        const float4 f0 = *reinterpret_cast<const float4*>(inv_freq + d0), f1 = *reinterpret_cast<const float4*>(inv_freq + d0 + 4);
-        const float fr[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        uint4 o0, o1;
+        rotate8<DT>(a, b, delta, inv_freq + d0, o0, o1);
+        *reinterpret_cast<uint4*>(row + d0) = o0;
+        *reinterpret_cast<uint4*>(row + d0 + half) = o1;
+    }
+}
+
+// ---- gather + re-rotation in ONE pass (KeyRerotationPress / FinchPress: key_rerotation_press.py:157-160 then :107-128) ------------
+// K'[b,h,j] = rotate(K[b,h,idx[j]], (j - idx[j]) * inv_freq), V'[b,h,j] = V[b,h,idx[j]]: the gathered keys never make the round trip
+// through HBM that kvp_gather_kv + kvp_rerotate_keys costs (n * D * esize written, read and written again).  A thread owns 8 dims of
+// both halves of a row (rotate8: the same arithmetic as rerotate_vec_kernel, bit for bit) and copies the matching 2 x 16 bytes of V;
+// GR_UNROLL rows per thread are in flight.
+constexpr int GR_UNROLL = 2;
+struct GrArgs {
+    const char* k;
+    const char* v;
+    char* ko;
+    char* vo;
+    const int32_t* idx;
+    const float* inv_freq;
+    int64_t k_sb, k_sh, k_ss;  // BYTE strides
+    int64_t v_sb, v_sh, v_ss;
+    uint32_t H, S, n, D;
+};
+template <int DT, bool NT>
+__global__ __launch_bounds__(256) void gather_rerotate_kernel(GrArgs a) {
+    const uint32_t half = a.D / 2, tpr = half / 8, rowbytes = a.D * 2;
+    const uint32_t bh = blockIdx.y;
+    const uint32_t b = bh / a.H, h = bh - b * a.H;
+    const char* __restrict__ kb = a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh;
+    const char* __restrict__ vb = a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh;
+    const int32_t* __restrict__ ib = a.idx + (size_t)bh * a.n;
+    char* __restrict__ kob = a.ko + (size_t)bh * a.n * rowbytes;
+    char* __restrict__ vob = a.vo + (size_t)bh * a.n * rowbytes;
+    const uint32_t total = a.n * tpr, stride = gridDim.x * 256;
+    for (uint32_t i0 = blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += stride * GR_UNROLL) {
+        uint4 ka[GR_UNROLL], kc[GR_UNROLL], va[GR_UNROLL], vc[GR_UNROLL];
+        uint32_t j[GR_UNROLL], d0[GR_UNROLL];
+        float delta[GR_UNROLL];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float freq = __fmul_rn(delta, fr[e]);
-            float sv, cv;
-            sincos_f32_angle(freq, sv, cv);
-            const float c = round_dt<DT>(cv), s = round_dt<DT>(sv);
-            o0[e] = rope_elem<DT>(k0[e], c, -k1[e], s);
-            o1[e] = rope_elem<DT>(k1[e], c, k0[e], s);
+        for (int u = 0; u < GR_UNROLL; ++u) {
+            const uint32_t i = i0 + u * stride;
+            j[u] = i / tpr;
+            d0[u] = (i - j[u] * tpr) * 8;
+            if (i < total) {
+                const int32_t raw = ib[j[u]];
+                const int32_t src = raw < 0 ? 0 : (raw >= (int32_t)a.S ? (int32_t)a.S - 1 : raw);  // never fault on a bad index
+                delta[u] = (float)((int32_t)j[u] - raw);
+                const char* ks = kb + (int64_t)src * a.k_ss + (size_t)d0[u] * 2;
+                const char* vs = vb + (int64_t)src * a.v_ss + (size_t)d0[u] * 2;
+                ka[u] = ld16<NT>(ks);
+                kc[u] = ld16<NT>(ks + half * 2);
+                va[u] = ld16<NT>(vs);
+                vc[u] = ld16<NT>(vs + half * 2);
+            }
         }
-        *reinterpret_cast<uint4*>(row + d0) = make_uint4(pack2<DT>(o0[0], o0[1]), pack2<DT>(o0[2], o0[3]), pack2<DT>(o0[4], o0[5]), pack2<DT>(o0[6], o0[7]));
-        *reinterpret_cast<uint4*>(row + d0 + half) = make_uint4(pack2<DT>(o1[0], o1[1]), pack2<DT>(o1[2], o1[3]), pack2<DT>(o1[4], o1[5]), pack2<DT>(o1[6], o1[7]));
+#pragma unroll
+        for (int u = 0; u < GR_UNROLL; ++u) {
+            const uint32_t i = i0 + u * stride;
+            if (i < total) {
+                uint4 o0, o1;
+                rotate8<DT>(ka[u], kc[u], delta[u], a.inv_freq + d0[u], o0, o1);
+                char* kd = kob + (size_t)j[u] * rowbytes + (size_t)d0[u] * 2;
+                char* vd = vob + (size_t)j[u] * rowbytes + (size_t)d0[u] * 2;
+                st16<NT>(kd, o0);
+                st16<NT>(kd + half * 2, o1);
+                st16<NT>(vd, va[u]);
+                st16<NT>(vd + half * 2, vc[u]);
+            }
+        }
     }
 }
 
@@ -124,5 +199,49 @@ extern "C" int kvp_rerotate_keys(void* k, int dtype, int64_t B, int64_t H, int64
         default: KVP_LAUNCH("rerotate_kernel", stream, rerotate_kernel<KVP_BF16><<<dim3(bx, BH), 256, 0, stream>>>(static_cast<uint16_t*>(k), idx, inv_freq, (uint32_t)n, (uint32_t)D)); break;
     }
     KVP_CHECK_LAUNCH("rerotate");
+    return KVP_OK;
+}
+
+extern "C" int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_ss,
+                             int dtype, int64_t B, int64_t H, int64_t S, int64_t D, const int32_t* idx, int64_t n, void* k_out, void* v_out,
+                             kvp_stream_t stream);
+
+extern "C" int kvp_gather_kv_rerotate(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, const void* v, int64_t v_sb, int64_t v_sh,
+                                      int64_t v_ss, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, const int32_t* idx, int64_t n,
+                                      const float* inv_freq, void* k_out, void* v_out, kvp_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "gather_rerotate: bad dtype %d", dtype);
+    KVP_CHECK_ARG(B >= 0 && H >= 0 && S >= 0 && D >= 2 && D % 2 == 0 && n >= 0 && n <= S, "gather_rerotate: bad shape B=%ld H=%ld S=%ld D=%ld n=%ld",
+                  (long)B, (long)H, (long)S, (long)D, (long)n);
+    if (B * H * n == 0) return KVP_OK;
+    KVP_CHECK_ARG(k && v && idx && inv_freq && k_out && v_out, "gather_rerotate: null pointer");
+    auto al16 = [](int64_t x) { return x % 16 == 0; };
+    const bool fused = dtype != KVP_F32 && D % 16 == 0 && B * H <= 65535 && n * D < ((int64_t)1 << 31) && S < ((int64_t)1 << 31) &&
+                       al16((int64_t)(uintptr_t)k) && al16((int64_t)(uintptr_t)v) && al16((int64_t)(uintptr_t)k_out) &&
+                       al16((int64_t)(uintptr_t)v_out) && al16((int64_t)(uintptr_t)inv_freq) && al16(k_sb * 2) && al16(k_sh * 2) && al16(k_ss * 2) &&
+                       al16(v_sb * 2) && al16(v_sh * 2) && al16(v_ss * 2) && kvp_env_int("KVP_GA_REROT_FUSED", 1) != 0;
+    if (!fused) {   // any other shape / dtype: the two kernels it replaces
+        if (int rc = kvp_gather_kv(k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, H, S, D, idx, n, k_out, v_out, stream_)) return rc;
+        return kvp_rerotate_keys(k_out, dtype, B, H, n, D, idx, inv_freq, stream_);
+    }
+    GrArgs a;
+    a.k = static_cast<const char*>(k); a.v = static_cast<const char*>(v);
+    a.ko = static_cast<char*>(k_out); a.vo = static_cast<char*>(v_out);
+    a.idx = idx; a.inv_freq = inv_freq;
+    a.k_sb = k_sb * 2; a.k_sh = k_sh * 2; a.k_ss = k_ss * 2;
+    a.v_sb = v_sb * 2; a.v_sh = v_sh * 2; a.v_ss = v_ss * 2;
+    a.H = (uint32_t)H; a.S = (uint32_t)S; a.n = (uint32_t)n; a.D = (uint32_t)D;
+    const uint32_t BH = (uint32_t)(B * H);
+    const uint64_t total = (uint64_t)n * (uint64_t)(D / 16);
+    const uint64_t bx_full = (total + 256 * GR_UNROLL - 1) / (256 * GR_UNROLL);
+    const uint64_t bx_cap = std::max<uint64_t>(1, ((uint64_t)256 * kvp_env_int("KVP_GR_WG_PER_CU", 8) + BH - 1) / BH);
+    const dim3 grid((uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap)), BH);
+    const int nt_env = kvp_env_int("KVP_GA_NT", -1);   // the same rule as kvp_gather_kv
+    const bool nt = nt_env >= 0 ? nt_env != 0 : (uint64_t)B * H * S * D * 2 * 2 > (192ull << 20);
+#define KVP_GR(DTV, NTV) KVP_LAUNCH("gather_rerotate_kernel", stream, (gather_rerotate_kernel<DTV, NTV><<<grid, 256, 0, stream>>>(a)))
+    if (dtype == KVP_F16) { if (nt) KVP_GR(KVP_F16, true); else KVP_GR(KVP_F16, false); }
+    else { if (nt) KVP_GR(KVP_BF16, true); else KVP_GR(KVP_BF16, false); }
+#undef KVP_GR
+    KVP_CHECK_LAUNCH("gather_rerotate");
     return KVP_OK;
 }

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(RN_THREADS) void rownorm_vec_kernel(
 // Two tensors of the same shape in ONE launch (CURPress: sum of squares of the keys' and of the values' rows, cur_press.py:40-41):
 // blockIdx.z selects the tensor, so both streams are in flight together (two launches ran 118 us for 537 MB at 8 x 131072; one
 // boundary and one ramp less, and the second stream starts while the first one drains).
-template <int DT, int LPR>
+template <int DT, int LPR, bool NT>
 __global__ __launch_bounds__(RN_THREADS) void rowsumsq2_vec_kernel(const typename Elem<DT>::T* __restrict__ x0, const typename Elem<DT>::T* __restrict__ x1,
                                                                    PlaneMap map0, PlaneMap map1, uint32_t chunks, float* __restrict__ out0,
                                                                    float* __restrict__ out1) {
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(RN_THREADS) void rowsumsq2_vec_kernel(const typenam
         for (int u = 0; u < RN_UNROLL; ++u) {
             const uint32_t s = s0 + u * TG;
             v[u] = make_uint4(0, 0, 0, 0);
-            if (s < S && lir < chunks) v[u] = *reinterpret_cast<const uint4*>(base + (int64_t)s * map.ss + (size_t)lir * PER16);
+            if (s < S && lir < chunks) v[u] = ld16<NT>(base + (int64_t)s * map.ss + (size_t)lir * PER16);
         }
 #pragma unroll
         for (int u = 0; u < RN_UNROLL; ++u) {
@@ -123,6 +123,49 @@ __global__ __launch_bounds__(RN_THREADS) void rowsumsq2_vec_kernel(const typenam
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
             if (lir == 0 && s < S) ob[s] = acc;
+        }
+    }
+}
+
+// Slot shape: every workgroup streams ONE contiguous range of rows (the walk of topk_cluster.hip's Knorm mode, which moves 268 MB in
+// ~38 us where the strided walk above takes 53-65), RN_UNROLL steps of THREADS / LPR rows in flight.  blockIdx.z selects the tensor
+// (CURPress: K and V energies in one launch).  Same lanes per row, same fma chain and shuffle order: same bits as rownorm_vec_kernel.
+template <int DT, int LPR, int THREADS, bool NT>
+__global__ __launch_bounds__(THREADS) void rownorm_slot_kernel(const typename Elem<DT>::T* __restrict__ x0, const typename Elem<DT>::T* __restrict__ x1,
+                                                               PlaneMap map0, PlaneMap map1, uint32_t chunks, float scale, float* __restrict__ out0,
+                                                               float* __restrict__ out1, uint32_t rows_per_wg) {
+    using T = typename Elem<DT>::T;
+    constexpr int PER16 = Elem<DT>::PER16;
+    constexpr int GPB = THREADS / LPR;
+    const bool second = blockIdx.z != 0;
+    const PlaneMap map = second ? map1 : map0;
+    const uint32_t bh = blockIdx.y;
+    const uint32_t b = bh / map.H, h = bh - b * map.H;
+    const T* __restrict__ base = (second ? x1 : x0) + (int64_t)b * map.sb + (int64_t)h * map.sh;
+    float* __restrict__ ob = (second ? out1 : out0) + (size_t)bh * map.S;
+    const uint32_t lir = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const uint32_t r0 = blockIdx.x * rows_per_wg;
+    const uint32_t r1 = min(map.S, r0 + rows_per_wg);
+    for (uint32_t it = r0; it < r1; it += GPB * RN_UNROLL) {
+        uint4 v[RN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RN_UNROLL; ++u) {
+            const uint32_t s = it + u * GPB + grp;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (s < r1 && lir < chunks) v[u] = ld16<NT>(base + (int64_t)s * map.ss + (size_t)lir * PER16);
+        }
+#pragma unroll
+        for (int u = 0; u < RN_UNROLL; ++u) {
+            const uint32_t s = it + u * GPB + grp;
+            float acc = sumsq16<DT>(v[u]);
+            if (LPR == 64 && s < r1) {
+                const T* rowp = base + (int64_t)s * map.ss;
+                for (uint32_t c = lir + LPR; c < chunks; c += LPR)
+                    acc += sumsq16<DT>(*reinterpret_cast<const uint4*>(rowp + (size_t)c * PER16));
+            }
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lir == 0 && s < r1) ob[s] = scale * (map.squared ? acc : sqrtf(acc));
         }
     }
 }
@@ -142,6 +185,46 @@ __global__ __launch_bounds__(RN_THREADS) void rownorm_scalar_kernel(
             acc = fmaf(f, f, acc);
         }
         out[(size_t)bh * map.S + s] = scale * (map.squared ? acc : sqrtf(acc));
+    }
+}
+
+// Streaming (non-temporal) loads when the tensor cannot stay in the 256 MiB memory-side cache anyway (the cutoff of kvp_gather_kv): a
+// read-once stream that allocates there first has to push out what the previous kernel left behind as dirty lines.  Measured at
+// 8 x 131072 x 128 bf16 right after a 512 MB copy (tools/stream_lab.py): 75 -> 55 us, with the slot walk 48.  KVP_RN_NT=0/1 forces either.
+bool rn_streaming(uint64_t bytes) {
+    const int e = kvp_env_int("KVP_RN_NT", -1);
+    return e >= 0 ? e != 0 : bytes > (192ull << 20);
+}
+
+template <int DT, int THREADS>
+void launch_rownorm_slot_t(const typename Elem<DT>::T* x0, const typename Elem<DT>::T* x1, PlaneMap m0, PlaneMap m1, uint32_t BH, uint32_t ntens,
+                           uint32_t chunks, int lpr, float scale, float* o0, float* o1, hipStream_t stream) {
+    const uint32_t gpb = THREADS / lpr;
+    const uint32_t wgs_per_cu = (uint32_t)std::max(1, kvp_env_int("KVP_RN_WGS", THREADS >= 1024 ? 1 : 2048 / THREADS));
+    const uint64_t want = std::max<uint64_t>(1, ((uint64_t)256 * wgs_per_cu + (uint64_t)BH * ntens - 1) / ((uint64_t)BH * ntens));
+    const uint32_t step = gpb * RN_UNROLL;
+    uint64_t rows = ((uint64_t)m0.S + want - 1) / want;
+    rows = (rows + step - 1) / step * step;
+    const uint32_t bx = (uint32_t)(((uint64_t)m0.S + rows - 1) / rows);
+    const dim3 grid(bx, BH, ntens);
+    const bool nt = rn_streaming((uint64_t)BH * ntens * m0.S * chunks * 16);
+#define KVP_RS_CASE(L)                                                                                                                    \
+    case L:                                                                                                                               \
+        if (nt) KVP_LAUNCH("rownorm_vec_kernel", stream, (rownorm_slot_kernel<DT, L, THREADS, true><<<grid, THREADS, 0, stream>>>(x0, x1, m0, m1, chunks, scale, o0, o1, (uint32_t)rows))); \
+        else KVP_LAUNCH("rownorm_vec_kernel", stream, (rownorm_slot_kernel<DT, L, THREADS, false><<<grid, THREADS, 0, stream>>>(x0, x1, m0, m1, chunks, scale, o0, o1, (uint32_t)rows))); \
+        break;
+    switch (lpr) {
+        KVP_RS_CASE(1) KVP_RS_CASE(2) KVP_RS_CASE(4) KVP_RS_CASE(8) KVP_RS_CASE(16) KVP_RS_CASE(32) KVP_RS_CASE(64)
+    }
+#undef KVP_RS_CASE
+}
+template <int DT>
+void launch_rownorm_slot(const typename Elem<DT>::T* x0, const typename Elem<DT>::T* x1, PlaneMap m0, PlaneMap m1, uint32_t BH, uint32_t ntens,
+                         uint32_t chunks, int lpr, float scale, float* o0, float* o1, hipStream_t stream) {
+    switch (kvp_env_int("KVP_RN_THREADS", 1024)) {
+        case 256: launch_rownorm_slot_t<DT, 256>(x0, x1, m0, m1, BH, ntens, chunks, lpr, scale, o0, o1, stream); break;
+        case 512: launch_rownorm_slot_t<DT, 512>(x0, x1, m0, m1, BH, ntens, chunks, lpr, scale, o0, o1, stream); break;
+        default: launch_rownorm_slot_t<DT, 1024>(x0, x1, m0, m1, BH, ntens, chunks, lpr, scale, o0, o1, stream); break;
     }
 }
 
@@ -167,7 +250,11 @@ int launch_rownorm(const void* x, PlaneMap map, uint32_t BH, uint32_t D, float s
     const uint64_t bx_full = (groups_needed + gpb - 1) / gpb;
     const uint64_t bx_cap = std::max<uint64_t>(1, (256 * 8 + BH - 1) / BH);  // ~8 workgroups per CU in total
     const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap));
-    const bool nt = kvp_env_int("KVP_RN_NT", 0) != 0;
+    const bool nt = rn_streaming((uint64_t)BH * map.S * rowbytes);
+    if (!hist1 && kvp_env_int("KVP_RN_SLOT", 1) != 0 && map.S >= 4096) {
+        launch_rownorm_slot<DT>(xp, xp, map, map, BH, 1, chunks, lpr, scale, out, out, stream);
+        return 0;
+    }
 #define KVP_RN_CASE(L)                                                                                     \
     case L:                                                                                                \
         if (hist1) KVP_LAUNCH("rownorm_vec_kernel", stream, rownorm_vec_kernel<DT, L, false, true><<<dim3(bx, BH), RN_THREADS, 0, stream>>>(xp, map, chunks, scale, out, hist1)); \
@@ -239,14 +326,21 @@ int kvp_rowsumsq2_launch(const void* k, const void* v, int dtype, int64_t B, int
     }
     PlaneMap mk{(uint32_t)H, (uint32_t)S, k_sb, k_sh, k_ss, true}, mv{(uint32_t)H, (uint32_t)S, v_sb, v_sh, v_ss, true};
     const uint32_t BH = (uint32_t)(B * H);
+    if (kvp_env_int("KVP_RN_SLOT", 1) != 0 && S >= 4096) {
+        if (dtype == KVP_BF16) launch_rownorm_slot<KVP_BF16>(static_cast<const uint16_t*>(k), static_cast<const uint16_t*>(v), mk, mv, BH, 2, 16, 16, 1.0f, out_k, out_v, stream);
+        else launch_rownorm_slot<KVP_F16>(static_cast<const _Float16*>(k), static_cast<const _Float16*>(v), mk, mv, BH, 2, 16, 16, 1.0f, out_k, out_v, stream);
+        KVP_CHECK_LAUNCH("rowsumsq2");
+        return KVP_OK;
+    }
     constexpr uint32_t gpb = RN_THREADS / 16;
     const uint64_t bx_full = (((uint64_t)S + RN_UNROLL - 1) / RN_UNROLL + gpb - 1) / gpb;
     const uint64_t bx_cap = std::max<uint64_t>(1, (256 * 4 + BH - 1) / BH);   // ~8 workgroups per CU over the two tensors
     const dim3 grid((uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap)), BH, 2);
-    if (dtype == KVP_BF16)
-        KVP_LAUNCH("rownorm_vec_kernel", stream, (rowsumsq2_vec_kernel<KVP_BF16, 16><<<grid, RN_THREADS, 0, stream>>>(static_cast<const uint16_t*>(k), static_cast<const uint16_t*>(v), mk, mv, 16, out_k, out_v)));
-    else
-        KVP_LAUNCH("rownorm_vec_kernel", stream, (rowsumsq2_vec_kernel<KVP_F16, 16><<<grid, RN_THREADS, 0, stream>>>(static_cast<const _Float16*>(k), static_cast<const _Float16*>(v), mk, mv, 16, out_k, out_v)));
+    const bool nt = rn_streaming((uint64_t)BH * 2 * S * 256);
+#define KVP_RS2(DTV, TT, NTV) KVP_LAUNCH("rownorm_vec_kernel", stream, (rowsumsq2_vec_kernel<DTV, 16, NTV><<<grid, RN_THREADS, 0, stream>>>(static_cast<const TT*>(k), static_cast<const TT*>(v), mk, mv, 16, out_k, out_v)))
+    if (dtype == KVP_BF16) { if (nt) KVP_RS2(KVP_BF16, uint16_t, true); else KVP_RS2(KVP_BF16, uint16_t, false); }
+    else { if (nt) KVP_RS2(KVP_F16, _Float16, true); else KVP_RS2(KVP_F16, _Float16, false); }
+#undef KVP_RS2
     KVP_CHECK_LAUNCH("rowsumsq2");
     return KVP_OK;
 }

@@ -85,6 +85,9 @@ struct ClusterArgs {
     float scale;
 };
 
+#ifndef TC_KN_UNROLL
+#define TC_KN_UNROLL 4   // 64-row steps of the Knorm stream in flight per workgroup (L = 1024 PER is a multiple of 64 * 8)
+#endif
 enum { TC_SCORES = 0, TC_POOL5 = 1, TC_KNORM_BF16 = 2, TC_KNORM_F16 = 3 };
 
 template <int DT>
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
                 keys[j] = tc_key(sum, kmask) & inside;
             }
         } else {
-            // -||k||: 16 lanes per 256-byte row, 64 rows per step of the workgroup, four steps in flight (rownorm_vec_kernel's
+            // -||k||: 16 lanes per 256-byte row, 64 rows per step of the workgroup, TC_KN_UNROLL steps in flight (rownorm_vec_kernel's
             // loads, fma chain, xor-shuffle order and rounding); the scores go through LDS to their owning threads
             constexpr int DT = MODE == TC_KNORM_BF16 ? KVP_BF16 : KVP_F16;
             using T = typename Elem<DT>::T;
@@ -178,16 +181,20 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             const uint32_t lir = threadIdx.x & 15u, g = threadIdx.x >> 4;
             const uint32_t r0 = slot * L;
 #pragma unroll 1
-            for (uint32_t it = 0; it < L; it += 256) {
-                uint4 v[4];
+            for (uint32_t it = 0; it < L; it += 64 * TC_KN_UNROLL) {
+                uint4 v[TC_KN_UNROLL];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < TC_KN_UNROLL; ++u) {
                     const uint32_t s = r0 + it + u * 64 + g;
                     v[u] = make_uint4(0, 0, 0, 0);
+                    #ifdef TC_KN_NT
+                    if (s < S) v[u] = ld16<true>(base + (int64_t)s * a.x_ss + (size_t)lir * 8);
+#else
                     if (s < S) v[u] = *reinterpret_cast<const uint4*>(base + (int64_t)s * a.x_ss + (size_t)lir * 8);
+#endif
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < TC_KN_UNROLL; ++u) {
                     float acc = tc_sumsq16<DT>(v[u]);
 #pragma unroll
                     for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);

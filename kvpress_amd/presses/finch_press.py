@@ -4,7 +4,7 @@ The input is ``context + delimiter token + question``; a hook on the embedding l
 tokens after it as the observation window and removes the delimiter from the sequence (:124-137).  Scores come from
 ``kvp_finch_score`` (window attention for any window length, rows weighted by their number of visible keys, no
 pooling); the selection is one global ``kvp_topk_select`` or one ``kvp_topk_select_segmented`` over the chunks, the kept
-keys are gathered in position order and -- by default -- re-rotated to positions 0..n-1 (``kvp_rerotate_keys``).
+keys are gathered in position order and -- by default -- re-rotated to positions 0..n-1 (``kvp_gather_kv_rerotate``).
 The reference's non-rerotating variant keeps torch.topk's order inside the cache; here it is position order, like every
 other press of this package (retained order)."""
 from __future__ import annotations
@@ -80,10 +80,9 @@ class FinchPress(BasePress):
                 parts.append(_native.topk_select_segmented(sc, tail, max(1, int(tail * (1 - self.compression_ratio))),
                                                            pos_base=n_full * L).view(B, H, -1))
             indices = parts[0] if len(parts) == 1 else torch.cat(parts, dim=-1)
-        keys, values = _native.gather_kv(keys, values, indices)       # ascending positions (:114)
-        if self.rerotate_keys:
-            _native.rerotate_keys_(keys, indices, module.rotary_emb.inv_freq)
-        return keys, values
+        if self.rerotate_keys:                                        # ascending positions (:114), gather + re-rotation in one pass
+            return _native.gather_kv_rerotate(keys, values, indices, module.rotary_emb.inv_freq)
+        return _native.gather_kv(keys, values, indices)
 
     def embed_token_forward_hook(self, module, input, output):
         """Find the delimiter between context and question, set the window, drop the delimiter (finch_press.py:124-137)."""

@@ -2,7 +2,7 @@
 keys so that they carry the RoPE phases of positions 0..n_kept-1 (as StreamingLLM does in the paper).
 
 score (wrapped press) -> kvp_topk_select (ascending positions = the reference's ``torch.sort(indices)``, :157) ->
-kvp_gather_kv -> kvp_rerotate_keys (in place on the gathered keys)."""
+kvp_gather_kv_rerotate (the gather and the re-rotation in one pass: the kept keys are written once, already rotated)."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -46,6 +46,4 @@ class KeyRerotationPress(BasePress):
         scores = self.press.score(module, hidden_states, keys, values, attentions, kwargs)
         n_kept = int(keys.shape[2] * (1 - self.press.compression_ratio))      # key_rerotation_press.py:154-155
         indices = _native.topk_select(scores, n_kept)                         # ascending positions (:157)
-        keys, values = _native.gather_kv(keys, values, indices)
-        _native.rerotate_keys_(keys, indices, module.rotary_emb.inv_freq)     # :107-128
-        return keys, values
+        return _native.gather_kv_rerotate(keys, values, indices, module.rotary_emb.inv_freq)   # :157-160 + :107-128 in one pass

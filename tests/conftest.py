@@ -156,6 +156,10 @@ def fake_native(monkeypatch):
         keys_kept.copy_(torch.from_numpy(out).to(keys_kept.dtype))
         return keys_kept
 
+    def gather_kv_rerotate(keys, values, idx, inv_freq):
+        ko, vo = gather_kv(keys, values, idx)
+        return rerotate_keys_(ko, idx, inv_freq), vo
+
     def qproj_rope_supported(module, hidden_states, window):
         return False  # CPU tensors: the model's own q_proj + the oracle-backed rope path
 
@@ -169,7 +173,7 @@ def fake_native(monkeypatch):
 
     for name, fn in dict(rownorm_score=rownorm_score, topk_select=topk_select, gather_kv=gather_kv,
                          snapkv_score=snapkv_score, snapkv_score_rope=snapkv_score_rope, finch_score=finch_score, snapkv_score_from_attn=snapkv_score_from_attn,
-                         keydiff_score=keydiff_score, rowdot_score=rowdot_score, rowl1_score=rowl1_score, think_channel_scores=think_channel_scores, zero_channels_=zero_channels_, lagkv_score=lagkv_score, observed_attention_score=observed_attention_score, cur_score=cur_score, scores_head_mean_=scores_head_mean_, knorm_compress=knorm_compress, qproj_rope_supported=qproj_rope_supported, scores_fill_at_=scores_fill_at_, topk_select_segmented=topk_select_segmented, rerotate_keys_=rerotate_keys_,
+                         keydiff_score=keydiff_score, rowdot_score=rowdot_score, rowl1_score=rowl1_score, think_channel_scores=think_channel_scores, zero_channels_=zero_channels_, lagkv_score=lagkv_score, observed_attention_score=observed_attention_score, cur_score=cur_score, scores_head_mean_=scores_head_mean_, knorm_compress=knorm_compress, qproj_rope_supported=qproj_rope_supported, scores_fill_at_=scores_fill_at_, topk_select_segmented=topk_select_segmented, rerotate_keys_=rerotate_keys_, gather_kv_rerotate=gather_kv_rerotate,
                          snapkv_compress_rope=snapkv_compress_rope, ea_qstats=ea_qstats, ea_score=ea_score).items():
         monkeypatch.setattr(_native, name, fn)
     return _native

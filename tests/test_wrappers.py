@@ -462,6 +462,36 @@ def test_rerotation_native_dtype_gpu(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])
+def test_gather_rerotate_one_pass_equals_two_kernels(dtype, knobs):
+    """kvp_gather_kv_rerotate (KeyRerotationPress / FinchPress) == kvp_gather_kv then kvp_rerotate_keys, bit for bit: the one-pass kernel
+    (2-byte dtypes, D % 16 == 0), its cached / streaming variants, views with strides, and the shapes that fall back to the two kernels."""
+    from kvpress_amd import _native
+
+    dt = _inputs.torch_dtype(dtype)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(11)
+    for B, H, S, D, n in ((1, 8, 4096, 128, 2048), (2, 3, 1000, 64, 333), (1, 2, 777, 128, 777), (1, 4, 513, 48, 100), (1, 1, 50, 6, 7),
+                          (1, 8, 70000, 128, 1)):
+        k = torch.randn((B, H, S, D), generator=g, device=DEV).to(dt)
+        v = torch.randn((B, H, S, D), generator=g, device=DEV).to(dt)
+        pos = torch.stack([torch.randperm(S, generator=g, device=DEV)[:n].sort().values for _ in range(B * H)]).view(B, H, n).to(torch.int32)
+        inv = (10000.0 ** (-torch.arange(0, D, 2, device=DEV, dtype=torch.float32) / D))
+        ko, vo = _native.gather_kv(k, v, pos)
+        _native.rerotate_keys_(ko, pos, inv)
+        for kv in (dict(), dict(KVP_GA_NT=1), dict(KVP_GA_NT=0), dict(KVP_GA_REROT_FUSED=0)):
+            knobs(**kv)
+            k1, v1 = _native.gather_kv_rerotate(k, v, pos, inv)
+            assert torch.equal(k1, ko) and torch.equal(v1, vo), (dtype, B, H, S, D, n, kv)
+            knobs(**{key: None for key in kv})
+        if D % 16 == 0:   # a [B, S, H, D] cache layout seen through transpose(1, 2): rows 16-byte aligned, not contiguous
+            kt = k.transpose(1, 2).contiguous().transpose(1, 2)
+            vt = v.transpose(1, 2).contiguous().transpose(1, 2)
+            k2, v2 = _native.gather_kv_rerotate(kt, vt, pos, inv)
+            assert torch.equal(k2, ko) and torch.equal(v2, vo), (dtype, B, H, S, D, n, "strided")
+
+
+@pytest.mark.gpu
 def test_topk_segmented_vs_oracle():
     from kvpress_amd import _native
 

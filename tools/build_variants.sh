@@ -31,3 +31,17 @@ for v in tc_l2 tc_l2_timing; do
     echo "built $v"
   fi
 done
+# tc_kn8: eight instead of four 64-row steps of the cluster select's Knorm stream in flight
+if [[ " $* " == *" tc_kn8 "* ]]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DTC_KN_UNROLL=8 -c kvpress_amd/csrc/topk_cluster.hip -o /tmp/topk_cluster_kn8.o
+  objs=$(ls kvpress_amd/build/*.o | grep -v topk_cluster.o)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o kvpress_amd/lib/variants/tc_kn8.so $objs /tmp/topk_cluster_kn8.o
+  echo "built tc_kn8"
+fi
+# tc_knnt: non-temporal loads in the cluster select's Knorm stream
+if [[ " $* " == *" tc_knnt "* ]]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DTC_KN_NT -c kvpress_amd/csrc/topk_cluster.hip -o /tmp/topk_cluster_knnt.o
+  objs=$(ls kvpress_amd/build/*.o | grep -v topk_cluster.o)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o kvpress_amd/lib/variants/tc_knnt.so $objs /tmp/topk_cluster_knnt.o
+  echo "built tc_knnt"
+fi
