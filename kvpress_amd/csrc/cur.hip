@@ -58,28 +58,38 @@ __global__ __launch_bounds__(CU_THREADS) void cur_combine_kernel(const float* __
     if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// The same for local windows (w >= 1): the windows are disjoint aligned blocks of w tokens, so ONE thread takes a whole window --
-// its two sums once, then its w scores -- instead of every token re-adding its window (2 x w loads per token: 12 of CUR's 19 us
-// of post-processing at 8 x 131072).  The window sums and the un-normalised scores are the per-token kernel's bit for bit; the row
-// total groups the tokens differently over the threads, so it may differ in its last bits (both orders are fixed: deterministic).
-__global__ __launch_bounds__(CU_THREADS) void cur_combine_win_kernel(const float* __restrict__ k2, const float* __restrict__ v2, uint32_t S, uint32_t w,
+// The same for local windows whose length divides the workgroup's 256-token span: the span's energies go through LDS once, one thread
+// per window adds them in window_sum's order, every token divides by its window's sum -- the same tokens per thread and the same
+// arithmetic as the per-token kernel (bit for bit), without its 2 x w loads per token.
+__global__ __launch_bounds__(CU_THREADS) void cur_combine_lds_kernel(const float* __restrict__ k2, const float* __restrict__ v2, uint32_t S, uint32_t w,
                                                                      int type, float* __restrict__ scores, float* __restrict__ partial) {
     __shared__ float red[CU_THREADS / 64];
+    __shared__ float sk[CU_THREADS], sv[CU_THREADS], tk[CU_THREADS], tv[CU_THREADS];
     const float* kr = k2 + (size_t)blockIdx.y * S;
     const float* vr = v2 + (size_t)blockIdx.y * S;
     float* out = scores + (size_t)blockIdx.y * S;
-    const uint32_t nwin = (S + w - 1) / w;
+    const uint32_t nwin = CU_THREADS / w, mywin = threadIdx.x / w;
     float acc = 0.f;
-    for (uint32_t win = blockIdx.x * CU_THREADS + threadIdx.x; win < nwin; win += gridDim.x * CU_THREADS) {
-        const uint32_t lo = win * w, hi = min(lo + w, S);
-        float tk = 0.f, tv = 0.f;
-        for (uint32_t i = lo; i < hi; ++i) {
-            tk += kr[i];
-            tv += vr[i];
+    for (uint32_t base = blockIdx.x * CU_THREADS; base < S; base += gridDim.x * CU_THREADS) {
+        const uint32_t s = base + threadIdx.x;
+        const float a = s < S ? kr[s] : 0.f, b = s < S ? vr[s] : 0.f;
+        sk[threadIdx.x] = a;
+        sv[threadIdx.x] = b;
+        __syncthreads();
+        if (threadIdx.x < nwin) {
+            const uint32_t lo = threadIdx.x * w, hi = min(lo + w, S - base);
+            float ta = 0.f, tb = 0.f;
+            for (uint32_t i = lo; i < hi; ++i) {
+                ta += sk[i];
+                tb += sv[i];
+            }
+            tk[threadIdx.x] = ta;
+            tv[threadIdx.x] = tb;
         }
-        for (uint32_t i = lo; i < hi; ++i) {
-            const float c = combine(type, kr[i] / tk, vr[i] / tv);
-            out[i] = c;
+        __syncthreads();
+        if (s < S) {
+            const float c = combine(type, a / tk[mywin], b / tv[mywin]);
+            out[s] = c;
             acc += c;
         }
     }
@@ -89,8 +99,9 @@ __global__ __launch_bounds__(CU_THREADS) void cur_combine_win_kernel(const float
     if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// (Round 3: one THREAD per window -- its two sums once, then its w scores -- was measured at 82 us against this kernel's 12: sixteen
-// dependent 4-byte loads per lane, 64 bytes apart across the wave, is the worst shape for the vector memory path.)
+// (Round 3: one THREAD per window straight from global memory -- its two sums once, then its w scores -- was measured at 82 us against
+// the per-token kernel's 12: sixteen dependent 4-byte loads per lane, 64 bytes apart across the wave, is the worst shape for the vector
+// memory path.  Hence the LDS staging above.)
 // pass 2: divide by the row total (the partials added in block order), sinks = 1
 __global__ __launch_bounds__(CU_THREADS) void cur_normalize_kernel(float* __restrict__ scores, const float* __restrict__ partial, uint32_t nblk, uint32_t S,
                                                                    uint32_t num_sinks) {
@@ -134,8 +145,8 @@ extern "C" int kvp_cur_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t 
     float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + 2 * half);
     const uint32_t R = (uint32_t)(B * H);
     const uint32_t nblk = (uint32_t)std::max<int64_t>(1, std::min<int64_t>({(S + CU_THREADS - 1) / CU_THREADS, (int64_t)CU_MAXBLK, std::max<int64_t>(1, 2048 / R)}));
-    if (local_window_size >= 4)   // one thread per window (the per-token kernel re-adds the window for every token)
-        KVP_LAUNCH("cur_combine_kernel", stream, cur_combine_win_kernel<<<dim3(nblk, R), CU_THREADS, 0, stream>>>(k2, v2, (uint32_t)S, (uint32_t)local_window_size,
+    if (local_window_size >= 2 && CU_THREADS % local_window_size == 0 && kvp_env_int("KVP_CUR_LDS", 1) != 0)   // windows never straddle a workgroup's 256-token span
+        KVP_LAUNCH("cur_combine_kernel", stream, cur_combine_lds_kernel<<<dim3(nblk, R), CU_THREADS, 0, stream>>>(k2, v2, (uint32_t)S, (uint32_t)local_window_size,
                                                                                                                  leverage_type, scores, partial));
     else
         KVP_LAUNCH("cur_combine_kernel", stream, cur_combine_kernel<<<dim3(nblk, R), CU_THREADS, 0, stream>>>(k2, v2, (uint32_t)S, (uint32_t)local_window_size,

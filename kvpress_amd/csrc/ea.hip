@@ -16,8 +16,8 @@
 #include "softmax_stats.h"
 #include "ea_internal.h"
 
-int kvp_rownorm_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh,
-                       int64_t ss, float scale, float* out, hipStream_t stream, uint32_t* hist1, bool* hist1_done);
+int kvp_rownorm_launch_read_once(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh, int64_t ss,
+                                 float scale, float* out, hipStream_t stream);
 
 namespace {
 
@@ -360,7 +360,7 @@ extern "C" int kvp_ea_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
     KVP_CHECK_LAUNCH("ea_score(logits)");
     if (use_vnorm) {
         const char* vp = static_cast<const char*>(v) + n_sink * v_ss * kvp_elem_size(dtype);
-        if (int rc = kvp_rownorm_launch(vp, dtype, B, Hkv, Sp, D, v_sb, v_sh, v_ss, 1.0f, w.vnorm, stream, nullptr, nullptr)) return rc;
+        if (int rc = kvp_rownorm_launch_read_once(vp, dtype, B, Hkv, Sp, D, v_sb, v_sh, v_ss, 1.0f, w.vnorm, stream)) return rc;
     }
     const uint64_t total = (uint64_t)B * Hkv * Sp;
     const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((total + EA_THREADS - 1) / EA_THREADS, 2048));

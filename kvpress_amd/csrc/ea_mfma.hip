@@ -239,7 +239,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_qstats_mfma_kernel(QstatArgs
 // workgroup, ET_NBUF - 1 tiles in flight); the 16-byte slots of a row are XOR-swizzled by (token & 3) << 2 on the global side so that the four token rows a
 // transposed read touches sit in different banks.  Per 16-token k-step and wave: 8 transposed reads (fragments of all four
 // 32-dim strips), 4 syrk MFMAs (own strip x every strip) + 1 MFMA against a ones fragment for the column sums.
-// Raw moments cancel when |mean| >> sigma: sum x x^T is accumulated in fp32 over the rows of one partial (4096 .. 16384 at 128k tokens,
+// Raw moments cancel when |mean| >> sigma: sum x x^T is accumulated in fp32 over the rows of one partial (4096 .. 8192 at 128k tokens,
 // qstats_plan), so the relative error of a covariance entry is ~2^-24 (mean / sigma)^2 sqrt(rows / 16): 1e-4 .. 2e-4 at |mean| = 10 sigma
 // (tests/test_gpu_fullsize.py::test_ea_qstats_128k_large_mean_adversarial, bound 1e-3).  The partials are merged by the same pairwise update.
 template <int DT, int ET_NBUF, int ET_OCC>
@@ -406,12 +406,13 @@ __global__ __launch_bounds__(256) void ea_qstats_combine(const float* __restrict
     for (int q = 0; q < 4; ++q) cov[(size_t)bh * 16384 + e0 + q * 256] = s[q] * invN;
 }
 
-// Partials per head: about one workgroup per CU over all heads (32 heads: 8 chunks of 16384 rows), at least 4096 rows each.  Measured
-// at 32 heads x 131072 rows (tools/stream_lab.py, statistics + combine): 32 chunks per head 273 us, 16: 230, 8: 219 (8 with the
-// streaming loads below: 194), 4: 446 -- fewer partials are less to write, re-read and merge (67 MB -> 17 MB), and a workgroup
-// that walks 16384 consecutive rows keeps its ring full for longer.  KVP_EA_QCHUNKS caps the count.
+// Partials per head: about two workgroups per CU over all heads (32 heads: 16 chunks of 8192 rows), at least 4096 rows each.  Fewer
+// partials are less to write, re-read and merge (32 per head: 67 MB), and a workgroup that walks more consecutive rows keeps its ring full
+// for longer; below one workgroup per CU the stream starves.  Inside the ExpectedAttention bench loop (scripts/ab_bench.sh,
+// profiles/r03_ab_bench.txt; statistics + combine, streaming loads): 32 per head 207 + 23 us, 16: 175 + 13, 8: 207 + 10.
+// KVP_EA_QCHUNKS caps the count.
 void qstats_plan(int64_t Sq, int64_t nbh, uint32_t& nchunk, uint32_t& rows) {
-    const int64_t target = std::max<int64_t>(1, 256 / std::max<int64_t>(1, nbh));
+    const int64_t target = std::max<int64_t>(1, 512 / std::max<int64_t>(1, nbh));
     const int64_t cap = std::min<int64_t>(32, std::max(1, kvp_env_int("KVP_EA_QCHUNKS", (int)std::min<int64_t>(32, target))));
     int64_t nc = std::min<int64_t>(cap, std::max<int64_t>(1, (Sq + 4095) / 4096));
     int64_t r = ((Sq + nc - 1) / nc + EM_TILE - 1) / EM_TILE * EM_TILE;

@@ -273,10 +273,10 @@ int launch_keydiff(const void* x, KdMap map, uint32_t BH, uint32_t D, float* sco
     const T* xp = static_cast<const T*>(x);
     const KdPlan p = plan_for<DT>(x, map, BH, D);
     const dim3 grid(p.nwg, BH);
-    // streaming loads in both passes when K cannot stay in the memory-side cache between them anyway (rownorm.hip: rn_streaming);
-    // KVP_KD_NT: bit 0 = anchor pass, bit 1 = score pass.  8 x 131072 x 128 bf16 after a 512 MB copy: 128 -> 109 us, with the slot walk 97.
-    const int nte = kvp_env_int("KVP_KD_NT", -1);
-    const int ntk = nte >= 0 ? nte : ((uint64_t)BH * map.S * D * sizeof(T) > (192ull << 20) ? 3 : 0);
+    // KVP_KD_NT (bit 0 = anchor pass, bit 1 = score pass): streaming loads.  Off: inside the bench loop the gather that follows re-reads the
+    // kept K rows, and a score pass that leaves nothing of K in the memory-side cache costs it 10 us (scripts/ab_bench.sh: 195 us per step
+    // cached, 203 / 208 / 210 with mask 1 / 2 / 3) -- although the two passes alone, after a copy that left dirty lines, win 20 us with it.
+    const int ntk = std::max(0, kvp_env_int("KVP_KD_NT", 0));
     const bool nta = (ntk & 1) != 0, ntb = (ntk & 2) != 0;
     if (p.vec) {
 #define KVP_KD_CASE(L)                                                                                                                 \

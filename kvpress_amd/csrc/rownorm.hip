@@ -188,17 +188,19 @@ __global__ __launch_bounds__(RN_THREADS) void rownorm_scalar_kernel(
     }
 }
 
-// Streaming (non-temporal) loads when the tensor cannot stay in the 256 MiB memory-side cache anyway (the cutoff of kvp_gather_kv): a
-// read-once stream that allocates there first has to push out what the previous kernel left behind as dirty lines.  Measured at
-// 8 x 131072 x 128 bf16 right after a 512 MB copy (tools/stream_lab.py): 75 -> 55 us, with the slot walk 48.  KVP_RN_NT=0/1 forces either.
-bool rn_streaming(uint64_t bytes) {
+// Streaming (non-temporal) loads for a tensor that is read ONCE on this path and cannot stay in the 256 MiB memory-side cache anyway (the
+// cutoff of kvp_gather_kv).  Whether that pays is decided by what runs next, so the caller says so (`read_once`), measured inside the
+// bench loops (scripts/ab_bench.sh, profiles/r03_ab_bench.txt): ExpectedAttention's ||V|| 58 -> 47 us, CUR's two energies 105 -> 91 us
+// (its gather + 7); but the stand-alone K norm of a press whose gather re-reads the kept K rows right after (Knorm through
+// KeyRerotationPress) LOSES 14 us when the stream leaves nothing of K behind -- kvp_rownorm_score stays cached.  KVP_RN_NT=0/1 forces either.
+bool rn_streaming(uint64_t bytes, bool read_once) {
     const int e = kvp_env_int("KVP_RN_NT", -1);
-    return e >= 0 ? e != 0 : bytes > (192ull << 20);
+    return e >= 0 ? e != 0 : (read_once && bytes > (192ull << 20));
 }
 
 template <int DT, int THREADS>
 void launch_rownorm_slot_t(const typename Elem<DT>::T* x0, const typename Elem<DT>::T* x1, PlaneMap m0, PlaneMap m1, uint32_t BH, uint32_t ntens,
-                           uint32_t chunks, int lpr, float scale, float* o0, float* o1, hipStream_t stream) {
+                           uint32_t chunks, int lpr, float scale, float* o0, float* o1, hipStream_t stream, bool nt) {
     const uint32_t gpb = THREADS / lpr;
     const uint32_t wgs_per_cu = (uint32_t)std::max(1, kvp_env_int("KVP_RN_WGS", THREADS >= 1024 ? 1 : 2048 / THREADS));
     const uint64_t want = std::max<uint64_t>(1, ((uint64_t)256 * wgs_per_cu + (uint64_t)BH * ntens - 1) / ((uint64_t)BH * ntens));
@@ -207,7 +209,6 @@ void launch_rownorm_slot_t(const typename Elem<DT>::T* x0, const typename Elem<D
     rows = (rows + step - 1) / step * step;
     const uint32_t bx = (uint32_t)(((uint64_t)m0.S + rows - 1) / rows);
     const dim3 grid(bx, BH, ntens);
-    const bool nt = rn_streaming((uint64_t)BH * ntens * m0.S * chunks * 16);
 #define KVP_RS_CASE(L)                                                                                                                    \
     case L:                                                                                                                               \
         if (nt) KVP_LAUNCH("rownorm_vec_kernel", stream, (rownorm_slot_kernel<DT, L, THREADS, true><<<grid, THREADS, 0, stream>>>(x0, x1, m0, m1, chunks, scale, o0, o1, (uint32_t)rows))); \
@@ -220,17 +221,17 @@ void launch_rownorm_slot_t(const typename Elem<DT>::T* x0, const typename Elem<D
 }
 template <int DT>
 void launch_rownorm_slot(const typename Elem<DT>::T* x0, const typename Elem<DT>::T* x1, PlaneMap m0, PlaneMap m1, uint32_t BH, uint32_t ntens,
-                         uint32_t chunks, int lpr, float scale, float* o0, float* o1, hipStream_t stream) {
+                         uint32_t chunks, int lpr, float scale, float* o0, float* o1, hipStream_t stream, bool nt) {
     switch (kvp_env_int("KVP_RN_THREADS", 1024)) {
-        case 256: launch_rownorm_slot_t<DT, 256>(x0, x1, m0, m1, BH, ntens, chunks, lpr, scale, o0, o1, stream); break;
-        case 512: launch_rownorm_slot_t<DT, 512>(x0, x1, m0, m1, BH, ntens, chunks, lpr, scale, o0, o1, stream); break;
-        default: launch_rownorm_slot_t<DT, 1024>(x0, x1, m0, m1, BH, ntens, chunks, lpr, scale, o0, o1, stream); break;
+        case 256: launch_rownorm_slot_t<DT, 256>(x0, x1, m0, m1, BH, ntens, chunks, lpr, scale, o0, o1, stream, nt); break;
+        case 512: launch_rownorm_slot_t<DT, 512>(x0, x1, m0, m1, BH, ntens, chunks, lpr, scale, o0, o1, stream, nt); break;
+        default: launch_rownorm_slot_t<DT, 1024>(x0, x1, m0, m1, BH, ntens, chunks, lpr, scale, o0, o1, stream, nt); break;
     }
 }
 
 // returns 1 if hist1 was requested and produced (vector path only), else 0
 template <int DT>
-int launch_rownorm(const void* x, PlaneMap map, uint32_t BH, uint32_t D, float scale, float* out, uint32_t* hist1, hipStream_t stream) {
+int launch_rownorm(const void* x, PlaneMap map, uint32_t BH, uint32_t D, float scale, float* out, uint32_t* hist1, hipStream_t stream, bool read_once) {
     using T = typename Elem<DT>::T;
     const T* xp = static_cast<const T*>(x);
     const size_t es = sizeof(T);
@@ -250,9 +251,9 @@ int launch_rownorm(const void* x, PlaneMap map, uint32_t BH, uint32_t D, float s
     const uint64_t bx_full = (groups_needed + gpb - 1) / gpb;
     const uint64_t bx_cap = std::max<uint64_t>(1, (256 * 8 + BH - 1) / BH);  // ~8 workgroups per CU in total
     const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap));
-    const bool nt = rn_streaming((uint64_t)BH * map.S * rowbytes);
+    const bool nt = rn_streaming((uint64_t)BH * map.S * rowbytes, read_once);
     if (!hist1 && kvp_env_int("KVP_RN_SLOT", 1) != 0 && map.S >= 4096) {
-        launch_rownorm_slot<DT>(xp, xp, map, map, BH, 1, chunks, lpr, scale, out, out, stream);
+        launch_rownorm_slot<DT>(xp, xp, map, map, BH, 1, chunks, lpr, scale, out, out, stream, nt);
         return 0;
     }
 #define KVP_RN_CASE(L)                                                                                     \
@@ -274,7 +275,7 @@ int launch_rownorm(const void* x, PlaneMap map, uint32_t BH, uint32_t D, float s
 // hist1 (nullable): [B*H][4096] first-pass radix histogram of the top-k over the rows (b, h); *hist1_done tells whether it
 // was produced (only the vector path does; the caller runs the separate pass otherwise).
 static int rownorm_launch_impl(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh,
-                               int64_t ss, float scale, float* out, hipStream_t stream, uint32_t* hist1, bool* hist1_done, bool squared) {
+                               int64_t ss, float scale, float* out, hipStream_t stream, uint32_t* hist1, bool* hist1_done, bool squared, bool read_once) {
     if (hist1_done) *hist1_done = false;
     KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "rownorm: bad dtype %d", dtype);
     KVP_CHECK_ARG(B >= 0 && H >= 0 && S >= 0 && D >= 1, "rownorm: bad shape B=%ld H=%ld S=%ld D=%ld", (long)B, (long)H,
@@ -291,9 +292,9 @@ static int rownorm_launch_impl(const void* x, int dtype, int64_t B, int64_t H, i
     const uint32_t BH = (uint32_t)(B * H);
     int done = 0;
     switch (dtype) {
-        case KVP_F32: done = launch_rownorm<KVP_F32>(x, map, BH, (uint32_t)D, scale, out, hist1, stream); break;
-        case KVP_F16: done = launch_rownorm<KVP_F16>(x, map, BH, (uint32_t)D, scale, out, hist1, stream); break;
-        default: done = launch_rownorm<KVP_BF16>(x, map, BH, (uint32_t)D, scale, out, hist1, stream); break;
+        case KVP_F32: done = launch_rownorm<KVP_F32>(x, map, BH, (uint32_t)D, scale, out, hist1, stream, read_once); break;
+        case KVP_F16: done = launch_rownorm<KVP_F16>(x, map, BH, (uint32_t)D, scale, out, hist1, stream, read_once); break;
+        default: done = launch_rownorm<KVP_BF16>(x, map, BH, (uint32_t)D, scale, out, hist1, stream, read_once); break;
     }
     if (hist1_done) *hist1_done = done != 0;
     KVP_CHECK_LAUNCH("rownorm");
@@ -302,12 +303,17 @@ static int rownorm_launch_impl(const void* x, int dtype, int64_t B, int64_t H, i
 
 int kvp_rownorm_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh,
                        int64_t ss, float scale, float* out, hipStream_t stream, uint32_t* hist1, bool* hist1_done) {
-    return rownorm_launch_impl(x, dtype, B, H, S, D, sb, sh, ss, scale, out, stream, hist1, hist1_done, false);
+    return rownorm_launch_impl(x, dtype, B, H, S, D, sb, sh, ss, scale, out, stream, hist1, hist1_done, false, false);
+}
+// the same for a tensor this path reads once (ExpectedAttention's ||V||): streaming loads when it is larger than the memory-side cache can hold
+int kvp_rownorm_launch_read_once(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh, int64_t ss,
+                                 float scale, float* out, hipStream_t stream) {
+    return rownorm_launch_impl(x, dtype, B, H, S, D, sb, sh, ss, scale, out, stream, nullptr, nullptr, false, true);
 }
 // out[b,h,s] = sum_d x^2  (the row "energy" of CURPress, kvpress/presses/cur_press.py:40-41)
 int kvp_rowsumsq_launch(const void* x, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, int64_t sb, int64_t sh, int64_t ss,
                         float* out, hipStream_t stream) {
-    return rownorm_launch_impl(x, dtype, B, H, S, D, sb, sh, ss, 1.0f, out, stream, nullptr, nullptr, true);
+    return rownorm_launch_impl(x, dtype, B, H, S, D, sb, sh, ss, 1.0f, out, stream, nullptr, nullptr, true, false);
 }
 
 // out_k[b,h,s] = sum_d k^2 and out_v likewise in one launch when both tensors take the 16-lanes-per-256-byte-row vector path (else two
@@ -327,8 +333,9 @@ int kvp_rowsumsq2_launch(const void* k, const void* v, int dtype, int64_t B, int
     PlaneMap mk{(uint32_t)H, (uint32_t)S, k_sb, k_sh, k_ss, true}, mv{(uint32_t)H, (uint32_t)S, v_sb, v_sh, v_ss, true};
     const uint32_t BH = (uint32_t)(B * H);
     if (kvp_env_int("KVP_RN_SLOT", 1) != 0 && S >= 4096) {
-        if (dtype == KVP_BF16) launch_rownorm_slot<KVP_BF16>(static_cast<const uint16_t*>(k), static_cast<const uint16_t*>(v), mk, mv, BH, 2, 16, 16, 1.0f, out_k, out_v, stream);
-        else launch_rownorm_slot<KVP_F16>(static_cast<const _Float16*>(k), static_cast<const _Float16*>(v), mk, mv, BH, 2, 16, 16, 1.0f, out_k, out_v, stream);
+        const bool nts = rn_streaming((uint64_t)BH * 2 * S * 256, true);
+        if (dtype == KVP_BF16) launch_rownorm_slot<KVP_BF16>(static_cast<const uint16_t*>(k), static_cast<const uint16_t*>(v), mk, mv, BH, 2, 16, 16, 1.0f, out_k, out_v, stream, nts);
+        else launch_rownorm_slot<KVP_F16>(static_cast<const _Float16*>(k), static_cast<const _Float16*>(v), mk, mv, BH, 2, 16, 16, 1.0f, out_k, out_v, stream, nts);
         KVP_CHECK_LAUNCH("rowsumsq2");
         return KVP_OK;
     }
@@ -336,7 +343,7 @@ int kvp_rowsumsq2_launch(const void* k, const void* v, int dtype, int64_t B, int
     const uint64_t bx_full = (((uint64_t)S + RN_UNROLL - 1) / RN_UNROLL + gpb - 1) / gpb;
     const uint64_t bx_cap = std::max<uint64_t>(1, (256 * 4 + BH - 1) / BH);   // ~8 workgroups per CU over the two tensors
     const dim3 grid((uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap)), BH, 2);
-    const bool nt = rn_streaming((uint64_t)BH * 2 * S * 256);
+    const bool nt = rn_streaming((uint64_t)BH * 2 * S * 256, true);
 #define KVP_RS2(DTV, TT, NTV) KVP_LAUNCH("rownorm_vec_kernel", stream, (rowsumsq2_vec_kernel<DTV, 16, NTV><<<grid, RN_THREADS, 0, stream>>>(static_cast<const TT*>(k), static_cast<const TT*>(v), mk, mv, 16, out_k, out_v)))
     if (dtype == KVP_BF16) { if (nt) KVP_RS2(KVP_BF16, uint16_t, true); else KVP_RS2(KVP_BF16, uint16_t, false); }
     else { if (nt) KVP_RS2(KVP_F16, _Float16, true); else KVP_RS2(KVP_F16, _Float16, false); }

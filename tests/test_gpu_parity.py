@@ -444,6 +444,37 @@ def test_keydiff_is_deterministic_and_handles_zero_rows():
     np.testing.assert_allclose(a.cpu().numpy(), O.keydiff_score(_inputs.round_to(k, "bf16")), rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])
+def test_streaming_walk_variants(dtype, knobs):
+    """The walk shapes of the streaming reductions (rownorm.hip / keydiff.hip / cur.hip): interleaved row groups or one contiguous slot
+    per workgroup, 256 / 512 / 1024 threads, cached or streaming loads, CUR's combine per token or staged through LDS.  The row norms
+    and CUR's scores are the same bits in every variant; KeyDiff's anchor is summed in another order (2e-6 of the oracle either way)."""
+    rs = np.random.RandomState(31)
+    N = native()
+    for B, H, S, D in ((1, 8, 5000, 128), (2, 2, 20001, 64), (1, 1, 4096, 128), (1, 3, 9000, 40)):
+        kn = _inputs.round_to(rs.standard_normal((B, H, S, D)).astype(np.float32), dtype)
+        vn = _inputs.round_to(rs.standard_normal((B, H, S, D)).astype(np.float32), dtype)
+        k, v = to_dev(kn, dtype), to_dev(vn, dtype)
+        knobs(KVP_RN_SLOT=0, KVP_RN_NT=0, KVP_KD_SLOT=0, KVP_KD_NT=0, KVP_CUR_LDS=0)
+        rn0, cur0, kd0 = N.rownorm_score(k, -1.0), N.cur_score(k, v, "kv_product", 16, 4), N.keydiff_score(k)
+        assert_scores_close(rn0.cpu().numpy(), O.knorm_score(kn), 1e-5)
+        np.testing.assert_allclose(kd0.cpu().numpy(), O.keydiff_score(kn), rtol=0, atol=2e-6)
+        assert_scores_close(cur0.cpu().numpy(), O.cur_score(kn, vn, "kv_product", True, 16, 4), 2e-5)
+        for thr, wgs, nt in ((1024, 1, 0), (1024, 1, 1), (512, 2, 1), (256, 4, 0), (256, 8, 1), (1024, 2, 0)):
+            knobs(KVP_RN_SLOT=1, KVP_RN_THREADS=thr, KVP_RN_WGS=wgs, KVP_RN_NT=nt, KVP_KD_SLOT=1, KVP_KD_THREADS=thr, KVP_KD_WGS=wgs, KVP_KD_NT=3 * nt,
+                  KVP_CUR_LDS=nt)
+            assert torch.equal(N.rownorm_score(k, -1.0), rn0), (dtype, S, D, thr, wgs, nt)
+            assert torch.equal(N.cur_score(k, v, "kv_product", 16, 4), cur0), (dtype, S, D, thr, wgs, nt)
+            np.testing.assert_allclose(N.keydiff_score(k).cpu().numpy(), O.keydiff_score(kn), rtol=0, atol=2e-6)
+        knobs(KVP_RN_SLOT=0, KVP_RN_NT=1, KVP_KD_SLOT=0, KVP_KD_NT=3)
+        assert torch.equal(N.rownorm_score(k, -1.0), rn0) and torch.equal(N.keydiff_score(k), kd0)
+        for w in (2, 4, 64, 256, 5):   # every window length the LDS-staged combine takes (divisors of 256) and one it does not
+            knobs(KVP_CUR_LDS=0)
+            ref = N.cur_score(k, v, "kv_avg", w, 0)
+            knobs(KVP_CUR_LDS=1)
+            assert torch.equal(N.cur_score(k, v, "kv_avg", w, 0), ref), (dtype, S, D, w)
+
+
 def test_scores_head_mean():
     rs = np.random.RandomState(4)
     x = rs.standard_normal((3, 8, 1001)).astype(np.float32)
