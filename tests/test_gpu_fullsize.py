@@ -352,6 +352,47 @@ def test_ea_qstats_128k_large_mean_adversarial():
     print(f"ea qstats 128k adversarial: cov err {err.max().item():.2e} sigma_i sigma_j, final score err {rel.max().item():.2e}")
 
 
+def test_f_rows_at_128k_properties(knobs):
+    """The §8(f) kernels at the BASELINE size (8 x 131072 x 128 bf16: the slot walks, the streaming loads and the one-pass gather +
+    re-rotation are what runs there), through size-independent properties: the row norms against torch in float64, the default walk ==
+    the interleaved walk bit for bit (row norms, CUR) / within 2e-6 (KeyDiff: the anchor is summed in another order), KeyDiff against
+    its float64 definition on a subsample of positions, the one-pass gather + re-rotation == the two kernels it replaces, a rotation
+    preserves every (d, d + D/2) pair's norm, and positions already in place (delta 0) come out untouched."""
+    nat = _native()
+    S = 131072
+    g = torch.Generator(device=DEV)
+    g.manual_seed(7)
+    k = torch.randn((1, H_KV, S, D), generator=g, device=DEV).to(torch.bfloat16)
+    v = torch.randn((1, H_KV, S, D), generator=g, device=DEV).to(torch.bfloat16)
+    rn = nat.rownorm_score(k, -1.0)
+    assert torch.allclose(rn.double(), -k.double().norm(dim=-1), rtol=1e-6, atol=0)
+    cur = nat.cur_score(k, v, "kv_product", 16, 4)
+    kd = nat.keydiff_score(k)
+    knobs(KVP_RN_SLOT=0, KVP_RN_NT=0, KVP_KD_SLOT=0, KVP_CUR_LDS=0)
+    assert torch.equal(nat.rownorm_score(k, -1.0), rn) and torch.equal(nat.cur_score(k, v, "kv_product", 16, 4), cur)
+    assert (nat.keydiff_score(k) - kd).abs().max() <= 2e-6
+    knobs(KVP_RN_SLOT=None, KVP_RN_NT=None, KVP_KD_SLOT=None, KVP_CUR_LDS=None)
+    kn = torch.nn.functional.normalize(k.double(), dim=-1)
+    anchor = kn.mean(dim=2, keepdim=True)
+    sub = torch.arange(0, S, 97, device=DEV)
+    want = -torch.nn.functional.cosine_similarity(k[:, :, sub].double(), anchor, dim=-1)
+    assert (kd[:, :, sub].double() - want).abs().max() <= 2e-6
+    assert abs(float(cur[:, :, 4:].sum(-1).mean()) - 1.0) < 1e-3 and bool((cur[:, :, :4] == 1.0).all())   # normalised rows, sinks = 1
+    # gather + re-rotation: keep every second position, the first 1000 in place (delta 0)
+    n = S // 2
+    pos = torch.cat([torch.arange(1000, device=DEV), 1000 + 2 * torch.arange(n - 1000, device=DEV) + 1]).to(torch.int32)
+    pos = pos.clamp_(max=S - 1).expand(1, H_KV, n).contiguous()
+    inv = 500000.0 ** (-torch.arange(0, D, 2, device=DEV, dtype=torch.float32) / D)
+    k1, v1 = nat.gather_kv_rerotate(k, v, pos, inv)
+    k2, v2 = nat.gather_kv(k, v, pos)
+    assert torch.equal(v1, v2) and torch.equal(k1[:, :, :1000], k2[:, :, :1000])
+    nat.rerotate_keys_(k2, pos, inv)
+    assert torch.equal(k1, k2)
+    src = k[:, :, pos[0, 0].long()].float()
+    pair = lambda x: (x[..., : D // 2] ** 2 + x[..., D // 2:] ** 2).sqrt()
+    assert ((pair(k1.float()) - pair(src)).abs() <= 2.0 ** -6 * pair(src) + 1e-6).all()
+
+
 def test_bench_two_ranks_real_kernels_on_one_gpu():
     """The N > 1 path of bench.py with the REAL kernels: `python bench.py --gpus 2` launches two ranks (one process per
     "GPU"); KVP_BENCH_SHARE_GPU=1 lets both use GPU 0 of this one-GPU box (gloo for the timing reduction: RCCL refuses two ranks on one
