@@ -483,6 +483,8 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = 0.f;
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] *= a.inv_2d;   // 1 / 2d = 2^-8 (D = 128 on this path): exact, and the chains deliver (cov k)_r / 2d directly
             uint32_t hw[4], lw[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -494,7 +496,8 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
         }
     }
     // mu of the 16 cov rows this lane sees in the C layout (row = 32 wv + (r&3) + 8 (r>>2) + 4 kg), pre-scaled
-    float muv[16];
+    // -- it is the accumulator every chain STARTS from: C = mu_r / sqrt(d) for every key, so the chain ends with mu_r / sqrt(d) + (cov k)_r / 2d
+    f32x16 muv;
 #pragma unroll
     for (int r = 0; r < 16; ++r) muv[r] = a.mu[(size_t)bhq * 128 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] * a.inv_sqrt_d;
 
@@ -511,30 +514,29 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) kf[ks] = frag16(buf, sub, ks * 2 + kg, n);
     };
-    // the MFMA chains of a sub-tile (cov strip x K sub-tile, hi and lo part of cov)
-    auto chains = [&](const uint4 (&kf)[8], f32x16& ah, f32x16& al) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { ah[i] = 0.f; al[i] = 0.f; }
+    // the MFMA chain of a sub-tile: cov strip (hi part, then lo part) x K sub-tile on ONE accumulator that starts at mu / sqrt(d).
+    // (Round 2 ran two chains from zero and left "(hi + lo) * 1/2d + mu" to the row-dot: 48 VALU per sub-tile where 16 suffice; the lo
+    // products are ~2^-9 of the hi ones and land in an fp32 accumulator of the sum's own magnitude: ~1e-6 relative, as before.)
+    auto chains = [&](const uint4 (&kf)[8], f32x16& acc) {
+        acc = muv;
         if (has_cov) {
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                ah = mma32<DT>(chi[ks], kf[ks], ah);  // C[cov row][key]
-                al = mma32<DT>(clo[ks], kf[ks], al);
-            }
+            for (int ks = 0; ks < 8; ++ks) acc = mma32<DT>(chi[ks], kf[ks], acc);  // C[cov row][key]
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc = mma32<DT>(clo[ks], kf[ks], acc);
         }
     };
     // row-dot of sub-tile `sub`: K in the C layout: key = sub*32 + n, dims 32 wv + 8 q + 4 kg + {0..3}: 8 bytes of 16-byte column 4 wv + q
-    auto rowdot = [&](const unsigned char* buf, int sub, const f32x16& ah, const f32x16& al, float* redrow) {
+    auto rowdot = [&](const unsigned char* buf, int sub, const f32x16& acc, float* redrow) {
         float val = 0.f;
         const uint32_t row = sub * 32 + n;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint2 kk = *reinterpret_cast<const uint2*>(buf + row * EM_ROWB + (((wv * 4 + q) ^ (row & 15)) << 4) + kg * 8);
-            const float k0 = lo16<DT>(kk.x), k1 = hi16<DT>(kk.x), k2 = lo16<DT>(kk.y), k3 = hi16<DT>(kk.y);
-            val = fmaf(k0, fmaf(ah[4 * q + 0] + al[4 * q + 0], a.inv_2d, muv[4 * q + 0]), val);
-            val = fmaf(k1, fmaf(ah[4 * q + 1] + al[4 * q + 1], a.inv_2d, muv[4 * q + 1]), val);
-            val = fmaf(k2, fmaf(ah[4 * q + 2] + al[4 * q + 2], a.inv_2d, muv[4 * q + 2]), val);
-            val = fmaf(k3, fmaf(ah[4 * q + 3] + al[4 * q + 3], a.inv_2d, muv[4 * q + 3]), val);
+            val = fmaf(lo16<DT>(kk.x), acc[4 * q + 0], val);
+            val = fmaf(hi16<DT>(kk.x), acc[4 * q + 1], val);
+            val = fmaf(lo16<DT>(kk.y), acc[4 * q + 2], val);
+            val = fmaf(hi16<DT>(kk.y), acc[4 * q + 3], val);
         }
         val += __shfl_xor(val, 32);
         if (kg == 0) redrow[sub * 32 + n] = val;
@@ -550,22 +552,22 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
         __builtin_amdgcn_sched_barrier(0);
         // software pipeline over the four sub-tiles: the chains of sub-tile s next to the row-dot of sub-tile s - 1 (two accumulator
         // pairs), so that the row-dot does not read a register file the matrix pipe is still writing
-        f32x16 ah, al;
+        f32x16 acc0, acc1;
         float* redw = red[t & 1][wv];
         uint4 kfa[8], kfb[8];
         static_assert(EL_SUBS == 4, "the pipeline below is written out for four sub-tiles");
         if (has_cov) frags(bufc, 0, kfa);
         if (has_cov) frags(bufc, 1, kfb);
-        chains(kfa, ah, al);
-        rowdot(bufc, 0, ah, al, redw);
+        chains(kfa, acc0);
         if (has_cov) frags(bufc, 2, kfa);
-        chains(kfb, ah, al);
-        rowdot(bufc, 1, ah, al, redw);
+        chains(kfb, acc1);
+        rowdot(bufc, 0, acc0, redw);          // beside the chain of sub-tile 1 (the other accumulator)
         if (has_cov) frags(bufc, 3, kfb);
-        chains(kfa, ah, al);
-        rowdot(bufc, 2, ah, al, redw);
-        chains(kfb, ah, al);
-        rowdot(bufc, 3, ah, al, redw);
+        chains(kfa, acc0);
+        rowdot(bufc, 1, acc1, redw);
+        chains(kfb, acc1);
+        rowdot(bufc, 2, acc0, redw);
+        rowdot(bufc, 3, acc1, redw);
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntiles) stagel_store(st, bufn);
         __syncthreads();
