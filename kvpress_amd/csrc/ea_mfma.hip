@@ -452,7 +452,7 @@ template <int DT, bool HAS_COV>
 __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk,
                                                                         float* __restrict__ part_m, float* __restrict__ part_z) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * EL_TILEB];
-    __shared__ float red[2][4][EL_TILE];
+    __shared__ float red[2][8][EL_TILE];   // [tile parity][wave strip x lane half][key]: the eight partial row-dots of a key
     // XCD-aware order: workgroups go round-robin over the 8 XCDs (linear id % 8), each with its own L2.  The G query heads of a
     // (kv-head, key chunk) unit read the same K chunk, so they take CONSECUTIVE slots of ONE XCD: the chunk enters that L2 once
     // instead of G times through G different XCDs (measured at 128k: L2 fetch traffic 1.09 GB -> see DESIGN section 5).
@@ -526,21 +526,34 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
             for (int ks = 0; ks < 8; ++ks) acc = mma32<DT>(clo[ks], kf[ks], acc);
         }
     };
-    // row-dot of sub-tile `sub`: K in the C layout: key = sub*32 + n, dims 32 wv + 8 q + 4 kg + {0..3}: 8 bytes of 16-byte column 4 wv + q
-    auto rowdot = [&](const unsigned char* buf, int sub, const f32x16& acc, float* redrow) {
-        float val = 0.f;
+    // row-dot of sub-tile `sub`: K in the C layout: key = sub*32 + n, dims 32 wv + 8 q + 4 kg + {0..3}: 8 bytes of 16-byte column 4 wv + q.
+    // The four reads (krows) are issued one pipeline group ahead of the arithmetic (rowdot).
+    auto krows = [&](const unsigned char* buf, int sub, uint2 (&kk)[4]) {
         const uint32_t row = sub * 32 + n;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint2 kk = *reinterpret_cast<const uint2*>(buf + row * EM_ROWB + (((wv * 4 + q) ^ (row & 15)) << 4) + kg * 8);
-            val = fmaf(lo16<DT>(kk.x), acc[4 * q + 0], val);
-            val = fmaf(hi16<DT>(kk.x), acc[4 * q + 1], val);
-            val = fmaf(lo16<DT>(kk.y), acc[4 * q + 2], val);
-            val = fmaf(hi16<DT>(kk.y), acc[4 * q + 3], val);
-        }
-        val += __shfl_xor(val, 32);
-        if (kg == 0) redrow[sub * 32 + n] = val;
+        for (int q = 0; q < 4; ++q) kk[q] = *reinterpret_cast<const uint2*>(buf + row * EM_ROWB + (((wv * 4 + q) ^ (row & 15)) << 4) + kg * 8);
     };
+    auto rowdot = [&](const uint2 (&kk)[4], int sub, const f32x16& acc, float* redrow) {
+        float v0 = 0.f, v1 = 0.f;   // two chains: sixteen dependent fma in a row would expose their latency
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v0 = fmaf(lo16<DT>(kk[q].x), acc[4 * q + 0], v0);
+            v1 = fmaf(hi16<DT>(kk[q].x), acc[4 * q + 1], v1);
+            v0 = fmaf(lo16<DT>(kk[q].y), acc[4 * q + 2], v0);
+            v1 = fmaf(hi16<DT>(kk[q].y), acc[4 * q + 3], v1);
+        }
+        redrow[kg * EL_TILE + sub * 32 + n] = v0 + v1;   // both lane halves store their half of the strip's dims: the fold across them (a
+                                                         // ds_bpermute round trip + a full LDS drain in the MFMA stream per sub-tile) happens in the tile's epilogue
+    };
+    // One pipeline group = the 16 MFMAs of a chain with the LDS reads of the NEXT group (nrd of them) and the row-dot arithmetic of the
+    // PREVIOUS sub-tile spread between them: hipcc's own order clusters the row-dot between MFMA bursts and waits for each of its reads in turn.
+#define EL_GROUP(nrd)                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              \
+        if (i_ < (nrd)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);              \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                              \
+    }                                                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
 
     unsigned char* bufc = lds;
     unsigned char* bufn = lds + EL_TILEB;
@@ -553,21 +566,34 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
         // software pipeline over the four sub-tiles: the chains of sub-tile s next to the row-dot of sub-tile s - 1 (two accumulator
         // pairs), so that the row-dot does not read a register file the matrix pipe is still writing
         f32x16 acc0, acc1;
-        float* redw = red[t & 1][wv];
+        float* redw = red[t & 1][2 * wv];
         uint4 kfa[8], kfb[8];
+        uint2 kr0[4], kr1[4];
         static_assert(EL_SUBS == 4, "the pipeline below is written out for four sub-tiles");
         if (has_cov) frags(bufc, 0, kfa);
         if (has_cov) frags(bufc, 1, kfb);
-        chains(kfa, acc0);
+        krows(bufc, 0, kr0);
+        __builtin_amdgcn_sched_barrier(0);
+        chains(kfa, acc0);                                 // sub-tile 0
+        __builtin_amdgcn_sched_barrier(0);
+        krows(bufc, 1, kr1);
         if (has_cov) frags(bufc, 2, kfa);
-        chains(kfb, acc1);
-        rowdot(bufc, 0, acc0, redw);          // beside the chain of sub-tile 1 (the other accumulator)
+        chains(kfb, acc1);                                 // sub-tile 1 || row-dot 0
+        rowdot(kr0, 0, acc0, redw);
+        EL_GROUP(12)
+        __builtin_amdgcn_sched_barrier(0);
+        krows(bufc, 2, kr0);
         if (has_cov) frags(bufc, 3, kfb);
-        chains(kfa, acc0);
-        rowdot(bufc, 1, acc1, redw);
-        chains(kfb, acc1);
-        rowdot(bufc, 2, acc0, redw);
-        rowdot(bufc, 3, acc1, redw);
+        chains(kfa, acc0);                                 // sub-tile 2 || row-dot 1
+        rowdot(kr1, 1, acc1, redw);
+        EL_GROUP(12)
+        __builtin_amdgcn_sched_barrier(0);
+        krows(bufc, 3, kr1);
+        chains(kfb, acc1);                                 // sub-tile 3 || row-dot 2
+        rowdot(kr0, 2, acc0, redw);
+        EL_GROUP(4)
+        __builtin_amdgcn_sched_barrier(0);
+        rowdot(kr1, 3, acc1, redw);
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntiles) stagel_store(st, bufn);
         __syncthreads();
@@ -575,7 +601,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
             const uint32_t kk = key0 + threadIdx.x;
             if (kk < kend) {
                 const float* rr = &red[t & 1][0][threadIdx.x];
-                const float l2 = (rr[0] + rr[EL_TILE] + rr[2 * EL_TILE] + rr[3 * EL_TILE]) * KVP_LOG2E;
+                const float l2 = (((rr[0] + rr[EL_TILE]) + (rr[2 * EL_TILE] + rr[3 * EL_TILE])) + ((rr[4 * EL_TILE] + rr[5 * EL_TILE]) + (rr[6 * EL_TILE] + rr[7 * EL_TILE]))) * KVP_LOG2E;
                 lrow[kk] = l2;
                 softmax_merge(m_run, z_run, l2, 1.0f);
             }
