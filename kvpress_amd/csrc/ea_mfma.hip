@@ -452,7 +452,8 @@ template <int DT, bool HAS_COV>
 __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk,
                                                                         float* __restrict__ part_m, float* __restrict__ part_z) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * EL_TILEB];
-    __shared__ float red[2][8][EL_TILE];   // [tile parity][wave strip x lane half][key]: the eight partial row-dots of a key
+    __shared__ float red[3][8][EL_TILE];   // [tile % 3][wave strip x lane half][key]: the eight partial row-dots of a key.  Three: a tile's
+                                           // last row-dot is written during the NEXT tile, its fold runs after that tile's barrier
     // XCD-aware order: workgroups go round-robin over the 8 XCDs (linear id % 8), each with its own L2.  The G query heads of a
     // (kv-head, key chunk) unit read the same K chunk, so they take CONSECUTIVE slots of ONE XCD: the chunk enters that L2 once
     // instead of G times through G different XCDs (measured at 128k: L2 fetch traffic 1.09 GB -> see DESIGN section 5).
@@ -555,26 +556,58 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
     }                                                                                   \
     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
 
+    // K tiles travel HBM / L2 -> LDS by LDS-DMA (no staging registers, no ds_write): request j of a tile moves rows 16 j + 4 wv + g (g = lane
+    // / 16), lane slot i16 fetches the 16-byte chunk i16 ^ (row & 15) -- the XOR swizzle of frag16 / krows applied on the global side.
+    const uint32_t ldsbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const uint32_t dg = lane >> 4, di16 = lane & 15;
+    auto request_tile = [&](uint32_t row0, uint32_t buf_off) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t trow = 16 * j + 4 * wv + dg;
+            const uint32_t r = min(row0 + trow, a.Sp - 1);   // rows past the end: any valid row (masked in the fold)
+            const char* gp = kb + (int64_t)r * row_bytes + ((di16 ^ (trow & 15)) << 4);
+            const uint32_t la = __builtin_amdgcn_readfirstlane(ldsbase + buf_off + (16 * j + 4 * wv) * EM_ROWB);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(gp) : "memory");
+        }
+    };
     unsigned char* bufc = lds;
     unsigned char* bufn = lds + EL_TILEB;
-    stagel_store(stagel_load(kb, row_bytes, kbeg, a.Sp), bufc);
+    request_tile(kbeg, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's part of tile 0 has landed
     __syncthreads();
+    // Software pipeline over the 32-key sub-tiles, across tile boundaries: the chain of sub-tile s runs beside the row-dot of sub-tile
+    // s - 1 (two accumulators) -- also the first chain of a tile, beside the LAST row-dot of the previous tile (its K values and its
+    // accumulator are still in registers) -- and a tile's partial row-dots are folded after the NEXT tile's barrier.
+    auto fold = [&](uint32_t tile, uint32_t rb) {   // threads 0..127: logit of key tile*128 + t from the eight partials, running softmax partial
+        if (threadIdx.x < EL_TILE) {
+            const uint32_t kk = kbeg + tile * EL_TILE + threadIdx.x;
+            if (kk < kend) {
+                const float* rr = &red[rb][0][threadIdx.x];
+                const float l2 = (((rr[0] + rr[EL_TILE]) + (rr[2 * EL_TILE] + rr[3 * EL_TILE])) + ((rr[4 * EL_TILE] + rr[5 * EL_TILE]) + (rr[6 * EL_TILE] + rr[7 * EL_TILE]))) * KVP_LOG2E;
+                lrow[kk] = l2;
+                softmax_merge(m_run, z_run, l2, 1.0f);
+            }
+        }
+    };
+    f32x16 acc0, acc1 = muv;
+    uint4 kfa[8], kfb[8];
+    uint2 kr0[4], kr1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kr1[q] = make_uint2(0, 0);   // tile 0 has no predecessor: its deferred row-dot writes zeros into a buffer nobody reads
+    uint32_t rcur = 0, rprev = 2;                            // red buffers of tile t and of tile t - 1 (t % 3, (t - 1) % 3)
+    static_assert(EL_SUBS == 4, "the pipeline below is written out for four sub-tiles");
     for (uint32_t t = 0; t < ntiles; ++t) {
         const uint32_t key0 = kbeg + t * EL_TILE;
-        const StageL st = stagel_load(kb, row_bytes, min(key0 + EL_TILE, kend - 1), a.Sp);
+        if (t + 1 < ntiles) request_tile(key0 + EL_TILE, (uint32_t)(bufn - lds));   // into the buffer tile t - 1 left at the last barrier
+        float* redw = red[rcur][2 * wv];
         __builtin_amdgcn_sched_barrier(0);
-        // software pipeline over the four sub-tiles: the chains of sub-tile s next to the row-dot of sub-tile s - 1 (two accumulator
-        // pairs), so that the row-dot does not read a register file the matrix pipe is still writing
-        f32x16 acc0, acc1;
-        float* redw = red[t & 1][2 * wv];
-        uint4 kfa[8], kfb[8];
-        uint2 kr0[4], kr1[4];
-        static_assert(EL_SUBS == 4, "the pipeline below is written out for four sub-tiles");
         if (has_cov) frags(bufc, 0, kfa);
+        __builtin_amdgcn_sched_barrier(0);
         if (has_cov) frags(bufc, 1, kfb);
         krows(bufc, 0, kr0);
-        __builtin_amdgcn_sched_barrier(0);
-        chains(kfa, acc0);                                 // sub-tile 0
+        chains(kfa, acc0);                                 // sub-tile 0 || row-dot 3 of the previous tile
+        rowdot(kr1, 3, acc1, red[rprev][2 * wv]);
+        EL_GROUP(12)
         __builtin_amdgcn_sched_barrier(0);
         krows(bufc, 1, kr1);
         if (has_cov) frags(bufc, 2, kfa);
@@ -593,21 +626,16 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
         rowdot(kr0, 2, acc0, redw);
         EL_GROUP(4)
         __builtin_amdgcn_sched_barrier(0);
-        rowdot(kr1, 3, acc1, redw);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < ntiles) stagel_store(st, bufn);
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): tile t + 1 has landed (this wave's part; the barrier covers the others)
         __syncthreads();
-        if (threadIdx.x < EL_TILE) {
-            const uint32_t kk = key0 + threadIdx.x;
-            if (kk < kend) {
-                const float* rr = &red[t & 1][0][threadIdx.x];
-                const float l2 = (((rr[0] + rr[EL_TILE]) + (rr[2 * EL_TILE] + rr[3 * EL_TILE])) + ((rr[4 * EL_TILE] + rr[5 * EL_TILE]) + (rr[6 * EL_TILE] + rr[7 * EL_TILE]))) * KVP_LOG2E;
-                lrow[kk] = l2;
-                softmax_merge(m_run, z_run, l2, 1.0f);
-            }
-        }
+        if (t > 0) fold(t - 1, rprev);
         unsigned char* tmp = bufc; bufc = bufn; bufn = tmp;
+        rprev = rcur;
+        rcur = rcur == 2 ? 0 : rcur + 1;
     }
+    rowdot(kr1, 3, acc1, red[rprev][2 * wv]);   // the last tile's last row-dot
+    __syncthreads();
+    fold(ntiles - 1, rprev);
     if (threadIdx.x < EL_TILE) {   // two waves own keys: merge inside each wave, then across the two through LDS
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
