@@ -428,26 +428,6 @@ constexpr int EL_TILE = 128;    // keys per LDS tile: ONE workgroup barrier per 
 constexpr int EL_SUBS = EL_TILE / 32;
 constexpr int EL_TILEB = EL_TILE * EM_ROWB;
 
-struct StageL { uint4 v[8]; };   // a 128-key tile in flight: 8 x 16 bytes per thread
-__device__ __forceinline__ StageL stagel_load(const char* __restrict__ base, int64_t row_bytes, uint32_t row0, uint32_t nrows) {
-    const uint32_t r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
-    StageL st;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t r = min(row0 + r0 + 16 * i, nrows - 1);  // unconditional loads; rows past the end are masked later
-        st.v[i] = *reinterpret_cast<const uint4*>(base + (int64_t)r * row_bytes + ch * 16);
-    }
-    return st;
-}
-__device__ __forceinline__ void stagel_store(const StageL st, unsigned char* buf) {   // (by value: a by-reference struct ends up in scratch)
-    const uint32_t r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t row = r0 + 16 * i;
-        *reinterpret_cast<uint4*>(buf + row * EM_ROWB + ((ch ^ (row & 15)) << 4)) = st.v[i];
-    }
-}
-
 template <int DT, bool HAS_COV>
 __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk,
                                                                         float* __restrict__ part_m, float* __restrict__ part_z) {
@@ -575,14 +555,18 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
     request_tile(kbeg, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's part of tile 0 has landed
     __syncthreads();
+    uint4 kfa[8], kfb[8];
     // Software pipeline over the 32-key sub-tiles, across tile boundaries: the chain of sub-tile s runs beside the row-dot of sub-tile
     // s - 1 (two accumulators) -- also the first chain of a tile, beside the LAST row-dot of the previous tile (its K values and its
     // accumulator are still in registers) -- and a tile's partial row-dots are folded after the NEXT tile's barrier.
-    auto fold = [&](uint32_t tile, uint32_t rb) {   // threads 0..127: logit of key tile*128 + t from the eight partials, running softmax partial
-        if (threadIdx.x < EL_TILE) {
-            const uint32_t kk = kbeg + tile * EL_TILE + threadIdx.x;
+    auto fold = [&](uint32_t tile, uint32_t rb) {   // logit of key tile*128 + (tid & 127) from the eight partials, running softmax partial;
+#ifndef EL_FOLD_ALT
+#define EL_FOLD_ALT 1
+#endif
+        if ((threadIdx.x >> 7) == (EL_FOLD_ALT ? (tile & 1) : 0u)) {     // waves 0-1 take the even tiles, waves 2-3 the odd ones (every thread keeps its own partial)
+            const uint32_t kk = kbeg + tile * EL_TILE + (threadIdx.x & 127);
             if (kk < kend) {
-                const float* rr = &red[rb][0][threadIdx.x];
+                const float* rr = &red[rb][0][threadIdx.x & 127];
                 const float l2 = (((rr[0] + rr[EL_TILE]) + (rr[2 * EL_TILE] + rr[3 * EL_TILE])) + ((rr[4 * EL_TILE] + rr[5 * EL_TILE]) + (rr[6 * EL_TILE] + rr[7 * EL_TILE]))) * KVP_LOG2E;
                 lrow[kk] = l2;
                 softmax_merge(m_run, z_run, l2, 1.0f);
@@ -590,7 +574,6 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
         }
     };
     f32x16 acc0, acc1 = muv;
-    uint4 kfa[8], kfb[8];
     uint2 kr0[4], kr1[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) kr1[q] = make_uint2(0, 0);   // tile 0 has no predecessor: its deferred row-dot writes zeros into a buffer nobody reads
@@ -628,26 +611,26 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): tile t + 1 has landed (this wave's part; the barrier covers the others)
         __syncthreads();
-        if (t > 0) fold(t - 1, rprev);
         unsigned char* tmp = bufc; bufc = bufn; bufn = tmp;
+        if (t > 0) fold(t - 1, rprev);
         rprev = rcur;
         rcur = rcur == 2 ? 0 : rcur + 1;
     }
     rowdot(kr1, 3, acc1, red[rprev][2 * wv]);   // the last tile's last row-dot
     __syncthreads();
     fold(ntiles - 1, rprev);
-    if (threadIdx.x < EL_TILE) {   // two waves own keys: merge inside each wave, then across the two through LDS
+    // every thread owns keys: merge inside each wave, then across the four through LDS
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float m2 = __shfl_xor(m_run, o), z2 = __shfl_xor(z_run, o);
-            softmax_merge(m_run, z_run, m2, z2);
-        }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m_run, o), z2 = __shfl_xor(z_run, o);
+        softmax_merge(m_run, z_run, m2, z2);
     }
     __syncthreads();
-    if (threadIdx.x == 64) { red[0][0][0] = m_run; red[0][0][1] = z_run; }
+    if (lane == 0 && wv > 0) { red[0][0][2 * wv] = m_run; red[0][0][2 * wv + 1] = z_run; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        softmax_merge(m_run, z_run, red[0][0][0], red[0][0][1]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) softmax_merge(m_run, z_run, red[0][0][2 * w], red[0][0][2 * w + 1]);
         part_m[(size_t)bhq * nblk + chunk] = m_run;
         part_z[(size_t)bhq * nblk + chunk] = z_run;
     }
