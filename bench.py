@@ -112,7 +112,7 @@ def kernel_bytes(name: str, kind: str, S: int, ratio: float) -> float:
     kbytes = S * H_KV * D * 2
     if name.startswith("gather"):
         return ab["gather"]
-    if name.startswith(("snapkv_p1", "snapkv_p2", "rownorm", "ea_logits", "keydiff_anchor_kernel", "keydiff_score", "colsumsq", "rowdot")):
+    if name.startswith(("snapkv_p1", "snapkv_p2", "rownorm", "ea_logits", "ea_vnorm_finalize", "keydiff_anchor_kernel", "keydiff_score", "colsumsq", "rowdot")):
         return kbytes   # one pass over K (or V)
     if name.startswith("ea_qstats_mfma"):
         return S * H_Q * D * 2  # Q [B, S, H_q * D] read once for the statistics

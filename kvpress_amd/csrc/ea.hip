@@ -202,6 +202,90 @@ __global__ __launch_bounds__(EA_THREADS) void ea_finalize_kernel(const float* __
     block_store_max(vmax, scr, bmax, blockIdx.x);
 }
 
+// The value norms, the row normalisers and the finalize above in ONE pass over V (bf16 / f16, 256-byte rows, G <= 16): what
+// rownorm_slot_kernel + softmax_combine_kernel + ea_finalize_kernel do in three launches (47 + 6 + 12 us at 8 x 131072), term for term
+// -- a_g = M + log2 Z with the combine kernel's merge order (one wave per query head of the group), ||v|| with the row-norm kernel's
+// lanes, fma chain and shuffle order, the group mean in ea_finalize_kernel's order: the same bits -- while V streams through once (slot
+// walk: a workgroup takes one contiguous range of keys; streaming loads when V is read once and cannot stay cached, rownorm.hip).
+// The 16 lanes of a row group share the score arithmetic of the group's four keys in flight: lane (u, g) = (lir / G, lir % G) loads the
+// logit of key u and query head g TOGETHER with the V rows (the first version left the whole finalize to lane 0 after the reduction: its
+// G dependent loads per key sat exposed behind every step, 85 us instead of the three kernels' 65), exponentiates it, and a G - 1 step
+// DPP scan (row_shr:1) adds the G terms in ea_finalize_kernel's order; the lane of the last head writes the score.  G = 1, 2 or 4.
+constexpr int EVF_THREADS = 1024;
+template <int DT, bool NT, int G>
+__global__ __launch_bounds__(EVF_THREADS) void ea_vnorm_finalize_kernel(const typename Elem<DT>::T* __restrict__ v, int64_t v_sb, int64_t v_sh, int64_t v_ss,
+                                                                        const float* __restrict__ logits, const float* __restrict__ part_m,
+                                                                        const float* __restrict__ part_z, uint32_t nblk, uint32_t Hq, uint32_t Hkv,
+                                                                        uint32_t S, uint32_t n_sink, float epsilon, float* __restrict__ scores,
+                                                                        float* __restrict__ bmax, uint32_t rows_per_wg) {
+    using T = typename Elem<DT>::T;
+    __shared__ float ag[16];
+    __shared__ float scr[EVF_THREADS / 64];
+    const uint32_t Sp = S - n_sink;
+    const uint32_t bh = blockIdx.y, b = bh / Hkv, h = bh - b * Hkv;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t row0 = b * Hq + h * G;   // first logits row of this kv-head's group
+    if (wv < G) {   // softmax_combine_kernel's merge for row row0 + wv
+        const uint32_t row = row0 + wv;
+        float m = KVP_NEG_INF, z = 0.f;
+        for (uint32_t j = lane; j < nblk; j += 64) softmax_merge(m, z, part_m[(size_t)row * nblk + j], part_z[(size_t)row * nblk + j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(m, o), z2 = __shfl_xor(z, o);
+            softmax_merge(m, z, m2, z2);
+        }
+        if (lane == 0) ag[wv] = m + log2f(z);
+    }
+    __syncthreads();
+    const T* __restrict__ base = v + (int64_t)b * v_sb + (int64_t)h * v_sh;
+    float* __restrict__ out = scores + (size_t)bh * S + n_sink;
+    const float invG = 1.0f / (float)G;
+    const uint32_t lir = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const uint32_t my_u = lir / G, my_g = lir % G;   // lanes 0 .. 4 G - 1 of the group: key in flight, query head
+    const bool scorer = lir < 4 * G;
+    const float my_a = scorer ? ag[my_g] : 0.f;
+    const float* __restrict__ lrow = logits + (size_t)(row0 + my_g) * Sp;
+    const uint32_t r0 = blockIdx.x * rows_per_wg, r1 = min(Sp, r0 + rows_per_wg);
+    float vmax = KVP_NEG_INF;
+    for (uint32_t it = r0; it < r1; it += 64 * 4) {
+        uint4 vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t s = it + u * 64 + grp;
+            vv[u] = make_uint4(0, 0, 0, 0);
+            if (s < r1) vv[u] = ld16<NT>(base + (int64_t)s * v_ss + (size_t)lir * 8);
+        }
+        const uint32_t my_s = it + my_u * 64 + grp;
+        const float lg = (scorer && my_s < r1) ? lrow[my_s] : 0.f;
+        float acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float f[8];
+            unpack16<DT>(vv[u], f);
+            acc[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[u] = fmaf(f[i], f[i], acc[u]);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o);   // every lane of the group ends with the row's sum
+        }
+        const float e = exp2f(lg - my_a);
+        float p = e;   // ea_finalize_kernel: p = 0; p += e_0; p += e_1; ...  (0 + e_0 = e_0)
+#pragma unroll
+        for (int k = 1; k < G; ++k) {
+            const float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+            if (my_g == (uint32_t)k) p = prev + e;
+        }
+        if (scorer && my_g == G - 1 && my_s < r1) {
+            const float ss = my_u == 0 ? acc[0] : my_u == 1 ? acc[1] : my_u == 2 ? acc[2] : acc[3];
+            p *= invG;
+            p = (p + epsilon) * (1.0f * sqrtf(ss));
+            out[my_s] = p;
+            vmax = fmaxf(vmax, p);
+        }
+    }
+    block_store_max(vmax, scr, bmax, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
 struct EaScoreWs {
     float* bmax;  // per-workgroup maxima of the finalize kernel (<= 2048)
     float* logits;
@@ -356,6 +440,32 @@ extern "C" int kvp_ea_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
         else KVP_LAUNCH("ea_logits_generic", stream, ea_logits_generic<KVP_BF16><<<grid, EA_THREADS, lds, stream>>>(a, w.logits, nblk, w.part_m, w.part_z));
     }
     const uint32_t nrows = (uint32_t)(B * Hq);
+    const int64_t es = kvp_elem_size(dtype);
+    auto al16 = [&](int64_t elems) { return (elems * es) % 16 == 0; };
+    if (use_vnorm && dtype != KVP_F32 && D * es == 256 && (Hq / Hkv == 1 || Hq / Hkv == 2 || Hq / Hkv == 4) && Sp >= 4096 && B * Hkv <= 1024 && ((uintptr_t)v % 16) == 0 && al16(v_sb) &&
+        al16(v_sh) && al16(v_ss) && kvp_env_int("KVP_EA_FUSED_FINALIZE", 1) != 0) {
+        const uint32_t BH = (uint32_t)(B * Hkv);
+        const uint64_t want = std::max<uint64_t>(1, (256 + BH - 1) / BH);   // about one 1024-thread workgroup per CU
+        uint64_t rows = ((uint64_t)Sp + want - 1) / want;
+        rows = (rows + 255) / 256 * 256;
+        const uint32_t nslot = (uint32_t)(((uint64_t)Sp + rows - 1) / rows);
+        const dim3 grid(nslot, BH);
+        const int nte = kvp_env_int("KVP_RN_NT", -1);   // read-once V (rownorm.hip: rn_streaming)
+        const bool nt = nte >= 0 ? nte != 0 : (uint64_t)BH * Sp * 256 > (192ull << 20);
+        const char* vp = static_cast<const char*>(v) + n_sink * v_ss * es;
+#define KVP_EVF(DTV, TT, NTV, GV) KVP_LAUNCH("ea_vnorm_finalize_kernel", stream, (ea_vnorm_finalize_kernel<DTV, NTV, GV><<<grid, EVF_THREADS, 0, stream>>>(reinterpret_cast<const TT*>(vp), v_sb, v_sh, v_ss, w.logits, w.part_m, w.part_z, nblk, (uint32_t)Hq, (uint32_t)Hkv, (uint32_t)S, (uint32_t)n_sink, epsilon, scores, w.bmax, (uint32_t)rows)))
+#define KVP_EVF_G(DTV, TT, NTV) do { switch (Hq / Hkv) { case 1: KVP_EVF(DTV, TT, NTV, 1); break; case 2: KVP_EVF(DTV, TT, NTV, 2); break; default: KVP_EVF(DTV, TT, NTV, 4); break; } } while (0)
+        if (dtype == KVP_BF16) { if (nt) KVP_EVF_G(KVP_BF16, uint16_t, true); else KVP_EVF_G(KVP_BF16, uint16_t, false); }
+        else { if (nt) KVP_EVF_G(KVP_F16, _Float16, true); else KVP_EVF_G(KVP_F16, _Float16, false); }
+#undef KVP_EVF_G
+#undef KVP_EVF
+        if (n_sink > 0) {
+            const uint32_t nfill = BH * (uint32_t)n_sink;
+            KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, 0, (uint32_t)n_sink, w.bmax, nslot * BH));
+        }
+        KVP_CHECK_LAUNCH("ea_score(vnorm + finalize)");
+        return KVP_OK;
+    }
     KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_kernel<<<(nrows + 3) / 4, 256, 0, stream>>>(w.part_m, w.part_z, nrows, nblk, w.rowstat));
     KVP_CHECK_LAUNCH("ea_score(logits)");
     if (use_vnorm) {

@@ -719,6 +719,30 @@ def test_snapkv_fused_rope_is_bit_identical_to_torch_rope(name):
         assert torch.allclose(b, c, rtol=1e-5, atol=0)
 
 
+def test_ea_fused_finalize_equals_three_kernels(knobs):
+    """kvp_ea_score's one-pass ||v|| + row normalisers + finalize (ea_vnorm_finalize_kernel: 256-byte rows, >= 4096 scored keys) against
+    the three kernels it replaces (KVP_EA_FUSED_FINALIZE=0): the same bits, with and without sinks, GQA groups of 1 / 2 / 4 (one pass) and 8 (the three kernels), ragged
+    lengths, a strided V view, cached and streaming loads."""
+    N = native()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    for dt in (torch.bfloat16, torch.float16):
+        for B, Hq, Hkv, S, n_sink in ((1, 8, 2, 6000, 4), (2, 4, 4, 4100, 0), (1, 16, 2, 9001, 7), (1, 32, 8, 20000, 4), (1, 4, 2, 5003, 1)):
+            k = (torch.randn((B, Hkv, S, 128), generator=g, device=DEV) * 0.5).to(dt)
+            vfull = torch.randn((B, S, Hkv, 128), generator=g, device=DEV).to(dt)
+            v = vfull.transpose(1, 2)                                   # [B, Hkv, S, 128] view of a [B, S, Hkv, 128] buffer
+            mu = torch.randn((B, Hq, 128), generator=g, device=DEV) * 0.3
+            a = torch.randn((B, Hq, 128, 128), generator=g, device=DEV) * 0.05
+            cov = a @ a.transpose(-1, -2)
+            knobs(KVP_EA_FUSED_FINALIZE=0, KVP_RN_NT=0)
+            ref = N.ea_score(k, v, mu, cov, n_sink, True, 0.02)
+            for nt in (0, 1):
+                knobs(KVP_EA_FUSED_FINALIZE=1, KVP_RN_NT=nt)
+                got = N.ea_score(k, v, mu, cov, n_sink, True, 0.02)
+                assert torch.equal(got, ref), (dt, B, Hq, Hkv, S, n_sink, nt, float((got - ref).abs().max()))
+            knobs(KVP_EA_FUSED_FINALIZE=None, KVP_RN_NT=None)
+
+
 def test_ea_qstats_mfma_multichunk():
     """bf16, D=128, 10 000 rows (3 chunks + ragged tail), non-zero mean and a few dominant channels:
     exercises the syrk on the matrix cores (transposed LDS reads) and the pairwise combine."""
