@@ -201,6 +201,64 @@ def pmc_traffic(kernel_name: str, workload: str):
     return int((2.0 * fetch + write) * 1024), f"{rel} (rocprofv3 --pmc passes of this command on this build, digest {digest})"
 
 
+def live_pmc_traffic(kernel_name: str, workload: str, timeout_s: float = 240.0):
+    """(HBM bytes per launch of `kernel_name`, provenance) measured NOW: this run spawns `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE` passes (separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes) around a 3-step child run of this
+    same script and workload, and reads the per-dispatch counters from the rocpd databases (scripts/rocpd_pmc.py).  None when rocprofv3 is
+    not on PATH, when this process is itself a child / already under a profiler, or when a pass fails -- the caller then falls back to the
+    committed summary of the same build."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    if os.environ.get("KVP_BENCH_CHILD") == "1" or os.environ.get("KVP_BENCH_LIVE_PMC") == "0":
+        return None, "live PMC passes disabled for this process"
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")) or any(
+            k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ):
+        return None, "already running under a profiler"
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import rocpd_pmc
+    finally:
+        sys.path.pop(0)
+    vals = {}
+    env = dict(os.environ, KVP_BENCH_CHILD="1", TMPDIR="/tmp")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory(dir="/tmp", prefix="kvp_pmc_") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--workload", workload, "--steps", "3", "--warmup", "1", "--prewarm-ms", "5", "--no-cpu-baseline"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=max(30.0, timeout_s - (time.perf_counter() - t0)))
+            except (subprocess.TimeoutExpired, OSError) as e:
+                return None, f"live {counter} pass failed: {type(e).__name__}"
+            if r.returncode != 0:
+                return None, f"live {counter} pass exited {r.returncode}"
+            dbs = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+            per = {}
+            for db in dbs:
+                try:
+                    loaded = rocpd_pmc.load(db)
+                except Exception as e:   # noqa: BLE001 (a profiler output this parser does not know: fall back)
+                    return None, f"live {counter} pass: cannot read {os.path.basename(db)} ({type(e).__name__})"
+                for name, cs in loaded.items():
+                    if kernel_name in name and counter in cs:
+                        per.update(cs[counter])
+            if not per:
+                return None, f"live {counter} pass recorded no dispatch of {kernel_name}"
+            vals[counter] = sum(per.values()) / len(per)
+    # MI355X_MICROARCH.md section HBM: both counters are in KiB; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), (
+        f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes spawned by this run (3 steps each, {time.perf_counter() - t0:.0f} s), "
+        "averaged over the kernel's dispatches; FETCH_SIZE doubled per the guide's gfx950 correction")
+
+
 def build_module(device):
     import torch
     from transformers import LlamaConfig
@@ -409,6 +467,9 @@ def main():
                     help="untimed device pre-warm before the W warm-up steps: repeat the step for this long so that the clocks have "
                          "ramped (they take ~100 steps; with a short warm-up the same build reads 10 %% slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--live-pmc", default="auto", choices=["auto", "off"],
+                    help="roofline.traffic: auto = measure it now with two rocprofv3 --pmc passes around a 3-step child run (N = 1, ~40 s); "
+                         "off = quote the committed summary of this build (profiles/r03_pmc_summary_<workload>.txt)")
     ap.add_argument("--profile-json", default=None, help="also dump the per-kernel HIP-event table here")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL); gloo + --stub-step exercises the launcher on CPU (tests)")
@@ -510,7 +571,13 @@ def main():
                 ks = [k for k in avg if k.startswith(prefix)]
                 return round(kernel_bytes(ks[0], kind, S, ratio) * B / (avg[ks[0]][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ks else None
 
-            traffic, traffic_source = pmc_traffic(dom, args.workload)
+            traffic, traffic_source = (None, "not requested")
+            if world == 1 and args.live_pmc != "off":
+                traffic, traffic_source = live_pmc_traffic(dom, args.workload)
+            if traffic is None:   # no profiler here (or a child / profiled run): the committed summary of this same build, if there is one
+                live_note = traffic_source
+                traffic, traffic_source = pmc_traffic(dom, args.workload)
+                traffic_source = f"{traffic_source} [{live_note}]"
             roofline = {
                 "kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,

@@ -4,7 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 wl=$1; shift
 for cfg in "$@"; do
-  out=$(env $cfg timeout 300 python bench.py --workload $wl --steps ${AB_STEPS:-50} --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1)
+  out=$(env $cfg timeout 300 python bench.py --workload $wl --steps ${AB_STEPS:-50} --warmup 5 --no-cpu-baseline --live-pmc off 2>/dev/null | tail -1)
   python - "$wl" "$cfg" "$out" <<'PY'
 import json, sys
 wl, cfg, out = sys.argv[1:4]

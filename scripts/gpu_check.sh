@@ -23,7 +23,7 @@ fi
 if [[ "$WHAT" == *frows* ]]; then
   # SURVEY section 8(f) workloads (no CPU baseline: the four BASELINE configs above carry it)
   for wl in keydiff128k cur128k finch128k chunk_snapkv128k rerotate128k decode_snapkv2k; do
-    timeout 600 python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/bench_$wl.log 2>&1
+    timeout 600 python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline --live-pmc off > gpurun_out/bench_$wl.log 2>&1
     echo "bench[$wl] rc=$? $(tail -1 gpurun_out/bench_$wl.log | cut -c1-200)"
     tail -1 gpurun_out/bench_$wl.log > gpurun_out/r03_bench_$wl.json
   done
@@ -32,7 +32,7 @@ if [[ "$WHAT" == *ab* ]]; then
   # A/B knobs: non-temporal loads/stores in the streaming kernels, workgroups per CU in the gather
   for cfg in "KVP_GA_NT=0 KVP_RN_NT=0" "KVP_GA_NT=1 KVP_RN_NT=1" "KVP_GA_NT=0 KVP_GA_WG_PER_CU=4" "KVP_GA_NT=0 KVP_GA_WG_PER_CU=16" "KVP_GA_NT=1 KVP_GA_WG_PER_CU=16"; do
     tag=$(echo "$cfg" | tr ' =' '__')
-    env $cfg timeout 300 python bench.py --workload knorm128k --steps 20 --warmup 3 --no-cpu-baseline --profile-json gpurun_out/ab_$tag.json > gpurun_out/ab_$tag.log 2>&1
+    env $cfg timeout 300 python bench.py --workload knorm128k --steps 20 --warmup 3 --no-cpu-baseline --live-pmc off --profile-json gpurun_out/ab_$tag.json > gpurun_out/ab_$tag.log 2>&1
     echo "ab[$cfg] rc=$? $(python -c "import json;d=json.load(open('gpurun_out/ab_$tag.json'));print(round(d['ms_per_step']*1e3,1),'us/step', {k:round(v*1e3,1) for k,v in d['kernels_avg_ms'].items()})" 2>&1)"
   done
 fi

@@ -393,6 +393,29 @@ def test_f_rows_at_128k_properties(knobs):
     assert ((pair(k1.float()) - pair(src)).abs() <= 2.0 ** -6 * pair(src) + 1e-6).all()
 
 
+def test_bench_measures_its_traffic_live():
+    """bench.py's roofline.traffic: with rocprofv3 on the box the number comes from two --pmc passes spawned by
+    the run itself (FETCH_SIZE, WRITE_SIZE; kernel trace only), not from a committed file.  Knorm 32k: the dominant kernel is the cluster
+    select with the norm stream inside, algorithmic bytes = K once (67 MB); the counters must land within [0.9, 1.5] x of that."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    import sys
+
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("no rocprofv3 on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KVP_BENCH_CHILD")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "knorm32k", "--steps", "20", "--warmup", "5", "--prewarm-ms", "5",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    roof = line["roofline"]
+    assert roof["traffic_source"].startswith("live:"), roof["traffic_source"]
+    assert 0.9 <= roof["traffic"] / roof["algorithmic_bytes_per_launch"] <= 1.5, (roof["traffic"], roof["algorithmic_bytes_per_launch"], roof["kernel"])
+
+
 def test_bench_two_ranks_real_kernels_on_one_gpu():
     """The N > 1 path of bench.py with the REAL kernels: `python bench.py --gpus 2` launches two ranks (one process per
     "GPU"); KVP_BENCH_SHARE_GPU=1 lets both use GPU 0 of this one-GPU box (gloo for the timing reduction: RCCL refuses two ranks on one
