@@ -130,6 +130,7 @@ __global__ __launch_bounds__(EA_THREADS) void ea_logits_generic(EaArgs a, float*
     float* kt = ea_lds;                       // [64][D+1]
     float* red = kt + EA_SUB * (a.D + 1);     // [2][4][64]
     const uint32_t blk = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
+    if (a.clear_word && blk == 0 && hq == 0 && b == 0 && threadIdx.x == 0) *a.clear_word = 0;
     const uint32_t h = hq / a.G;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const T* kb = static_cast<const T*>(a.k) + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh + (int64_t)a.n_sink * a.k_ss;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(EVF_THREADS) void ea_vnorm_finalize_kernel(const ty
                                                                         const float* __restrict__ logits, const float* __restrict__ part_m,
                                                                         const float* __restrict__ part_z, uint32_t nblk, uint32_t Hq, uint32_t Hkv,
                                                                         uint32_t S, uint32_t n_sink, float epsilon, float* __restrict__ scores,
-                                                                        float* __restrict__ bmax, uint32_t rows_per_wg) {
+                                                                        float* __restrict__ bmax, uint32_t rows_per_wg, uint32_t* __restrict__ arrivals) {
     using T = typename Elem<DT>::T;
     __shared__ float ag[16];
     __shared__ float scr[EVF_THREADS / 64];
@@ -283,7 +284,36 @@ __global__ __launch_bounds__(EVF_THREADS) void ea_vnorm_finalize_kernel(const ty
             vmax = fmaxf(vmax, p);
         }
     }
-    block_store_max(vmax, scr, bmax, blockIdx.y * gridDim.x + blockIdx.x);
+    // Global maximum and the sink pad (max + 1, expected_attention_press.py:163) without a second launch: every workgroup publishes its
+    // maximum and takes a ticket; the LAST one to arrive folds them all and writes the pads.  No workgroup waits for another (nothing can
+    // hang); the words other workgroups read are written and read with agent-scope atomics (the XCDs' L2s are not coherent for plain
+    // accesses within a launch), the store is drained (vmcnt) before the relaxed ticket.  `arrivals` was zeroed by the logits kernel earlier in the stream.
+    __shared__ uint32_t ticket;
+    vmax = wave_max(vmax);
+    if (lane == 0) scr[wv] = vmax;
+    __syncthreads();
+    const uint32_t nwg = gridDim.x * gridDim.y, slot = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) {
+        float m = scr[0];
+        for (uint32_t i = 1; i < EVF_THREADS / 64; ++i) m = fmaxf(m, scr[i]);
+        __hip_atomic_store(&bmax[slot], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the maximum has reached the agent-coherent level before the ticket is taken (an
+                                              // acquire / release ticket made every workgroup write back its XCD's L2: + 10 us)
+        ticket = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (ticket != nwg - 1 || n_sink == 0) return;
+    float m = KVP_NEG_INF;
+    for (uint32_t i = threadIdx.x; i < nwg; i += EVF_THREADS) m = fmaxf(m, __hip_atomic_load(&bmax[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    m = wave_max(m);
+    __syncthreads();
+    if (lane == 0) scr[wv] = m;
+    __syncthreads();
+    m = scr[0];
+    for (uint32_t i = 1; i < EVF_THREADS / 64; ++i) m = fmaxf(m, scr[i]);
+    const float fill = m + 1.0f;
+    const uint32_t BH = gridDim.y;
+    for (uint32_t i = threadIdx.x; i < BH * n_sink; i += EVF_THREADS) scores[(size_t)(i / n_sink) * S + (i % n_sink)] = fill;
 }
 
 struct EaScoreWs {
@@ -425,6 +455,7 @@ extern "C" int kvp_ea_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
     a.S = (uint32_t)S; a.Sp = (uint32_t)Sp; a.D = (uint32_t)D; a.n_sink = (uint32_t)n_sink;
     a.inv_sqrt_d = (float)(1.0 / sqrt((double)D));
     a.inv_2d = (float)(1.0 / (2.0 * (double)D));
+    a.clear_word = reinterpret_cast<uint32_t*>(w.bmax + 2047);   // the last word of the maxima buffer (<= 1280 of its 2048 are maxima): arrival counter
 
     uint32_t nblk;
     if (ea_mfma_logits_eligible(a, dtype)) {
@@ -453,16 +484,12 @@ extern "C" int kvp_ea_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
         const int nte = kvp_env_int("KVP_RN_NT", -1);   // read-once V (rownorm.hip: rn_streaming)
         const bool nt = nte >= 0 ? nte != 0 : (uint64_t)BH * Sp * 256 > (192ull << 20);
         const char* vp = static_cast<const char*>(v) + n_sink * v_ss * es;
-#define KVP_EVF(DTV, TT, NTV, GV) KVP_LAUNCH("ea_vnorm_finalize_kernel", stream, (ea_vnorm_finalize_kernel<DTV, NTV, GV><<<grid, EVF_THREADS, 0, stream>>>(reinterpret_cast<const TT*>(vp), v_sb, v_sh, v_ss, w.logits, w.part_m, w.part_z, nblk, (uint32_t)Hq, (uint32_t)Hkv, (uint32_t)S, (uint32_t)n_sink, epsilon, scores, w.bmax, (uint32_t)rows)))
+#define KVP_EVF(DTV, TT, NTV, GV) KVP_LAUNCH("ea_vnorm_finalize_kernel", stream, (ea_vnorm_finalize_kernel<DTV, NTV, GV><<<grid, EVF_THREADS, 0, stream>>>(reinterpret_cast<const TT*>(vp), v_sb, v_sh, v_ss, w.logits, w.part_m, w.part_z, nblk, (uint32_t)Hq, (uint32_t)Hkv, (uint32_t)S, (uint32_t)n_sink, epsilon, scores, w.bmax, (uint32_t)rows, a.clear_word)))
 #define KVP_EVF_G(DTV, TT, NTV) do { switch (Hq / Hkv) { case 1: KVP_EVF(DTV, TT, NTV, 1); break; case 2: KVP_EVF(DTV, TT, NTV, 2); break; default: KVP_EVF(DTV, TT, NTV, 4); break; } } while (0)
         if (dtype == KVP_BF16) { if (nt) KVP_EVF_G(KVP_BF16, uint16_t, true); else KVP_EVF_G(KVP_BF16, uint16_t, false); }
         else { if (nt) KVP_EVF_G(KVP_F16, _Float16, true); else KVP_EVF_G(KVP_F16, _Float16, false); }
 #undef KVP_EVF_G
 #undef KVP_EVF
-        if (n_sink > 0) {
-            const uint32_t nfill = BH * (uint32_t)n_sink;
-            KVP_LAUNCH("fill_pad_kernel", stream, fill_pad_kernel<<<(nfill + 255) / 256, 256, 0, stream>>>(scores, BH, (uint32_t)S, 0, (uint32_t)n_sink, w.bmax, nslot * BH));
-        }
         KVP_CHECK_LAUNCH("ea_score(vnorm + finalize)");
         return KVP_OK;
     }

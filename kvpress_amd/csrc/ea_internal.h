@@ -9,6 +9,7 @@ struct EaArgs {
     const float* cov;  // [B,Hq,D,D] post-RoPE covariance, or nullptr
     uint32_t B, Hq, Hkv, G, S, Sp, D, n_sink;  // Sp = S - n_sink
     float inv_sqrt_d, inv_2d;
+    uint32_t* clear_word;  // nullable: a word the logits kernel sets to 0 (the arrival counter of the finalize pass that follows it in the stream)
 };
 
 // MFMA fast paths (bf16/f16, D = 128)

@@ -437,6 +437,7 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
     // XCD-aware order: workgroups go round-robin over the 8 XCDs (linear id % 8), each with its own L2.  The G query heads of a
     // (kv-head, key chunk) unit read the same K chunk, so they take CONSECUTIVE slots of ONE XCD: the chunk enters that L2 once
     // instead of G times through G different XCDs (measured at 128k: L2 fetch traffic 1.09 GB -> see DESIGN section 5).
+    if (a.clear_word && blockIdx.x == 0 && threadIdx.x == 0) *a.clear_word = 0;
     const uint32_t slot = blockIdx.x >> 3, g = slot % a.G;
     const uint32_t unit = (slot / a.G) * 8 + (blockIdx.x & 7);
     if (unit >= nblk * a.B * a.Hkv) return;   // padding of the last round of 8 units
