@@ -637,6 +637,244 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
     }
 }
 
+// ---- (2b) the quadratic form on the UPPER TRIANGLE of the covariance ----------------------------------------------------------------
+// k^T C k = k^T U k with U_jj = C_jj, U_jc = C_jc + C_cj for c > j, 0 below the diagonal (exact for any C; for a symmetric one the doubled
+// upper triangle).  Strip s (rows 32 s .. 32 s + 31) of U only has columns >= 32 s, i.e. the 16-wide k-steps 2 s .. 7: 8 + 6 + 4 + 2 = 20
+// (strip, k-step) products per 32-key sub-tile instead of 32 -- 40 MFMAs with the hi / lo split instead of 64.  Balance: waves 0 / 1 hold
+// strips 0 and 3 (8 + 2 k-steps), waves 2 / 3 strips 1 and 2 (6 + 4); within a pair the even wave takes sub-tiles 0, 1 of every 128-key
+// tile, the odd one sub-tiles 2, 3: 2 x 10 x 2 = 40 MFMAs per wave and tile each, and a wave reads the K fragments of only two sub-tiles.
+// A first version (VERDICT r2 #4b) measured slower than the full form: the round-2 kernel was bound by LDS round trips, not by the matrix
+// pipe.  With the pipeline of (2) -- LDS-DMA tiles, chain of unit u || row-dot of unit u - 1 || reads of unit u + 1, pinned by
+// sched_group_barrier, across tile boundaries -- the matrix pipe and its power are what is left, and fewer MFMAs are fewer microseconds.
+// mu / sqrt(d) lives in LDS: a chain's accumulator is initialised by four broadcast reads (no registers held for it).
+template <int DT, int S_> struct ElTriFrag { uint4 hi[8 - 2 * S_], lo[8 - 2 * S_]; };
+
+template <int DT, int S_>
+__device__ __forceinline__ void el_tri_build(const float* __restrict__ cov_head, uint32_t n, uint32_t kg, float inv_2d, ElTriFrag<DT, S_>& f) {
+    const uint32_t j = 32 * S_ + n;   // this lane's row of U
+#pragma unroll
+    for (int i = 0; i < 8 - 2 * S_; ++i) {
+        const int ks = 2 * S_ + i;
+        const float* crow = cov_head + (size_t)j * 128 + ks * 16 + kg * 8;
+        const float4 u = *reinterpret_cast<const float4*>(crow), w = *reinterpret_cast<const float4*>(crow + 4);
+        float x[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t c = ks * 16 + kg * 8 + e;
+            const float t = cov_head[(size_t)c * 128 + j];   // C_cj: lanes n -> consecutive addresses
+            x[e] = (c > j ? x[e] + t : (c == j ? x[e] : 0.f)) * inv_2d;   // 1 / 2d = 2^-8: exact
+        }
+        uint32_t hw[4], lw[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            hw[p] = pack2<DT>(x[2 * p], x[2 * p + 1]);
+            lw[p] = pack2<DT>(x[2 * p] - lo16<DT>(hw[p]), x[2 * p + 1] - hi16<DT>(hw[p]));
+        }
+        f.hi[i] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        f.lo[i] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    }
+}
+
+// One pipeline group: the chain's MFMAs with, in its FIRST half, the LDS reads of the next unit and the row-dot of the previous one (so that
+// the accumulator it consumed is free early), and in its second half the four reads that re-initialise that accumulator for the next group.
+#define EL_TRI_GROUP(nmfma, nrd, nvalu)                                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < (nmfma) / 2; ++i_) {                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x100, ((nrd) + (nmfma) / 2 - 1) / ((nmfma) / 2), 0);              \
+        __builtin_amdgcn_sched_group_barrier(0x002, ((nvalu) + (nmfma) / 2 - 1) / ((nmfma) / 2), 0);            \
+    }                                                                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < (nmfma) - (nmfma) / 2; ++i_) {                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x100, (4 + (nmfma) - (nmfma) / 2 - 1) / ((nmfma) - (nmfma) / 2), 0); \
+    }
+
+template <int DT>
+__global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_tri_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk,
+                                                                       float* __restrict__ part_m, float* __restrict__ part_z) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * EL_TILEB];
+    __shared__ float red[3][8][EL_TILE];
+    __shared__ __attribute__((aligned(16))) float mus[128];
+    if (a.clear_word && blockIdx.x == 0 && threadIdx.x == 0) *a.clear_word = 0;
+    const uint32_t slot = blockIdx.x >> 3, g = slot % a.G;   // XCD-aware order: see ea_logits_mfma_kernel
+    const uint32_t unit = (slot / a.G) * 8 + (blockIdx.x & 7);
+    if (unit >= nblk * a.B * a.Hkv) return;
+    const uint32_t chunk = unit % nblk, bh = unit / nblk;
+    const uint32_t b = bh / a.Hkv, h = bh - b * a.Hkv;
+    const uint32_t hq = h * a.G + g, bhq = b * a.Hq + hq;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t n = lane & 31, kg = lane >> 5;
+    const char* kb = static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh + (int64_t)a.n_sink * a.k_ss) * 2;
+    const int64_t row_bytes = a.k_ss * 2;
+    if (threadIdx.x < 128) mus[threadIdx.x] = a.mu[(size_t)bhq * 128 + threadIdx.x] * a.inv_sqrt_d;
+
+    const uint32_t kbeg = chunk * EL_CHUNK;
+    const uint32_t kend = min(kbeg + EL_CHUNK, a.Sp);
+    const uint32_t ntiles = (kend - kbeg + EL_TILE - 1) / EL_TILE;
+    float* lrow = logits + (size_t)bhq * a.Sp;
+    float m_run = KVP_NEG_INF, z_run = 0.f;
+
+    const uint32_t ldsbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const uint32_t dg = lane >> 4, di16 = lane & 15;
+    auto request_tile = [&](uint32_t row0, uint32_t buf_off) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t trow = 16 * j + 4 * wv + dg;
+            const uint32_t r = min(row0 + trow, a.Sp - 1);
+            const char* gp = kb + (int64_t)r * row_bytes + ((di16 ^ (trow & 15)) << 4);
+            const uint32_t la = __builtin_amdgcn_readfirstlane(ldsbase + buf_off + (16 * j + 4 * wv) * EM_ROWB);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(gp) : "memory");
+        }
+    };
+    auto fold = [&](uint32_t tile, uint32_t rb) {
+        if ((threadIdx.x >> 7) == (tile & 1)) {
+            const uint32_t kk = kbeg + tile * EL_TILE + (threadIdx.x & 127);
+            if (kk < kend) {
+                const float* rr = &red[rb][0][threadIdx.x & 127];
+                const float l2 = (((rr[0] + rr[EL_TILE]) + (rr[2 * EL_TILE] + rr[3 * EL_TILE])) + ((rr[4 * EL_TILE] + rr[5 * EL_TILE]) + (rr[6 * EL_TILE] + rr[7 * EL_TILE]))) * KVP_LOG2E;
+                lrow[kk] = l2;
+                softmax_merge(m_run, z_run, l2, 1.0f);
+            }
+        }
+    };
+    unsigned char* bufc = lds;
+    unsigned char* bufn = lds + EL_TILEB;
+    request_tile(kbeg, 0);
+
+    // the walk of one wave: strips SA (the longer chain) and SB, sub-tiles sa = 2 (wv & 1) and sa + 1 of every tile
+    auto walk = [&](auto sa_tag, auto sb_tag) {
+        constexpr int SA = decltype(sa_tag)::value, SB = decltype(sb_tag)::value;
+        constexpr int NA = 8 - 2 * SA, NB = 8 - 2 * SB, KS0 = 2 * (SA < SB ? SA : SB);
+        ElTriFrag<DT, SA> fa;
+        ElTriFrag<DT, SB> fb;
+        const float* cov_head = a.cov + (size_t)bhq * 128 * 128;
+        el_tri_build<DT, SA>(cov_head, n, kg, a.inv_2d, fa);
+        el_tri_build<DT, SB>(cov_head, n, kg, a.inv_2d, fb);
+        const uint32_t sa = 2 * (wv & 1), sb = sa + 1;
+        auto frags = [&](const unsigned char* buf, uint32_t sub, uint4 (&kf)[8]) {
+#pragma unroll
+            for (int ks = KS0; ks < 8; ++ks) kf[ks] = frag16(buf, sub, ks * 2 + kg, n);
+        };
+        auto krows = [&](const unsigned char* buf, uint32_t sub, int strip, uint2 (&kk)[4]) {
+            const uint32_t row = sub * 32 + n;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kk[q] = *reinterpret_cast<const uint2*>(buf + row * EM_ROWB + (((strip * 4 + q) ^ (row & 15)) << 4) + kg * 8);
+        };
+        // an accumulator is (re)initialised with mu / sqrt(d) by four broadcast LDS reads issued at the END of the group in which its
+        // previous contents were consumed -- one whole group before its next chain starts, so that chain never waits for them
+        auto acc_init = [&](int strip, f32x16& acc) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 m4 = *reinterpret_cast<const float4*>(&mus[32 * strip + 8 * q + 4 * kg]);
+                acc[4 * q] = m4.x; acc[4 * q + 1] = m4.y; acc[4 * q + 2] = m4.z; acc[4 * q + 3] = m4.w;
+            }
+        };
+        auto chain_a = [&](const uint4 (&kf)[8], f32x16& acc) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) acc = mma32<DT>(fa.hi[i], kf[2 * SA + i], acc);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) acc = mma32<DT>(fa.lo[i], kf[2 * SA + i], acc);
+        };
+        auto chain_b = [&](const uint4 (&kf)[8], f32x16& acc) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) acc = mma32<DT>(fb.hi[i], kf[2 * SB + i], acc);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) acc = mma32<DT>(fb.lo[i], kf[2 * SB + i], acc);
+        };
+        auto rowdot = [&](const uint2 (&kk)[4], uint32_t sub, int strip, const f32x16& acc, float (*redb)[EL_TILE]) {
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v0 = fmaf(lo16<DT>(kk[q].x), acc[4 * q + 0], v0);
+                v1 = fmaf(hi16<DT>(kk[q].x), acc[4 * q + 1], v1);
+                v0 = fmaf(lo16<DT>(kk[q].y), acc[4 * q + 2], v0);
+                v1 = fmaf(hi16<DT>(kk[q].y), acc[4 * q + 3], v1);
+            }
+            redb[2 * strip + kg][sub * 32 + n] = v0 + v1;
+        };
+        f32x16 acc0, acc1;
+        uint4 kfa[8], kfb[8];
+        uint2 krAa[4], krBa[4], krAb[4], krBb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) krBb[q] = make_uint2(0, 0);   // tile 0 has no predecessor: its deferred row-dot writes zeros nobody reads
+        uint32_t rcur = 0, rprev = 2;
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's part of tile 0 has landed
+        __syncthreads();                      // (also publishes mus)
+        acc_init(SA, acc0);
+        acc_init(SB, acc1);
+        for (uint32_t t = 0; t < ntiles; ++t) {
+            const uint32_t key0 = kbeg + t * EL_TILE;
+            if (t + 1 < ntiles) request_tile(key0 + EL_TILE, (uint32_t)(bufn - lds));
+            __builtin_amdgcn_sched_barrier(0);
+            frags(bufc, sa, kfa);
+            krows(bufc, sa, SA, krAa);
+            __builtin_amdgcn_sched_barrier(0);
+            krows(bufc, sa, SB, krBa);
+            {   // unit (sa, SA) || row-dot (sb, SB) of the previous tile, then acc1 <- mu
+                const f32x16 prev = acc1;
+                chain_a(kfa, acc0);
+                rowdot(krBb, sb, SB, prev, red[rprev]);
+                acc_init(SB, acc1);
+            }
+            EL_TRI_GROUP(2 * NA, 4, 26)
+            __builtin_amdgcn_sched_barrier(0);
+            frags(bufc, sb, kfb);       // (here, not a unit earlier: sixteen fragment registers live at once were the register budget)
+            krows(bufc, sb, SA, krAb);
+            {   // unit (sa, SB) || row-dot (sa, SA), then acc0 <- mu
+                const f32x16 prev = acc0;
+                chain_b(kfa, acc1);
+                rowdot(krAa, sa, SA, prev, red[rcur]);
+                acc_init(SA, acc0);
+            }
+            EL_TRI_GROUP(2 * NB, 8 - KS0 + 4, 26)
+            __builtin_amdgcn_sched_barrier(0);
+            krows(bufc, sb, SB, krBb);
+            {   // unit (sb, SA) || row-dot (sa, SB), then acc1 <- mu
+                const f32x16 prev = acc1;
+                chain_a(kfb, acc0);
+                rowdot(krBa, sa, SB, prev, red[rcur]);
+                acc_init(SB, acc1);
+            }
+            EL_TRI_GROUP(2 * NA, 4, 26)
+            __builtin_amdgcn_sched_barrier(0);
+            {   // unit (sb, SB) || row-dot (sb, SA), then acc0 <- mu
+                const f32x16 prev = acc0;
+                chain_b(kfb, acc1);
+                rowdot(krAb, sb, SA, prev, red[rcur]);
+                acc_init(SA, acc0);
+            }
+            EL_TRI_GROUP(2 * NB, 0, 26)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): tile t + 1 has landed
+            __syncthreads();
+            unsigned char* tmp = bufc; bufc = bufn; bufn = tmp;
+            if (t > 0) fold(t - 1, rprev);
+            rprev = rcur;
+            rcur = rcur == 2 ? 0 : rcur + 1;
+        }
+        rowdot(krBb, sb, SB, acc1, red[rprev]);   // the last tile's last row-dot
+        __syncthreads();
+        fold(ntiles - 1, rprev);
+    };
+    if (wv < 2) walk(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+    else walk(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m_run, o), z2 = __shfl_xor(z_run, o);
+        softmax_merge(m_run, z_run, m2, z2);
+    }
+    __syncthreads();
+    if (lane == 0 && wv > 0) { red[0][0][2 * wv] = m_run; red[0][0][2 * wv + 1] = z_run; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) softmax_merge(m_run, z_run, red[0][0][2 * w], red[0][0][2 * w + 1]);
+        part_m[(size_t)bhq * nblk + chunk] = m_run;
+        part_z[(size_t)bhq * nblk + chunk] = z_run;
+    }
+}
+
 bool aligned8(int64_t x) { return x % 8 == 0; }
 
 }  // namespace
@@ -702,7 +940,10 @@ int ea_mfma_logits(const EaArgs& a, int dtype, float* logits, uint32_t nblk, flo
     KVP_CHECK_ARG((units + 7) / 8 * 8 * a.G < ((uint64_t)1 << 31), "ea_logits_mfma: grid too large");
     const dim3 grid((uint32_t)((units + 7) / 8 * 8 * a.G));   // (unit, head-in-group) -> linear id: see the kernel
 #define KVP_EL_LAUNCH(DTV, COV) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_kernel<DTV, COV><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)))
-    if (dtype == KVP_BF16) { if (a.cov) KVP_EL_LAUNCH(KVP_BF16, true); else KVP_EL_LAUNCH(KVP_BF16, false); }
+    if (a.cov && kvp_env_int("KVP_EA_TRI", 1) != 0) {   // the quadratic form on the upper triangle of the covariance (2b)
+        if (dtype == KVP_BF16) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_tri_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)));
+        else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_tri_kernel<KVP_F16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)));
+    } else if (dtype == KVP_BF16) { if (a.cov) KVP_EL_LAUNCH(KVP_BF16, true); else KVP_EL_LAUNCH(KVP_BF16, false); }
     else { if (a.cov) KVP_EL_LAUNCH(KVP_F16, true); else KVP_EL_LAUNCH(KVP_F16, false); }
 #undef KVP_EL_LAUNCH
     KVP_CHECK_LAUNCH("ea_logits_mfma");
