@@ -719,6 +719,31 @@ def test_snapkv_fused_rope_is_bit_identical_to_torch_rope(name):
         assert torch.allclose(b, c, rtol=1e-5, atol=0)
 
 
+def test_ea_logits_triangular_vs_full_form(knobs):
+    """ea_logits_tri_kernel (k^T C k on the doubled upper triangle of C, 40 instead of 64 MFMAs per tile and wave) against the full form
+    (KVP_EA_TRI=0) and the oracle: symmetric covariances as the press produces them, an ASYMMETRIC matrix (U_jc = C_jc + C_cj is exact
+    for any C), ragged lengths, one tile and many, both 16-bit dtypes."""
+    N = native()
+    rs = np.random.RandomState(12)
+    for dtype in ("bf16", "f16"):
+        for B, Hq, Hkv, S, n_sink, sym in ((1, 8, 2, 4500, 4, True), (2, 4, 4, 130, 0, True), (1, 4, 1, 9000, 3, False), (1, 32, 8, 12345, 4, True)):
+            kn = _inputs.round_to((rs.standard_normal((B, Hkv, S, 128)) * 0.7).astype(np.float32), dtype)
+            vn = _inputs.round_to(rs.standard_normal((B, Hkv, S, 128)).astype(np.float32), dtype)
+            mu = (rs.standard_normal((B, Hq, 128)) * 0.4).astype(np.float32)
+            a = (rs.standard_normal((B, Hq, 128, 128)) * 0.04).astype(np.float32)
+            cov = (a @ a.transpose(0, 1, 3, 2)) if sym else (a @ a.transpose(0, 1, 3, 2) + 0.01 * rs.standard_normal((B, Hq, 128, 128)).astype(np.float32))
+            k, v = to_dev(kn, dtype), to_dev(vn, dtype)
+            want = O.ea_score(kn, vn, mu, cov, n_sink, True, 0.0)
+            out = {}
+            for tri in (1, 0):
+                knobs(KVP_EA_TRI=tri)
+                out[tri] = N.ea_score(k, v, torch.from_numpy(mu).to(DEV), torch.from_numpy(cov).to(DEV), n_sink, True, 0.0).cpu().numpy()
+                rel = np.abs(out[tri][..., n_sink:] - want[..., n_sink:]) / np.abs(want[..., n_sink:])
+                assert rel.max() <= 1e-3, (dtype, S, sym, tri, rel.max())
+            assert (np.abs(out[1] - out[0]) <= 2e-5 * np.abs(out[0])).all(), (dtype, S, sym)
+            knobs(KVP_EA_TRI=None)
+
+
 def test_ea_fused_finalize_equals_three_kernels(knobs):
     """kvp_ea_score's one-pass ||v|| + row normalisers + finalize (ea_vnorm_finalize_kernel: 256-byte rows, >= 4096 scored keys) against
     the three kernels it replaces (KVP_EA_FUSED_FINALIZE=0): the same bits, with and without sinks, GQA groups of 1 / 2 / 4 (one pass) and 8 (the three kernels), ragged
