@@ -690,7 +690,7 @@ __device__ __forceinline__ void el_tri_build(const float* __restrict__ cov_head,
     }
 
 template <int DT>
-__global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_tri_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk,
+__global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_tri_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk,
                                                                        float* __restrict__ part_m, float* __restrict__ part_z) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * EL_TILEB];
     __shared__ float red[3][8][EL_TILE];
@@ -941,8 +941,8 @@ int ea_mfma_logits(const EaArgs& a, int dtype, float* logits, uint32_t nblk, flo
     const dim3 grid((uint32_t)((units + 7) / 8 * 8 * a.G));   // (unit, head-in-group) -> linear id: see the kernel
 #define KVP_EL_LAUNCH(DTV, COV) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_kernel<DTV, COV><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)))
     if (a.cov && kvp_env_int("KVP_EA_TRI", 1) != 0) {   // the quadratic form on the upper triangle of the covariance (2b)
-        if (dtype == KVP_BF16) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_tri_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)));
-        else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_tri_kernel<KVP_F16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)));
+        if (dtype == KVP_BF16) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)));
+        else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_F16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)));
     } else if (dtype == KVP_BF16) { if (a.cov) KVP_EL_LAUNCH(KVP_BF16, true); else KVP_EL_LAUNCH(KVP_BF16, false); }
     else { if (a.cov) KVP_EL_LAUNCH(KVP_F16, true); else KVP_EL_LAUNCH(KVP_F16, false); }
 #undef KVP_EL_LAUNCH

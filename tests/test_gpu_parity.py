@@ -720,7 +720,7 @@ def test_snapkv_fused_rope_is_bit_identical_to_torch_rope(name):
 
 
 def test_ea_logits_triangular_vs_full_form(knobs):
-    """ea_logits_tri_kernel (k^T C k on the doubled upper triangle of C, 40 instead of 64 MFMAs per tile and wave) against the full form
+    """ea_logits_mfma_tri_kernel (k^T C k on the doubled upper triangle of C, 40 instead of 64 MFMAs per tile and wave) against the full form
     (KVP_EA_TRI=0) and the oracle: symmetric covariances as the press produces them, an ASYMMETRIC matrix (U_jc = C_jc + C_cj is exact
     for any C), ragged lengths, one tile and many, both 16-bit dtypes."""
     N = native()
