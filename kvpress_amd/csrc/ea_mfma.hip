@@ -415,6 +415,7 @@ void qstats_plan(int64_t Sq, int64_t nbh, uint32_t& nchunk, uint32_t& rows) {
     const int64_t target = std::max<int64_t>(1, 512 / std::max<int64_t>(1, nbh));
     const int64_t cap = std::min<int64_t>(32, std::max(1, kvp_env_int("KVP_EA_QCHUNKS", (int)std::min<int64_t>(32, target))));
     int64_t nc = std::min<int64_t>(cap, std::max<int64_t>(1, (Sq + 4095) / 4096));
+    nc = std::max<int64_t>(nc, std::min<int64_t>(32, (Sq + 16383) / 16384));   // many heads: still <= 16384 rows per fp32 partial (the raw moments' accuracy, see (1b))
     int64_t r = ((Sq + nc - 1) / nc + EM_TILE - 1) / EM_TILE * EM_TILE;
     nchunk = (uint32_t)((Sq + r - 1) / r);
     rows = (uint32_t)r;
