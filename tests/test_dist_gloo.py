@@ -84,6 +84,34 @@ def test_path_model_is_the_sum_of_measured_ceilings():
     assert 190 < m["total_us"] < 200                             # vs 100.7 us for the bytes alone at 8 TB/s and ~270 us measured
 
 
+def test_live_pmc_is_skipped_in_children_and_under_a_profiler(monkeypatch):
+    """bench.live_pmc_traffic never recurses: a child of its own rocprofv3 passes (KVP_BENCH_CHILD=1), a run that is itself profiled
+    (rocprofv3 around bench.py: ROCPROF* / rocprofiler in LD_PRELOAD) and an explicit opt-out return None with the reason, and the caller
+    falls back to the committed summary (pmc_traffic: digest-guarded)."""
+    import bench
+
+    monkeypatch.setenv("KVP_BENCH_CHILD", "1")
+    assert bench.live_pmc_traffic("gather_vec_kernel", "snapkv128k")[0] is None
+    monkeypatch.delenv("KVP_BENCH_CHILD")
+    monkeypatch.setenv("KVP_BENCH_LIVE_PMC", "0")
+    assert bench.live_pmc_traffic("gather_vec_kernel", "snapkv128k")[0] is None
+    monkeypatch.delenv("KVP_BENCH_LIVE_PMC")
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    v, why = bench.live_pmc_traffic("gather_vec_kernel", "snapkv128k")
+    assert v is None and "profiler" in why
+    monkeypatch.delenv("LD_PRELOAD")
+    monkeypatch.setenv("ROCPROF_OUTPUT_PATH", "/tmp/x")
+    assert bench.live_pmc_traffic("gather_vec_kernel", "snapkv128k")[0] is None
+    # a committed summary is quoted only for the kernel sources it was measured on (digest in its header)
+    for wl, kern in (("snapkv128k", "gather_vec_kernel"), ("knorm32k", "topk_cluster_kernel"), ("ea128k", "ea_logits_mfma")):
+        head = open(os.path.join(ROOT, "profiles", f"r03_pmc_summary_{wl}.txt")).read(400)
+        v, why = bench.pmc_traffic(kern, wl)
+        if f"csrc_digest {bench.csrc_digest()}" in head:
+            assert v is not None and v > 0, (wl, why)
+        else:
+            assert v is None and "another build" in why, (wl, why)
+
+
 def _run_bench(cmd):
     import json
     import subprocess
