@@ -573,7 +573,10 @@ def main():
 
             traffic, traffic_source = (None, "not requested")
             if world == 1 and args.live_pmc != "off":
-                traffic, traffic_source = live_pmc_traffic(dom, args.workload)
+                try:
+                    traffic, traffic_source = live_pmc_traffic(dom, args.workload)
+                except Exception as e:   # noqa: BLE001 -- the bench line must never die in its optional profiler pass
+                    traffic, traffic_source = None, f"live PMC pass raised {type(e).__name__}: {e}"
             if traffic is None:   # no profiler here (or a child / profiled run): the committed summary of this same build, if there is one
                 live_note = traffic_source
                 traffic, traffic_source = pmc_traffic(dom, args.workload)
