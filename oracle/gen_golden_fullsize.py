@@ -34,7 +34,7 @@ def main(argv):
     _install_shims()
     import numpy as np
     import torch
-    from kvpress import ExpectedAttentionPress, KnormPress, SnapKVPress  # the reference
+    from kvpress import CURPress, ExpectedAttentionPress, KeyDiffPress, KnormPress, SnapKVPress  # the reference
 
     import _fullsize as F
     import bench
@@ -49,7 +49,9 @@ def main(argv):
         att, rot = bench.build_module(torch.device("cpu"))   # bf16 module, seeded
         press = {"knorm": lambda: KnormPress(compression_ratio=ratio),
                  "snapkv": lambda: SnapKVPress(compression_ratio=ratio, window_size=F.WINDOW, kernel_size=5),
-                 "ea": lambda: ExpectedAttentionPress(compression_ratio=ratio)}[spec["kind"]]()
+                 "ea": lambda: ExpectedAttentionPress(compression_ratio=ratio),
+                 "keydiff": lambda: KeyDiffPress(compression_ratio=ratio),
+                 "cur": lambda: CURPress(compression_ratio=ratio)}[spec["kind"]]()
         out = {}
         with torch.no_grad():
             pe_bf = rot(hidden, torch.arange(S)[None])
@@ -85,7 +87,7 @@ def main(argv):
                 out["sub_pure"] = sc32[0, :, F.SUB_OFFSET::F.SUBSAMPLE].numpy().astype(np.float32)
                 sc32 = press.score(att32, h32, k32, v32, None, {"position_embeddings": pe_id})          # :61-105 in float32
                 handle.remove()
-        pad = {"knorm": (0, 0), "snapkv": (S - F.WINDOW, S), "ea": (0, 4)}[spec["kind"]]
+        pad = {"knorm": (0, 0), "snapkv": (S - F.WINDOW, S), "ea": (0, 4), "keydiff": (0, 0), "cur": (0, 4)}[spec["kind"]]   # (CUR: its 4 sinks = 1.0)
         out.update(F.pack_reference(sc32, n_kept, *pad))
         out["ref_seconds"] = np.asarray([t_nat, t_f32])
         out["ref_threads"] = np.int64(torch.get_num_threads())

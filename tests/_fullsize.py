@@ -18,6 +18,9 @@ FULL_CASES = {
     "full_snapkv128k": dict(kind="snapkv", S=131072, ratio=0.5, data="A", seed=103),               # BASELINE config 3 (the bench workload)
     "full_snapkv128k_B": dict(kind="snapkv", S=131072 - 1000 + 37, ratio=0.5, data="B", seed=113),  # ragged length, structured keys
     "full_ea128k": dict(kind="ea", S=131072, ratio=0.7, data="B", seed=104),                       # BASELINE config 4
+    # SURVEY §8(f-2) scorers at the BASELINE size (round 3: the kernels they run on were reshaped for this size)
+    "full_keydiff128k": dict(kind="keydiff", S=131072, ratio=0.5, data="B", seed=105),
+    "full_cur128k": dict(kind="cur", S=131072, ratio=0.5, data="B", seed=106),
 }
 # BASELINE config 5's shard shape: ONE reference run over a batch of two different elements (flat data, then structured data with
 # ~100x larger score maxima), i.e. with the reference's pad constant `scores.max().item() + 1` taken over BOTH (snapkv_press.py:103).
@@ -92,11 +95,12 @@ def pack_reference(scores: torch.Tensor, n_kept: int, pad_lo: int, pad_hi: int, 
     return out
 
 
-def check_against_reference(fx, scores: torch.Tensor, idx: torch.Tensor, rtol: float = 1e-3):
+def check_against_reference(fx, scores: torch.Tensor, idx: torch.Tensor, rtol: float = 1e-3, atol: float = 0.0):
     """The kernel's float32 scores [1,H,S] and kept indices [1,H,n] against a fixture of pack_reference():
     (i) every stored reference score (subsample + threshold band) within rtol; (ii) tie-tolerant set parity:
     everything the reference keeps with a margin > rtol above its threshold is kept, nothing it drops with such a margin is
-    kept, and the rest of the set differs only inside the band.  Returns (max rel err, #positions where the sets differ)."""
+    kept, and the rest of the set differs only inside the band.  `atol`: absolute slack for scorers whose values cross zero (KeyDiff's
+    cosines: a relative error is meaningless at |score| ~ 1e-6).  Returns (max rel err beyond atol, #positions where the sets differ)."""
     sc = scores[0].float().cpu()
     H, S = sc.shape
     n = int(fx["n_kept"])
@@ -106,7 +110,7 @@ def check_against_reference(fx, scores: torch.Tensor, idx: torch.Tensor, rtol: f
     cols = torch.arange(SUB_OFFSET, S, int(fx["subsample"]) if "subsample" in fx else SUBSAMPLE)
     numeric = (cols < pad_lo) | (cols >= pad_hi)
     got = sc[:, cols]
-    rel = ((got - sub).abs() / sub.abs().clamp_min(1e-30))[:, numeric]
+    rel = (((got - sub).abs() - atol).clamp_min(0) / sub.abs().clamp_min(1e-30))[:, numeric]
     worst = float(rel.max())
     assert worst <= rtol, f"scores differ from the reference by {worst:.3e} (subsample)"
     if "sub_pure" in fx:   # all-float32 reference run (queries never rounded to bf16): differs by the model's bf16 q / cos / sin
@@ -123,7 +127,7 @@ def check_against_reference(fx, scores: torch.Tensor, idx: torch.Tensor, rtol: f
     for h in range(H):
         p = torch.from_numpy(fx["band_pos"][off[h]:off[h + 1]]).long()
         v = torch.from_numpy(fx["band_val"][off[h]:off[h + 1]])
-        r = ((sc[h, p] - v).abs() / v.abs().clamp_min(1e-30))
+        r = (((sc[h, p] - v).abs() - atol).clamp_min(0) / v.abs().clamp_min(1e-30))
         m = (p < pad_lo) | (p >= pad_hi)
         if m.any():
             worst = max(worst, float(r[m].max()))
@@ -133,7 +137,7 @@ def check_against_reference(fx, scores: torch.Tensor, idx: torch.Tensor, rtol: f
         differ += d.numel()
         if d.numel():
             # any disagreement must sit inside the tolerance band around the reference threshold
-            band = set(p[((v - t).abs() <= 2 * rtol * abs(t))].tolist())   # |s_k - s_r| <= rtol moves a score AND the threshold
+            band = set(p[((v - t).abs() <= 2 * (rtol * abs(t) + atol))].tolist())   # |s_k - s_r| <= rtol moves a score AND the threshold
             bad = [int(x) for x in d.tolist() if int(x) not in band]
             assert not bad, f"row {h}: {len(bad)} kept/dropped positions disagree with the reference outside the {rtol:g} band, e.g. {bad[:5]}"
     return worst, differ
