@@ -37,7 +37,7 @@ extern "C" {
 typedef void* kvp_stream_t; /* hipStream_t */
 
 enum kvp_dtype { KVP_F32 = 0, KVP_F16 = 1, KVP_BF16 = 2 };
-enum kvp_status { KVP_OK = 0, KVP_EINVAL = -1, KVP_EUNSUPPORTED = -2, KVP_EWORKSPACE = -3, KVP_EHIP = -4 };
+enum kvp_status { KVP_OK = 0, KVP_EINVAL = -1, KVP_EUNSUPPORTED = -2, KVP_EWORKSPACE = -3, KVP_EHIP = -4, KVP_EASYNC = -5 };
 /* Order of the retained indices.  POSITION: ascending token position (default; makes the gather a
  * monotone stream).  SCORE: descending score, ties by ascending position -- the element order
  * torch.topk(sorted=True) produces at scorer_press.py:95, for tensor-exact comparisons. */
@@ -52,6 +52,16 @@ enum kvp_order { KVP_ORDER_POSITION = 0, KVP_ORDER_SCORE = 1 };
 
 int kvp_version(void);
 const char* kvp_last_error(void);
+/* Failures a kernel can only detect while it RUNS.  The one-launch select of long rows (kvp_topk_select and the fused
+ * kvp_*_compress entry points on rows of 16385 .. 262144 scores) synchronises the 32 workgroups of a row with in-kernel barriers;
+ * if they never become co-resident (CU masking, a partitioned device) its bounded spin gives up.  torch.topk
+ * (kvpress/presses/scorer_press.py:95) cannot return wrong indices silently, so neither does this library: the affected rows'
+ * indices are written as -1 (kvp_gather_kv* turn a negative index into a row of all-ones bit patterns = NaN instead of reading
+ * anywhere), a process-wide host-pinned status word is set, and the NEXT call of kvp_topk_select*, kvp_*_compress*, kvp_gather_kv*
+ * or kvp_async_error_check on any thread returns KVP_EASYNC (once per report; kvp_last_error() has the text).  After KVP_EASYNC
+ * every workspace that was being used with KVP_TOPK_WS_CLEAN must be zero-filled again.  kvp_async_error_check() only polls the
+ * word (no synchronisation): call it after a stream sync to learn about everything enqueued before. */
+int kvp_async_error_check(void);
 
 /* ---- KnormPress.score: -keys.norm(dim=-1)  (kvpress/presses/knorm_press.py:38) -------------
  * out[b,h,s] = scale * ||x[b,h,s,:]||_2   (scale = -1 for Knorm; +1 for ||V|| in ExpectedAttention,
@@ -259,6 +269,10 @@ int kvp_prof_kernel_clock(float* mhz);
  * memory) it saw: s_memtime ticks per 100 MHz s_memrealtime tick.  Enqueued right behind a kernel it shows the clock that
  * kernel ran at (the governor is slow compared with a kernel). */
 int kvp_clock_probe(float* mhz_out, int spin_us, kvp_stream_t stream);
+/* kvp_occupy_cus (test aid): enqueue `blocks` workgroups of `threads` threads (a multiple of 64, <= 1024) that hold `lds_bytes`
+ * of LDS each and spin spin_us microseconds (<= 200000) -- CUs that some other stream cannot use meanwhile.  The tests of the
+ * one-launch select's residency behaviour run it beside kvp_topk_select (tests/test_gpu_cluster_failure.py). */
+int kvp_occupy_cus(int blocks, int threads, int lds_bytes, int spin_us, kvp_stream_t stream);
 /* kvp_tuning_reload: the library's tuning knobs (KVP_* environment variables: launch geometries and kernel-variant switches
  * for A/B runs) are read from the environment once, at first use, and cached; this drops the cache so that the next use of
  * every knob re-reads the environment.  Not needed in production; tests and lab scripts call it after changing a variable. */

@@ -30,6 +30,7 @@ _I64 = c_int64
 SIGNATURES = {
     "kvp_version": (c_int, []),
     "kvp_last_error": (c_char_p, []),
+    "kvp_async_error_check": (c_int, []),
     "kvp_rownorm_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_float, c_void_p, c_void_p]),
     "kvp_observed_attention_score": (c_int, [c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, c_void_p, c_void_p]),
     "kvp_lagkv_score": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, _I64, c_int,
@@ -90,6 +91,7 @@ SIGNATURES = {
     "kvp_prof_count": (c_int, []),
     "kvp_prof_get": (c_int, [c_int, ctypes.POINTER(c_char_p), ctypes.POINTER(c_float)]),
     "kvp_clock_probe": (c_int, [c_void_p, c_int, c_void_p]),
+    "kvp_occupy_cus": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
     "kvp_tuning_reload": (c_int, []),
     "kvp_prof_kernel_clock": (c_int, [ctypes.POINTER(c_float)]),
 }
@@ -117,10 +119,25 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+KVP_EASYNC = -5
+
+
 def _check(rc: int, what: str):
     if rc != 0:
         msg = lib().kvp_last_error()
+        if rc == KVP_EASYNC:
+            # a kernel of an EARLIER call reported at run time that its result is invalid (the cluster select's barrier timed out:
+            # include/kvpress_hip.h).  Its workspace -- whichever it was -- is dirty: no cached "clean" workspace survives.
+            with _TOPK_WS_LOCK:
+                _TOPK_WS.clear()
         raise KvpressHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def async_error_check() -> None:
+    """Raise KvpressHipError if a kernel has reported an asynchronous failure since the last check (no synchronisation: call it
+    after a stream sync to cover everything enqueued so far).  No-op when the library has not been loaded."""
+    if _lib is not None:
+        _check(_lib.kvp_async_error_check(), "kvp_async_error_check")
 
 
 def _dev(t: torch.Tensor):
@@ -737,6 +754,13 @@ def clock_probe(device=None, spin_us: int = 20) -> torch.Tensor:
     with torch.cuda.device(dev):
         _check(lib().kvp_clock_probe(_p(out), int(spin_us), _stream(out)), "kvp_clock_probe")
     return out
+
+
+def occupy_cus(blocks: int, threads: int, lds_bytes: int, spin_us: int, stream=None) -> None:
+    """TEST AID: enqueue `blocks` workgroups that hold `threads` threads + `lds_bytes` of LDS for `spin_us` microseconds on
+    `stream` (default: the current one)."""
+    st = stream if stream is not None else torch.cuda.current_stream()
+    _check(lib().kvp_occupy_cus(int(blocks), int(threads), int(lds_bytes), int(spin_us), c_void_p(st.cuda_stream)), "kvp_occupy_cus")
 
 
 def prof_enable(on: bool) -> None:

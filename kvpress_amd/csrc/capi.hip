@@ -42,6 +42,49 @@ extern "C" int kvp_tuning_reload(void) {
     return KVP_OK;
 }
 
+// ---- asynchronous failure reports (kvp_common.h) ----------------------------------------------------------------------------
+// One 64-byte host-pinned, device-mapped, coherent allocation per process, made at the first launch that may report through it
+// (the only allocation this library ever makes on a launch path, once).  Kernels store a non-zero code with system scope; the
+// host polls the word with plain loads -- no synchronisation, no stream traffic.
+namespace {
+std::mutex g_async_mu;
+volatile uint32_t* g_async_host = nullptr;
+uint32_t* g_async_dev = nullptr;
+bool g_async_tried = false;
+}  // namespace
+uint32_t* kvp_async_flag() {
+    std::lock_guard<std::mutex> lk(g_async_mu);
+    if (!g_async_tried) {
+        g_async_tried = true;
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && h) {
+            memset(h, 0, 64);
+            if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
+                g_async_host = static_cast<volatile uint32_t*>(h);
+                g_async_dev = static_cast<uint32_t*>(d);
+            } else {
+                (void)hipHostFree(h);
+            }
+        }
+        (void)hipGetLastError();   // a failed pinned allocation must not surface as some later launch's error
+    }
+    return g_async_dev;
+}
+int kvp_async_check(const char* who) {
+    volatile uint32_t* f = g_async_host;
+    if (!f) return KVP_OK;
+    const uint32_t code = *f;
+    if (code == 0) return KVP_OK;
+    *f = 0;
+    kvp_set_error("%s: an EARLIER cluster select on this process gave up at its barrier %u (its 32 workgroups per row never became "
+                  "co-resident within KVP_TC_TIMEOUT_US); the indices of that call were poisoned with -1 (gathered rows: all-ones bit "
+                  "patterns = NaN) and every workspace used with KVP_TOPK_WS_CLEAN since must be zero-filled again",
+                  who, (unsigned)code);
+    return KVP_EASYNC;
+}
+extern "C" int kvp_async_error_check(void) { return kvp_async_check("kvp_async_error_check"); }
+
 extern "C" int kvp_version(void) { return KVP_VERSION; }
 extern "C" const char* kvp_last_error(void) { return g_err; }
 
@@ -126,5 +169,29 @@ extern "C" int kvp_clock_probe(float* mhz_out, int spin_us, kvp_stream_t stream_
     KVP_CHECK_ARG(mhz_out && spin_us >= 1 && spin_us <= 100000, "clock_probe: bad arguments");
     clock_probe_kernel<<<1, 64, 0, stream>>>(mhz_out, (uint32_t)spin_us * 100u);
     KVP_CHECK_LAUNCH("clock_probe");
+    return KVP_OK;
+}
+
+// ---- CU occupier (test aid) -------------------------------------------------------------------------------------------------
+namespace {
+__global__ void occupy_kernel(uint32_t spin_ticks) {
+    extern __shared__ unsigned char occ_lds[];
+    if (threadIdx.x == 0) occ_lds[0] = 1;   // the allocation is what matters
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - r0 < spin_ticks) __builtin_amdgcn_s_sleep(16);
+}
+}  // namespace
+extern "C" int kvp_occupy_cus(int blocks, int threads, int lds_bytes, int spin_us, kvp_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    KVP_CHECK_ARG(blocks >= 1 && blocks <= 65535 && threads >= 64 && threads <= 1024 && threads % 64 == 0 && lds_bytes >= 0 &&
+                      lds_bytes <= 160 * 1024 && spin_us >= 1 && spin_us <= 200000,
+                  "occupy_cus: bad arguments");
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
+        kvp_set_error("occupy_cus: cannot raise the dynamic LDS limit to %d", lds_bytes);
+        return KVP_EHIP;
+    }
+    occupy_kernel<<<blocks, threads, (size_t)std::max(lds_bytes, 16), stream>>>((uint32_t)spin_us * 100u);
+    KVP_CHECK_LAUNCH("occupy_cus");
     return KVP_OK;
 }

@@ -74,6 +74,7 @@ extern "C" int kvp_knorm_compress(const void* k, int64_t k_sb, int64_t k_sh, int
                                   int64_t n_kept, void* k_out, void* v_out, void* ws, size_t ws_bytes, int flags,
                                   kvp_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = kvp_async_check("kvp_knorm_compress")) return rc;
     KVP_CHECK_ARG(B >= 1 && H >= 1 && S >= 1 && D >= 1 && n_kept >= 0 && n_kept <= S, "knorm_compress: bad shape B=%ld H=%ld S=%ld D=%ld n=%ld",
                   (long)B, (long)H, (long)S, (long)D, (long)n_kept);
     if (n_kept == 0) return KVP_OK;
@@ -148,6 +149,7 @@ extern "C" int kvp_snapkv_compress_hidden(const void* hidden_win, int64_t x_sb, 
                                           int64_t n_kept, void* k_out, void* v_out, void* ws, size_t ws_bytes, int flags,
                                           kvp_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = kvp_async_check("kvp_snapkv_compress")) return rc;
     KVP_CHECK_ARG(B >= 1 && Hq >= 1 && Hkv >= 1 && W >= 1 && S > W && D >= 1 && n_kept >= 0 && n_kept <= S,
                   "snapkv_compress: bad shape B=%ld Hq=%ld Hkv=%ld S=%ld W=%ld D=%ld n=%ld", (long)B, (long)Hq, (long)Hkv, (long)S, (long)W,
                   (long)D, (long)n_kept);
@@ -175,6 +177,7 @@ extern "C" int kvp_snapkv_compress_rope(const void* q, int64_t q_sb, int64_t q_s
                                         int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size, int64_t n_kept, void* k_out,
                                         void* v_out, void* ws, size_t ws_bytes, int flags, kvp_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = kvp_async_check("kvp_snapkv_compress")) return rc;
     KVP_CHECK_ARG(B >= 1 && Hq >= 1 && Hkv >= 1 && W >= 1 && S > W && D >= 1 && n_kept >= 0 && n_kept <= S,
                   "snapkv_compress: bad shape B=%ld Hq=%ld Hkv=%ld S=%ld W=%ld D=%ld n=%ld", (long)B, (long)Hq, (long)Hkv, (long)S, (long)W,
                   (long)D, (long)n_kept);

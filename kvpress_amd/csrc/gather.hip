@@ -5,6 +5,7 @@
 // HBM-bound row copy: algorithmic bytes = 2 * n*B*H*D*esize read + the same written.
 // One output row = `chunks` 16-byte vectors handled by LPR adjacent lanes; K and V rows for the
 // same index are moved by the same lanes (one index load, two dwordx4 loads, two dwordx4 stores).
+// An index outside [0, S) -- in particular the -1 a failed select writes -- yields a row of all-ones bytes (NaN), never a read.
 // With position-ordered indices (the default of kvp_topk_select) the source addresses of a
 // (b,h) row are monotone, so consecutive lane groups stream forward through HBM pages.
 // The kernel is dtype-agnostic (bytes); four rows per lane group are in flight.
@@ -49,16 +50,22 @@ __global__ __launch_bounds__(GA_THREADS) void gather_vec_kernel(GatherArgs a) {
 #pragma unroll
         for (int u = 0; u < GA_UNROLL; ++u) {
             const uint32_t j = j0 + u * TG;
-            int32_t s = j < n ? ib[j] : 0;
-            src[u] = s < 0 ? 0 : (s >= (int32_t)a.S ? (int32_t)a.S - 1 : s);  // never fault on a bad index
+            const int32_t s = j < n ? ib[j] : 0;
+            // an index outside [0, S) is never dereferenced AND never papered over: -1 marks it (a select that reported a failure
+            // writes -1, topk_cluster.hip) and the output row becomes all-ones bit patterns -- NaN in every supported dtype
+            src[u] = (uint32_t)s < a.S ? s : -1;
         }
         uint4 kv[GA_UNROLL], vv[GA_UNROLL];
 #pragma unroll
         for (int u = 0; u < GA_UNROLL; ++u) {
             const uint32_t j = j0 + u * TG;
             if (j < n && lir < chunks) {
-                kv[u] = ld16<NT>(kb + (int64_t)src[u] * a.k_ss + (size_t)lir * 16);
-                vv[u] = ld16<NT>(vb + (int64_t)src[u] * a.v_ss + (size_t)lir * 16);
+                if (src[u] >= 0) {
+                    kv[u] = ld16<NT>(kb + (int64_t)src[u] * a.k_ss + (size_t)lir * 16);
+                    vv[u] = ld16<NT>(vb + (int64_t)src[u] * a.v_ss + (size_t)lir * 16);
+                } else {
+                    kv[u] = vv[u] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                }
             }
         }
 #pragma unroll
@@ -72,11 +79,13 @@ __global__ __launch_bounds__(GA_THREADS) void gather_vec_kernel(GatherArgs a) {
                     st16<NT>(vd + (size_t)lir * 16, vv[u]);
                 }
                 if (LPR == 64) {  // rows longer than 1 KiB
-                    const char* ks = kb + (int64_t)src[u] * a.k_ss;
-                    const char* vs = vb + (int64_t)src[u] * a.v_ss;
+                    const int64_t sr = src[u] >= 0 ? src[u] : 0;
+                    const char* ks = kb + sr * a.k_ss;
+                    const char* vs = vb + sr * a.v_ss;
+                    const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
                     for (uint32_t c = lir + LPR; c < chunks; c += LPR) {
-                        st16<NT>(kd + (size_t)c * 16, ld16<NT>(ks + (size_t)c * 16));
-                        st16<NT>(vd + (size_t)c * 16, ld16<NT>(vs + (size_t)c * 16));
+                        st16<NT>(kd + (size_t)c * 16, src[u] >= 0 ? ld16<NT>(ks + (size_t)c * 16) : ones);
+                        st16<NT>(vd + (size_t)c * 16, src[u] >= 0 ? ld16<NT>(vs + (size_t)c * 16) : ones);
                     }
                 }
             }
@@ -92,12 +101,13 @@ __global__ __launch_bounds__(GA_THREADS) void gather_scalar_kernel(GatherArgs a,
     const uint32_t total = a.n * D;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const uint32_t j = i / D, d = i - j * D;
-        int32_t s = a.idx[(size_t)bh * a.n + j];
-        s = s < 0 ? 0 : (s >= (int32_t)a.S ? (int32_t)a.S - 1 : s);
-        const E* ks = reinterpret_cast<const E*>(a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh + (int64_t)s * a.k_ss);
-        const E* vs = reinterpret_cast<const E*>(a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh + (int64_t)s * a.v_ss);
-        reinterpret_cast<E*>(a.ko)[(size_t)bh * total + i] = ks[d];
-        reinterpret_cast<E*>(a.vo)[(size_t)bh * total + i] = vs[d];
+        const int32_t raw = a.idx[(size_t)bh * a.n + j];
+        const bool ok = (uint32_t)raw < a.S;   // otherwise: a NaN row (see gather_vec_kernel)
+        const int64_t s = ok ? raw : 0;
+        const E* ks = reinterpret_cast<const E*>(a.k + (int64_t)b * a.k_sb + (int64_t)h * a.k_sh + s * a.k_ss);
+        const E* vs = reinterpret_cast<const E*>(a.v + (int64_t)b * a.v_sb + (int64_t)h * a.v_sh + s * a.v_ss);
+        reinterpret_cast<E*>(a.ko)[(size_t)bh * total + i] = ok ? ks[d] : (E)~(E)0;
+        reinterpret_cast<E*>(a.vo)[(size_t)bh * total + i] = ok ? vs[d] : (E)~(E)0;
     }
 }
 
@@ -107,6 +117,7 @@ extern "C" int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t 
                              int64_t v_sh, int64_t v_ss, int dtype, int64_t B, int64_t H, int64_t S, int64_t D,
                              const int32_t* idx, int64_t n, void* k_out, void* v_out, kvp_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = kvp_async_check("kvp_gather_kv")) return rc;
     KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "gather: bad dtype %d", dtype);
     KVP_CHECK_ARG(B >= 0 && H >= 0 && S >= 0 && D >= 1 && n >= 0 && n <= S, "gather: bad shape B=%ld H=%ld S=%ld D=%ld n=%ld",
                   (long)B, (long)H, (long)S, (long)D, (long)n);

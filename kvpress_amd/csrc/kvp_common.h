@@ -29,6 +29,13 @@ void kvp_set_error(const char* fmt, ...);
         }                                                                          \
     } while (0)
 
+// ---- asynchronous failure reports (capi.hip) -------------------------------------------------------------------------------
+// A kernel that detects at RUN time that its result is invalid (the cluster select when its workgroups never become co-resident,
+// topk_cluster.hip) poisons its output AND stores a code into one process-wide, host-pinned status word; every entry point that
+// produces or consumes a selection calls kvp_async_check() first and turns a pending report into KVP_EASYNC + kvp_last_error().
+uint32_t* kvp_async_flag();             // device-visible address of the status word (nullptr: pinned allocation failed -> poison only)
+int kvp_async_check(const char* who);   // KVP_OK, or KVP_EASYNC exactly once per report
+
 // ---- opt-in per-kernel timing (kvp_prof_* in include/kvpress_hip.h; implemented in capi.hip) ----
 bool kvp_prof_enabled();
 void kvp_prof_begin(const char* name, hipStream_t stream);

@@ -22,7 +22,7 @@ __device__ __forceinline__ void sincos_f32_angle(float angle, float& s, float& c
     const double t = (double)angle * 0.6366197723675814;       // 2 / pi
     const double kq = rint(t);
     const float r = (float)((t - kq) * 1.5707963267948966);     // pi / 2
-    const int q = (int)kq;
+    const int q = fabs(kq) < 2147483520.0 ? (int)kq : 0;   // non-finite / absurd angles: r is NaN or garbage anyway, the conversion must stay defined
     const float z = r * r;
     const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
     const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z, fmaf(-0.5f, z, 1.0f));
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void gather_rerotate_kernel(GrArgs a) {
         uint4 ka[GR_UNROLL], kc[GR_UNROLL], va[GR_UNROLL], vc[GR_UNROLL];
         uint32_t j[GR_UNROLL], d0[GR_UNROLL];
         float delta[GR_UNROLL];
+        bool ok[GR_UNROLL];
 #pragma unroll
         for (int u = 0; u < GR_UNROLL; ++u) {
             const uint32_t i = i0 + u * stride;
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(256) void gather_rerotate_kernel(GrArgs a) {
             d0[u] = (i - j[u] * tpr) * 8;
             if (i < total) {
                 const int32_t raw = ib[j[u]];
-                const int32_t src = raw < 0 ? 0 : (raw >= (int32_t)a.S ? (int32_t)a.S - 1 : raw);  // never fault on a bad index
+                ok[u] = (uint32_t)raw < a.S;   // else (the -1 of a select that reported a failure): a NaN row, as in gather_vec_kernel
+                const int32_t src = ok[u] ? raw : 0;
                 delta[u] = (float)((int32_t)j[u] - raw);
                 const char* ks = kb + (int64_t)src * a.k_ss + (size_t)d0[u] * 2;
                 const char* vs = vb + (int64_t)src * a.v_ss + (size_t)d0[u] * 2;
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(256) void gather_rerotate_kernel(GrArgs a) {
             if (i < total) {
                 uint4 o0, o1;
                 rotate8<DT>(ka[u], kc[u], delta[u], a.inv_freq + d0[u], o0, o1);
+                if (!ok[u]) o0 = o1 = va[u] = vc[u] = make_uint4(~0u, ~0u, ~0u, ~0u);
                 char* kd = kob + (size_t)j[u] * rowbytes + (size_t)d0[u] * 2;
                 char* vd = vob + (size_t)j[u] * rowbytes + (size_t)d0[u] * 2;
                 st16<NT>(kd, o0);
@@ -210,6 +213,7 @@ extern "C" int kvp_gather_kv_rerotate(const void* k, int64_t k_sb, int64_t k_sh,
                                       int64_t v_ss, int dtype, int64_t B, int64_t H, int64_t S, int64_t D, const int32_t* idx, int64_t n,
                                       const float* inv_freq, void* k_out, void* v_out, kvp_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (int rc = kvp_async_check("kvp_gather_kv_rerotate")) return rc;
     KVP_CHECK_ARG(dtype == KVP_F32 || dtype == KVP_F16 || dtype == KVP_BF16, "gather_rerotate: bad dtype %d", dtype);
     KVP_CHECK_ARG(B >= 0 && H >= 0 && S >= 0 && D >= 2 && D % 2 == 0 && n >= 0 && n <= S, "gather_rerotate: bad shape B=%ld H=%ld S=%ld D=%ld n=%ld",
                   (long)B, (long)H, (long)S, (long)D, (long)n);

@@ -654,6 +654,7 @@ int topk_select_pooled_rows(const float* colsum, int64_t R, int64_t Sm, float in
 
 extern "C" int kvp_topk_select(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int order,
                                int32_t* idx, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
+    if (int rc = kvp_async_check("kvp_topk_select")) return rc;
     KVP_CHECK_ARG(R >= 0 && S >= 0 && k >= 0 && k <= S, "topk: bad shape R=%ld S=%ld k=%ld", (long)R, (long)S, (long)k);
     const int ord = order & ~(KVP_TOPK_WS_CLEAN | KVP_TOPK_SMALLEST);
     KVP_CHECK_ARG(ord == KVP_ORDER_POSITION || ord == KVP_ORDER_SCORE, "topk: bad order %d", order);
@@ -678,6 +679,7 @@ extern "C" size_t kvp_topk_segmented_workspace_bytes(int64_t R, int64_t nseg, in
 }
 extern "C" int kvp_topk_select_segmented(const float* scores, int64_t R, int64_t nseg, int64_t seg_len, int64_t k, int64_t pos_base,
                                          int order, int32_t* idx, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
+    if (int rc = kvp_async_check("kvp_topk_select_segmented")) return rc;
     KVP_CHECK_ARG(R >= 0 && nseg >= 1 && seg_len >= 1 && k >= 0 && k <= seg_len && pos_base >= 0, "topk_segmented: bad shape R=%ld nseg=%ld seg_len=%ld k=%ld",
                   (long)R, (long)nseg, (long)seg_len, (long)k);
     KVP_CHECK_ARG((order & ~KVP_TOPK_WS_CLEAN) == KVP_ORDER_POSITION, "topk_segmented: only KVP_ORDER_POSITION");

@@ -7,14 +7,19 @@
 // flush, kernel boundary, load the keys again ...  (4 launches of 5-7 us for ~2 us of work each).  Here a row belongs to a
 // CLUSTER of TC_SLOTS = 32 workgroups of 1024 threads; a workgroup keeps its 1024 * PER keys in registers from the first
 // load to the compaction, and the three digit steps are separated by cluster barriers (one monotonic arrival counter per
-// cluster, 32 arrivals) instead of kernel boundaries.  256 workgroups = 8 clusters, one per XCD when the dispatcher places
-// block b on XCD b % 8 (observed; MI355X_MICROARCH.md "Workgroup dispatch"): a speed assumption only.  Correctness is
+// cluster, 32 arrivals) instead of kernel boundaries.  256 workgroups = 8 clusters; a row's 32 workgroups are CONSECUTIVE blocks
+// (block / 32 = cluster), i.e. spread over all XCDs -- measured, a hop costs the same ~0.8 us round trip from anywhere
+// (profiles/r03_select_cluster_lab.txt), and consecutive blocks make partial residency harmless (see the kernel).  Correctness is
 // placement-independent: every word another workgroup reads -- the row histograms, the per-slot suffix tables, the
 // counter -- is written AND read with agent-scope (sc1) atomics / loads / stores, every wave drains its vector-memory
 // counter before the arrival, no fences, nothing relies on two workgroups sharing an L2 (cdna_hip_programming.md
 // Guideline 16, the "agent atomics on both sides" form).  One launch selects up to 8 rows; more rows take the (chunk, row) passes.
-// The barrier spins are bounded (give-up code in the workspace) so that a grid that is not fully resident cannot hang the GPU;
-// the host launches this kernel only on a device with at least 256 CUs (one workgroup each).
+//
+// Failure is LOUD (torch.topk cannot return wrong indices silently, scorer_press.py:95).  The barrier spins are bounded
+// (KVP_TC_TIMEOUT_US, default 1 s) so that a cluster that never becomes co-resident cannot hang the GPU; a spin that times out
+// sets the cluster's flag, the workspace's flag and the process-wide host-pinned status word (kvp_async_check: the next call of
+// the library returns KVP_EASYNC), and every workgroup of that cluster writes -1 instead of indices (kvp_gather_kv* turn a
+// negative index into a NaN row).  The host launches this kernel only on a device with at least 256 CUs.
 //
 // Key sources (MODE):  SCORES  the row is read from memory (kvp_topk_select, every scorer);
 //                      POOL5   SnapKV's un-pooled column sums: avg_pool1d(kernel 5) + scale in the loader, term for term the
@@ -30,37 +35,45 @@
 
 namespace {
 
-#ifndef KVP_TC_L2LOCAL
 #define TC_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 __device__ __forceinline__ uint32_t tc_ld(const uint32_t* p) { return __hip_atomic_load(p, TC_RLX); }
 __device__ __forceinline__ void tc_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, TC_RLX); }
 __device__ __forceinline__ void tc_add(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, TC_RLX); }
-#else
-// LAB ONLY (tools/build_variants.sh tc_l2): the same protocol on XCD-local traffic -- atomics executed in the XCD's L2 (no sc1),
-// loads that bypass the L1 but are served by the L2 (nt), plain write-through stores.  Correct only while the 32 workgroups of
-// a cluster really share an XCD (block b on XCD b % 8): a measurement of what placement-DEPENDENT traffic would buy.
-#define TC_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP
-__device__ __forceinline__ uint32_t tc_ld(const uint32_t* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void tc_st(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
-__device__ __forceinline__ void tc_add(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, TC_RLX); }
-#endif
 
-constexpr uint32_t TC_TIMEOUT_TICKS = 20000000u;  // 0.2 s of the 100 MHz real-time counter
+// Where a cluster's barrier state lives: bar + cluster * 32 (its own 128-byte line): [0] the monotonic arrival counter,
+// [1] the cluster's give-up code (0 = none).  bar[TC_CLUSTERS * 32] = the workspace-wide give-up code.
+struct ClusterSync {
+    uint32_t* ctr;
+    uint32_t* cl_flag;
+    uint32_t* ws_flag;
+    uint32_t* host_flag;      // process-wide pinned status word (kvp_async_flag(); may be null)
+    uint32_t timeout_ticks;   // of the 100 MHz real-time counter
+    uint32_t delay_ticks;     // TEST AID (KVP_TC_TEST_DELAY_SLOT): this workgroup arrives at its first barrier this late
+};
 
 // Arrive at / wait for the cluster's next barrier.  Every wave first drains its own agent-scope stores and atomics
-// (they are what the other workgroups read after the barrier).
-__device__ __forceinline__ void cluster_barrier(uint32_t* ctr, uint32_t* give_up, uint32_t code) {
+// (they are what the other workgroups read after the barrier).  A spin that times out REPORTS it -- the cluster's flag (read by
+// every workgroup of the cluster before it writes indices: see the poison path of the kernel), the workspace's flag and the host's
+// status word -- and goes on, so that every workgroup still makes all its arrivals and the counter stays a multiple of TC_SLOTS.
+__device__ __forceinline__ void cluster_barrier(const ClusterSync& cs, uint32_t code, uint32_t* lds_gave_up, bool first) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t old = __hip_atomic_fetch_add(ctr, 1u, TC_RLX);
-        const uint32_t target = (old & ~(uint32_t)(TC_SLOTS - 1)) + TC_SLOTS;
-        if ((int32_t)(tc_ld(ctr) - target) < 0) {
+        if (first && cs.delay_ticks) {
             const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-            while ((int32_t)(tc_ld(ctr) - target) < 0) {
+            while (__builtin_amdgcn_s_memrealtime() - t0 < cs.delay_ticks) __builtin_amdgcn_s_sleep(8);
+        }
+        const uint32_t old = __hip_atomic_fetch_add(cs.ctr, 1u, TC_RLX);
+        const uint32_t target = (old & ~(uint32_t)(TC_SLOTS - 1)) + TC_SLOTS;
+        if ((int32_t)(tc_ld(cs.ctr) - target) < 0) {
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            while ((int32_t)(tc_ld(cs.ctr) - target) < 0) {
                 __builtin_amdgcn_s_sleep(1);
-                if (__builtin_amdgcn_s_memrealtime() - t0 > TC_TIMEOUT_TICKS) {  // not all workgroups resident: give up (results invalid)
-                    tc_st(give_up, code);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > cs.timeout_ticks) {  // the cluster is not co-resident: give up, loudly
+                    *lds_gave_up = code;
+                    tc_st(cs.cl_flag, code);
+                    tc_st(cs.ws_flag, code);
+                    if (cs.host_flag) __hip_atomic_store(cs.host_flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
             }
@@ -83,6 +96,11 @@ struct ClusterArgs {
     int64_t x_sb, x_sh, x_ss;  // element strides
     uint32_t H;
     float scale;
+    // barrier protocol
+    uint32_t* host_flag;
+    uint32_t timeout_ticks;
+    int32_t test_delay_slot;   // TEST AID: slot (of cluster 0) that arrives 2 x timeout late at its first barrier; -1 = none
+    uint32_t interleave;       // 1: cluster = block % 8 (the 32 workgroups of a row on ONE XCD under the observed placement, lab only)
 };
 
 #ifndef TC_KN_UNROLL
@@ -108,9 +126,21 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
     constexpr uint32_t L = TR_THREADS * PER;   // keys per workgroup
     __shared__ __attribute__((aligned(16))) uint32_t lh[L > 4096 ? L : 4096];   // histogram; KNORM: first the staged scores; last the staged output
     __shared__ uint32_t scr[TR_WAVES + 2];
-    const uint32_t cluster = blockIdx.x % TC_CLUSTERS, slot = blockIdx.x / TC_CLUSTERS;
-    uint32_t* bar = a.w.bar + cluster * 32;
-    uint32_t* give_up = a.w.bar + TC_CLUSTERS * 32;
+    __shared__ uint32_t s_fail[2];   // [0] this workgroup gave up at a barrier, [1] the cluster's flag as read after the last barrier
+    // A row's 32 workgroups are CONSECUTIVE blocks: whatever part of the grid the device can hold at once, whole clusters become
+    // resident in dispatch order and finish, so a device with fewer free CUs than the grid (CU masking, a busy neighbour) makes
+    // the launch slower, not stuck.  (interleave = 1, lab: cluster = block % 8 puts a row on one XCD under the observed
+    // placement -- and deadlocks into the give-up path as soon as fewer than all 256 workgroups fit.)
+    const uint32_t cluster = a.interleave ? blockIdx.x % TC_CLUSTERS : blockIdx.x / TC_SLOTS;
+    const uint32_t slot = a.interleave ? blockIdx.x / TC_CLUSTERS : blockIdx.x % TC_SLOTS;
+    ClusterSync cs;
+    cs.ctr = a.w.bar + cluster * 32;
+    cs.cl_flag = cs.ctr + 1;
+    cs.ws_flag = a.w.bar + TC_CLUSTERS * 32;
+    cs.host_flag = a.host_flag;
+    cs.timeout_ticks = a.timeout_ticks;
+    cs.delay_ticks = (cluster == 0 && (int32_t)slot == a.test_delay_slot) ? 2u * a.timeout_ticks : 0u;
+    if (threadIdx.x < 2) s_fail[threadIdx.x] = 0;   // (ordered before its first use by the barriers of the key loaders / histograms)
     const uint32_t S = a.S, k = a.k, kmask = a.kmask;
     const uint32_t p0 = slot * L + threadIdx.x * PER;   // this thread's PER consecutive positions
 
@@ -187,11 +217,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
                 for (int u = 0; u < TC_KN_UNROLL; ++u) {
                     const uint32_t s = r0 + it + u * 64 + g;
                     v[u] = make_uint4(0, 0, 0, 0);
-                    #ifdef TC_KN_NT
-                    if (s < S) v[u] = ld16<true>(base + (int64_t)s * a.x_ss + (size_t)lir * 8);
-#else
                     if (s < S) v[u] = *reinterpret_cast<const uint4*>(base + (int64_t)s * a.x_ss + (size_t)lir * 8);
-#endif
                 }
 #pragma unroll
                 for (int u = 0; u < TC_KN_UNROLL; ++u) {
@@ -233,7 +259,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
                 if (c) tc_add(&h1[i], c);
             }
             TC_STAMP(2);   // first histogram flushed
-            cluster_barrier(bar, give_up, 1);
+            cluster_barrier(cs, 1, &s_fail[0], true);
             TC_STAMP(3);
         }
         uint32_t b1, k1;
@@ -261,7 +287,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             if (c) tc_add(&h2[i], c);
         }
         TC_STAMP(5);   // second histogram flushed
-        cluster_barrier(bar, give_up, 2);
+        cluster_barrier(cs, 2, &s_fail[0], HIST1);
         TC_STAMP(6);
         uint32_t b2, k2;
         {
@@ -306,13 +332,26 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             }
         }
         TC_STAMP(8);   // third histogram + suffix table
-        cluster_barrier(bar, give_up, 3);
+        cluster_barrier(cs, 3, &s_fail[0], false);
         TC_STAMP(9);
         uint32_t b3, quota;
         {
             uint32_t loc[1];
             loc[0] = threadIdx.x < 256 ? tc_ld(&h3[255u - threadIdx.x]) : 0u;
-            row_find_bin_regs<1>(loc, 256, k2, scr, b3, quota);
+            // the cluster's give-up flag rides on the same round trip as the histogram read-back (thread 256 has no bin to fetch)
+            if (threadIdx.x == 256) s_fail[1] = tc_ld(cs.cl_flag);
+            row_find_bin_regs<1>(loc, 256, k2, scr, b3, quota);   // (its barriers publish s_fail[1])
+        }
+        int32_t* out = a.idx + (int64_t)row * a.idx_stride;
+        // ---- a barrier of this cluster timed out: NO index of this row is trustworthy ------------------------------------------
+        // Every give-up of a cluster happens before any of its workgroups gets past the last barrier legitimately (that takes all
+        // 32 arrivals, and a workgroup arrives at barrier 3 only after its own earlier give-ups), and a workgroup that gave up at
+        // barrier 3 itself knows it from s_fail[0]: so every workgroup of the cluster takes this branch, none writes an index, and
+        // together they fill the row's k + tail_n entries with -1 (kvp_gather_kv: a row of NaN instead of somebody else's token).
+        if (s_fail[0] | s_fail[1]) {
+            const uint32_t tot_out = k + a.tail_n, per = (tot_out + TC_SLOTS - 1) / TC_SLOTS;
+            for (uint32_t j = slot * per + threadIdx.x; j < min((slot + 1) * per, tot_out); j += TR_THREADS) out[j] = -1;
+            return;
         }
         const uint32_t T = (prefix << 8) | b3;
         TC_STAMP(10);  // threshold known
@@ -346,7 +385,6 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
         // ranks of this workgroup: [rank0, rank0 + nmine)
         const uint32_t rank0 = gt_before + min(eq_before, quota);
         const uint32_t nmine = (tot & 0xFFFFu) + (min(eq_before + (tot >> 16), quota) - min(eq_before, quota));
-        int32_t* out = a.idx + (int64_t)row * a.idx_stride;
         const uint32_t off = a.pos_base + (a.nseg > 1 ? (row % a.nseg) * a.seg_len : 0u);
         if (slot == 0)
             for (uint32_t j = threadIdx.x; j < a.tail_n; j += TR_THREADS) out[k + j] = (int32_t)(off + a.tail_start + j);
@@ -374,6 +412,10 @@ template <int PER, int MODE, bool HIST1>
 int launch_one(const ClusterArgs& a, hipStream_t stream) {
     if (!topk_cluster_launchable()) return 1;
     ClusterArgs b = a;
+    b.host_flag = kvp_async_flag();
+    b.timeout_ticks = (uint32_t)std::min<int64_t>(std::max<int64_t>(kvp_env_int("KVP_TC_TIMEOUT_US", 1000000), 100), 20000000) * 100u;
+    b.test_delay_slot = kvp_env_int("KVP_TC_TEST_DELAY_SLOT", -1);
+    b.interleave = kvp_env_int("KVP_TC_INTERLEAVE", 0) ? 1u : 0u;
     for (b.row_base = 0; b.row_base < b.R; b.row_base += TC_CLUSTERS)
         KVP_LAUNCH("topk_cluster_kernel", stream, (topk_cluster_kernel<PER, MODE, HIST1><<<TC_CLUSTERS * TC_SLOTS, TR_THREADS, 0, stream>>>(b)));
     return 0;

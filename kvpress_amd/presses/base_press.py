@@ -21,6 +21,7 @@ from typing import Generator
 import torch
 from torch import nn
 
+from kvpress_amd import _native
 from kvpress_amd.utils import _is_quantized, extract_keys_and_values
 
 logger = logging.getLogger(__name__)
@@ -133,3 +134,6 @@ class BasePress:
         finally:
             for hook in hooks:
                 hook.remove()
+        # a select kernel that found at RUN time that it could not produce valid indices (include/kvpress_hip.h, KVP_EASYNC) must
+        # not pass silently: poll the library's status word on the way out (no sync; reached only when the body did not raise)
+        _native.async_error_check()

@@ -1,0 +1,165 @@
+"""The one-launch select of long rows must never return wrong indices silently.
+
+`torch.topk` (kvpress/presses/scorer_press.py:95) either returns the right indices or raises.  The cluster select
+(kvpress_amd/csrc/topk_cluster.hip) synchronises the 32 workgroups of a row inside the kernel; these tests pin what happens
+when they are NOT all resident at once:
+  * CUs held by another stream for a while -> the select waits, the indices are right;
+  * a reduced CU set (HSA_CU_MASK, own process) -> right indices or a raised KvpressHipError, never garbage;
+  * a barrier that really times out (test knobs: one workgroup arrives late) -> indices -1, gathered rows NaN, the NEXT library
+    call raises KVP_EASYNC, the workspace cache is dropped, and the call after that is correct again.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kvpress_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def native():
+    from kvpress_amd import _native
+
+    return _native
+
+
+def _scores(R=8, S=131008, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(R, S, generator=g, dtype=torch.float32)
+
+
+def test_select_waits_for_cus_held_by_another_stream():
+    """200 x 1024-thread workgroups with 150 KiB of LDS each (no select workgroup fits beside one) hold 200 of the 256 CUs for
+    30 ms on a second stream while the cluster select is enqueued on the first: only 56 of its 256 workgroups are resident at
+    first, the rest as CUs free up; the result must be the oracle's (and the same when all 256 CUs are held)."""
+    n = native()
+    sc = _scores()
+    want = O.topk_select(sc.numpy(), 65472)
+    d = sc.to(DEV)
+    side = torch.cuda.Stream(device=DEV)
+    torch.cuda.synchronize()
+    for rep in range(4):
+        n.occupy_cus(200 if rep < 2 else 256, 1024, 150 * 1024, 30000, stream=side)
+        got = n.topk_select(d, 65472)
+        torch.cuda.synchronize()
+        n.async_error_check()
+        assert np.array_equal(got.cpu().numpy(), want), f"rep {rep}"
+
+
+_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from kvpress_amd import _native as n
+from oracle import kvpress_oracle as O
+g = torch.Generator().manual_seed(0)
+sc = torch.randn(8, 131008, generator=g, dtype=torch.float32)
+want = O.topk_select(sc.numpy(), 65472)
+d = sc.to("cuda:0")
+try:
+    for _ in range(3):
+        got = n.topk_select(d, 65472)
+        torch.cuda.synchronize()
+        n.async_error_check()
+        assert np.array_equal(got.cpu().numpy(), want), "WRONG INDICES"
+    print("CHILD_OK correct")
+except n.KvpressHipError as e:
+    print("CHILD_OK raised", str(e)[:80])
+"""
+
+
+@pytest.mark.parametrize("mask", ["0:0-127", "0:0-63"])
+def test_select_under_a_cu_mask_is_right_or_raises(mask):
+    """Half / a quarter of the CUs (HSA_CU_MASK) in a process of its own: with a row's workgroups on consecutive blocks whole
+    clusters still become resident -> correct indices (or, if the runtime reports the reduced CU count, the (chunk, row) passes);
+    a raised KvpressHipError is acceptable, wrong indices are not.  A runtime that rejects the mask syntax skips the test."""
+    env = dict(os.environ, HSA_CU_MASK=mask, PYTHONDONTWRITEBYTECODE="1", KVP_TC_TIMEOUT_US="300000")
+    r = subprocess.run([sys.executable, "-c", _CHILD.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert "WRONG INDICES" not in out, out[-2000:]
+    if "CHILD_OK" not in out:
+        pytest.skip(f"child did not run under HSA_CU_MASK={mask}: {out[-300:]}")
+
+
+def test_barrier_timeout_is_loud(knobs):
+    """One workgroup of cluster 0 arrives 2 x timeout late at its first barrier (test knob): the others give up.  Row 0's indices
+    are -1 (other rows: untouched clusters, correct), the gather turns them into NaN rows, the next library call raises, the
+    cached clean workspaces are gone, and then everything works again."""
+    n = native()
+    sc = _scores(seed=1)
+    want = O.topk_select(sc.numpy(), 65472)
+    d = sc.to(DEV)
+    k = torch.randn(1, 8, 131008, 128, device=DEV, dtype=torch.bfloat16)
+    v = torch.randn(1, 8, 131008, 128, device=DEV, dtype=torch.bfloat16)
+    assert np.array_equal(n.topk_select(d, 65472).cpu().numpy(), want)   # sanity, default knobs
+    n.gather_kv(k, v, torch.from_numpy(want).to(DEV).view(1, 8, -1))       # (the allocator now holds the output blocks)
+    torch.cuda.synchronize()
+    n.async_error_check()
+
+    knobs(KVP_TC_TIMEOUT_US=20000, KVP_TC_TEST_DELAY_SLOT=5)
+    got = n.topk_select(d, 65472)            # returns KVP_OK: the failure happens on the device, later
+    ko, vo = n.gather_kv(k, v, got.view(1, 8, -1))
+    torch.cuda.synchronize()
+    g = got.cpu().numpy()
+    assert (g[0] == -1).all(), "row of the cluster that timed out must be poisoned"
+    assert np.array_equal(g[1:], want[1:]), "clusters that did not time out are unaffected"
+    assert torch.isnan(ko[0, 0].float()).all() and torch.isnan(vo[0, 0].float()).all(), "poisoned indices must gather NaN rows"
+    assert torch.equal(ko[0, 1], k[0, 1][torch.from_numpy(want[1]).long().to(DEV)])
+    knobs(KVP_TC_TIMEOUT_US=None, KVP_TC_TEST_DELAY_SLOT=None)
+    with pytest.raises(n.KvpressHipError, match="cluster select"):
+        n.topk_select(d, 65472)
+    assert not n._TOPK_WS, "a reported failure must drop every cached 'clean' workspace"
+    for _ in range(2):
+        assert np.array_equal(n.topk_select(d, 65472).cpu().numpy(), want)
+    torch.cuda.synchronize()
+    n.async_error_check()
+
+
+def test_fused_compress_timeout_is_loud(knobs):
+    """The same through the fused Knorm compress (the cluster kernel computes the norms itself): poisoned rows come out as NaN."""
+    n = native()
+    g = torch.Generator().manual_seed(3)
+    k = torch.randn(1, 8, 32768, 128, generator=g).to(DEV, torch.bfloat16)
+    v = torch.randn(1, 8, 32768, 128, generator=g).to(DEV, torch.bfloat16)
+    ko_ref, vo_ref = n.knorm_compress(k, v, 16384)
+    torch.cuda.synchronize()
+    knobs(KVP_TC_TIMEOUT_US=20000, KVP_TC_TEST_DELAY_SLOT=0)
+    ko, vo = n.knorm_compress(k, v, 16384)
+    torch.cuda.synchronize()
+    assert torch.isnan(ko[0, 0].float()).all() and torch.isnan(vo[0, 0].float()).all()
+    assert torch.equal(ko[0, 1:], ko_ref[0, 1:]) and torch.equal(vo[0, 1:], vo_ref[0, 1:])
+    knobs(KVP_TC_TIMEOUT_US=None, KVP_TC_TEST_DELAY_SLOT=None)
+    with pytest.raises(n.KvpressHipError, match="cluster select"):
+        n.knorm_compress(k, v, 16384)
+    ko2, vo2 = n.knorm_compress(k, v, 16384)
+    torch.cuda.synchronize()
+    n.async_error_check()
+    assert torch.equal(ko2, ko_ref) and torch.equal(vo2, vo_ref)
+
+
+def test_gather_never_reads_through_a_bad_index():
+    """Indices outside [0, S) -- not only -1 -- give NaN rows in every dtype and path (vector, scalar, with re-rotation)."""
+    n = native()
+    for dt, D in ((torch.bfloat16, 128), (torch.float16, 64), (torch.float32, 6), (torch.bfloat16, 6)):
+        k = torch.randn(1, 2, 50, D, device=DEV).to(dt)
+        v = torch.randn(1, 2, 50, D, device=DEV).to(dt)
+        idx = torch.tensor([[[0, -1, 7, 50, 49], [3, 4, -7, 2**30, 1]]], dtype=torch.int32, device=DEV)
+        ko, vo = n.gather_kv(k, v, idx)
+        bad = torch.tensor([[[0, 1, 0, 1, 0], [0, 0, 1, 1, 0]]], dtype=torch.bool, device=DEV)
+        for o, src in ((ko, k), (vo, v)):
+            assert torch.isnan(o.float()[bad]).all(), (dt, D)
+            good = ~bad
+            want = torch.gather(src, 2, idx.clamp(0, 49).long()[..., None].expand(-1, -1, -1, D))
+            assert torch.equal(o[good], want[good]), (dt, D)
+    k = torch.randn(1, 2, 50, 128, device=DEV).to(torch.bfloat16)
+    v = torch.randn(1, 2, 50, 128, device=DEV).to(torch.bfloat16)
+    idx = torch.tensor([[[0, -1, 7, 20, 49], [3, 4, 9, -1, 11]]], dtype=torch.int32, device=DEV)
+    inv = (1.0 / (10000 ** (torch.arange(0, 64, dtype=torch.float32) / 64))).to(DEV)
+    ko, vo = n.gather_kv_rerotate(k, v, idx, inv)
+    assert torch.isnan(ko[0, 0, 1].float()).all() and torch.isnan(vo[0, 1, 3].float()).all()
+    assert torch.equal(vo[0, 0, 2], v[0, 0, 7]) and not torch.isnan(ko[0, 0, 2].float()).any()
