@@ -384,7 +384,7 @@ def snapkv_score_rope(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
 # 21.9 us against 16.4 + 6.3, 0.296 vs 0.287 ms per layer; a split-K variant with a second reduction pass measured 18.4 us
 # against 15.4 us for the one-pass kernel) and rounds 0.01 % of the queries differently from the GEMM library, so the presses
 # keep the model's q_proj unless this switch is turned on.
-USE_LIBRARY_QPROJ = False
+USE_LIBRARY_QPROJ = os.environ.get("KVP_LIBRARY_QPROJ", "0") == "1"
 
 
 def qproj_rope_supported(module, hidden_states: torch.Tensor, window: int) -> bool:

@@ -6,18 +6,19 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
 WHAT="${*:-tests bench}"
+R="${ROUND_TAG:-r04}"
 python __graft_entry__.py > gpurun_out/build.log 2>&1; echo "build rc=$?"
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
 if [[ "$WHAT" == *tests* ]]; then
-  timeout 2400 python -m pytest tests -m gpu -q --no-header > gpurun_out/r03_gpu_tests.log 2>&1
-  echo "tests rc=$? $(tail -1 gpurun_out/r03_gpu_tests.log)"
+  timeout 2400 python -m pytest tests -m gpu -q --no-header > gpurun_out/${R}_gpu_tests.log 2>&1
+  echo "tests rc=$? $(tail -1 gpurun_out/${R}_gpu_tests.log)"
   timeout 300 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$? $(tail -1 gpurun_out/smoke.log)"
 fi
 if [[ "$WHAT" == *bench* ]]; then
   for wl in ${BENCH_WL:-knorm32k knorm128k snapkv128k ea128k}; do
-    timeout 900 python bench.py --workload $wl --profile-json gpurun_out/r03_kernels_$wl.json > gpurun_out/bench_$wl.log 2>&1
+    timeout 900 python bench.py --workload $wl --profile-json gpurun_out/${R}_kernels_$wl.json > gpurun_out/bench_$wl.log 2>&1
     echo "bench[$wl] rc=$? $(tail -1 gpurun_out/bench_$wl.log | cut -c1-300)"
-    tail -1 gpurun_out/bench_$wl.log > gpurun_out/r03_bench_$wl.json
+    tail -1 gpurun_out/bench_$wl.log > gpurun_out/${R}_bench_$wl.json
   done
 fi
 if [[ "$WHAT" == *frows* ]]; then
@@ -25,7 +26,7 @@ if [[ "$WHAT" == *frows* ]]; then
   for wl in keydiff128k cur128k finch128k chunk_snapkv128k rerotate128k decode_snapkv2k; do
     timeout 600 python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline --live-pmc off > gpurun_out/bench_$wl.log 2>&1
     echo "bench[$wl] rc=$? $(tail -1 gpurun_out/bench_$wl.log | cut -c1-200)"
-    tail -1 gpurun_out/bench_$wl.log > gpurun_out/r03_bench_$wl.json
+    tail -1 gpurun_out/bench_$wl.log > gpurun_out/${R}_bench_$wl.json
   done
 fi
 if [[ "$WHAT" == *ab* ]]; then
@@ -50,22 +51,22 @@ if [[ "$WHAT" == *pmc* ]]; then
     done
     ( cd "$GRAFT_REPO_ROOT"; echo "# rocprofv3 --kernel-trace --pmc <set> -- python bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline (four separate passes)";
       echo "# csrc_digest $(python -c 'import bench; print(bench.csrc_digest())')";
-      python scripts/rocpd_pmc.py $(find gpurun_out/pmc_${wl}_[0-9] -name '*.db' | sort) ) > "$GRAFT_REPO_ROOT/gpurun_out/r03_pmc_summary_$wl.txt" 2>&1
+      python scripts/rocpd_pmc.py $(find gpurun_out/pmc_${wl}_[0-9] -name '*.db' | sort) ) > "$GRAFT_REPO_ROOT/gpurun_out/${R}_pmc_summary_$wl.txt" 2>&1
     rm -rf "$GRAFT_REPO_ROOT"/gpurun_out/pmc_${wl}_[0-9]
   done
   cd "$GRAFT_REPO_ROOT"
 fi
 if [[ "$WHAT" == *e2e* ]]; then
   # random-init Llama-3.1-8B body, prefill with / without the press (tools/e2e_prefill.py)
-  : > gpurun_out/r03_e2e_prefill.jsonl
-  timeout 900 python tools/e2e_prefill.py --seq-len 131072 --press snapkv --reps 3 2> gpurun_out/e2e.err | tail -1 >> gpurun_out/r03_e2e_prefill.jsonl; echo "e2e[128k snapkv] rc=$?"
-  timeout 600 python tools/e2e_prefill.py --seq-len 32768 --press knorm --reps 5 2>> gpurun_out/e2e.err | tail -1 >> gpurun_out/r03_e2e_prefill.jsonl; echo "e2e[32k knorm] rc=$?"
+  : > gpurun_out/${R}_e2e_prefill.jsonl
+  timeout 900 python tools/e2e_prefill.py --seq-len 131072 --press snapkv --reps 3 2> gpurun_out/e2e.err | tail -1 >> gpurun_out/${R}_e2e_prefill.jsonl; echo "e2e[128k snapkv] rc=$?"
+  timeout 600 python tools/e2e_prefill.py --seq-len 32768 --press knorm --reps 5 2>> gpurun_out/e2e.err | tail -1 >> gpurun_out/${R}_e2e_prefill.jsonl; echo "e2e[32k knorm] rc=$?"
 fi
 if [[ "$WHAT" == *timeline* ]]; then
   cd /tmp
   for wl in ${TL_WL:-snapkv128k knorm32k}; do
     timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/tl_$wl" -o t -- python "$GRAFT_REPO_ROOT/bench.py" --workload $wl --steps 6 --warmup 2 --prewarm-ms 5 --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/tl_$wl.log" 2>&1
-    python "$GRAFT_REPO_ROOT/scripts/timeline.py" "$GRAFT_REPO_ROOT/gpurun_out/tl_$wl" > "$GRAFT_REPO_ROOT/gpurun_out/r03_timeline_$wl.txt" 2>&1
+    python "$GRAFT_REPO_ROOT/scripts/timeline.py" "$GRAFT_REPO_ROOT/gpurun_out/tl_$wl" > "$GRAFT_REPO_ROOT/gpurun_out/${R}_timeline_$wl.txt" 2>&1
     echo "timeline[$wl] rc=$?"
     rm -rf "$GRAFT_REPO_ROOT/gpurun_out/tl_$wl"
   done
@@ -76,8 +77,8 @@ if [[ "$WHAT" == *prof* ]]; then
   for wl in ${PROF_WL:-snapkv128k knorm32k knorm128k ea128k}; do
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -o $wl -- python "$GRAFT_REPO_ROOT/bench.py" --workload $wl --no-cpu-baseline > "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" 2>&1
     echo "prof[$wl] rc=$?"
-    find "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -name "*kernel_stats.csv" -exec cp {} "$GRAFT_REPO_ROOT/gpurun_out/r03_rocprofv3_kernel_stats_$wl.csv" \;
-    grep "^{" "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" | tail -1 > "$GRAFT_REPO_ROOT/gpurun_out/r03_bench_under_rocprof_$wl.json"
+    find "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl" -name "*kernel_stats.csv" -exec cp {} "$GRAFT_REPO_ROOT/gpurun_out/${R}_rocprofv3_kernel_stats_$wl.csv" \;
+    grep "^{" "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl.log" | tail -1 > "$GRAFT_REPO_ROOT/gpurun_out/${R}_bench_under_rocprof_$wl.json"
     rm -rf "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl"
   done
   cd "$GRAFT_REPO_ROOT"

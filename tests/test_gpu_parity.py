@@ -984,6 +984,32 @@ def test_qproj_rope_kernel_vs_torch(name, dtname):
     assert ((g.double() - want64).abs() <= 4.0 * ulp * want64.abs().amax(dim=-1, keepdim=True) + 1e-6).all()
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("K,Hq,dtname", [(4096, 32, "bf16"), (8192, 4, "bf16"), (4096, 4, "f16"), (1280, 2, "bf16")])
+def test_qproj_rope_kernel_llama_sizes(K, Hq, dtname, variant, knobs):
+    """Both kernels of qproj.hip at the hidden sizes of Llama-3.1-8B (4096: one group of 16 K tiles) and 70B (8192: two groups) and
+    at an odd tile count, batch 2, a strided hidden window, against the float64 product rounded once (<= 1 ulp of the projected
+    value's magnitude through the RoPE pair) -- and against each other: same k-step partials, same fixed summation order."""
+    knobs(KVP_QP_VARIANT=variant)
+    N = native()
+    dt = _inputs.torch_dtype(dtname)
+    g = torch.Generator().manual_seed(K + Hq)
+    hidden = torch.randn(2, 96, K, generator=g).to(DEV, dt)
+    wq = (torch.randn(Hq * 128, K, generator=g) * 0.02).to(DEV, dt)
+    ang = torch.rand(2, 64, 64, generator=g) * 6.28
+    cos, sin = torch.cat([ang.cos()] * 2, -1).to(DEV, dt), torch.cat([ang.sin()] * 2, -1).to(DEV, dt)
+    hw = hidden[:, -64:]
+    got = N.snapkv_qproj_rope(hw, wq, cos, sin)
+    q64 = (hw.double() @ wq.double().T).view(2, 64, Hq, 128).transpose(1, 2)
+    c, si = cos.double().unsqueeze(1), sin.double().unsqueeze(1)
+    want64 = q64 * c + torch.cat((-q64[..., 64:], q64[..., :64]), dim=-1) * si
+    ulp = 2.0 ** (-7 if dtname == "bf16" else -10)
+    assert got.shape == (2, Hq, 64, 128) and got.dtype == dt
+    assert ((got.double() - want64).abs() <= 4.0 * ulp * want64.abs().amax(dim=-1, keepdim=True) + 1e-6).all()
+    knobs(KVP_QP_VARIANT=3 - variant)
+    assert torch.equal(N.snapkv_qproj_rope(hw, wq, cos, sin), got)
+
+
 @pytest.mark.parametrize("name", ["sk_h512_bf16", "sk_h1024_f16"])
 def test_hidden_path_scores_and_compress(name):
     """score / compress from the hidden states == the same from the library's own q_rot through the rotated-query entry."""
