@@ -106,9 +106,15 @@ template <> __device__ __forceinline__ float round_dt<KVP_F16>(float x) {
 template <> __device__ __forceinline__ float round_dt<KVP_BF16>(float x) {  // round-to-nearest-even to bf16
     // the hardware conversion (gfx950): one instruction + a shift instead of the 7-instruction integer emulation with its
     // inf / nan branch -- the RoPE / re-rotation kernels round six times per output pair and were bound by exactly that
+#if defined(__gfx950__)
     uint32_t r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(x));
     return __uint_as_float(r << 16);
+#else   // any other target of a stray --offload-arch: the integer round-to-nearest-even (NaN stays a quiet NaN)
+    const uint32_t u = __float_as_uint(x);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return __uint_as_float((u | 0x00400000u) & 0xFFFF0000u);
+    return __uint_as_float((u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u);
+#endif
 }
 // one RoPE output element with torch's rounding: round(round(a * ca) + round(b * sb)); __fmul_rn / __fadd_rn keep the
 // ops separately rounded as in torch's eager mul, mul, add (never contracted to an fma)

@@ -180,7 +180,7 @@ constexpr int Q2_REQ = Q2_HTILEB / 1024 / Q2_LWAVES;   // 1 KiB LDS-DMA requests
 constexpr int Q2_GROUP = 16;                      // tiles whose B fragments a compute wave holds at once
 static_assert(Q2_HTILEB % (1024 * Q2_LWAVES) == 0, "whole requests");
 
-template <int DT>
+template <int DT, bool VSTAGE>
 __global__ __launch_bounds__(Q2_THREADS) void qproj_rope2_kernel(QprojArgs a) {
     using T = typename Elem<DT>::T;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];   // Q2_NBUF * Q2_HTILEB
@@ -191,8 +191,55 @@ __global__ __launch_bounds__(Q2_THREADS) void qproj_rope2_kernel(QprojArgs a) {
     const uint32_t l16 = lane & 15, kq = lane >> 4;
     const uint32_t ntiles = a.K / QP_KT;
 
-    if (wv >= Q2_CWAVES) {
-        // ---------------- loaders: tile t = rows 0..63 x 512 B; request r moves rows 2r, 2r+1 (32 slots of 16 B each) -------------
+    if (VSTAGE && wv >= Q2_CWAVES) {
+        // ---------------- loaders, variant 3: the hidden window through REGISTERS (global_load_dwordx4 -> ds_write_b128) --------------
+        // (variant 2's LDS-DMA ring moved the L2-resident window at ~25 GB/s per CU: 21.6 us for the kernel.)  A loader wave owns 4 of a
+        // tile's 32 row pairs: one 16-byte chunk per lane and row pair, coalesced 512-byte rows; three tiles in flight in registers;
+        // the XOR swizzle is applied on the LDS side (8 consecutive lanes of a ds_write_b128 group still cover 32 distinct banks).
+        const uint32_t lw = wv - Q2_CWAVES;
+        const char* gsrc[Q2_REQ];
+        uint32_t ldst[Q2_REQ];
+#pragma unroll
+        for (int i = 0; i < Q2_REQ; ++i) {
+            const uint32_t r = lw * Q2_REQ + i, row = 2 * r + (lane >> 5), slot = lane & 31;
+            gsrc[i] = a.x + (int64_t)b * a.x_sb + (int64_t)row * a.x_sw + (slot << 4);
+            ldst[i] = row * QP_ROWB + ((slot ^ (row & 15)) << 4);
+        }
+        // Three tiles in flight in three NAMED register sets, the 16 tiles of a group written out one by one (as on the compute
+        // side): a set indexed by a loop variable -- rs[t % 3] -- stays a scratch-memory array (hipcc promotes arrays before it
+        // unrolls), and any loop-carried form rotates the sets with copies; both wait for every load right after issuing it.
+        for (uint32_t g0 = 0; g0 < ntiles; g0 += Q2_GROUP) {
+            static_assert(Q2_REQ == 4, "the register sets below are written out for four requests per tile");
+            uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rc0, rc1, rc2, rc3;   // (scalars: small arrays assigned under a branch stayed in scratch)
+#define Q3_FETCH(R, T)                                                                                               \
+    {                                                                                                                \
+        const int64_t off__ = (int64_t)min(g0 + (T), ntiles - 1) * QP_ROWB; /* past the end: never stored */         \
+        R##0 = *reinterpret_cast<const uint4*>(gsrc[0] + off__);                                                     \
+        R##1 = *reinterpret_cast<const uint4*>(gsrc[1] + off__);                                                     \
+        R##2 = *reinterpret_cast<const uint4*>(gsrc[2] + off__);                                                     \
+        R##3 = *reinterpret_cast<const uint4*>(gsrc[3] + off__);                                                     \
+    }
+#define Q3_TILE(R, T) /* tile g0 + T: registers -> LDS, publish (barrier A), refill the set with tile g0 + T + 3 */    \
+    if (g0 + (T) < ntiles) { /* (uniform) */                                                                         \
+        unsigned char* buf__ = lds2 + ((g0 + (T)) % Q2_NBUF) * Q2_HTILEB;                                            \
+        *reinterpret_cast<uint4*>(buf__ + ldst[0]) = R##0;                                                           \
+        *reinterpret_cast<uint4*>(buf__ + ldst[1]) = R##1;                                                           \
+        *reinterpret_cast<uint4*>(buf__ + ldst[2]) = R##2;                                                           \
+        *reinterpret_cast<uint4*>(buf__ + ldst[3]) = R##3;                                                           \
+        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): the tile is in LDS */                                     \
+        __builtin_amdgcn_s_barrier();                                                                                \
+        if ((T) + 3 < Q2_GROUP) Q3_FETCH(R, (T) + 3)                                                                 \
+    }
+            Q3_FETCH(ra, 0) Q3_FETCH(rb, 1) Q3_FETCH(rc, 2)
+            Q3_TILE(ra, 0) Q3_TILE(rb, 1) Q3_TILE(rc, 2) Q3_TILE(ra, 3) Q3_TILE(rb, 4) Q3_TILE(rc, 5) Q3_TILE(ra, 6) Q3_TILE(rb, 7)
+            Q3_TILE(rc, 8) Q3_TILE(ra, 9) Q3_TILE(rb, 10) Q3_TILE(rc, 11) Q3_TILE(ra, 12) Q3_TILE(rb, 13) Q3_TILE(rc, 14) Q3_TILE(ra, 15)
+#undef Q3_TILE
+#undef Q3_FETCH
+        }
+        __builtin_amdgcn_s_barrier();         // E1
+        __builtin_amdgcn_s_barrier();         // E2
+    } else if (wv >= Q2_CWAVES) {
+        // ---------------- loaders, variant 2: tile t = rows 0..63 x 512 B by LDS-DMA; request r moves rows 2r, 2r+1 -------------------
         const uint32_t lw = wv - Q2_CWAVES;
         const char* gsrc[Q2_REQ];
 #pragma unroll
@@ -306,18 +353,24 @@ int kvp_qproj_rope_launch(const void* x, int64_t x_sb, int64_t x_sw, const void*
         return KVP_OK;
     }
     constexpr size_t lds_bytes = (size_t)Q2_NBUF * Q2_HTILEB;   // 128 KiB: above the 64 KiB a kernel gets without asking
-    static bool raised[2] = {false, false};
-    const int vi = dtype == KVP_BF16 ? 0 : 1;
+    const bool vstage = kvp_env_int("KVP_QP_VARIANT", 2) == 3;
+    static bool raised[4] = {false, false, false, false};
+    const int vi = (dtype == KVP_BF16 ? 0 : 1) + (vstage ? 2 : 0);
+    const void* fns[4] = {reinterpret_cast<const void*>(qproj_rope2_kernel<KVP_BF16, false>), reinterpret_cast<const void*>(qproj_rope2_kernel<KVP_F16, false>),
+                          reinterpret_cast<const void*>(qproj_rope2_kernel<KVP_BF16, true>), reinterpret_cast<const void*>(qproj_rope2_kernel<KVP_F16, true>)};
     if (!raised[vi]) {
-        const void* fn = dtype == KVP_BF16 ? reinterpret_cast<const void*>(qproj_rope2_kernel<KVP_BF16>) : reinterpret_cast<const void*>(qproj_rope2_kernel<KVP_F16>);
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+        if (hipFuncSetAttribute(fns[vi], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
             kvp_set_error("qproj_rope: cannot raise the dynamic LDS limit to %zu", lds_bytes);
             return KVP_EHIP;
         }
         raised[vi] = true;
     }
-    if (dtype == KVP_BF16) KVP_LAUNCH("qproj_rope2_kernel", stream, qproj_rope2_kernel<KVP_BF16><<<grid, Q2_THREADS, lds_bytes, stream>>>(a));
-    else KVP_LAUNCH("qproj_rope2_kernel", stream, qproj_rope2_kernel<KVP_F16><<<grid, Q2_THREADS, lds_bytes, stream>>>(a));
+    switch (vi) {
+        case 0: KVP_LAUNCH("qproj_rope2_kernel", stream, (qproj_rope2_kernel<KVP_BF16, false><<<grid, Q2_THREADS, lds_bytes, stream>>>(a))); break;
+        case 1: KVP_LAUNCH("qproj_rope2_kernel", stream, (qproj_rope2_kernel<KVP_F16, false><<<grid, Q2_THREADS, lds_bytes, stream>>>(a))); break;
+        case 2: KVP_LAUNCH("qproj_rope3_kernel", stream, (qproj_rope2_kernel<KVP_BF16, true><<<grid, Q2_THREADS, lds_bytes, stream>>>(a))); break;
+        default: KVP_LAUNCH("qproj_rope3_kernel", stream, (qproj_rope2_kernel<KVP_F16, true><<<grid, Q2_THREADS, lds_bytes, stream>>>(a))); break;
+    }
     KVP_CHECK_LAUNCH("qproj_rope2");
     return KVP_OK;
 }

@@ -522,8 +522,8 @@ __global__ void topk_iota_kernel(int32_t* __restrict__ idx, int64_t idx_stride, 
 
 // ordering step (topk_order.hip)
 size_t topk_order_workspace_bytes(int64_t R, int64_t k);
-int topk_order_by_score(const float* scores, int64_t R, int64_t row_stride, int64_t k, int32_t* idx, bool smallest, void* ws, size_t ws_bytes,
-                        hipStream_t stream);
+int topk_order_by_score(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, bool smallest, void* ws,
+                        size_t ws_bytes, hipStream_t stream);
 
 extern "C" size_t kvp_topk_order_workspace_bytes(int64_t R, int64_t S, int64_t k) {
     return kvp_topk_workspace_bytes(R, S, k) + topk_order_workspace_bytes(R, k);
@@ -666,7 +666,7 @@ extern "C" int kvp_topk_select(const float* scores, int64_t R, int64_t S, int64_
         return rc;
     if (ord == KVP_ORDER_SCORE) {  // descending score (ascending for KVP_TOPK_SMALLEST), ties by position: sort the selection
         KVP_CHECK_ARG(ws && ws_bytes >= sel_bytes, "topk: workspace too small for KVP_ORDER_SCORE");
-        return topk_order_by_score(scores, R, row_stride, k, idx, smallest, static_cast<char*>(ws) + sel_bytes, ws_bytes - sel_bytes, stream);
+        return topk_order_by_score(scores, R, S, row_stride, k, idx, smallest, static_cast<char*>(ws) + sel_bytes, ws_bytes - sel_bytes, stream);
     }
     return KVP_OK;
 }

@@ -26,11 +26,28 @@ def _masks_keys(press) -> bool:
     return isinstance(press, (AdaKVPress, CriticalAdaKVPress, DMSPress, DuoAttentionPress)) or any(_masks_keys(p) for p in _inner_presses(press))
 
 
+def _masking_only_types():
+    from kvpress_amd.presses.criticalkv_press import CriticalAdaKVPress
+    from kvpress_amd.presses.dms_press import DMSPress
+    from kvpress_amd.presses.duo_attention_press import DuoAttentionPress
+
+    return (CriticalAdaKVPress, DMSPress, DuoAttentionPress)
+
+
 def _prunes_positions(press) -> bool:
-    """press removes or reorders cache positions (everything but the channel-pruning ThinKPress and other masking presses)"""
+    """press removes or reorders cache positions.  Classified by the OUTERMOST type: the channel-pruning ThinKPress and the
+    masking-only presses (CriticalAdaKVPress, DMSPress, DuoAttentionPress -- whatever scorer they wrap, they only record
+    module.masked_key_indices) leave the positions alone."""
     from kvpress_amd.presses.think_press import ThinKPress
 
-    return not isinstance(press, ThinKPress) and not (_masks_keys(press) and not _inner_presses(press))
+    return not isinstance(press, (ThinKPress,) + _masking_only_types())
+
+
+def _overwrites_mask(press) -> bool:
+    """press ASSIGNS module.masked_key_indices (an earlier press's mask is lost); DMSPress merges into the existing indices."""
+    from kvpress_amd.presses.dms_press import DMSPress
+
+    return isinstance(press, _masking_only_types()) and not isinstance(press, DMSPress)
 
 
 @dataclass
@@ -61,6 +78,11 @@ class ComposedPress(BasePress):
 
                 warnings.warn(f"ComposedPress: {type(press).__name__} masks keys through module.masked_key_indices, but a later press "
                               f"prunes positions: the masked indices will no longer refer to the same tokens", stacklevel=2)
+            if _masks_keys(press) and any(_overwrites_mask(later) for later in self.presses[i + 1:]):
+                import warnings
+
+                warnings.warn(f"ComposedPress: {type(press).__name__} records module.masked_key_indices, but a later masking press assigns "
+                              f"them anew: the earlier mask is discarded", stacklevel=2)
 
     def post_init_from_model(self, model):
         for press in self.presses:

@@ -59,7 +59,13 @@ class ExpectedAttentionPress(ScorerPress):
         It depends on the rotary embedding (shared by all layers), q_len and n_future_positions only, so the 32 layers of a
         forward pass share ONE computation (the reference rebuilds it per layer: ~10 small launches each): cached per press
         instance, a handful of 64 KiB matrices at most."""
-        key = (id(module.rotary_emb), int(q_len), int(self.n_future_positions), int(module.head_dim), str(device), dtype)
+        rot = module.rotary_emb
+        inv = getattr(rot, "inv_freq", None)
+        # the table depends on the module's CURRENT frequencies: dynamic / NTK rope re-derives inv_freq in place, users edit the
+        # scaling -- so the buffer's identity, its in-place version counter and the attention scaling are part of the key
+        key = (id(rot), int(q_len), int(self.n_future_positions), int(module.head_dim), str(device), dtype,
+               inv.data_ptr() if inv is not None else 0, inv._version if inv is not None else 0, float(getattr(rot, "attention_scaling", 1.0)),
+               str(getattr(rot, "rope_type", "default")))
         cache = self.__dict__.setdefault("_rope_cache", {})
         hit = cache.get(key)
         R = hit[1] if hit is not None and hit[0]() is module.rotary_emb else None   # (the id of a dead module may be reused)
@@ -79,6 +85,11 @@ class ExpectedAttentionPress(ScorerPress):
                 cache.clear()
             cache[key] = (weakref.ref(module.rotary_emb), R)
         return R
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_rope_cache", None)   # weak references to the rotary module: a used press must stay picklable
+        return state
 
     def apply_avg_rope(self, module: nn.Module, mu: torch.Tensor, cov: torch.Tensor, q_len: int):
         """mu <- mu R^T, cov <- R cov R^T with R the RoPE matrix averaged over positions

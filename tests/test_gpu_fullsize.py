@@ -466,3 +466,28 @@ def test_bench_two_ranks_real_kernels_on_one_gpu():
     assert 0.02 < line["ms_per_step"] < 5.0, line["ms_per_step"]
     assert abs(line["value"] - 2 * 32768 / (32 * line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
     assert line["roofline"] is not None and line["roofline"]["path_frac"] > 0
+
+
+def test_bench_two_ranks_rccl():
+    """The RCCL leg itself: `python bench.py --gpus 2 --backend nccl` -- one process per GPU, init_process_group("nccl",
+    device_id=...), barriers and the MAX all-reduce over RCCL.  Needs two GPUs: skipped on the one-GPU boxes, executed by the first
+    multi-GPU box that runs this suite."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KVP_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "nccl", "--workload", "knorm32k", "--steps", "3",
+                        "--warmup", "1", "--prewarm-ms", "5", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["config"]["batch_per_gpu"] == 1
+    assert abs(line["value"] - 2 * 32768 / (32 * line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3

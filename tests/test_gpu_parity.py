@@ -984,8 +984,8 @@ def test_qproj_rope_kernel_vs_torch(name, dtname):
     assert ((g.double() - want64).abs() <= 4.0 * ulp * want64.abs().amax(dim=-1, keepdim=True) + 1e-6).all()
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-@pytest.mark.parametrize("K,Hq,dtname", [(4096, 32, "bf16"), (8192, 4, "bf16"), (4096, 4, "f16"), (1280, 2, "bf16")])
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("K,Hq,dtname", [(4096, 32, "bf16"), (8192, 4, "bf16"), (4096, 4, "f16"), (1280, 2, "bf16"), (256, 2, "bf16")])
 def test_qproj_rope_kernel_llama_sizes(K, Hq, dtname, variant, knobs):
     """Both kernels of qproj.hip at the hidden sizes of Llama-3.1-8B (4096: one group of 16 K tiles) and 70B (8192: two groups) and
     at an odd tile count, batch 2, a strided hidden window, against the float64 product rounded once (<= 1 ulp of the projected
@@ -1006,7 +1006,7 @@ def test_qproj_rope_kernel_llama_sizes(K, Hq, dtname, variant, knobs):
     ulp = 2.0 ** (-7 if dtname == "bf16" else -10)
     assert got.shape == (2, Hq, 64, 128) and got.dtype == dt
     assert ((got.double() - want64).abs() <= 4.0 * ulp * want64.abs().amax(dim=-1, keepdim=True) + 1e-6).all()
-    knobs(KVP_QP_VARIANT=3 - variant)
+    knobs(KVP_QP_VARIANT=1 if variant != 1 else 2)
     assert torch.equal(N.snapkv_qproj_rope(hw, wq, cos, sin), got)
 
 

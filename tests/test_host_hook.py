@@ -186,6 +186,46 @@ def test_composed_press_masking_presses():
         P.ComposedPress([dms(), P.KnormPress(0.2)])
     with pytest.warns(UserWarning, match="masked_key_indices"):
         P.ComposedPress([P.ComposedPress([dms()]), P.KnormPress(0.2)])   # nested inside a wrapper
+    # a masking-only press that WRAPS a scorer does not prune positions (no false warning when it comes later) ...
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        P.ComposedPress([P.DuoAttentionPress(head_compression_ratio=0.5), dms()])   # DMS merges into the existing indices
+    # ... and a later masking press that ASSIGNS the indices discards the earlier mask: its own warning
+    with pytest.warns(UserWarning, match="earlier mask is discarded"):
+        P.ComposedPress([dms(), P.DuoAttentionPress(head_compression_ratio=0.5)])
+
+
+def test_expected_attention_rope_cache_key_and_pickle():
+    """the averaged-RoPE matrix is cached per press; the key must follow the rotary module's CURRENT frequencies (an
+    in-place change of inv_freq or of attention_scaling is a different table) and a used press must stay picklable."""
+    import pickle
+
+    import kvpress_amd as P
+
+    class Rot(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.register_buffer("inv_freq", 1.0 / (10000 ** (torch.arange(0, 4, dtype=torch.float32) / 4)))
+            self.attention_scaling = 1.0
+
+        def forward(self, x, position_ids):
+            f = position_ids[:, :, None].float() * self.inv_freq[None, None, :]
+            emb = torch.cat((f, f), dim=-1)
+            return emb.cos() * self.attention_scaling, emb.sin() * self.attention_scaling
+
+    module = type("M", (), {})()
+    module.rotary_emb, module.head_dim = Rot(), 8
+    press = P.ExpectedAttentionPress(0.5)
+    R0 = press._avg_rope_matrix(module, 100, torch.device("cpu"), torch.float32)
+    assert press._avg_rope_matrix(module, 100, torch.device("cpu"), torch.float32) is R0   # cached
+    module.rotary_emb.inv_freq.mul_(0.5)                                                  # dynamic rope re-derives inv_freq in place
+    R1 = press._avg_rope_matrix(module, 100, torch.device("cpu"), torch.float32)
+    assert R1 is not R0 and not torch.equal(R1, R0)
+    module.rotary_emb.attention_scaling = 0.8
+    R2 = press._avg_rope_matrix(module, 100, torch.device("cpu"), torch.float32)
+    assert torch.allclose(R2, 0.8 * R1)
+    clone = pickle.loads(pickle.dumps(press))
+    assert clone == press and "_rope_cache" not in clone.__dict__
 
 
 def test_kept_order_switch(fake_native):

@@ -21,6 +21,9 @@ ORDER_CASES = ["kn_readme", "kn_tiny_d6", "kn_d96_bf16", "sk_257_A", "sk_257_B",
 # relative score margin below which the order of two neighbours is not considered defined (>= 4 x the measured kernel-vs-reference
 # float32 score error of DESIGN.md §2: Knorm / SnapKV ~4e-7, ExpectedAttention < 1e-4)
 MARGIN = {"knorm": 2e-6, "snapkv": 4e-6, "ea": 4e-4}
+# ... when the press runs on a bf16 / f16 MODULE (as users run it) the window / all-token queries themselves differ from the
+# float32 run's by the model's own rounding of q, cos and sin (3e-4 flat data, 4.5e-3 structured keys; bound 6e-3)
+MARGIN_NATIVE = {"knorm": 2e-6, "snapkv": 1.2e-2, "ea": 1.2e-2}
 WHOLE_TENSOR = {("kn_readme", 0), ("kn_readme", 1), ("kn_tiny_d6", 1), ("kn_tiny_d6", 2)}   # every gap of these exceeds the margin
 
 
@@ -53,7 +56,7 @@ def check_case(name, device, native, force_f32=False):
     keys = torch.from_numpy(s["keys"]).to(device=device, dtype=dt)
     values = torch.from_numpy(s["values"]).to(device=device, dtype=dt)
     kwargs = {"position_embeddings": pe}
-    margin = MARGIN[s["kind"]]
+    margin = (MARGIN if dt == torch.float32 else MARGIN_NATIVE)[s["kind"]]
     stats = []
     for i, r in enumerate(fx["ratios"]):
         press = _press(P, s, float(r))
@@ -90,7 +93,7 @@ def check_case(name, device, native, force_f32=False):
                             exact_rows += 1
                     start = j + 1
                 total_rows += n
-        if (name, i) in WHOLE_TENSOR:
+        if (name, i) in WHOLE_TENSOR and (dt == torch.float32 or s["kind"] == "knorm"):
             assert torch.equal(ko_c, ko_ref) and torch.equal(vo_c, vo_ref), f"{name} ratio {r}: whole-tensor equality with the reference"
             assert exact_rows == total_rows
         stats.append((float(r), exact_rows, total_rows))
@@ -98,12 +101,15 @@ def check_case(name, device, native, force_f32=False):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["float32", "native"])
 @pytest.mark.parametrize("name", ORDER_CASES)
-def test_kept_order_score_equals_reference_tensors_gpu(name):
+def test_kept_order_score_equals_reference_tensors_gpu(name, mode):
+    """mode float32: module and tensors in float32, like the reference run that made the fixture (the tight margins);
+    native: the case's own bf16 / f16 module and tensors (the kernels of the fast paths; the queries differ by the model's rounding)."""
     from kvpress_amd import _native
 
-    stats = check_case(name, "cuda:0", _native)
-    print(name, [(r, f"{a}/{t} rows pinned bit for bit") for r, a, t in stats])
+    stats = check_case(name, "cuda:0", _native, force_f32=(mode == "float32"))
+    print(name, mode, [(r, f"{a}/{t} rows pinned bit for bit") for r, a, t in stats])
     assert any(a > 0 for _, a, _ in stats), stats
 
 
