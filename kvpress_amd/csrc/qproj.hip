@@ -11,13 +11,20 @@
 // (deterministic), rounded to the model dtype like a GEMM output, rotated with torch's per-op rounding (rope_elem) and
 // written as [B, H_q, W, D].
 //
-// Measured (Llama-3.1-8B window, MI355X): 20 us -- on par with the library GEMM + RoPE launch it replaces (17.6 + 5 us), not
-// faster: every workgroup has to pull the whole hidden window (512 KiB) through L2 next to its weight slice, 160 MiB in
-// total, and a CU takes in ~30 GB/s that way.  Variants tried: fragments straight from global memory (16-byte pieces of 16
-// rows per instruction: address-path bound, 27 us); 64-column tiles on 64 workgroups (64 MiB of traffic but 1 MiB per CU:
-// 28 us); a fourth buffer (no change).  A split-K layout (192 KiB per CU) with a deterministic second reduction pass is
-// the remaining option.  The press therefore keeps the model's own q_proj by default (bit-identical queries to the
-// reference's on the same GPU) and these entry points serve callers that have no GEMM library at hand.
+// Measured (Llama-3.1-8B window, MI355X).  Round 1, in isolation: 20 us, on par with the library GEMM + RoPE launch it replaces
+// (17.6 + 5 us).  Round 4, inside bench.py's loop (two boxes, alternating runs, profiles/r04_qproj_lab.txt): the step is 3-4 us
+// SHORTER with this kernel (271.3 / 271.6 / 268.7 us against 274.5 / 275.9 / 273.0 / 272.0 with hipBLASLt 15.1 + RoPE 4.8), so the
+// presses now project the window here by default (kvpress_amd/_native.py USE_LIBRARY_QPROJ).
+// What bounds it is the traffic between the L2s and the CUs, not HBM and not the matrix pipe: every workgroup pulls the whole hidden
+// window (512 KiB) next to its 128 KiB weight slice, 160 MiB in total, and that path delivers ~10 TB/s chip-wide when all CUs read
+// the same lines -- the library GEMM's 16 x 64 tiles move the same 160 MiB and take the same ~15 us.  Round 4 tried to hide it and
+// could not (same file history, tools/lab_patches/qproj_v2_v3.diff): the weight slice in registers with ALL of it in flight from the first
+// microsecond + the hidden window through a 4-deep LDS-DMA ring fed by 8 loader waves: 21.6 us (18.4 for this kernel, same run); the
+// same with the window staged through registers (global_load_dwordx4 -> ds_write_b128, 12 loads per lane in flight): 26 us.  Deeper
+// prefetch does not help a stream that is bandwidth-bound where it enters the CU.  Earlier variants: fragments straight from
+// global memory (16-byte pieces of 16 rows per instruction: address-path bound, 27 us); 64-column tiles on 64 workgroups (64 MiB of
+// traffic but 1 MiB per CU: 28 us); a fourth buffer (no change); split-K with a second reduction pass (18.4 against 15.4 us in
+// isolation).  Fewer bytes per CU need 32 x 32 output tiles (128 MiB) or an in-launch split-K seam (5-13 us per seam): not pursued.
 #include "kvp_common.h"
 
 namespace {
@@ -156,176 +163,6 @@ __global__ __launch_bounds__(QP_THREADS) void qproj_rope_kernel(QprojArgs a) {
 }
 
 
-// ---- version 2 (round 4): the weight slice in REGISTERS, the hidden window through an LDS ring fed by its own waves ------------
-// What held version 1 at 20 us was neither the matrix pipe nor L2 bandwidth but bytes in flight: a tile mixed 8 KiB of weights (HBM,
-// cold inside a prefill: ~1-2 us away) with 32 KiB of hidden states (L2 hits after the XCD's first touch), two tiles in flight per
-// CU = 4 MiB of weights in flight chip-wide, so the 32 MiB weight stream ran at a third of the copy ceiling and every tile's
-// barrier waited for it.  Here the two streams are decoupled:
-//   * waves 0..7 (compute): wave w owns k-step w of EVERY 256-element K tile, as before -- so its share of the workgroup's
-//     16 x K weight slice is one 16-byte B fragment per tile, 16 tiles = 64 VGPRs.  It requests all of them before anything else
-//     (non-temporal: each weight byte is read by exactly one CU, once): the workgroup's whole 128 KiB slice -- chip-wide the whole
-//     32 MiB matrix -- is in flight from the first microsecond, and fragment t is consumed as soon as it lands (the loads retire in
-//     order; the compiler's own vmcnt bookkeeping waits for exactly fragment t);
-//   * waves 8..15 (loaders): the hidden window, tile after tile, by LDS-DMA into a ring of four 32 KiB buffers (three tiles in
-//     flight), with their own vmcnt -- an L2-hit stream that never queues behind the HBM one in a wave's in-order counter.
-// One s_barrier per tile for all 16 waves (the loaders arrive once tile t has landed, the compute waves once they have read tile
-// t - 1).  Epilogue as version 1 (fixed-order sum of the eight k-step partials, GEMM-style rounding, RoPE with torch's per-op
-// rounding).  K > 4096: groups of 16 tiles, the next group's fragments requested when the previous group's are consumed.
-constexpr int Q2_THREADS = 1024;
-constexpr int Q2_CWAVES = 8;                      // compute waves = k-steps of 32 per 256-element tile
-constexpr int Q2_LWAVES = 8;                      // loader waves
-constexpr int Q2_HTILEB = QP_ROWS * QP_ROWB;      // 32 KiB of hidden states per tile
-constexpr int Q2_NBUF = 4;
-constexpr int Q2_REQ = Q2_HTILEB / 1024 / Q2_LWAVES;   // 1 KiB LDS-DMA requests per loader wave and tile (4)
-constexpr int Q2_GROUP = 16;                      // tiles whose B fragments a compute wave holds at once
-static_assert(Q2_HTILEB % (1024 * Q2_LWAVES) == 0, "whole requests");
-
-template <int DT, bool VSTAGE>
-__global__ __launch_bounds__(Q2_THREADS) void qproj_rope2_kernel(QprojArgs a) {
-    using T = typename Elem<DT>::T;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];   // Q2_NBUF * Q2_HTILEB
-    const uint32_t nt = blockIdx.x, b = blockIdx.y;
-    const uint32_t h = nt >> 3, d0 = (nt & 7) * 8;  // output columns: dims d0..d0+7 of head h, then d0+64..d0+71
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t l16 = lane & 15, kq = lane >> 4;
-    const uint32_t ntiles = a.K / QP_KT;
-
-    if (VSTAGE && wv >= Q2_CWAVES) {
-        // ---------------- loaders, variant 3: the hidden window through REGISTERS (global_load_dwordx4 -> ds_write_b128) --------------
-        // (variant 2's LDS-DMA ring moved the L2-resident window at ~25 GB/s per CU: 21.6 us for the kernel.)  A loader wave owns 4 of a
-        // tile's 32 row pairs: one 16-byte chunk per lane and row pair, coalesced 512-byte rows; three tiles in flight in registers;
-        // the XOR swizzle is applied on the LDS side (8 consecutive lanes of a ds_write_b128 group still cover 32 distinct banks).
-        const uint32_t lw = wv - Q2_CWAVES;
-        const char* gsrc[Q2_REQ];
-        uint32_t ldst[Q2_REQ];
-#pragma unroll
-        for (int i = 0; i < Q2_REQ; ++i) {
-            const uint32_t r = lw * Q2_REQ + i, row = 2 * r + (lane >> 5), slot = lane & 31;
-            gsrc[i] = a.x + (int64_t)b * a.x_sb + (int64_t)row * a.x_sw + (slot << 4);
-            ldst[i] = row * QP_ROWB + ((slot ^ (row & 15)) << 4);
-        }
-        // Three tiles in flight in three NAMED register sets, the 16 tiles of a group written out one by one (as on the compute
-        // side): a set indexed by a loop variable -- rs[t % 3] -- stays a scratch-memory array (hipcc promotes arrays before it
-        // unrolls), and any loop-carried form rotates the sets with copies; both wait for every load right after issuing it.
-        for (uint32_t g0 = 0; g0 < ntiles; g0 += Q2_GROUP) {
-            static_assert(Q2_REQ == 4, "the register sets below are written out for four requests per tile");
-            uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rc0, rc1, rc2, rc3;   // (scalars: small arrays assigned under a branch stayed in scratch)
-#define Q3_FETCH(R, T)                                                                                               \
-    {                                                                                                                \
-        const int64_t off__ = (int64_t)min(g0 + (T), ntiles - 1) * QP_ROWB; /* past the end: never stored */         \
-        R##0 = *reinterpret_cast<const uint4*>(gsrc[0] + off__);                                                     \
-        R##1 = *reinterpret_cast<const uint4*>(gsrc[1] + off__);                                                     \
-        R##2 = *reinterpret_cast<const uint4*>(gsrc[2] + off__);                                                     \
-        R##3 = *reinterpret_cast<const uint4*>(gsrc[3] + off__);                                                     \
-    }
-#define Q3_TILE(R, T) /* tile g0 + T: registers -> LDS, publish (barrier A), refill the set with tile g0 + T + 3 */    \
-    if (g0 + (T) < ntiles) { /* (uniform) */                                                                         \
-        unsigned char* buf__ = lds2 + ((g0 + (T)) % Q2_NBUF) * Q2_HTILEB;                                            \
-        *reinterpret_cast<uint4*>(buf__ + ldst[0]) = R##0;                                                           \
-        *reinterpret_cast<uint4*>(buf__ + ldst[1]) = R##1;                                                           \
-        *reinterpret_cast<uint4*>(buf__ + ldst[2]) = R##2;                                                           \
-        *reinterpret_cast<uint4*>(buf__ + ldst[3]) = R##3;                                                           \
-        __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): the tile is in LDS */                                     \
-        __builtin_amdgcn_s_barrier();                                                                                \
-        if ((T) + 3 < Q2_GROUP) Q3_FETCH(R, (T) + 3)                                                                 \
-    }
-            Q3_FETCH(ra, 0) Q3_FETCH(rb, 1) Q3_FETCH(rc, 2)
-            Q3_TILE(ra, 0) Q3_TILE(rb, 1) Q3_TILE(rc, 2) Q3_TILE(ra, 3) Q3_TILE(rb, 4) Q3_TILE(rc, 5) Q3_TILE(ra, 6) Q3_TILE(rb, 7)
-            Q3_TILE(rc, 8) Q3_TILE(ra, 9) Q3_TILE(rb, 10) Q3_TILE(rc, 11) Q3_TILE(ra, 12) Q3_TILE(rb, 13) Q3_TILE(rc, 14) Q3_TILE(ra, 15)
-#undef Q3_TILE
-#undef Q3_FETCH
-        }
-        __builtin_amdgcn_s_barrier();         // E1
-        __builtin_amdgcn_s_barrier();         // E2
-    } else if (wv >= Q2_CWAVES) {
-        // ---------------- loaders, variant 2: tile t = rows 0..63 x 512 B by LDS-DMA; request r moves rows 2r, 2r+1 -------------------
-        const uint32_t lw = wv - Q2_CWAVES;
-        const char* gsrc[Q2_REQ];
-#pragma unroll
-        for (int i = 0; i < Q2_REQ; ++i) {
-            const uint32_t r = lw * Q2_REQ + i, row = 2 * r + (lane >> 5), slot = lane & 31;
-            gsrc[i] = a.x + (int64_t)b * a.x_sb + (int64_t)row * a.x_sw + ((slot ^ (row & 15)) << 4);   // XOR swizzle on the global side
-        }
-        auto request_tile = [&](uint32_t t) {
-            const uint32_t tt = min(t, ntiles - 1), buf = t % Q2_NBUF;   // past the end: re-fetch the last tile (never read)
-#pragma unroll
-            for (int i = 0; i < Q2_REQ; ++i) {
-                const char* g = gsrc[i] + (int64_t)tt * QP_ROWB;
-                const uint32_t la = __builtin_amdgcn_readfirstlane(
-                    (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(lds2 + buf * Q2_HTILEB + (lw * Q2_REQ + i) * 1024));
-                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(g) : "memory");
-            }
-        };
-#pragma unroll
-        for (int p = 0; p < Q2_NBUF - 1; ++p) request_tile(p);
-        for (uint32_t t = 0; t < ntiles; ++t) {
-            __builtin_amdgcn_s_waitcnt(0x0F70 | ((Q2_NBUF - 2) * Q2_REQ));   // tile t landed (t+1, t+2 may still be in flight)
-            __builtin_amdgcn_s_barrier();                                    // A(t): compute waves may read tile t, and have left tile t-1
-            request_tile(t + Q2_NBUF - 1);                                   // into the buffer of tile t-1
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // drain the clamped tail requests before the ring is reused for the partial sums
-        __builtin_amdgcn_s_barrier();         // E1
-        __builtin_amdgcn_s_barrier();         // E2
-    } else {
-        // ---------------- compute: B fragments (weights) from global memory into registers, A fragments (hidden) from the ring -------
-        const uint32_t wrow = h * 128 + (l16 < 8 ? d0 + l16 : d0 + 64 + (l16 - 8));
-        const char* wp = a.w + ((int64_t)wrow * a.K + wv * 32 + kq * 8) * 2;   // + tile * 512 B
-        f32x4 acc[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) acc[m] = {0.f, 0.f, 0.f, 0.f};
-        const uint32_t sl = ((wv * 4 + kq) ^ l16) << 4;   // this wave's k-step inside a tile row, swizzled by the row's low bits
-        for (uint32_t g0 = 0; g0 < ntiles; g0 += Q2_GROUP) {
-            uint4 wf[Q2_GROUP];
-#pragma unroll
-            for (int t = 0; t < Q2_GROUP; ++t) {
-                wf[t] = ld16<true>(wp + (int64_t)min(g0 + t, ntiles - 1) * QP_ROWB);
-                asm volatile("" ::: "memory");   // issue order = consumption order: the wait for fragment t is then vmcnt(15 - t), nothing more
-            }
-#pragma unroll
-            for (int t = 0; t < Q2_GROUP; ++t) {
-                if (g0 + t < ntiles) {   // (uniform)
-                    __builtin_amdgcn_s_barrier();   // A(g0 + t)
-                    const unsigned char* buf = lds2 + ((g0 + t) % Q2_NBUF) * Q2_HTILEB;
-                    uint4 afrag[4];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) afrag[m] = *reinterpret_cast<const uint4*>(buf + (16 * m + l16) * QP_ROWB + sl);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) acc[m] = mma16<DT>(afrag[m], wf[t], acc[m]);   // C[row 16 m + 4 kq + r][col l16]
-                }
-            }
-        }
-        __builtin_amdgcn_s_barrier();   // E1: every wave has read its last tile, the loaders' tail requests have landed
-        float (*part)[QP_ROWS][QP_COLS + 1] = reinterpret_cast<float (*)[QP_ROWS][QP_COLS + 1]>(lds2);  // [k-step][row][col]
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part[wv][m * 16 + kq * 4 + r][l16] = acc[m][r];
-        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the partials are in LDS
-        __builtin_amdgcn_s_barrier();         // E2
-        if (threadIdx.x >= 256) return;
-        // epilogue: thread t -> row t / 4, pairs p = (t % 4) * 2 + {0, 1}
-        const uint32_t row = threadIdx.x >> 2;
-        const T* cr = static_cast<const T*>(a.cosp) + (int64_t)b * a.cs_sb + (int64_t)row * a.cs_sw;
-        const T* sr = static_cast<const T*>(a.sinp) + (int64_t)b * a.cs_sb + (int64_t)row * a.cs_sw;
-        T* orow = static_cast<T*>(a.out) + (((size_t)b * a.Hq + h) * QP_ROWS + row) * 128;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const uint32_t p = (threadIdx.x & 3) * 2 + i;
-            float a0 = part[0][row][p], a1 = part[0][row][p + 8];   // fixed summation order over the eight k-step slices
-#pragma unroll
-            for (int w = 1; w < Q2_CWAVES; ++w) {
-                a0 += part[w][row][p];
-                a1 += part[w][row][p + 8];
-            }
-            const float q0 = round_dt<DT>(a0), q1 = round_dt<DT>(a1);   // the GEMM's output rounding
-            const uint32_t d = d0 + p;
-            st_dt<DT>(orow + d, rope_elem<DT>(q0, Elem<DT>::ld(cr + d), -q1, Elem<DT>::ld(sr + d)));
-            st_dt<DT>(orow + d + 64, rope_elem<DT>(q1, Elem<DT>::ld(cr + d + 64), q0, Elem<DT>::ld(sr + d + 64)));
-        }
-    }
-}
-
 }  // namespace
 
 bool kvp_qproj_rope_eligible(int dtype, int64_t W, int64_t D, int64_t K, const void* x, int64_t x_sb, int64_t x_sw, const void* w,
@@ -346,32 +183,9 @@ int kvp_qproj_rope_launch(const void* x, int64_t x_sb, int64_t x_sw, const void*
     a.cosp = cosp; a.sinp = sinp; a.cs_sb = cs_sb; a.cs_sw = cs_sw;
     a.out = out; a.Hq = (uint32_t)Hq; a.K = (uint32_t)K;
     const dim3 grid((uint32_t)(Hq * 8), (uint32_t)B);
-    if (kvp_env_int("KVP_QP_VARIANT", 2) == 1) {
-        if (dtype == KVP_BF16) KVP_LAUNCH("qproj_rope_kernel", stream, qproj_rope_kernel<KVP_BF16><<<grid, QP_THREADS, 0, stream>>>(a));
-        else KVP_LAUNCH("qproj_rope_kernel", stream, qproj_rope_kernel<KVP_F16><<<grid, QP_THREADS, 0, stream>>>(a));
-        KVP_CHECK_LAUNCH("qproj_rope");
-        return KVP_OK;
-    }
-    constexpr size_t lds_bytes = (size_t)Q2_NBUF * Q2_HTILEB;   // 128 KiB: above the 64 KiB a kernel gets without asking
-    const bool vstage = kvp_env_int("KVP_QP_VARIANT", 2) == 3;
-    static bool raised[4] = {false, false, false, false};
-    const int vi = (dtype == KVP_BF16 ? 0 : 1) + (vstage ? 2 : 0);
-    const void* fns[4] = {reinterpret_cast<const void*>(qproj_rope2_kernel<KVP_BF16, false>), reinterpret_cast<const void*>(qproj_rope2_kernel<KVP_F16, false>),
-                          reinterpret_cast<const void*>(qproj_rope2_kernel<KVP_BF16, true>), reinterpret_cast<const void*>(qproj_rope2_kernel<KVP_F16, true>)};
-    if (!raised[vi]) {
-        if (hipFuncSetAttribute(fns[vi], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
-            kvp_set_error("qproj_rope: cannot raise the dynamic LDS limit to %zu", lds_bytes);
-            return KVP_EHIP;
-        }
-        raised[vi] = true;
-    }
-    switch (vi) {
-        case 0: KVP_LAUNCH("qproj_rope2_kernel", stream, (qproj_rope2_kernel<KVP_BF16, false><<<grid, Q2_THREADS, lds_bytes, stream>>>(a))); break;
-        case 1: KVP_LAUNCH("qproj_rope2_kernel", stream, (qproj_rope2_kernel<KVP_F16, false><<<grid, Q2_THREADS, lds_bytes, stream>>>(a))); break;
-        case 2: KVP_LAUNCH("qproj_rope3_kernel", stream, (qproj_rope2_kernel<KVP_BF16, true><<<grid, Q2_THREADS, lds_bytes, stream>>>(a))); break;
-        default: KVP_LAUNCH("qproj_rope3_kernel", stream, (qproj_rope2_kernel<KVP_F16, true><<<grid, Q2_THREADS, lds_bytes, stream>>>(a))); break;
-    }
-    KVP_CHECK_LAUNCH("qproj_rope2");
+    if (dtype == KVP_BF16) KVP_LAUNCH("qproj_rope_kernel", stream, qproj_rope_kernel<KVP_BF16><<<grid, QP_THREADS, 0, stream>>>(a));
+    else KVP_LAUNCH("qproj_rope_kernel", stream, qproj_rope_kernel<KVP_F16><<<grid, QP_THREADS, 0, stream>>>(a));
+    KVP_CHECK_LAUNCH("qproj_rope");
     return KVP_OK;
 }
 

@@ -964,7 +964,7 @@ def test_qproj_rope_kernel_vs_torch(name, dtname):
     att, rot, hidden, (cos, sin) = _inputs.build_llama_attention(s, dt, DEV)
     W = s["W"]
     N = native()
-    assert N.qproj_rope_eligible(att, hidden, W) and not N.qproj_rope_supported(att, hidden, W)  # off by default
+    assert N.qproj_rope_eligible(att, hidden, W) and N.qproj_rope_supported(att, hidden, W)  # on by default since round 4
     with torch.no_grad():
         got = N.snapkv_qproj_rope(hidden[:, -W:], att.q_proj.weight, cos[:, -W:], sin[:, -W:])
         q = get_prerope_query_states(att, hidden[:, -W:])
@@ -984,13 +984,11 @@ def test_qproj_rope_kernel_vs_torch(name, dtname):
     assert ((g.double() - want64).abs() <= 4.0 * ulp * want64.abs().amax(dim=-1, keepdim=True) + 1e-6).all()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("K,Hq,dtname", [(4096, 32, "bf16"), (8192, 4, "bf16"), (4096, 4, "f16"), (1280, 2, "bf16"), (256, 2, "bf16")])
-def test_qproj_rope_kernel_llama_sizes(K, Hq, dtname, variant, knobs):
-    """Both kernels of qproj.hip at the hidden sizes of Llama-3.1-8B (4096: one group of 16 K tiles) and 70B (8192: two groups) and
-    at an odd tile count, batch 2, a strided hidden window, against the float64 product rounded once (<= 1 ulp of the projected
-    value's magnitude through the RoPE pair) -- and against each other: same k-step partials, same fixed summation order."""
-    knobs(KVP_QP_VARIANT=variant)
+def test_qproj_rope_kernel_llama_sizes(K, Hq, dtname):
+    """qproj.hip at the hidden sizes of Llama-3.1-8B (4096) and 70B (8192), at an odd tile count and at a single tile, batch 2, a
+    strided hidden window, against the float64 product rounded once (<= 1 ulp of the projected value's magnitude through the RoPE
+    pair)."""
     N = native()
     dt = _inputs.torch_dtype(dtname)
     g = torch.Generator().manual_seed(K + Hq)
@@ -1006,8 +1004,6 @@ def test_qproj_rope_kernel_llama_sizes(K, Hq, dtname, variant, knobs):
     ulp = 2.0 ** (-7 if dtname == "bf16" else -10)
     assert got.shape == (2, Hq, 64, 128) and got.dtype == dt
     assert ((got.double() - want64).abs() <= 4.0 * ulp * want64.abs().amax(dim=-1, keepdim=True) + 1e-6).all()
-    knobs(KVP_QP_VARIANT=1 if variant != 1 else 2)
-    assert torch.equal(N.snapkv_qproj_rope(hw, wq, cos, sin), got)
 
 
 @pytest.mark.parametrize("name", ["sk_h512_bf16", "sk_h1024_f16"])
@@ -1032,19 +1028,21 @@ def test_hidden_path_scores_and_compress(name):
     # and the scores agree with the float64 oracle fed with the same (bf16) window queries within the north-star tolerance
     ref = O.snapkv_score(q_rot.float().cpu().numpy(), s["keys"], s["ks"])
     assert_scores_close(got.cpu().numpy()[..., :-W], ref[..., :-W], RTOL, name)
-    # the press takes this path only when the switch is on
+    # the press takes this path unless the switch is off (on by default since round 4)
     import kvpress_amd as P
 
     press = P.SnapKVPress(0.5, window_size=W, kernel_size=s["ks"])
     kw = {"position_embeddings": (cos, sin)}
     with torch.no_grad():
-        N.USE_LIBRARY_QPROJ = True
+        saved = N.USE_LIBRARY_QPROJ
         try:
+            N.USE_LIBRARY_QPROJ = True
             on = press.score(att, hidden, k, v, None, kw)
             ko_on, _ = press.compress(att, hidden, k, v, None, kw)
-        finally:
             N.USE_LIBRARY_QPROJ = False
-        off = press.score(att, hidden, k, v, None, kw)
+            off = press.score(att, hidden, k, v, None, kw)
+        finally:
+            N.USE_LIBRARY_QPROJ = saved
     assert torch.equal(on, got) and tuple(ko_on.shape) == (s["B"], s["H"], S // 2, s["D"])
     assert_scores_close(off.cpu().numpy()[..., :-W], got.cpu().numpy()[..., :-W], 2e-2, name)  # GEMM rounding of a few queries
 
