@@ -60,7 +60,7 @@ def stamps(R, S, flat=True):
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     al = lambda x: (x + 255) // 256 * 256
-    bar_off = (2 * al(R * 4096 * 4) + al(R * 256 * 4)) // 4 + 8 * 32 + 32
+    bar_off = (3 * al(R * 4096 * 4) + al(R * 256 * 4)) // 4 + 8 * 32 + 32   # hist1, hist2, hist3, hist2s, then bar
     names = ["start", "keys", "h1 flushed", "B1", "digit1", "h2 flushed", "B2", "digit2", "h3+table", "B3", "T", "offsets", "end"]
     for it in range(6):
         rc = L.kvp_topk_select(P(sc), R, S, S, S // 2, N.TOPK_WS_CLEAN, P(idx), P(ws), nws, st)
@@ -94,13 +94,15 @@ def main():
         wide = torch.randn((R, S), generator=g, device=DEV)
         for name, sc in (("flat", flat), ("wide", wide)):
             out = {}
-            for var, kv in (("cluster", dict(KVP_TK_CLUSTER=None)), ("passes", dict(KVP_TK_CLUSTER=0))):
+            for var, kv in (("cluster", dict(KVP_TK_CLUSTER=None, KVP_TC_SPEC=None)), ("cluster_nospec", dict(KVP_TK_CLUSTER=None, KVP_TC_SPEC=0)),
+                            ("passes", dict(KVP_TK_CLUSTER=0, KVP_TC_SPEC=None))):
                 knobs(**ALL)
                 knobs(**kv)
                 ref = N.topk_select(sc, S // 2)
                 out[var] = (timeit(lambda: N.topk_select(sc, S // 2), args.reps), ref)
-            same = torch.equal(out["cluster"][1], out["passes"][1])
-            print(f"select R={R} S={S} {name}: cluster {out['cluster'][0]:.1f} us, passes {out['passes'][0]:.1f} us, identical={same}", flush=True)
+            same = torch.equal(out["cluster"][1], out["passes"][1]) and torch.equal(out["cluster_nospec"][1], out["passes"][1])
+            print(f"select R={R} S={S} {name}: cluster {out['cluster'][0]:.1f} us, without speculation {out['cluster_nospec'][0]:.1f} us, "
+                  f"passes {out['passes'][0]:.1f} us, identical={same}", flush=True)
     # ---- fused Knorm compress ----
     for S in (32768, 131072):
         k = torch.randn((1, 8, S, 128), generator=g, device=DEV).to(torch.bfloat16)
