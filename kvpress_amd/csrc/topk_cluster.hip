@@ -100,7 +100,6 @@ struct ClusterArgs {
     uint32_t* host_flag;
     uint32_t timeout_ticks;
     int32_t test_delay_slot;   // TEST AID: slot (of cluster 0) that arrives 2 x timeout late at its first barrier; -1 = none
-    uint32_t spec;             // 1: count the second digit of a PREDICTED first digit in round 1 (see the kernel)
     uint32_t interleave;       // 1: cluster = block % 8 (the 32 workgroups of a row on ONE XCD under the observed placement, lab only)
 };
 
@@ -126,7 +125,6 @@ template <int PER, int MODE, bool HIST1>
 __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a) {
     constexpr uint32_t L = TR_THREADS * PER;   // keys per workgroup
     __shared__ __attribute__((aligned(16))) uint32_t lh[L > 4096 ? L : 4096];   // histogram; KNORM: first the staged scores; last the staged output
-    __shared__ uint32_t lh2[HIST1 ? 1 : 4096];   // the speculative second-digit histogram of round 1
     __shared__ uint32_t scr[TR_WAVES + 2];
     __shared__ uint32_t s_fail[2];   // [0] this workgroup gave up at a barrier, [1] the cluster's flag as read after the last barrier
     // A row's 32 workgroups are CONSECUTIVE blocks: whatever part of the grid the device can hold at once, whole clusters become
@@ -248,88 +246,17 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
 
         uint32_t* h1 = a.w.hist1 + (size_t)row * 4096;
         uint32_t* h2 = a.w.hist2 + (size_t)row * 4096;
-        uint32_t* h2s = a.w.hist2s + (size_t)row * 4096;
         uint32_t* h3 = a.w.hist3 + (size_t)row * 256;
-        // ---- speculation (round 4): a digit round costs ~5 us of dependent L2 round trips (flush, arrive, poll, read back, search)
-        // whatever it counts, so round 1 also counts the SECOND digit -- of a first digit b1p predicted from a sample that every
-        // workgroup of the cluster evaluates identically (1024 scores of the row at fixed strides; Knorm: the norms of 256 rows).
-        // After the first barrier the real first digit b1 is known: b1 == b1p (the usual case: the threshold's bin holds a large
-        // share of a row and the sample's quantile lands in it) -> the speculative table IS round 2's histogram and round 2 with its
-        // barrier is skipped; otherwise the three rounds run as before.  Either way the digits, thresholds and indices are those of
-        // the unspeculated kernel: the prediction only decides which path computes them.
-        uint32_t b1p = 0xFFFFFFFFu;
-        if (!HIST1 && a.spec) {
-            for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh2[i] = 0;
-            __syncthreads();
-            uint32_t ns;
-            if (MODE == TC_SCORES || MODE == TC_POOL5) {
-                ns = TR_THREADS;
-                const uint32_t ps = (uint32_t)(((uint64_t)threadIdx.x * S) >> 10);   // S > 16384: distinct positions
-                const float* rp = a.scores + (int64_t)row * a.row_stride;
-                float v;
-                if (MODE == TC_SCORES) {
-                    v = rp[ps];
-                } else {
-                    v = 0.f;
-#pragma unroll
-                    for (int d = 0; d < 5; ++d) {
-                        const int32_t pos = (int32_t)ps + d - 2;
-                        const uint32_t inside = (uint32_t)(((pos - (int32_t)S) >> 31) & ~(pos >> 31));
-                        v += __uint_as_float(__float_as_uint(rp[min(max(pos, 0), (int32_t)S - 1)]) & inside);
-                    }
-                    v *= a.inv;
-                }
-                atomicAdd(&lh2[tc_key(v, kmask) >> 20], 1u);
-            } else {
-                constexpr int DT = MODE == TC_KNORM_BF16 ? KVP_BF16 : KVP_F16;
-                using T = typename Elem<DT>::T;
-                ns = 256;
-                const uint32_t b = row / a.H, h = row - b * a.H;
-                const T* __restrict__ base = static_cast<const T*>(a.x) + (int64_t)b * a.x_sb + (int64_t)h * a.x_sh;
-                const uint32_t lir = threadIdx.x & 15u, g = threadIdx.x >> 4;
-                uint4 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t ps = (uint32_t)(((uint64_t)(u * 64 + g) * S) >> 8);
-                    v[u] = *reinterpret_cast<const uint4*>(base + (int64_t)ps * a.x_ss + (size_t)lir * 8);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float acc = tc_sumsq16<DT>(v[u]);
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-                    if (lir == 0) atomicAdd(&lh2[tc_key(a.scale * sqrtf(acc), kmask) >> 20], 1u);
-                }
-            }
-            __syncthreads();
-            const uint32_t ks = min(ns, max(1u, (uint32_t)(((uint64_t)k * ns + S - 1) / S)));   // the sample's rank of the k-th largest
-            uint32_t kr;
-            row_find_bin<4096>(lh2, ks, scr, b1p, kr);
-            TC_STAMP(1);   // (keys loaded + digit predicted)
-        }
-        // ---- digit 1: key >> 20 (+ the second digit of the keys whose first digit is the predicted one) -------------------------
+        // ---- digit 1: key >> 20 ----------------------------------------------------------------------------------
         if (!HIST1) {
-            for (int i = threadIdx.x; i < 4096; i += TR_THREADS) {
-                lh[i] = 0;
-                lh2[i] = 0;
-            }
+            for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < PER; ++j) topk_hist_add_bin(lh, keys[j] >> 20, keys[j] != 0u);
-            if (b1p != 0xFFFFFFFFu) {
-                if (full && (kmin >> 8) == (kmax >> 8)) {   // (rows of equal scores: one weighted add, as in round 2)
-                    if ((kmin >> 20) == b1p) atomicAdd(&lh2[(kmin >> 8) & 0xFFFu], (uint32_t)PER);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < PER; ++j)
-                        if ((keys[j] >> 20) == b1p && keys[j]) atomicAdd(&lh2[(keys[j] >> 8) & 0xFFFu], 1u);
-                }
-            }
             __syncthreads();
             for (int i = threadIdx.x; i < 4096; i += TR_THREADS) {
-                const uint32_t c = lh[i], c2 = lh2[i];
+                const uint32_t c = lh[i];
                 if (c) tc_add(&h1[i], c);
-                if (c2) tc_add(&h2s[i], c2);
             }
             TC_STAMP(2);   // first histogram flushed
             cluster_barrier(cs, 1, &s_fail[0], true);
@@ -343,34 +270,30 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             row_find_bin_regs<4>(loc, TR_THREADS, k, scr, b1, k1);
         }
         TC_STAMP(4);   // first digit found
-        const bool hit = !HIST1 && b1 == b1p;   // (uniform over the cluster: every workgroup computed the same b1p and reads the same h1)
         // ---- digit 2: (key >> 8) & 0xFFF among key >> 20 == b1 -----------------------------------------------------
         if (slot == 0 && threadIdx.x < 256) tc_st(&h3[threadIdx.x], 0u);   // self-cleaning: filled below, read after the last barrier
-        if (!hit) {
-            for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
-            __syncthreads();
-            if (full && (kmin >> 8) == (kmax >> 8)) {   // all of this thread's keys in one bin (rows of equal scores): one weighted add
-                if ((kmin >> 20) == b1) atomicAdd(&lh[(kmin >> 8) & 0xFFFu], (uint32_t)PER);
-            } else {
+        for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
+        __syncthreads();
+        if (full && (kmin >> 8) == (kmax >> 8)) {   // all of this thread's keys in one bin (rows of equal scores): one weighted add
+            if ((kmin >> 20) == b1) atomicAdd(&lh[(kmin >> 8) & 0xFFFu], (uint32_t)PER);
+        } else {
 #pragma unroll
-                for (int j = 0; j < PER; ++j)
-                    if ((keys[j] >> 20) == b1 && keys[j]) atomicAdd(&lh[(keys[j] >> 8) & 0xFFFu], 1u);
-            }
-            __syncthreads();
-            for (int i = threadIdx.x; i < 4096; i += TR_THREADS) {
-                const uint32_t c = lh[i];
-                if (c) tc_add(&h2[i], c);
-            }
-            TC_STAMP(5);   // second histogram flushed
-            cluster_barrier(cs, 2, &s_fail[0], HIST1);
-            TC_STAMP(6);
+            for (int j = 0; j < PER; ++j)
+                if ((keys[j] >> 20) == b1 && keys[j]) atomicAdd(&lh[(keys[j] >> 8) & 0xFFFu], 1u);
         }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4096; i += TR_THREADS) {
+            const uint32_t c = lh[i];
+            if (c) tc_add(&h2[i], c);
+        }
+        TC_STAMP(5);   // second histogram flushed
+        cluster_barrier(cs, 2, &s_fail[0], HIST1);
+        TC_STAMP(6);
         uint32_t b2, k2;
         {
-            const uint32_t* hsrc = hit ? h2s : h2;   // a hit: round 1 already counted this digit
             uint32_t loc[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) loc[i] = tc_ld(&hsrc[(TR_THREADS - 1 - threadIdx.x) * 4 + i]);
+            for (int i = 0; i < 4; ++i) loc[i] = tc_ld(&h2[(TR_THREADS - 1 - threadIdx.x) * 4 + i]);
             row_find_bin_regs<4>(loc, TR_THREADS, k1, scr, b2, k2);
         }
         const uint32_t prefix = (b1 << 12) | b2;
@@ -447,7 +370,6 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
         for (uint32_t i = slot * TR_THREADS + threadIdx.x; i < 4096; i += TC_SLOTS * TR_THREADS) {
             tc_st(&h1[i], 0u);
             tc_st(&h2[i], 0u);
-            if (!HIST1) tc_st(&h2s[i], 0u);
         }
         TC_STAMP(11);  // offsets of the earlier slots, histograms zeroed
         // ---- ordered compaction: keys > T, and the first `quota` keys == T ---------------------------------------------
@@ -494,7 +416,6 @@ int launch_one(const ClusterArgs& a, hipStream_t stream) {
     b.timeout_ticks = (uint32_t)std::min<int64_t>(std::max<int64_t>(kvp_env_int("KVP_TC_TIMEOUT_US", 1000000), 100), 20000000) * 100u;
     b.test_delay_slot = kvp_env_int("KVP_TC_TEST_DELAY_SLOT", -1);
     b.interleave = kvp_env_int("KVP_TC_INTERLEAVE", 0) ? 1u : 0u;
-    b.spec = kvp_env_int("KVP_TC_SPEC", 1) ? 1u : 0u;
     for (b.row_base = 0; b.row_base < b.R; b.row_base += TC_CLUSTERS)
         KVP_LAUNCH("topk_cluster_kernel", stream, (topk_cluster_kernel<PER, MODE, HIST1><<<TC_CLUSTERS * TC_SLOTS, TR_THREADS, 0, stream>>>(b)));
     return 0;

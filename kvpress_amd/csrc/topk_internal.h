@@ -20,7 +20,6 @@ struct TopkWs {
     uint32_t* hist1;       // [R][4096]
     uint32_t* hist2;       // [R][4096]
     uint32_t* hist3;       // [R][256]
-    uint32_t* hist2s;      // [R][4096] cluster select: the SPECULATIVE second-digit histogram (counted in round 1 for a predicted first digit)
     uint32_t* bar;         // [TC_CLUSTERS][32] cluster select: one monotonic arrival counter per row cluster (own 128-byte line);
                            // [TC_CLUSTERS * 32] = give-up code of a barrier that timed out (0 = none)
     uint32_t* sel;         // [R][4] : b1, k1, b2, k2
@@ -43,7 +42,6 @@ inline TopkWs topk_carve_ws(void* ws, int64_t R, int64_t nchunks) {
     w.hist1 = (uint32_t*)take((size_t)R * 4096 * 4);
     w.hist2 = (uint32_t*)take((size_t)R * 4096 * 4);
     w.hist3 = (uint32_t*)take((size_t)R * 256 * 4);
-    w.hist2s = (uint32_t*)take((size_t)R * 4096 * 4);
     w.bar = (uint32_t*)take((size_t)(TC_CLUSTERS * 32 + 32 + TC_SLOTS * 16) * 4);   // (+ phase time stamps of the KVP_TC_TIMING lab build)
     w.zero_bytes = off;
     w.sel = (uint32_t*)take((size_t)R * 4 * 4);

@@ -163,8 +163,7 @@ def test_topk_second_pass_variants(S, knobs):
     flat = (2.0 ** -17 * (1 + 0.05 * rs.standard_normal((3, S)))).astype(np.float32)   # pooled-attention-like: +-5 % around one value
     ties = _inputs.round_to(-np.sqrt(rs.chisquare(64, size=(3, S))).astype(np.float32), "bf16")
     const = np.full((2, S), 0.25, np.float32)
-    variants = ([dict(KVP_TK_CLUSTER=None, KVP_TK_H2_WIDE=None, KVP_TC_SPEC=None), dict(KVP_TK_CLUSTER=None, KVP_TK_H2_WIDE=None, KVP_TC_SPEC=0)]
-                + [dict(KVP_TK_CLUSTER=0, KVP_TK_H2_WIDE=w, KVP_TC_SPEC=None) for w in (None, 4, 16, 32, 0)])
+    variants = [dict(KVP_TK_CLUSTER=None, KVP_TK_H2_WIDE=None)] + [dict(KVP_TK_CLUSTER=0, KVP_TK_H2_WIDE=w) for w in (None, 4, 16, 32, 0)]
     for variant in variants:
         knobs(**variant)
         for sc_np in (wide, flat, ties, const):
@@ -208,33 +207,6 @@ def test_topk_cluster_select_rows_and_lengths(R, S, knobs):
     got = N.topk_select(view, (S - 5) // 2)
     knobs(KVP_TK_CLUSTER=0)
     assert torch.equal(got, N.topk_select(view, (S - 5) // 2))
-
-
-@pytest.mark.parametrize("S", [16385, 50000, 131072, 262144])
-def test_topk_cluster_speculation_hit_and_miss(S, knobs):
-    """Round 4: the cluster select counts the second digit of a PREDICTED first digit in its first round (the prediction: a
-    1024-score sample at fixed strides that every workgroup reads).  A right prediction skips a round, a wrong one must change
-    nothing: rows built so that the sample lies -- large scores exactly at the sampled positions of an otherwise small row, and the
-    other way round -- rows where it is right, and rows with the threshold on a bin edge; with and without speculation, against
-    the oracle, twice through the same self-cleaning workspace (the speculative table must be left clean on both paths)."""
-    rs = np.random.RandomState(S)
-    N = native()
-    pos = ((np.arange(1024, dtype=np.uint64) * np.uint64(S)) >> np.uint64(10)).astype(np.int64)
-    small = (2.0 ** -17 * (1 + 0.05 * rs.standard_normal((4, S)))).astype(np.float32)
-    lie_hi, lie_lo = small.copy(), (small * 64).astype(np.float32)
-    lie_hi[:, pos] *= 64.0          # the sample sees only the large scores
-    lie_lo[:, pos] /= 64.0          # ... only the small ones
-    edge = np.where(rs.rand(4, S) < 0.5, np.float32(1.0), np.float32(2.0)).astype(np.float32) * (1 + 1e-3 * rs.rand(4, S)).astype(np.float32)
-    wide = rs.standard_normal((4, S)).astype(np.float32)
-    for sc_np in (small, lie_hi, lie_lo, edge, wide):
-        t = torch.from_numpy(sc_np).to(DEV)
-        for k in sorted({1, 1024, S // 2, S - 1024, S - 1}):
-            want = O.topk_select(sc_np, k)
-            for spec in (None, 0, None):
-                knobs(KVP_TC_SPEC=spec)
-                assert np.array_equal(N.topk_select(t, k).cpu().numpy(), want), f"S={S} k={k} spec={spec}"
-    torch.cuda.synchronize()
-    N.async_error_check()
 
 
 @pytest.mark.parametrize("S", [1, 2, 63, 1023, 1024, 1025, 2048, 2049, 4096, 4097, 8191, 8193, 16383, 16384, 16385, 20000, 32767, 32768, 32769, 40000])

@@ -60,7 +60,7 @@ def stamps(R, S, flat=True):
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     al = lambda x: (x + 255) // 256 * 256
-    bar_off = (3 * al(R * 4096 * 4) + al(R * 256 * 4)) // 4 + 8 * 32 + 32   # hist1, hist2, hist3, hist2s, then bar
+    bar_off = (2 * al(R * 4096 * 4) + al(R * 256 * 4)) // 4 + 8 * 32 + 32
     names = ["start", "keys", "h1 flushed", "B1", "digit1", "h2 flushed", "B2", "digit2", "h3+table", "B3", "T", "offsets", "end"]
     for it in range(6):
         rc = L.kvp_topk_select(P(sc), R, S, S, S // 2, N.TOPK_WS_CLEAN, P(idx), P(ws), nws, st)
