@@ -160,7 +160,25 @@ def _st(t: torch.Tensor, i: int) -> int:
 
 
 def _stream(t: torch.Tensor):
-    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return torch.cuda.current_stream(t.device).cuda_stream   # (an int: ctypes converts it for a c_void_p parameter)
+
+
+class _on_device:
+    """``with _on_device(dev)`` only when ``dev`` is not already current: the context manager costs several microseconds
+    per call, which is a tenth of a whole decode-regime compress (tools/host_overhead_probe.py)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        self.ctx = None if dev.index is None or torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
 
 
 def _ws(nbytes: int, like: torch.Tensor) -> torch.Tensor:
@@ -168,7 +186,7 @@ def _ws(nbytes: int, like: torch.Tensor) -> torch.Tensor:
 
 
 def _p(t: Optional[torch.Tensor]):
-    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+    return t.data_ptr() if t is not None else None   # (ints / None: ctypes converts them for a c_void_p parameter)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -177,7 +195,7 @@ def rownorm_score(x: torch.Tensor, scale: float) -> torch.Tensor:
     x = _rows_last_contig(_dev(x))
     B, H, S, D = x.shape
     out = torch.empty((B, H, S), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         _check(lib().kvp_rownorm_score(_p(x), _DTYPES[x.dtype], B, H, S, D, _st(x, 0), _st(x, 1), _st(x, 2),
                                        float(scale), _p(out), _stream(x)), "kvp_rownorm_score")
     return out
@@ -189,7 +207,7 @@ def observed_attention_score(attentions: torch.Tensor, num_kv_heads: int) -> tor
     B, Hq, Sq, S = a.shape
     assert Hq % num_kv_heads == 0, (a.shape, num_kv_heads)
     out = torch.empty((B, num_kv_heads, S), dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
+    with _on_device(a.device):
         _check(lib().kvp_observed_attention_score(_p(a), _st(a, 0), _st(a, 1), _st(a, 2), _DTYPES[a.dtype], B, Hq, num_kv_heads, Sq, S,
                                                   _p(out), _stream(a)), "kvp_observed_attention_score")
     return out
@@ -202,7 +220,7 @@ def lagkv_score(keys: torch.Tensor, values: torch.Tensor, n_sink: int, lag_size:
     assert keys.dtype == values.dtype and keys.shape == values.shape
     B, H, S, D = keys.shape
     out = torch.empty((B, H, S), dtype=torch.float32, device=keys.device)
-    with torch.cuda.device(keys.device):
+    with _on_device(keys.device):
         _check(lib().kvp_lagkv_score(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _p(values), _st(values, 0), _st(values, 1),
                                      _st(values, 2), _DTYPES[keys.dtype], B, H, S, D, int(n_sink), int(lag_size), int(bool(cross_scoring)),
                                      _p(out), _stream(keys)), "kvp_lagkv_score")
@@ -219,7 +237,7 @@ def think_channel_scores(q_win: torch.Tensor, keys: torch.Tensor) -> torch.Tenso
     Bk, Hkv, S, Dk = keys.shape
     assert B == Bk and D == Dk and Hq % Hkv == 0, (q_win.shape, keys.shape)
     out = torch.empty((B, Hkv, D), dtype=torch.float32, device=keys.device)
-    with torch.cuda.device(keys.device):
+    with _on_device(keys.device):
         nws = lib().kvp_think_workspace_bytes(B, Hkv, S, D)
         ws = _ws(nws, keys)
         _check(lib().kvp_think_channel_scores(_p(q_win), _st(q_win, 0), _st(q_win, 1), _st(q_win, 2), _p(keys), _st(keys, 0), _st(keys, 1),
@@ -234,7 +252,7 @@ def zero_channels_(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     B, H, S, D = x.shape
     assert idx.is_cuda and idx.device == x.device and tuple(idx.shape[:2]) == (B, H), (idx.shape, x.shape)
     idx = idx.to(torch.int32).contiguous()
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         _check(lib().kvp_zero_channels(_p(x), _st(x, 0), _st(x, 1), _st(x, 2), _DTYPES[x.dtype], B, H, S, D, _p(idx), idx.shape[2], _stream(x)),
                "kvp_zero_channels")
     return x
@@ -248,7 +266,7 @@ def rowl1_score(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
     out = torch.empty((x2.shape[0],), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         _check(lib().kvp_rowl1_score(_p(x2), _DTYPES[x2.dtype], x2.shape[0], N, x2.stride(0) if x2.shape[0] > 1 else N, float(scale), _p(out),
                                      _stream(x2)), "kvp_rowl1_score")
     return out.view(lead)
@@ -265,7 +283,7 @@ def rowdot_score(x: torch.Tensor, filt: torch.Tensor, scale: float) -> torch.Ten
     if filt.stride(-1) != 1:
         filt = filt.contiguous()
     out = torch.empty((B, H, S), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         _check(lib().kvp_rowdot_score(_p(x), _DTYPES[x.dtype], B, H, S, D, _st(x, 0), _st(x, 1), _st(x, 2), _p(filt), _st(filt, 0),
                                       float(scale), _p(out), _stream(x)), "kvp_rowdot_score")
     return out
@@ -283,7 +301,7 @@ def cur_score(keys: torch.Tensor, values: torch.Tensor, leverage_type: str, loca
         raise ValueError("Unknown leverage type: choose from 'kv_avg', 'key', 'value' or 'kv_product'")
     B, H, S, D = keys.shape
     scores = torch.empty((B, H, S), dtype=torch.float32, device=keys.device)
-    with torch.cuda.device(keys.device):
+    with _on_device(keys.device):
         ws = _ws(lib().kvp_cur_workspace_bytes(B, H, S), keys)
         _check(lib().kvp_cur_score(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _p(values), _st(values, 0), _st(values, 1),
                                    _st(values, 2), _DTYPES[keys.dtype], B, H, S, D, CUR_LEVERAGE[leverage_type], int(local_window_size),
@@ -296,7 +314,7 @@ def keydiff_score(keys: torch.Tensor) -> torch.Tensor:
     keys = _rows_last_contig(_dev(keys))
     B, H, S, D = keys.shape
     scores = torch.empty((B, H, S), dtype=torch.float32, device=keys.device)
-    with torch.cuda.device(keys.device):
+    with _on_device(keys.device):
         nws = lib().kvp_keydiff_workspace_bytes(B, H, S, D)
         ws = _ws(nws, keys)
         _check(lib().kvp_keydiff_score(_p(keys), _DTYPES[keys.dtype], B, H, S, D, _st(keys, 0), _st(keys, 1), _st(keys, 2),
@@ -309,7 +327,7 @@ def scores_head_mean_(scores: torch.Tensor) -> torch.Tensor:
     assert scores.dtype == torch.float32 and scores.dim() == 3 and scores.stride(2) == 1
     _dev(scores)
     B, H, S = scores.shape
-    with torch.cuda.device(scores.device):
+    with _on_device(scores.device):
         _check(lib().kvp_scores_head_mean(_p(scores), B, H, S, _st(scores, 0), _st(scores, 1), _stream(scores)),
                "kvp_scores_head_mean")
     return scores
@@ -325,7 +343,7 @@ def snapkv_score(q_win: torch.Tensor, keys: torch.Tensor, kernel_size: int) -> t
     Bk, Hkv, S, Dk = keys.shape
     assert B == Bk and D == Dk and Hq % Hkv == 0, (q_win.shape, keys.shape)
     scores = torch.empty((B, Hkv, S), dtype=torch.float32, device=keys.device)
-    with torch.cuda.device(keys.device):
+    with _on_device(keys.device):
         nws = lib().kvp_snapkv_workspace_bytes(B, Hq, Hkv, S, W, D)
         ws = _ws(nws, keys)
         _check(lib().kvp_snapkv_score(_p(q_win), _st(q_win, 0), _st(q_win, 1), _st(q_win, 2),
@@ -368,7 +386,7 @@ def snapkv_score_rope(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
     assert B == Bk and D == Dk and Hq % Hkv == 0, (q_pre.shape, keys.shape)
     cos, sin = _window_tables(cos, sin, B, W, D)
     scores = torch.empty((B, Hkv, S), dtype=torch.float32, device=keys.device)
-    with torch.cuda.device(keys.device):
+    with _on_device(keys.device):
         nws = lib().kvp_snapkv_workspace_bytes(B, Hq, Hkv, S, W, D)
         ws = _ws(nws, keys)
         fn, last, what = ((lib().kvp_snapkv_score_rope, int(kernel_size), "kvp_snapkv_score_rope") if _finch_normalize is None
@@ -390,8 +408,11 @@ USE_LIBRARY_QPROJ = os.environ.get("KVP_LIBRARY_QPROJ", "1") != "0"
 
 
 def qproj_rope_supported(module, hidden_states: torch.Tensor, window: int) -> bool:
-    """Should the press project the window in the library?  (USE_LIBRARY_QPROJ and qproj_rope_eligible.)"""
-    return USE_LIBRARY_QPROJ and qproj_rope_eligible(module, hidden_states, window)
+    """Should the press project the window in the library?  USE_LIBRARY_QPROJ, qproj_rope_eligible, and ONE batch element: the
+    kernel streams the whole q_proj weight once per batch element (its grid is (columns, batch)), which is what a single window
+    costs anyway but not what a batch does -- ChunkPress hands the wrapped press its 128 chunks as a batch of 128 windows, and a
+    GEMM over all 8192 rows reads the weight once."""
+    return USE_LIBRARY_QPROJ and hidden_states.shape[0] == 1 and qproj_rope_eligible(module, hidden_states, window)
 
 
 def qproj_rope_eligible(module, hidden_states: torch.Tensor, window: int) -> bool:
@@ -423,7 +444,7 @@ def snapkv_qproj_rope(hidden_win: torch.Tensor, wq: torch.Tensor, cos: torch.Ten
     B, W, K = hidden_win.shape
     Hq = wq.shape[0] // head_dim
     out = torch.empty((B, Hq, W, head_dim), dtype=dt, device=hidden_win.device)
-    with torch.cuda.device(hidden_win.device):
+    with _on_device(hidden_win.device):
         _check(lib().kvp_snapkv_qproj_rope(_p(hidden_win), _st(hidden_win, 0), _st(hidden_win, 1), _p(wq), _p(cos), _p(sin), _st(cos, 0),
                                            _st(cos, 1), _DTYPES[dt], B, Hq, W, head_dim, K, _p(out), _stream(hidden_win)),
                "kvp_snapkv_qproj_rope")
@@ -441,7 +462,7 @@ def snapkv_score_hidden(hidden_win: torch.Tensor, wq: torch.Tensor, cos: torch.T
     Hq = wq.shape[0] // D
     assert B == Bk and Hq % Hkv == 0
     scores = torch.empty((B, Hkv, S), dtype=torch.float32, device=keys.device)
-    with torch.cuda.device(keys.device):
+    with _on_device(keys.device):
         ws = _ws(lib().kvp_snapkv_workspace_bytes(B, Hq, Hkv, S, W, D), keys)
         _check(lib().kvp_snapkv_score_hidden(_p(hidden_win), _st(hidden_win, 0), _st(hidden_win, 1), _p(wq), K, _p(cos), _p(sin),
                                              _st(cos, 0), _st(cos, 1), _p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _DTYPES[dt],
@@ -466,8 +487,8 @@ def snapkv_compress_hidden(hidden_win: torch.Tensor, wq: torch.Tensor, cos: torc
     ko = torch.empty((B, Hkv, n, D), dtype=dt, device=keys.device)
     vo = torch.empty_like(ko)
     if n:
-        with torch.cuda.device(keys.device):
-            ws = _clean_ws("snapkv", (B, Hq, Hkv, S, W, D, n), lib().kvp_snapkv_compress_workspace_bytes(B, Hq, Hkv, S, W, D, n), keys)
+        with _on_device(keys.device):
+            ws = _clean_ws("snapkv", (B, Hq, Hkv, S, W, D, n), _ws_bytes("kvp_snapkv_compress_workspace_bytes", B, Hq, Hkv, S, W, D, n), keys)
             rc = lib().kvp_snapkv_compress_hidden(_p(hidden_win), _st(hidden_win, 0), _st(hidden_win, 1), _p(wq), K, _p(cos), _p(sin),
                                                   _st(cos, 0), _st(cos, 1), _p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2),
                                                   _p(values), _st(values, 0), _st(values, 1), _st(values, 2), _DTYPES[dt], B, Hq, Hkv, S,
@@ -486,7 +507,7 @@ def snapkv_score_from_attn(attn_win: torch.Tensor, num_kv_heads: int, k_len: int
     S = int(k_len)
     assert Sm == S - W, (attn_win.shape, S)
     scores = torch.empty((B, num_kv_heads, S), dtype=torch.float32, device=attn_win.device)
-    with torch.cuda.device(attn_win.device):
+    with _on_device(attn_win.device):
         nws = lib().kvp_snapkv_workspace_bytes(B, Hq, num_kv_heads, S, W, 1)
         ws = _ws(nws, attn_win)
         _check(lib().kvp_snapkv_score_from_attn(_p(attn_win), _st(attn_win, 0), _st(attn_win, 1), _st(attn_win, 2),
@@ -502,7 +523,7 @@ def ea_qstats(q: torch.Tensor, use_covariance: bool = True):
     B, Hq, Sq, D = q.shape
     mu = torch.empty((B, Hq, D), dtype=torch.float32, device=q.device)
     cov = torch.empty((B, Hq, D, D), dtype=torch.float32, device=q.device) if use_covariance else None
-    with torch.cuda.device(q.device):
+    with _on_device(q.device):
         nws = lib().kvp_ea_qstats_workspace_bytes(B, Hq, Sq, D)
         ws = _ws(nws, q)
         _check(lib().kvp_ea_qstats(_p(q), _st(q, 0), _st(q, 1), _st(q, 2), _DTYPES[q.dtype], B, Hq, Sq, D,
@@ -522,7 +543,7 @@ def ea_score(keys: torch.Tensor, values: torch.Tensor, mu: torch.Tensor, cov: Op
     Hq = mu.shape[1]
     assert mu.shape == (B, Hq, D) and (cov is None or cov.shape == (B, Hq, D, D))
     scores = torch.empty((B, Hkv, S), dtype=torch.float32, device=keys.device)
-    with torch.cuda.device(keys.device):
+    with _on_device(keys.device):
         nws = lib().kvp_ea_score_workspace_bytes(B, Hq, Hkv, S, D)
         ws = _ws(nws, keys)
         _check(lib().kvp_ea_score(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2),
@@ -543,7 +564,7 @@ def scores_fill_at_(scores: torch.Tensor, idx: torch.Tensor, value: float) -> to
     n = idx.shape[-1]
     R = scores.numel() // S if S else 0
     assert idx.numel() == R * n
-    with torch.cuda.device(scores.device):
+    with _on_device(scores.device):
         _check(lib().kvp_scores_fill_at(_p(scores), R, S, S, _p(idx), n, float(value), _stream(scores)), "kvp_scores_fill_at")
     return scores
 
@@ -564,7 +585,7 @@ def topk_select(scores: torch.Tensor, k: int, order: int = ORDER_POSITION) -> to
     R = s2.shape[0]
     idx = torch.empty((R, k), dtype=torch.int32, device=s.device)
     if R and k:
-        with torch.cuda.device(s.device):
+        with _on_device(s.device):
             if (int(order) & 0xFF) == ORDER_SCORE:
                 # descending-score order: select + sort, in a workspace of its own (zero-filled: the select's histograms)
                 ws = torch.zeros(max(int(lib().kvp_topk_order_workspace_bytes(R, S, k)), 256), dtype=torch.uint8, device=s.device)
@@ -597,7 +618,7 @@ def topk_select_segmented(scores: torch.Tensor, seg_len: int, k: int, pos_base: 
     R = s2.shape[0]
     idx = torch.empty((R, nseg * k), dtype=torch.int32, device=s.device)
     if R and k:
-        with torch.cuda.device(s.device):
+        with _on_device(s.device):
             ws = torch.zeros(max(int(lib().kvp_topk_segmented_workspace_bytes(R, nseg, seg_len, k)), 256), dtype=torch.uint8, device=s.device)
             _check(lib().kvp_topk_select_segmented(_p(s2), R, nseg, int(seg_len), int(k), int(pos_base), TOPK_WS_CLEAN, _p(idx), _p(ws),
                                                    ws.numel(), _stream(s)), "kvp_topk_select_segmented")
@@ -613,10 +634,24 @@ def rerotate_keys_(keys_kept: torch.Tensor, idx: torch.Tensor, inv_freq: torch.T
     assert idx.shape == (B, H, n)
     inv = inv_freq.to(device=keys_kept.device, dtype=torch.float32).contiguous()
     assert inv.numel() == D // 2
-    with torch.cuda.device(keys_kept.device):
+    with _on_device(keys_kept.device):
         _check(lib().kvp_rerotate_keys(_p(keys_kept), _DTYPES[keys_kept.dtype], B, H, n, D, _p(idx), _p(inv), _stream(keys_kept)),
                "kvp_rerotate_keys")
     return keys_kept
+
+
+_WS_BYTES: dict = {}
+
+
+def _ws_bytes(fn_name: str, *shape) -> int:
+    """kvp_*_workspace_bytes(shape), remembered per shape (a ctypes call per compress is measurable in the decode regime)."""
+    key = (fn_name,) + shape
+    n = _WS_BYTES.get(key)
+    if n is None:
+        if len(_WS_BYTES) > 256:
+            _WS_BYTES.clear()
+        n = _WS_BYTES[key] = int(getattr(lib(), fn_name)(*shape))
+    return n
 
 
 def _clean_ws(kind: str, shape: tuple, nbytes: int, like: torch.Tensor) -> torch.Tensor:
@@ -656,8 +691,8 @@ def knorm_compress(keys: torch.Tensor, values: torch.Tensor, n_kept: int):
     ko = torch.empty((B, H, n, D), dtype=keys.dtype, device=keys.device)
     vo = torch.empty_like(ko)
     if n and B and H:
-        with torch.cuda.device(keys.device):
-            ws = _clean_ws("knorm", (B, H, S, n), lib().kvp_knorm_compress_workspace_bytes(B, H, S, n), keys)
+        with _on_device(keys.device):
+            ws = _clean_ws("knorm", (B, H, S, n), _ws_bytes("kvp_knorm_compress_workspace_bytes", B, H, S, n), keys)
             rc = lib().kvp_knorm_compress(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _p(values), _st(values, 0), _st(values, 1),
                                           _st(values, 2), _DTYPES[keys.dtype], B, H, S, D, n, _p(ko), _p(vo), _p(ws), ws.numel(),
                                           TOPK_WS_CLEAN, _stream(keys))
@@ -687,8 +722,8 @@ def snapkv_compress_rope(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tens
     ko = torch.empty((B, Hkv, n, D), dtype=dt, device=keys.device)
     vo = torch.empty_like(ko)
     if n:
-        with torch.cuda.device(keys.device):
-            ws = _clean_ws("snapkv", (B, Hq, Hkv, S, W, D, n), lib().kvp_snapkv_compress_workspace_bytes(B, Hq, Hkv, S, W, D, n), keys)
+        with _on_device(keys.device):
+            ws = _clean_ws("snapkv", (B, Hq, Hkv, S, W, D, n), _ws_bytes("kvp_snapkv_compress_workspace_bytes", B, Hq, Hkv, S, W, D, n), keys)
             rc = lib().kvp_snapkv_compress_rope(_p(q_pre), _st(q_pre, 0), _st(q_pre, 1), _st(q_pre, 2), _p(cos), _p(sin), _st(cos, 0),
                                                 _st(cos, 1), _p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _p(values),
                                                 _st(values, 0), _st(values, 1), _st(values, 2), _DTYPES[dt], B, Hq, Hkv, S, W, D,
@@ -711,7 +746,7 @@ def gather_kv(keys: torch.Tensor, values: torch.Tensor, idx: torch.Tensor):
     ko = torch.empty((B, H, n, D), dtype=keys.dtype, device=keys.device)
     vo = torch.empty((B, H, n, D), dtype=values.dtype, device=values.device)
     if B * H * n:
-        with torch.cuda.device(keys.device):
+        with _on_device(keys.device):
             _check(lib().kvp_gather_kv(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2),
                                        _p(values), _st(values, 0), _st(values, 1), _st(values, 2), _DTYPES[keys.dtype],
                                        B, H, S, D, _p(idx), n, _p(ko), _p(vo), _stream(keys)), "kvp_gather_kv")
@@ -733,7 +768,7 @@ def gather_kv_rerotate(keys: torch.Tensor, values: torch.Tensor, idx: torch.Tens
     ko = torch.empty((B, H, n, D), dtype=keys.dtype, device=keys.device)
     vo = torch.empty((B, H, n, D), dtype=values.dtype, device=values.device)
     if B * H * n:
-        with torch.cuda.device(keys.device):
+        with _on_device(keys.device):
             _check(lib().kvp_gather_kv_rerotate(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2),
                                                 _p(values), _st(values, 0), _st(values, 1), _st(values, 2), _DTYPES[keys.dtype],
                                                 B, H, S, D, _p(idx), n, _p(inv), _p(ko), _p(vo), _stream(keys)), "kvp_gather_kv_rerotate")
@@ -753,7 +788,7 @@ def clock_probe(device=None, spin_us: int = 20) -> torch.Tensor:
     once the stream has run it."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     out = torch.zeros(1, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _check(lib().kvp_clock_probe(_p(out), int(spin_us), _stream(out)), "kvp_clock_probe")
     return out
 

@@ -79,7 +79,15 @@ def pack_reference(scores: torch.Tensor, n_kept: int, pad_lo: int, pad_hi: int, 
     kept = torch.zeros((H, S), dtype=torch.bool)
     kept.scatter_(1, idx, True)
     t = sc.gather(1, idx).amin(-1)
+    # EVERY score of the row, in half precision relative to a per-row power of two (the subsample pins 1 column in 8
+    # to float32; this pins all of them to 2^-11): all16 = fp16(score * 2^e) with 2^e = 2^14 / (largest finite non-pad |score|)
+    numeric_cols = torch.ones(S, dtype=torch.bool)
+    numeric_cols[pad_lo:pad_hi] = False
+    amax = sc[:, numeric_cols].abs().amax(-1).clamp_min(1e-30)
+    e16 = torch.floor(14.0 - torch.log2(amax)).clamp(-100, 100)
+    all16 = (sc * torch.exp2(e16)[:, None]).clamp(-65504, 65504).to(torch.float16)
     out = {
+        "all16": all16.view(torch.int16).numpy().view(np.uint16), "all16_exp": e16.numpy().astype(np.float32),
         "sub": sc[:, SUB_OFFSET::subsample].numpy().astype(np.float32), "subsample": np.int64(subsample),
         "kept_bits": np.packbits(kept.numpy(), axis=-1),
         "threshold": t.numpy().astype(np.float32),
@@ -113,6 +121,15 @@ def check_against_reference(fx, scores: torch.Tensor, idx: torch.Tensor, rtol: f
     rel = (((got - sub).abs() - atol).clamp_min(0) / sub.abs().clamp_min(1e-30))[:, numeric]
     worst = float(rel.max())
     assert worst <= rtol, f"scores differ from the reference by {worst:.3e} (subsample)"
+    if "all16" in fx:   # every column: the reference's score in scaled half precision (2^-11 relative; subnormal results below 2^-24 of the row's maximum)
+        ref16 = torch.from_numpy(fx["all16"].view(np.int16).copy()).view(torch.float16).double() * torch.exp2(-torch.from_numpy(fx["all16_exp"]).double())[:, None]
+        allc = torch.arange(S)
+        num_all = (allc < pad_lo) | (allc >= pad_hi)
+        floor16 = torch.exp2(-torch.from_numpy(fx["all16_exp"]).double() - 24.0)[:, None]   # half an fp16 subnormal step, in score units
+        err = ((sc.double() - ref16).abs() - atol - floor16).clamp_min(0) / ref16.abs().clamp_min(1e-300)
+        err = err[:, num_all]
+        bad = int((err > rtol + 2.0 ** -11).sum())
+        assert bad == 0, f"{bad} scores differ from the reference's (all columns, half precision) by more than {rtol + 2.0 ** -11:.2e}: worst {float(err.max()):.3e}"
     if "sub_pure" in fx:   # all-float32 reference run (queries never rounded to bf16): differs by the model's bf16 q / cos / sin
         pure = torch.from_numpy(fx["sub_pure"])
         rel_pure = ((got - pure).abs() / pure.abs().clamp_min(1e-30))[:, numeric]
