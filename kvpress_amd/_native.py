@@ -415,9 +415,30 @@ def qproj_rope_supported(module, hidden_states: torch.Tensor, window: int) -> bo
     return USE_LIBRARY_QPROJ and hidden_states.shape[0] == 1 and qproj_rope_eligible(module, hidden_states, window)
 
 
+_QP_ELIGIBLE: dict = {}   # (id(module), weight data_ptr, weight version, dtype, window) -> the module-side half of the answer
+
+
 def qproj_rope_eligible(module, hidden_states: torch.Tensor, window: int) -> bool:
     """True if the window's q_proj + RoPE can run in the library (qproj.hip): a plain bias-free ``nn.Linear`` q_proj in
     bf16 / f16 (not a quantised or LoRA-wrapped subclass), no per-head q_norm, window 64, head_dim 128, hidden % 256 == 0."""
+    lin = module.__dict__.get("_modules", {}).get("q_proj")
+    if type(lin) is torch.nn.Linear and hidden_states.is_cuda and hidden_states.stride(-1) == 1:
+        w = lin._parameters.get("weight")
+        if w is not None:   # (the module-side checks are remembered per weight tensor: they cost more than the rest of the call's Python)
+            key = (id(module), w.data_ptr(), w._version, hidden_states.dtype, window, lin._parameters.get("bias") is None,
+                   "q_norm" in module.__dict__["_modules"])
+            hit = _QP_ELIGIBLE.get(key)
+            if hit is not None:
+                return hit
+            ok = _qproj_rope_eligible_slow(module, hidden_states, window)
+            if len(_QP_ELIGIBLE) > 512:
+                _QP_ELIGIBLE.clear()
+            _QP_ELIGIBLE[key] = ok
+            return ok
+    return _qproj_rope_eligible_slow(module, hidden_states, window)
+
+
+def _qproj_rope_eligible_slow(module, hidden_states: torch.Tensor, window: int) -> bool:
     lin = getattr(module, "q_proj", None)
     if type(lin) is not torch.nn.Linear or lin.bias is not None or hasattr(module, "q_norm"):
         return False
@@ -488,12 +509,12 @@ def snapkv_compress_hidden(hidden_win: torch.Tensor, wq: torch.Tensor, cos: torc
     vo = torch.empty_like(ko)
     if n:
         with _on_device(keys.device):
-            ws = _clean_ws("snapkv", (B, Hq, Hkv, S, W, D, n), _ws_bytes("kvp_snapkv_compress_workspace_bytes", B, Hq, Hkv, S, W, D, n), keys)
+            st = _stream(keys)
+            ws = _clean_ws("snapkv", (B, Hq, Hkv, S, W, D, n), _ws_bytes("kvp_snapkv_compress_workspace_bytes", B, Hq, Hkv, S, W, D, n), keys, st)
             rc = lib().kvp_snapkv_compress_hidden(_p(hidden_win), _st(hidden_win, 0), _st(hidden_win, 1), _p(wq), K, _p(cos), _p(sin),
                                                   _st(cos, 0), _st(cos, 1), _p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2),
                                                   _p(values), _st(values, 0), _st(values, 1), _st(values, 2), _DTYPES[dt], B, Hq, Hkv, S,
-                                                  W, D, int(kernel_size), n, _p(ko), _p(vo), _p(ws), ws.numel(), TOPK_WS_CLEAN,
-                                                  _stream(keys))
+                                                  W, D, int(kernel_size), n, _p(ko), _p(vo), _p(ws), ws.numel(), TOPK_WS_CLEAN, st)
             if rc != 0:
                 _drop_ws(ws)
             _check(rc, "kvp_snapkv_compress_hidden")
@@ -654,11 +675,12 @@ def _ws_bytes(fn_name: str, *shape) -> int:
     return n
 
 
-def _clean_ws(kind: str, shape: tuple, nbytes: int, like: torch.Tensor) -> torch.Tensor:
+def _clean_ws(kind: str, shape: tuple, nbytes: int, like: torch.Tensor, stream_handle: Optional[int] = None) -> torch.Tensor:
     """Zero-filled-once workspace of a fused compress call, one per (device, stream, call shape): the calls leave its
     histogram region clean, so it is passed with KVP_TOPK_WS_CLEAN from then on."""
-    stream = torch.cuda.current_stream(like.device)
-    key = (kind, like.device.index, stream.cuda_stream) + tuple(shape)
+    if stream_handle is None:
+        stream_handle = torch.cuda.current_stream(like.device).cuda_stream
+    key = (kind, like.device.index, stream_handle) + tuple(shape)
     return _cached_ws(key, nbytes, like.device)
 
 
@@ -692,10 +714,11 @@ def knorm_compress(keys: torch.Tensor, values: torch.Tensor, n_kept: int):
     vo = torch.empty_like(ko)
     if n and B and H:
         with _on_device(keys.device):
-            ws = _clean_ws("knorm", (B, H, S, n), _ws_bytes("kvp_knorm_compress_workspace_bytes", B, H, S, n), keys)
+            st = _stream(keys)
+            ws = _clean_ws("knorm", (B, H, S, n), _ws_bytes("kvp_knorm_compress_workspace_bytes", B, H, S, n), keys, st)
             rc = lib().kvp_knorm_compress(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _p(values), _st(values, 0), _st(values, 1),
                                           _st(values, 2), _DTYPES[keys.dtype], B, H, S, D, n, _p(ko), _p(vo), _p(ws), ws.numel(),
-                                          TOPK_WS_CLEAN, _stream(keys))
+                                          TOPK_WS_CLEAN, st)
             if rc != 0:
                 _drop_ws(ws)
             _check(rc, "kvp_knorm_compress")
@@ -723,11 +746,12 @@ def snapkv_compress_rope(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tens
     vo = torch.empty_like(ko)
     if n:
         with _on_device(keys.device):
-            ws = _clean_ws("snapkv", (B, Hq, Hkv, S, W, D, n), _ws_bytes("kvp_snapkv_compress_workspace_bytes", B, Hq, Hkv, S, W, D, n), keys)
+            st = _stream(keys)
+            ws = _clean_ws("snapkv", (B, Hq, Hkv, S, W, D, n), _ws_bytes("kvp_snapkv_compress_workspace_bytes", B, Hq, Hkv, S, W, D, n), keys, st)
             rc = lib().kvp_snapkv_compress_rope(_p(q_pre), _st(q_pre, 0), _st(q_pre, 1), _st(q_pre, 2), _p(cos), _p(sin), _st(cos, 0),
                                                 _st(cos, 1), _p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _p(values),
                                                 _st(values, 0), _st(values, 1), _st(values, 2), _DTYPES[dt], B, Hq, Hkv, S, W, D,
-                                                int(kernel_size), n, _p(ko), _p(vo), _p(ws), ws.numel(), TOPK_WS_CLEAN, _stream(keys))
+                                                int(kernel_size), n, _p(ko), _p(vo), _p(ws), ws.numel(), TOPK_WS_CLEAN, st)
             if rc != 0:
                 _drop_ws(ws)
             _check(rc, "kvp_snapkv_compress_rope")
