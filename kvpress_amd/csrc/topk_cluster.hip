@@ -148,12 +148,6 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
     // into lane masks that overflow the scalar register file; the host launches once per 8 rows instead)
     const uint32_t row = a.row_base + cluster;
     if (row >= a.R) return;
-#ifdef KVP_TC_TIMING   // lab build (tools/select_lab.py --stamps): 10 ns time stamps of cluster 0's workgroups at the phase boundaries
-#define TC_STAMP(i) do { if (threadIdx.x == 0 && cluster == 0) a.w.bar[TC_CLUSTERS * 32 + 32 + slot * 16 + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define TC_STAMP(i) do { } while (0)
-#endif
-    TC_STAMP(0);
     {
         // ---- keys ------------------------------------------------------------------------------------------------
         uint32_t keys[PER];
@@ -241,7 +235,6 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             kmin = min(kmin, keys[j]);
             kmax = max(kmax, keys[j]);
         }
-        TC_STAMP(1);   // keys loaded
         const bool full = kmin != 0u;   // all PER positions inside the row
 
         uint32_t* h1 = a.w.hist1 + (size_t)row * 4096;
@@ -258,9 +251,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
                 const uint32_t c = lh[i];
                 if (c) tc_add(&h1[i], c);
             }
-            TC_STAMP(2);   // first histogram flushed
             cluster_barrier(cs, 1, &s_fail[0], true);
-            TC_STAMP(3);
         }
         uint32_t b1, k1;
         {
@@ -269,7 +260,6 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             for (int i = 0; i < 4; ++i) loc[i] = tc_ld(&h1[(TR_THREADS - 1 - threadIdx.x) * 4 + i]);
             row_find_bin_regs<4>(loc, TR_THREADS, k, scr, b1, k1);
         }
-        TC_STAMP(4);   // first digit found
         // ---- digit 2: (key >> 8) & 0xFFF among key >> 20 == b1 -----------------------------------------------------
         if (slot == 0 && threadIdx.x < 256) tc_st(&h3[threadIdx.x], 0u);   // self-cleaning: filled below, read after the last barrier
         for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
@@ -286,9 +276,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             const uint32_t c = lh[i];
             if (c) tc_add(&h2[i], c);
         }
-        TC_STAMP(5);   // second histogram flushed
         cluster_barrier(cs, 2, &s_fail[0], HIST1);
-        TC_STAMP(6);
         uint32_t b2, k2;
         {
             uint32_t loc[4];
@@ -297,7 +285,6 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             row_find_bin_regs<4>(loc, TR_THREADS, k1, scr, b2, k2);
         }
         const uint32_t prefix = (b1 << 12) | b2;
-        TC_STAMP(7);   // second digit found
         // ---- digit 3: key & 0xFF among key >> 8 == prefix; per-slot suffix table + count of larger prefixes ------------
         if (threadIdx.x < 256) lh[threadIdx.x] = 0;
         __syncthreads();
@@ -331,9 +318,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
                 tc_st(&a.w.chunk_gt[(size_t)row * TC_SLOTS + slot], ngt_tot);
             }
         }
-        TC_STAMP(8);   // third histogram + suffix table
         cluster_barrier(cs, 3, &s_fail[0], false);
-        TC_STAMP(9);
         uint32_t b3, quota;
         {
             uint32_t loc[1];
@@ -354,7 +339,6 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             return;
         }
         const uint32_t T = (prefix << 8) | b3;
-        TC_STAMP(10);  // threshold known
         // kept elements in the slots before this one
         uint32_t gt_part = 0, eq_part = 0;
         if (threadIdx.x < slot) {
@@ -371,7 +355,6 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             tc_st(&h1[i], 0u);
             tc_st(&h2[i], 0u);
         }
-        TC_STAMP(11);  // offsets of the earlier slots, histograms zeroed
         // ---- ordered compaction: keys > T, and the first `quota` keys == T ---------------------------------------------
         uint32_t cg = 0, ce = 0;
 #pragma unroll
@@ -404,7 +387,6 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < nmine; i += TR_THREADS)
             if (rank0 + i < k) out[rank0 + i] = ob[i];
-        TC_STAMP(12);
     }
 }
 

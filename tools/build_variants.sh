@@ -14,34 +14,14 @@ for spec in "$@"; do
   echo "built $name ($abl)"
 done
 python tools/gen_stage_asm.py kernel > /dev/null   # restore the production loops
-# tc_timing: the cluster select with phase time stamps (tools/select_lab.py --stamps)
+# tc_timing: the cluster select with phase time stamps (tools/select_lab.py --stamps): the stamps are a PATCH on the production source
+# (tools/lab_patches/tc_timing.diff), not #ifdefs inside it
 if [[ " $* " == *" tc_timing "* ]]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DKVP_TC_TIMING -c kvpress_amd/csrc/topk_cluster.hip -o /tmp/topk_cluster_timing.o
+  patch -s -o /tmp/topk_cluster_timing.hip kvpress_amd/csrc/topk_cluster.hip tools/lab_patches/tc_timing.diff
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Ikvpress_amd/csrc -c /tmp/topk_cluster_timing.hip -o /tmp/topk_cluster_timing.o
   objs=$(ls kvpress_amd/build/*.o | grep -v topk_cluster.o)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o kvpress_amd/lib/variants/tc_timing.so $objs /tmp/topk_cluster_timing.o
   echo "built tc_timing"
 fi
-# tc_l2 / tc_l2_timing: the cluster select on XCD-local (placement-dependent) traffic -- lab measurement only
-for v in tc_l2 tc_l2_timing; do
-  if [[ " $* " == *" $v "* ]]; then
-    fl="-DKVP_TC_L2LOCAL"; [[ $v == *timing ]] && fl="$fl -DKVP_TC_TIMING"
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $fl -c kvpress_amd/csrc/topk_cluster.hip -o /tmp/topk_cluster_$v.o
-    objs=$(ls kvpress_amd/build/*.o | grep -v topk_cluster.o)
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o kvpress_amd/lib/variants/$v.so $objs /tmp/topk_cluster_$v.o
-    echo "built $v"
-  fi
-done
-# tc_kn8: eight instead of four 64-row steps of the cluster select's Knorm stream in flight
-if [[ " $* " == *" tc_kn8 "* ]]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DTC_KN_UNROLL=8 -c kvpress_amd/csrc/topk_cluster.hip -o /tmp/topk_cluster_kn8.o
-  objs=$(ls kvpress_amd/build/*.o | grep -v topk_cluster.o)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o kvpress_amd/lib/variants/tc_kn8.so $objs /tmp/topk_cluster_kn8.o
-  echo "built tc_kn8"
-fi
-# tc_knnt: non-temporal loads in the cluster select's Knorm stream
-if [[ " $* " == *" tc_knnt "* ]]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DTC_KN_NT -c kvpress_amd/csrc/topk_cluster.hip -o /tmp/topk_cluster_knnt.o
-  objs=$(ls kvpress_amd/build/*.o | grep -v topk_cluster.o)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o kvpress_amd/lib/variants/tc_knnt.so $objs /tmp/topk_cluster_knnt.o
-  echo "built tc_knnt"
-fi
+# (round 3's other cluster-select lab variants -- XCD-local traffic, 8 steps in flight / non-temporal loads in the Knorm stream -- were
+# measured and dropped: profiles/r03_select_cluster_lab.txt, r03_stream_lab.txt; round 4's: tools/lab_patches/tc_speculation.diff)
