@@ -14,7 +14,9 @@
 // Measured (Llama-3.1-8B window, MI355X).  Round 1, in isolation: 20 us, on par with the library GEMM + RoPE launch it replaces
 // (17.6 + 5 us).  Round 4, inside bench.py's loop (two boxes, alternating runs, profiles/r04_qproj_lab.txt): the step is 3-4 us
 // SHORTER with this kernel (271.3 / 271.6 / 268.7 us against 274.5 / 275.9 / 273.0 / 272.0 with hipBLASLt 15.1 + RoPE 4.8), so the
-// presses now project the window here by default (kvpress_amd/_native.py USE_LIBRARY_QPROJ).
+// presses now project the window here by default (kvpress_amd/_native.py USE_LIBRARY_QPROJ).  A rotated tile walk (workgroup j of an
+// XCD starts at K tile j % 16, so the 32 CUs of an XCD do not ask their L2 for the same hidden-window lines at the same moment)
+// is worth another ~0.8 us of the kernel, 1.6 us of the step (three alternating A/B pairs: 271.9 against 273.5 us; KVP_QP_ROTATE=0).
 // What bounds it is the traffic between the L2s and the CUs, not HBM and not the matrix pipe: every workgroup pulls the whole hidden
 // window (512 KiB) next to its 128 KiB weight slice, 160 MiB in total, and that path delivers ~10 TB/s chip-wide when all CUs read
 // the same lines -- the library GEMM's 16 x 64 tiles move the same 160 MiB and take the same ~15 us.  Round 4 tried to hide it and
@@ -65,6 +67,7 @@ struct QprojArgs {
     int64_t cs_sb, cs_sw;  // element strides
     void* out;          // [B, Hq, 64, 128] contiguous
     uint32_t Hq, K;
+    uint32_t rotate;    // 1: workgroup j of an XCD starts its walk over the K tiles at tile j % ntiles (see the kernel)
 };
 
 // Tile rows 0..15 = the 16 weight rows (columns of the output tile), rows 16..79 = the 64 hidden-state rows; 512 B per row,
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(QP_THREADS) void qproj_rope_kernel(QprojArgs a) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t l16 = lane & 15, kq = lane >> 4;  // fragment row / column, k-slot group (8 elements)
     const uint32_t ntiles = a.K / QP_KT;
+    const uint32_t rot = a.rotate ? (blockIdx.x >> 3) % ntiles : 0u;
 
     // ---- LDS-DMA requests: request i of a tile moves chunks e = i * 512 + t; a wave's 64 chunks = 2 rows x 32 slots
     const char* gsrc[QP_REQ];     // global address of this thread's chunk in K tile 0
@@ -96,7 +100,12 @@ __global__ __launch_bounds__(QP_THREADS) void qproj_rope_kernel(QprojArgs a) {
         gsrc[i] = rowp + chunk * 16;
     }
     auto request_tile = [&](uint32_t t, uint32_t buf) {
-        const uint32_t tt = min(t, ntiles - 1);  // past the end: re-fetch the last tile (never read)
+        // Every workgroup reads the SAME hidden window; walking it in lockstep makes the 32 CUs of an XCD ask their L2 for the same
+        // lines at the same moment.  A rotated walk (workgroup j of an XCD starts at tile j % ntiles; blocks b, b + 8, ... share an
+        // XCD) spreads them over the window.  The sum over the tiles then runs in a rotated order per workgroup: still a fixed order.
+        uint32_t tt = min(t, ntiles - 1);  // past the end: re-fetch the last tile (never read)
+        tt += rot;
+        tt -= tt >= ntiles ? ntiles : 0u;
 #pragma unroll
         for (int i = 0; i < QP_REQ; ++i) {
             const char* g = gsrc[i] + (int64_t)tt * QP_ROWB;
@@ -182,6 +191,7 @@ int kvp_qproj_rope_launch(const void* x, int64_t x_sb, int64_t x_sw, const void*
     a.w = static_cast<const char*>(w);
     a.cosp = cosp; a.sinp = sinp; a.cs_sb = cs_sb; a.cs_sw = cs_sw;
     a.out = out; a.Hq = (uint32_t)Hq; a.K = (uint32_t)K;
+    a.rotate = kvp_env_int("KVP_QP_ROTATE", 1) ? 1u : 0u;
     const dim3 grid((uint32_t)(Hq * 8), (uint32_t)B);
     if (dtype == KVP_BF16) KVP_LAUNCH("qproj_rope_kernel", stream, qproj_rope_kernel<KVP_BF16><<<grid, QP_THREADS, 0, stream>>>(a));
     else KVP_LAUNCH("qproj_rope_kernel", stream, qproj_rope_kernel<KVP_F16><<<grid, QP_THREADS, 0, stream>>>(a));
