@@ -94,15 +94,14 @@ def main():
         wide = torch.randn((R, S), generator=g, device=DEV)
         for name, sc in (("flat", flat), ("wide", wide)):
             out = {}
-            for var, kv in (("cluster", dict(KVP_TK_CLUSTER=None, KVP_TC_SPEC=None)), ("cluster_nospec", dict(KVP_TK_CLUSTER=None, KVP_TC_SPEC=0)),
-                            ("passes", dict(KVP_TK_CLUSTER=0, KVP_TC_SPEC=None))):
+            # (with tools/lab_patches/tc_speculation.diff applied, KVP_TC_SPEC=0/1 switches the speculative second digit: profiles/r04_select_spec_lab.txt)
+            for var, kv in (("cluster", dict(KVP_TK_CLUSTER=None)), ("passes", dict(KVP_TK_CLUSTER=0))):
                 knobs(**ALL)
                 knobs(**kv)
                 ref = N.topk_select(sc, S // 2)
                 out[var] = (timeit(lambda: N.topk_select(sc, S // 2), args.reps), ref)
-            same = torch.equal(out["cluster"][1], out["passes"][1]) and torch.equal(out["cluster_nospec"][1], out["passes"][1])
-            print(f"select R={R} S={S} {name}: cluster {out['cluster'][0]:.1f} us, without speculation {out['cluster_nospec'][0]:.1f} us, "
-                  f"passes {out['passes'][0]:.1f} us, identical={same}", flush=True)
+            same = torch.equal(out["cluster"][1], out["passes"][1])
+            print(f"select R={R} S={S} {name}: cluster {out['cluster'][0]:.1f} us, passes {out['passes'][0]:.1f} us, identical={same}", flush=True)
     # ---- fused Knorm compress ----
     for S in (32768, 131072):
         k = torch.randn((1, 8, S, 128), generator=g, device=DEV).to(torch.bfloat16)
