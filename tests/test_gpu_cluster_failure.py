@@ -89,7 +89,8 @@ def test_select_under_a_cu_mask_is_right_or_raises(mask):
         pytest.skip(f"child did not run under HSA_CU_MASK={mask}: {out[-300:]}")
 
 
-def test_barrier_timeout_is_loud(knobs):
+@pytest.mark.parametrize("poll", [1, 0])
+def test_barrier_timeout_is_loud(knobs, poll):
     """One workgroup of cluster 0 arrives 2 x timeout late at its first barrier (test knob): the others give up.  Row 0's indices
     are -1 (other rows: untouched clusters, correct), the gather turns them into NaN rows, the next library call raises, the
     cached clean workspaces are gone, and then everything works again."""
@@ -104,7 +105,7 @@ def test_barrier_timeout_is_loud(knobs):
     torch.cuda.synchronize()
     n.async_error_check()
 
-    knobs(KVP_TC_TIMEOUT_US=20000, KVP_TC_TEST_DELAY_SLOT=5)
+    knobs(KVP_TC_TIMEOUT_US=20000, KVP_TC_TEST_DELAY_SLOT=5, KVP_TC_POLL=poll)   # both protocols: polled totals / counter barriers
     got = n.topk_select(d, 65472)            # returns KVP_OK: the failure happens on the device, later
     ko, vo = n.gather_kv(k, v, got.view(1, 8, -1))
     torch.cuda.synchronize()
@@ -113,7 +114,7 @@ def test_barrier_timeout_is_loud(knobs):
     assert np.array_equal(g[1:], want[1:]), "clusters that did not time out are unaffected"
     assert torch.isnan(ko[0, 0].float()).all() and torch.isnan(vo[0, 0].float()).all(), "poisoned indices must gather NaN rows"
     assert torch.equal(ko[0, 1], k[0, 1][torch.from_numpy(want[1]).long().to(DEV)])
-    knobs(KVP_TC_TIMEOUT_US=None, KVP_TC_TEST_DELAY_SLOT=None)
+    knobs(KVP_TC_TIMEOUT_US=None, KVP_TC_TEST_DELAY_SLOT=None, KVP_TC_POLL=None)
     with pytest.raises(n.KvpressHipError, match="cluster select"):
         n.topk_select(d, 65472)
     assert not n._TOPK_WS, "a reported failure must drop every cached 'clean' workspace"

@@ -163,7 +163,8 @@ def test_topk_second_pass_variants(S, knobs):
     flat = (2.0 ** -17 * (1 + 0.05 * rs.standard_normal((3, S)))).astype(np.float32)   # pooled-attention-like: +-5 % around one value
     ties = _inputs.round_to(-np.sqrt(rs.chisquare(64, size=(3, S))).astype(np.float32), "bf16")
     const = np.full((2, S), 0.25, np.float32)
-    variants = [dict(KVP_TK_CLUSTER=None, KVP_TK_H2_WIDE=None)] + [dict(KVP_TK_CLUSTER=0, KVP_TK_H2_WIDE=w) for w in (None, 4, 16, 32, 0)]
+    variants = ([dict(KVP_TK_CLUSTER=None, KVP_TK_H2_WIDE=None, KVP_TC_POLL=None), dict(KVP_TK_CLUSTER=None, KVP_TK_H2_WIDE=None, KVP_TC_POLL=0)]
+                + [dict(KVP_TK_CLUSTER=0, KVP_TK_H2_WIDE=w, KVP_TC_POLL=None) for w in (None, 4, 16, 32, 0)])
     for variant in variants:
         knobs(**variant)
         for sc_np in (wide, flat, ties, const):
@@ -189,9 +190,11 @@ def test_topk_cluster_select_rows_and_lengths(R, S, knobs):
     for sc_np in (flat, ties):
         t = torch.from_numpy(sc_np).to(DEV)
         for k in sorted({1, S // 2, S - 1}) * 2:
-            knobs(KVP_TK_CLUSTER=None)
+            knobs(KVP_TK_CLUSTER=None, KVP_TC_POLL=None)
             got = N.topk_select(t, k)
-            knobs(KVP_TK_CLUSTER=0)
+            knobs(KVP_TK_CLUSTER=None, KVP_TC_POLL=0)   # counter barriers instead of polled totals: same workspace, alternating
+            assert torch.equal(N.topk_select(t, k), got), f"R={R} S={S} k={k}: polled != barriers"
+            knobs(KVP_TK_CLUSTER=0, KVP_TC_POLL=None)
             legacy = N.topk_select(t, k)
             assert torch.equal(got, legacy), f"R={R} S={S} k={k}: cluster != passes"
             if R * S <= 8 * 131072:

@@ -15,9 +15,9 @@ for spec in "$@"; do
 done
 python tools/gen_stage_asm.py kernel > /dev/null   # restore the production loops
 # tc_timing: the cluster select with phase time stamps (tools/select_lab.py --stamps): the stamps are a PATCH on the production source
-# (tools/lab_patches/tc_timing.diff), not #ifdefs inside it
+# (inserted by tools/make_tc_timing.py), not #ifdefs inside it
 if [[ " $* " == *" tc_timing "* ]]; then
-  patch -s -o /tmp/topk_cluster_timing.hip kvpress_amd/csrc/topk_cluster.hip tools/lab_patches/tc_timing.diff
+  python tools/make_tc_timing.py /tmp/topk_cluster_timing.hip
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Ikvpress_amd/csrc -c /tmp/topk_cluster_timing.hip -o /tmp/topk_cluster_timing.o
   objs=$(ls kvpress_amd/build/*.o | grep -v topk_cluster.o)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o kvpress_amd/lib/variants/tc_timing.so $objs /tmp/topk_cluster_timing.o
