@@ -133,7 +133,7 @@ struct ClusterArgs {
     uint32_t* host_flag;
     uint32_t timeout_ticks;
     int32_t test_delay_slot;   // TEST AID: slot (of cluster 0) that arrives 2 x timeout late at its first barrier; -1 = none
-    uint32_t poll;             // 1: no arrival counters -- a round is complete when its histogram's total says so (see the kernel)
+    uint32_t poll;             // 1: round 1 without a counter barrier -- complete when its histogram's total says so (see the kernel)
     uint32_t interleave;       // 1: cluster = block % 8 (the 32 workgroups of a row on ONE XCD under the observed placement, lab only)
 };
 
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
     constexpr uint32_t L = TR_THREADS * PER;   // keys per workgroup
     __shared__ __attribute__((aligned(16))) uint32_t lh[L > 4096 ? L : 4096];   // histogram; KNORM: first the staged scores; last the staged output
     __shared__ uint32_t scr[TR_WAVES + 3];
-    __shared__ uint32_t s_fail[3];   // [0] this workgroup gave up at a barrier, [1] the cluster's flag as read after the last barrier, [2] round-3 arrivals (polling)
+    __shared__ uint32_t s_fail[2];   // [0] this workgroup gave up at a barrier, [1] the cluster's flag as read after the last barrier
     // A row's 32 workgroups are CONSECUTIVE blocks: whatever part of the grid the device can hold at once, whole clusters become
     // resident in dispatch order and finish, so a device with fewer free CUs than the grid (CU masking, a busy neighbour) makes
     // the launch slower, not stuck.  (interleave = 1, lab: cluster = block % 8 puts a row on one XCD under the observed
@@ -174,19 +174,15 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
     cs.host_flag = a.host_flag;
     cs.timeout_ticks = a.timeout_ticks;
     cs.delay_ticks = (cluster == 0 && (int32_t)slot == a.test_delay_slot) ? 2u * a.timeout_ticks : 0u;
-    if (threadIdx.x < 3) s_fail[threadIdx.x] = 0;   // (ordered before its first use by the barriers of the key loaders / histograms)
-    // Polling protocol (a.poll, rounds that count their own digit: not HIST1).  What a counter barrier buys -- "every workgroup's
-    // atomics have landed" -- the histogram itself can say: a round's global histogram is complete exactly when its total equals
-    // the number of keys that take part (round 1: the row's S valid keys; round 2: the count of the first digit's bin; round 3:
-    // the count of the second digit's bin), so a workgroup flushes and then repeats {read the histogram, search} until the total
-    // is right: no drain, no arrival atomic, no separate poll.  Round 3 also publishes plain tables, so there every workgroup
-    // drains its table stores first and then adds 1 to an arrival word next to its histogram counts; both must be complete.
-    // Slot 0 zeroes the third histogram and that word at the START of the launch and drains before its round-1 flush: nobody
-    // gets past round 1 before slot 0 has flushed (it always holds valid keys), so the zeros are in place before the first add.
+    if (threadIdx.x < 2) s_fail[threadIdx.x] = 0;   // (ordered before its first use by the barriers of the key loaders / histograms)
+    // Round 1 without a counter barrier (a.poll; rounds that count their own first digit: not HIST1).  What the barrier buys --
+    // "every workgroup's atomics have landed" -- the histogram itself can say: the row's first histogram is complete exactly when
+    // its total equals the row's S valid keys, so a workgroup flushes and then repeats {read the histogram, search} until the
+    // total is right: no drain, no arrival atomic, no separate poll (-1.6 us, profiles/r04_select_poll_lab.txt).  Rounds 2 and 3
+    // keep their counter barriers: on flat rows round 2 drains ~2400 atomics per workgroup, and pollers re-reading the
+    // histogram while those are in flight slow them down (measured: +1.9 us); round 3 publishes plain tables anyway.
     const bool poll = !HIST1 && a.poll != 0;
-    uint32_t* arr3 = cs.ctr + 3;
     const uint32_t max_poll = a.timeout_ticks / 100u + 8u;   // iterations: each costs >= one L2 round trip (~1 us)
-
     const uint32_t S = a.S, k = a.k, kmask = a.kmask;
     const uint32_t p0 = slot * L + threadIdx.x * PER;   // this thread's PER consecutive positions
 
@@ -194,10 +190,6 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
     // into lane masks that overflow the scalar register file; the host launches once per 8 rows instead)
     const uint32_t row = a.row_base + cluster;
     if (row >= a.R) return;
-    if (poll && slot == 0) {   // (see above: in place before anybody's first add; drained before this workgroup's round-1 flush)
-        if (threadIdx.x < 256) tc_st(&a.w.hist3[(size_t)row * 256 + threadIdx.x], 0u);
-        if (threadIdx.x == 256) tc_st(arr3, 0u);
-    }
     {
         // ---- keys ------------------------------------------------------------------------------------------------
         uint32_t keys[PER];
@@ -298,7 +290,6 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             for (int j = 0; j < PER; ++j) topk_hist_add_bin(lh, keys[j] >> 20, keys[j] != 0u);
             __syncthreads();
             if (poll) {
-                if (slot == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zeros of hist3 / arr3 are in L2 before this flush
                 if (cs.delay_ticks && threadIdx.x == 0) {                         // TEST AID: this workgroup flushes late
                     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
                     while (__builtin_amdgcn_s_memrealtime() - t0 < 2ull * cs.delay_ticks) __builtin_amdgcn_s_sleep(8);   // (a poll round is ~1.6 us, not 1)
@@ -332,8 +323,9 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             if (it >= max_poll) { TC_POLL_GIVE_UP(1u); break; }
             __builtin_amdgcn_s_sleep(2);
         }
+#undef TC_POLL_GIVE_UP
         // ---- digit 2: (key >> 8) & 0xFFF among key >> 20 == b1 -----------------------------------------------------
-        if (!poll && slot == 0 && threadIdx.x < 256) tc_st(&h3[threadIdx.x], 0u);   // self-cleaning: filled below, read after the last barrier
+        if (slot == 0 && threadIdx.x < 256) tc_st(&h3[threadIdx.x], 0u);   // self-cleaning: filled below, read after the last barrier
         for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
         __syncthreads();
         if (full && (kmin >> 8) == (kmax >> 8)) {   // all of this thread's keys in one bin (rows of equal scores): one weighted add
@@ -348,16 +340,13 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             const uint32_t c = lh[i];
             if (c) tc_add(&h2[i], c);
         }
-        if (!poll) cluster_barrier(cs, 2, &s_fail[0], HIST1);
-        uint32_t b2, k2, c2;
-        for (uint32_t it = 0;; ++it) {
+        cluster_barrier(cs, 2, &s_fail[0], HIST1 || poll);   // (the first counter barrier of the launch when round 1 was polled)
+        uint32_t b2, k2;
+        {
             uint32_t loc[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) loc[i] = tc_ld(&h2[(TR_THREADS - 1 - threadIdx.x) * 4 + i]);
-            const uint32_t total = tc_find<4>(loc, TR_THREADS, k1, scr, b2, k2, c2);
-            if (!poll || total == c1) break;   // c1 = the keys that carry the first digit: exactly those take part in this round
-            if (it >= max_poll) { TC_POLL_GIVE_UP(2u); break; }
-            __builtin_amdgcn_s_sleep(2);
+            row_find_bin_regs<4>(loc, TR_THREADS, k1, scr, b2, k2);
         }
         const uint32_t prefix = (b1 << 12) | b2;
         // ---- digit 3: key & 0xFF among key >> 8 == prefix; per-slot suffix table + count of larger prefixes ------------
@@ -384,43 +373,32 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             uint32_t tot2;
             const uint32_t above = row_excl_scan(c, scr, &tot2);
             uint32_t* tab = a.w.chunk_hist + ((size_t)row * TC_SLOTS + slot) * 257;
-            if (threadIdx.x < 256) tc_st(&tab[d], above + c);   // suffix[d] = #(digit >= d)
+            if (threadIdx.x < 256) {
+                tc_st(&tab[d], above + c);   // suffix[d] = #(digit >= d)
+                if (c) tc_add(&h3[d], c);
+            }
             if (threadIdx.x == 0) {
                 tc_st(&tab[256], 0u);
                 tc_st(&a.w.chunk_gt[(size_t)row * TC_SLOTS + slot], ngt_tot);
             }
-            if (poll) {   // the tables are what the other workgroups read once this workgroup has "arrived": drain them first
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                // (a workgroup that gave up in an earlier round says so IN its arrival: the others learn it from the very word
-                // whose value lets them pass, not from a second load that could be served a moment earlier)
-                if (threadIdx.x == 0) tc_add(arr3, 1u + (s_fail[0] ? 0x10000u : 0u));
-            }
-            if (threadIdx.x < 256 && c) tc_add(&h3[d], c);
         }
-        if (!poll) cluster_barrier(cs, 3, &s_fail[0], false);
-        uint32_t b3, quota, c3;
-        for (uint32_t it = 0;; ++it) {
+        cluster_barrier(cs, 3, &s_fail[0], false);
+        uint32_t b3, quota;
+        {
             uint32_t loc[1];
             loc[0] = threadIdx.x < 256 ? tc_ld(&h3[255u - threadIdx.x]) : 0u;
-            // the cluster's give-up flag (and the arrival word) ride on the same round trip as the histogram read-back
+            // the cluster's give-up flag rides on the same round trip as the histogram read-back (thread 256 has no bin to fetch)
             if (threadIdx.x == 256) s_fail[1] = tc_ld(cs.cl_flag);
-            if (poll && threadIdx.x == 257) s_fail[2] = tc_ld(arr3);
-            const uint32_t total = tc_find<1>(loc, 256, k2, scr, b3, quota, c3);   // (its barriers publish s_fail[1], s_fail[2])
-            if (!poll || (total == c2 && (s_fail[2] & 0xFFFFu) == (uint32_t)TC_SLOTS)) break;
-            if (it >= max_poll) { TC_POLL_GIVE_UP(3u); break; }
-            __builtin_amdgcn_s_sleep(2);
+            row_find_bin_regs<1>(loc, 256, k2, scr, b3, quota);   // (its barriers publish s_fail[1])
         }
-#undef TC_POLL_GIVE_UP
         int32_t* out = a.idx + (int64_t)row * a.idx_stride;
         // ---- a barrier of this cluster timed out: NO index of this row is trustworthy ------------------------------------------
         // Every give-up of a cluster happens before any of its workgroups gets past the last barrier legitimately (that takes all
         // 32 arrivals, and a workgroup arrives at barrier 3 only after its own earlier give-ups), and a workgroup that gave up at
         // barrier 3 itself knows it from s_fail[0]: so every workgroup of the cluster takes this branch, none writes an index, and
         // together they fill the row's k + tail_n entries with -1 (kvp_gather_kv: a row of NaN instead of somebody else's token).
-        // (Polling protocol: the same argument with "arrival word == 32" in place of the last barrier; a workgroup that gave up in
-        // round 1 or 2 still makes its round-3 arrival, marked.)
-        if (s_fail[0] | s_fail[1] | (s_fail[2] >> 16)) {
+        // (A polled round 1 that timed out is one more "earlier give-up".)
+        if (s_fail[0] | s_fail[1]) {
             const uint32_t tot_out = k + a.tail_n, per = (tot_out + TC_SLOTS - 1) / TC_SLOTS;
             for (uint32_t j = slot * per + threadIdx.x; j < min((slot + 1) * per, tot_out); j += TR_THREADS) out[j] = -1;
             return;

@@ -18,11 +18,11 @@ ANCHORS = [
     ("            if (!poll) cluster_barrier(cs, 1, &s_fail[0], true);", 2, "before"),      # first histogram flushed
     ("            if (!poll) cluster_barrier(cs, 1, &s_fail[0], true);", 3, "after"),       # (counter barrier 1 passed)
     ("        // ---- digit 2: (key >> 8) & 0xFFF among key >> 20 == b1", 4, "before"),      # first digit found
-    ("        if (!poll) cluster_barrier(cs, 2, &s_fail[0], HIST1);", 5, "before"),          # second histogram flushed
-    ("        if (!poll) cluster_barrier(cs, 2, &s_fail[0], HIST1);", 6, "after"),
+    ("        cluster_barrier(cs, 2, &s_fail[0], HIST1 || poll);", 5, "before"),          # second histogram flushed
+    ("        cluster_barrier(cs, 2, &s_fail[0], HIST1 || poll);", 6, "after"),
     ("        const uint32_t prefix = (b1 << 12) | b2;", 7, "after"),                        # second digit found
-    ("        if (!poll) cluster_barrier(cs, 3, &s_fail[0], false);", 8, "before"),          # third histogram + suffix table
-    ("        if (!poll) cluster_barrier(cs, 3, &s_fail[0], false);", 9, "after"),
+    ("        cluster_barrier(cs, 3, &s_fail[0], false);", 8, "before"),          # third histogram + suffix table
+    ("        cluster_barrier(cs, 3, &s_fail[0], false);", 9, "after"),
     ("        const uint32_t T = (prefix << 8) | b3;", 10, "after"),                          # threshold known
     ("        // ---- ordered compaction: keys > T", 11, "before"),                           # offsets of the earlier slots, histograms zeroed
 ]
