@@ -152,6 +152,24 @@ __device__ __forceinline__ float tc_sumsq16(const uint4& v) {   // = rownorm.hip
     return a;
 }
 
+// topk_hist_add_bin (topk_internal.h) with a per-lane weight of `w` for the lanes flagged `heavy` and 1 for the others: two rounds of
+// wave-level aggregation, then plain LDS atomics.  Every thread of the wave must call it together.
+__device__ __forceinline__ void tc_hist_add_weighted(uint32_t* lds_hist, uint32_t bin, bool valid, bool heavy, uint32_t w) {
+    const uint64_t hv = __ballot(heavy);
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const uint64_t todo = __ballot(valid);
+        if (todo == 0) return;
+        const int leader = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
+        const uint64_t same = __ballot(valid && bin == b0);
+        if ((int)(threadIdx.x & 63) == leader)
+            atomicAdd(&lds_hist[b0], (uint32_t)__popcll(same & hv) * w + (uint32_t)__popcll(same & ~hv));
+        valid = valid && bin != b0;
+    }
+    if (valid) atomicAdd(&lds_hist[bin], heavy ? w : 1u);
+}
+
 // out-of-range positions carry key 0; real keys are >= 1 (as in topk_row_kernel)
 __device__ __forceinline__ uint32_t tc_key(float f, uint32_t kmask) { return max(float_to_key(f) ^ kmask, 1u); }
 
@@ -286,8 +304,16 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
         if (!HIST1) {
             for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
             __syncthreads();
+            if (PER == 1) {
+                topk_hist_add_bin(lh, keys[0] >> 20, keys[0] != 0u);
+            } else {
+                // a thread whose PER consecutive keys share their first digit (the usual case: neighbouring scores of a row) adds them
+                // in ONE wave-aggregated step with weight PER; only the threads with mixed digits take part in the steps 1 .. PER-1
+                const bool uni = full && (kmin >> 20) == (kmax >> 20);
+                tc_hist_add_weighted(lh, keys[0] >> 20, keys[0] != 0u, uni, (uint32_t)PER);
 #pragma unroll
-            for (int j = 0; j < PER; ++j) topk_hist_add_bin(lh, keys[j] >> 20, keys[j] != 0u);
+                for (int j = 1; j < PER; ++j) topk_hist_add_bin(lh, keys[j] >> 20, !uni && keys[j] != 0u);
+            }
             __syncthreads();
             if (poll) {
                 if (cs.delay_ticks && threadIdx.x == 0) {                         // TEST AID: this workgroup flushes late
