@@ -537,7 +537,7 @@ def main():
     _native.lib()  # fail loudly if the HIP extension is missing
     lo, hi = shard_batch(world, world, rank)  # global batch = one element per GPU (weak scaling)
     head = measure(args.workload, args.steps, args.warmup, args.prewarm_ms, world, rank, lo, hi, device, args.live_pmc, args.profile_json,
-                   cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline), parity=(rank == 0))
+                   cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline), parity=(rank == 0 and world == 1))   # (N > 1: timing only)
     # ---- BASELINE.json's other single-GPU configurations, measured in the SAME run so that the driver's record carries them
     # (VERDICT r3 #7): config 2 (Knorm 32k) and config 4 (ExpectedAttention 128k).  After the headline's timed region; N = 1 only.
     extra = None
