@@ -262,9 +262,6 @@ int kvp_snapkv_compress_hidden(const void* hidden_win, int64_t x_sb, int64_t x_s
 int kvp_prof_enable(int on);
 int kvp_prof_count(void);
 int kvp_prof_get(int i, const char** name, float* ms);
-/* kvp_prof_kernel_clock: with profiling enabled, snapkv_p1_mfma (the dominant kernel of the SnapKV path) measures the
- * shader clock over its own lifetime (s_memtime / s_memrealtime); this returns the last value in MHz (0 if none). */
-int kvp_prof_kernel_clock(float* mhz);
 /* kvp_clock_probe: enqueue a one-wave kernel that spins spin_us microseconds and writes the shader clock (MHz, float, device
  * memory) it saw: s_memtime ticks per 100 MHz s_memrealtime tick.  Enqueued right behind a kernel it shows the clock that
  * kernel ran at (the governor is slow compared with a kernel). */

@@ -93,7 +93,6 @@ SIGNATURES = {
     "kvp_clock_probe": (c_int, [c_void_p, c_int, c_void_p]),
     "kvp_occupy_cus": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
     "kvp_tuning_reload": (c_int, []),
-    "kvp_prof_kernel_clock": (c_int, [ctypes.POINTER(c_float)]),
 }
 
 _lib = None
@@ -800,13 +799,6 @@ def gather_kv_rerotate(keys: torch.Tensor, values: torch.Tensor, idx: torch.Tens
 
 
 # ------------------------------------------------------------------------------------------------
-def prof_kernel_clock() -> float:
-    """Shader clock (MHz) snapkv_p1_mfma measured inside its last profiled launch (0.0 if none)."""
-    v = c_float(0.0)
-    _check(lib().kvp_prof_kernel_clock(ctypes.byref(v)), "kvp_prof_kernel_clock")
-    return float(v.value)
-
-
 def clock_probe(device=None, spin_us: int = 20) -> torch.Tensor:
     """Enqueue a shader-clock probe on the current stream; returns a 1-element float32 device tensor (MHz) that is valid
     once the stream has run it."""

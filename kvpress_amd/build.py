@@ -17,6 +17,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libkvpress_hip.so")
+# Test-only twin of the library: identical objects except topk_cluster.hip compiled with -DKVP_TC_FAULT_INJECTION (one workgroup of the
+# cluster select can be made to arrive late at its barrier: tests/test_gpu_cluster_failure.py loads it in a child process through
+# KVPRESS_HIP_LIB).  The product library carries no test hooks.
+FAULT_LIB = os.path.join(LIBDIR, "libkvpress_hip_faultinject.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -47,9 +51,9 @@ def _deps():
 
 
 def up_to_date() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(FAULT_LIB):
         return False
-    t = os.path.getmtime(LIB)
+    t = min(os.path.getmtime(LIB), os.path.getmtime(FAULT_LIB))
     return all(os.path.getmtime(p) <= t for p in sources() + _deps() + [os.path.abspath(__file__)])
 
 
@@ -84,6 +88,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     os.replace(LIB + ".tmp", LIB)
+    # the fault-injection twin (tests only)
+    src = os.path.join(CSRC, "topk_cluster.hip")
+    fobj = os.path.join(OBJDIR, "topk_cluster.faultinject.obj")
+    cmd = [hipcc, *flags_for(src), "-DKVP_TC_FAULT_INJECTION", "-c", src, "-o", fobj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src} (fault injection):\n{r.stdout}\n{r.stderr}")
+    fobjs = [fobj if os.path.basename(o) == "topk_cluster.o" else o for o in objs]
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", FAULT_LIB + ".tmp", *fobjs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed (fault injection):\n{r.stdout}\n{r.stderr}")
+    os.replace(FAULT_LIB + ".tmp", FAULT_LIB)
     return LIB
 
 

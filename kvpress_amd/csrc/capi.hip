@@ -20,6 +20,7 @@ void kvp_set_error(const char* fmt, ...) {
 // ONCE -- at its first use -- and then served from this table, so the launch path never calls getenv (a data race in glibc
 // if another host thread calls setenv concurrently) and the launch geometry cannot change silently in the middle of a run.
 // kvp_tuning_reload() drops the table: the next use of every knob re-reads the environment (tests, lab scripts).
+#include <atomic>
 #include <mutex>
 #include <vector>
 namespace {
@@ -71,15 +72,30 @@ uint32_t* kvp_async_flag() {
     }
     return g_async_dev;
 }
+uint32_t kvp_async_next_seq() {
+    static std::atomic<uint32_t> seq{0};
+    uint32_t v;
+    do v = (seq.fetch_add(1, std::memory_order_relaxed) + 1) & 0xFFFFFFu; while (v == 0);
+    return v;
+}
 int kvp_async_check(const char* who) {
-    volatile uint32_t* f = g_async_host;
+    volatile uint32_t* f = g_async_host;   // (set once, under the mutex, before any kernel could have been handed the address)
     if (!f) return KVP_OK;
-    const uint32_t code = *f;
-    if (code == 0) return KVP_OK;
-    *f = 0;
-    kvp_set_error("%s: an EARLIER cluster select on this process gave up at its barrier %u (its 32 workgroups per row never became "
-                  "co-resident within KVP_TC_TIMEOUT_US); the indices of that call were poisoned with -1 (gathered rows: all-ones bit "
-                  "patterns = NaN) and every workspace used with KVP_TOPK_WS_CLEAN since must be zero-filled again",
+    if (*f == 0) return KVP_OK;
+    // consume the report atomically: two host threads polling at once must not both see it, and a store that lands between a plain
+    // read and a plain clear must not be lost
+    const uint32_t word = __atomic_exchange_n(const_cast<uint32_t*>(f), 0u, __ATOMIC_ACQ_REL);
+    if (word == 0) return KVP_OK;
+    {
+        // a late store of a launch whose failure was already reported (its other workgroups' stores came first): not a new event
+        static std::atomic<uint32_t> last_reported{0};
+        const uint32_t seq = word >> 8;
+        if (seq != 0 && last_reported.exchange(seq, std::memory_order_acq_rel) == seq) return KVP_OK;
+    }
+    const uint32_t code = word & 0xFFu;
+    kvp_set_error("%s: an EARLIER cluster select of this process (any thread) gave up at its barrier %u -- its 32 workgroups per row never "
+                  "became co-resident within KVP_TC_TIMEOUT_US, or its 'clean' workspace still carried an earlier failure.  That call's "
+                  "indices are -1 (gathered rows: NaN); zero-fill every workspace used with KVP_TOPK_WS_CLEAN since",
                   who, (unsigned)code);
     return KVP_EASYNC;
 }
@@ -131,23 +147,6 @@ extern "C" int kvp_prof_get(int i, const char** name, float* ms) {
         return KVP_EHIP;
     }
     *name = g_prof[i].name.c_str();
-    return KVP_OK;
-}
-
-// ---- in-kernel clock of the dominant kernel (measurement aid) -------------------------------------------------------
-static thread_local float* g_clock_slot = nullptr;
-float* kvp_prof_clock_slot() {
-    if (!g_clock_slot && hipMalloc(&g_clock_slot, sizeof(float)) != hipSuccess) g_clock_slot = nullptr;
-    return g_clock_slot;
-}
-extern "C" int kvp_prof_kernel_clock(float* mhz) {
-    KVP_CHECK_ARG(mhz, "kvp_prof_kernel_clock: null pointer");
-    *mhz = 0.f;
-    if (!g_clock_slot) return KVP_OK;  // no profiled snapkv_p1_mfma launch yet
-    if (hipMemcpy(mhz, g_clock_slot, sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
-        kvp_set_error("kvp_prof_kernel_clock: copy failed");
-        return KVP_EHIP;
-    }
     return KVP_OK;
 }
 

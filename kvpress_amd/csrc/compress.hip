@@ -87,9 +87,9 @@ extern "C" int kvp_knorm_compress(const void* k, int64_t k_sb, int64_t k_sh, int
         return KVP_EHIP;
     }
     // long rows of 256-byte keys (Llama: D = 128, bf16 / f16): norms, select digits and compaction in ONE launch, the scores stay
-    // in registers (topk_cluster.hip); KVP_TK_CLUSTER_KNORM=0 / other shapes / a device that cannot hold the grid: the sequence below
+    // in registers (topk_cluster.hip); other shapes / a device that cannot hold the grid / KVP_TK_CLUSTER=0: the sequence below
     if (n_kept < S && topk_cluster_eligible(R, S) && (dtype == KVP_BF16 || dtype == KVP_F16) && D == 128 && ((uintptr_t)k % 16) == 0 &&
-        (k_sb * 2) % 16 == 0 && (k_sh * 2) % 16 == 0 && (k_ss * 2) % 16 == 0 && kvp_env_int("KVP_TK_CLUSTER_KNORM", 1)) {
+        (k_sb * 2) % 16 == 0 && (k_sh * 2) % 16 == 0 && (k_ss * 2) % 16 == 0) {
         TopkWs tw = topk_carve_ws(w.topk, R, (S + TK_CHUNK - 1) / TK_CHUNK);
         const int rc = topk_cluster_select(TOPK_CLUSTER_KNORM, nullptr, 0, 1.f, k, dtype, k_sb, k_sh, k_ss, H, -1.0f, R, S, n_kept, w.idx, n_kept, 0, 0, tw,
                                            false, stream);
@@ -112,7 +112,7 @@ extern "C" size_t kvp_snapkv_compress_workspace_bytes(int64_t B, int64_t Hq, int
 
 // long rows, kernel_size 5: the cluster select pools SnapKV's column sums in its loader (no pooling launch, no score round trip)
 static bool snapkv_cluster_pooled(int64_t R, int64_t Sm, int kernel_size) {
-    return kernel_size == 5 && topk_cluster_eligible(R, Sm) && topk_cluster_launchable() && kvp_env_int("KVP_TK_CLUSTER_POOL", 1);
+    return kernel_size == 5 && topk_cluster_eligible(R, Sm) && topk_cluster_launchable();
 }
 
 // select + gather after a SnapKV scorer has run (fused: hist1 holds the first pass over the S - W non-window columns)

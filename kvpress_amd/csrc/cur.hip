@@ -145,7 +145,7 @@ extern "C" int kvp_cur_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t 
     float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + 2 * half);
     const uint32_t R = (uint32_t)(B * H);
     const uint32_t nblk = (uint32_t)std::max<int64_t>(1, std::min<int64_t>({(S + CU_THREADS - 1) / CU_THREADS, (int64_t)CU_MAXBLK, std::max<int64_t>(1, 2048 / R)}));
-    if (local_window_size >= 2 && CU_THREADS % local_window_size == 0 && kvp_env_int("KVP_CUR_LDS", 1) != 0)   // windows never straddle a workgroup's 256-token span
+    if (local_window_size >= 2 && CU_THREADS % local_window_size == 0)   // windows never straddle a workgroup's 256-token span
         KVP_LAUNCH("cur_combine_kernel", stream, cur_combine_lds_kernel<<<dim3(nblk, R), CU_THREADS, 0, stream>>>(k2, v2, (uint32_t)S, (uint32_t)local_window_size,
                                                                                                                  leverage_type, scores, partial));
     else

@@ -481,8 +481,7 @@ extern "C" int kvp_ea_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
         rows = (rows + 255) / 256 * 256;
         const uint32_t nslot = (uint32_t)(((uint64_t)Sp + rows - 1) / rows);
         const dim3 grid(nslot, BH);
-        const int nte = kvp_env_int("KVP_RN_NT", -1);   // read-once V (rownorm.hip: rn_streaming)
-        const bool nt = nte >= 0 ? nte != 0 : (uint64_t)BH * Sp * 256 > (192ull << 20);
+        const bool nt = (uint64_t)BH * Sp * 256 > (192ull << 20);   // read-once V (rownorm.hip: rn_streaming)
         const char* vp = static_cast<const char*>(v) + n_sink * v_ss * es;
 #define KVP_EVF(DTV, TT, NTV, GV) KVP_LAUNCH("ea_vnorm_finalize_kernel", stream, (ea_vnorm_finalize_kernel<DTV, NTV, GV><<<grid, EVF_THREADS, 0, stream>>>(reinterpret_cast<const TT*>(vp), v_sb, v_sh, v_ss, w.logits, w.part_m, w.part_z, nblk, (uint32_t)Hq, (uint32_t)Hkv, (uint32_t)S, (uint32_t)n_sink, epsilon, scores, w.bmax, (uint32_t)rows, a.clear_word)))
 #define KVP_EVF_G(DTV, TT, NTV) do { switch (Hq / Hkv) { case 1: KVP_EVF(DTV, TT, NTV, 1); break; case 2: KVP_EVF(DTV, TT, NTV, 2); break; default: KVP_EVF(DTV, TT, NTV, 4); break; } } while (0)

@@ -1,18 +1,11 @@
 // ExpectedAttention on the matrix cores (bf16 / f16, D = 128): query statistics and quadratic-form logits.
 //
 // (1) ea_qstats_mfma  -- mu, cov of the pre-RoPE queries (expected_attention_press.py:74-80), one pass over Q.
-//     cov = X^T X needs, for both MFMA operands, "column fragments" (a lane holds several ROWS s of one
-//     dimension d), while X is stored row-major.  The transpose is done BY the MFMA: T = X_tile . E with a
-//     32x32 selection matrix E puts X^T into the C layout (lane = one dim, 16 rows), where the fp32 values are
-//     shifted by a per-workgroup estimate m0 of the mean (shifted-data algorithm: no cancellation), rounded
-//     to 16 bits and used directly as A and B fragments of the syrk MFMAs -- the k-index (row) assignment of a
-//     fragment slot is arbitrary as long as A and B agree, and they are built by the same procedure.
-//     Each workgroup writes a partial (S2 about m0, sum(x - m0), m0, n); ea_qstats_combine merges them with
-//     the pairwise (Chan) update.  Rounding (x - m0) to bf16 perturbs each product by ~2^-9 |x - m0| with
-//     zero mean on random data (~4.6e-3 / sqrt(n) relative), but the inputs themselves live on a 16-bit grid, so
-//     for structured data the rounding is partly systematic: measured worst entry 1.8e-3 sigma_i sigma_j, mean
-//     2.5e-5; end-to-end scores stay within 1e-3 (tests/test_gpu_parity.py::test_ea_full_chain_mfma_vs_oracle).
-//     The path is taken for Sq >= 4096; shorter sequences use the exact fp32 generic kernels.
+//     cov = X^T X needs, for both MFMA operands, "column fragments" (a lane holds several ROWS s of one dimension d), while X is
+//     stored row-major: the transpose happens in the LDS read (ds_read_b64_tr_b16, see (1b) below).  Each workgroup writes a
+//     partial (raw second moments, column sums, row count); ea_qstats_combine merges them with the pairwise (Chan) update.
+//     Accuracy of the raw moments: see (1b); end-to-end scores stay within 1e-3 (tests/test_gpu_parity.py::
+//     test_ea_full_chain_mfma_vs_oracle).  The path is taken for Sq >= 4096; shorter sequences use the exact fp32 generic kernels.
 //
 // (2) ea_logits_mfma  -- log2-logits k.mu/sqrt(D) + k^T cov k/(2D) per q-head (:148-151) and per-chunk
 //     softmax partials.  C = cov_strip . K_tile^T with cov split into hi + lo 16-bit parts (two MFMA chains,
@@ -58,33 +51,10 @@ template <> __device__ __forceinline__ float lo16<KVP_BF16>(uint32_t w) { return
 template <> __device__ __forceinline__ float hi16<KVP_BF16>(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
 template <> __device__ __forceinline__ float lo16<KVP_F16>(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xFFFFu)); }
 template <> __device__ __forceinline__ float hi16<KVP_F16>(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
-template <int DT> __device__ __forceinline__ float round16(float x) { return lo16<DT>(pack2<DT>(x, 0.f)); }
 template <int DT> __device__ __forceinline__ uint32_t one16();
 template <> __device__ __forceinline__ uint32_t one16<KVP_BF16>() { return 0x3F80u; }
 template <> __device__ __forceinline__ uint32_t one16<KVP_F16>() { return 0x3C00u; }
 
-// --- row tile staging: 64 rows x 256 B, XOR-swizzled by (row & 15) << 4 (conflict-free ds_read_b128) ------
-struct Stage {
-    uint4 v[4];
-};
-__device__ __forceinline__ Stage stage_load(const char* __restrict__ base, int64_t row_bytes, uint32_t row0, uint32_t nrows) {
-    const uint32_t r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
-    Stage st;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t r = min(row0 + r0 + 16 * i, nrows - 1);  // unconditional loads; rows past the end are masked later
-        st.v[i] = *reinterpret_cast<const uint4*>(base + (int64_t)r * row_bytes + ch * 16);
-    }
-    return st;
-}
-__device__ __forceinline__ void stage_store(const Stage st, unsigned char* buf) {
-    const uint32_t r0 = threadIdx.x >> 4, ch = threadIdx.x & 15;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t row = r0 + 16 * i;
-        *reinterpret_cast<uint4*>(buf + row * EM_ROWB + ((ch ^ (row & 15)) << 4)) = st.v[i];
-    }
-}
 // 16-byte fragment: row sub*32 + n, 16-byte column c16
 __device__ __forceinline__ uint4 frag16(const unsigned char* buf, uint32_t sub, uint32_t c16, uint32_t n) {
     const uint32_t row = sub * 32 + n;
@@ -104,134 +74,9 @@ struct QstatArgs {
     uint32_t nt;  // non-temporal Q stream (read once)
 };
 
-// transpose the 32 rows x 32 dims block (sub, ct) of the tile into the C layout: lane (dim j = lane & 31, kg),
-// T[r] = x[row (r&3)+8(r>>2)+4kg][dim ct*32+j]
-template <int DT>
-__device__ __forceinline__ f32x16 transpose_block(const unsigned char* buf, uint32_t sub, uint32_t ct, uint32_t n, uint32_t kg,
-                                                  const uint4& e0, const uint4& e1) {
-    f32x16 T;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) T[i] = 0.f;
-    T = mma32<DT>(frag16(buf, sub, ct * 4 + 0 + kg, n), e0, T);  // dims ct*32 + [0,16): 16-byte columns ct*4 + {0,1}
-    T = mma32<DT>(frag16(buf, sub, ct * 4 + 2 + kg, n), e1, T);  // dims ct*32 + [16,32)
-    return T;
-}
-
-template <int DT>
-__global__ __launch_bounds__(EM_THREADS, 2) void ea_qstats_mfma_kernel(QstatArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * EM_TILEB];
-    const uint32_t hq = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t n = lane & 31, kg = lane >> 5;
-    const uint32_t bh = b * a.Hq + hq;
-    const char* base = static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh) * 2;
-    const int64_t row_bytes = a.q_ss * 2;
-    const uint32_t rbeg = chunk * a.rows_per_chunk;
-    const uint32_t rend = min(rbeg + a.rows_per_chunk, a.Sq);
-    if (rbeg >= rend) return;  // (cannot happen: nchunk is derived from Sq)
-    const uint32_t ntiles = (rend - rbeg + EM_TILE - 1) / EM_TILE;
-
-    // selection matrices E_t (16 x 32): B[k][j] = 1 iff j == 16 t + k; lane (j, kg) holds k = 8 kg + e
-    uint32_t ew[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int e_lo = 2 * p, e_hi = 2 * p + 1;
-            const uint32_t lo = ((int)n == 16 * t + 8 * (int)kg + e_lo) ? one16<DT>() : 0u;
-            const uint32_t hi = ((int)n == 16 * t + 8 * (int)kg + e_hi) ? one16<DT>() : 0u;
-            ew[t][p] = lo | (hi << 16);
-        }
-    const uint4 e0 = make_uint4(ew[0][0], ew[0][1], ew[0][2], ew[0][3]);
-    const uint4 e1 = make_uint4(ew[1][0], ew[1][1], ew[1][2], ew[1][3]);
-
-    unsigned char* bufc = lds;
-    unsigned char* bufn = lds + EM_TILEB;
-    stage_store(stage_load(base, row_bytes, rbeg, a.Sq), bufc);
-    __syncthreads();
-
-    // relative column tiles: ct = (wv + i) & 3, so that index 0 is this wave's own strip (static indexing)
-    float m0r[4];
-    {
-        const uint32_t nv = min(32u, rend - rbeg);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t ct = (wv + i) & 3;
-            const f32x16 T = transpose_block<DT>(bufc, 0, ct, n, kg, e0, e1);
-            float s = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s += ((uint32_t)((r & 3) + 8 * (r >> 2) + 4 * kg) < nv) ? T[r] : 0.f;
-            s += __shfl_xor(s, 32);
-            // rounded to the input grid: where |mean| >> sigma the inputs sit on a coarse 16-bit grid and x - m0 is
-            // then exactly representable (no systematic rounding of the shifted values)
-            m0r[i] = round16<DT>(s / (float)nv);
-        }
-    }
-    f32x16 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    float dsum = 0.f;
-
-    for (uint32_t t = 0; t < ntiles; ++t) {
-        const uint32_t row0 = rbeg + t * EM_TILE;
-        Stage st = stage_load(base, row_bytes, min(row0 + EM_TILE, rend - 1), a.Sq);  // next tile (clamped)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const bool tail = row0 + sub * 32 + 32 > rend;
-            uint4 F[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t ct = (wv + i) & 3;
-                const f32x16 T = transpose_block<DT>(bufc, sub, ct, n, kg, e0, e1);
-                float y[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    y[r] = T[r] - m0r[i];
-                    if (tail && row0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg >= rend) y[r] = 0.f;
-                }
-                if (i == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) dsum += y[r];
-                }
-                F[i][0] = make_uint4(pack2<DT>(y[0], y[1]), pack2<DT>(y[2], y[3]), pack2<DT>(y[4], y[5]), pack2<DT>(y[6], y[7]));
-                F[i][1] = make_uint4(pack2<DT>(y[8], y[9]), pack2<DT>(y[10], y[11]), pack2<DT>(y[12], y[13]), pack2<DT>(y[14], y[15]));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i] = mma32<DT>(F[0][0], F[i][0], acc[i]);  // C[own dim][dim of tile (wv+i)&3] += sum over 16 rows
-                acc[i] = mma32<DT>(F[0][1], F[i][1], acc[i]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < ntiles) stage_store(st, bufn);
-        __syncthreads();
-        unsigned char* tmp = bufc; bufc = bufn; bufn = tmp;
-    }
-
-    // NOTE: dsum above is accumulated on the fp32 (unrounded) shifted values; S2 on their 16-bit roundings.
-    float* s2 = a.s2 + ((size_t)bh * a.nchunk + chunk) * 128 * 128;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t jt = (wv + i) & 3;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t di = wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            s2[(size_t)di * 128 + jt * 32 + n] = acc[i][r];
-        }
-    }
-    dsum += __shfl_xor(dsum, 32);
-    if (kg == 0) {
-        a.dsum[((size_t)bh * a.nchunk + chunk) * 128 + wv * 32 + n] = dsum;
-        a.m0[((size_t)bh * a.nchunk + chunk) * 128 + wv * 32 + n] = m0r[0];
-    }
-}
-
 // ---- (1b) query statistics with transposed LDS reads (gfx950 ds_read_b64_tr_b16) -------------------------------------------------
-// The same partials as ea_qstats_mfma_kernel (raw second moments: m0 = 0) at half its matrix-core work and almost none of its
-// VALU work: the row -> column transpose happens in the LDS read.  Within a 16-lane group, lane i supplies the address of an
+// Per (head, chunk of rows) partials: raw second moments sum x x^T (m0 = 0) and column sums; the row -> column transpose a syrk needs
+// happens in the LDS read (round 1 transposed BY an MFMA against a selection matrix: twice the matrix-core work, removed in round 5).  Within a 16-lane group, lane i supplies the address of an
 // 8-byte piece and lane c receives element c % 4 of pieces c / 4 + {0, 4, 8, 12} (tools/probe_tr.hip): with lane i pointing
 // at X[token t0 + i / 4][dim d0 + 4 (i % 4) ..], lane c gets X[t0 .. t0 + 3][d0 + c] -- four tokens of ONE dimension, which is
 // what both operands of the syrk MFMA want (a lane = one dimension, 8 consecutive tokens of the 16-token k-step: two reads).
@@ -410,10 +255,9 @@ __global__ __launch_bounds__(256) void ea_qstats_combine(const float* __restrict
 // partials are less to write, re-read and merge (32 per head: 67 MB), and a workgroup that walks more consecutive rows keeps its ring full
 // for longer; below one workgroup per CU the stream starves.  Inside the ExpectedAttention bench loop (scripts/ab_bench.sh,
 // profiles/r03_ab_bench.txt; statistics + combine, streaming loads): 32 per head 207 + 23 us, 16: 175 + 13, 8: 207 + 10.
-// KVP_EA_QCHUNKS caps the count.
 void qstats_plan(int64_t Sq, int64_t nbh, uint32_t& nchunk, uint32_t& rows) {
     const int64_t target = std::max<int64_t>(1, 512 / std::max<int64_t>(1, nbh));
-    const int64_t cap = std::min<int64_t>(32, std::max(1, kvp_env_int("KVP_EA_QCHUNKS", (int)std::min<int64_t>(32, target))));
+    const int64_t cap = std::min<int64_t>(32, target);
     int64_t nc = std::min<int64_t>(cap, std::max<int64_t>(1, (Sq + 4095) / 4096));
     nc = std::max<int64_t>(nc, std::min<int64_t>(32, (Sq + 16383) / 16384));   // many heads: still <= 16384 rows per fp32 partial (the raw moments' accuracy, see (1b))
     int64_t r = ((Sq + nc - 1) / nc + EM_TILE - 1) / EM_TILE * EM_TILE;
@@ -882,8 +726,6 @@ bool aligned8(int64_t x) { return x % 8 == 0; }
 
 // ---- host ---------------------------------------------------------------------------------------
 bool ea_mfma_qstats_eligible(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int dtype, int64_t Sq, int64_t D) {
-    const int off = kvp_env_int("KVP_EA_GENERIC", 0);
-    if (off) return false;
     // 16-bit rounding of the shifted products: relative covariance error ~ 4.6e-3 / sqrt(Sq) (1 sigma); shorter
     // sequences take the exact fp32 generic kernels
     return (dtype == KVP_BF16 || dtype == KVP_F16) && D == 128 && Sq >= 4096 && (uintptr_t)q % 16 == 0 && aligned8(q_sb) &&
@@ -904,23 +746,15 @@ int ea_mfma_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int 
     a.q = q; a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss;
     a.B = (uint32_t)B; a.Hq = (uint32_t)Hq; a.Sq = (uint32_t)Sq;
     qstats_plan(Sq, B * Hq, a.nchunk, a.rows_per_chunk);
-    const int nt_env = kvp_env_int("KVP_EA_QNT", -1);   // streaming Q loads when Q cannot stay in the memory-side cache anyway (as kvp_gather_kv)
-    a.nt = nt_env >= 0 ? nt_env != 0 : (uint64_t)B * Hq * Sq * 256 > (192ull << 20);
+    a.nt = (uint64_t)B * Hq * Sq * 256 > (192ull << 20);   // streaming Q loads when Q cannot stay in the memory-side cache anyway (as kvp_gather_kv)
     const size_t nbh = (size_t)B * Hq;
     a.s2 = static_cast<float*>(ws);
     a.dsum = a.s2 + nbh * a.nchunk * 16384;
     a.m0 = a.dsum + nbh * a.nchunk * 128;
     const dim3 grid((uint32_t)Hq, a.nchunk, (uint32_t)B);
-    if (kvp_env_int("KVP_EA_QSTATS_TR", 1)) {   // transposed LDS reads, raw moments (0: the MFMA-transposing, mean-shifted kernel)
-        // ring of three 64-token tiles, three workgroups per CU (measured 211 us at 128k x 32 heads; 4 x 2: 215, 5 x 2: 230, 2 x 4: 213)
-        const int ring = kvp_env_int("KVP_EA_QRING", 3);
-        if (ring >= 6) {
-            if (dtype == KVP_BF16) KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_BF16, 6, 1><<<grid, EM_THREADS, 0, stream>>>(a)));
-            else KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_F16, 6, 1><<<grid, EM_THREADS, 0, stream>>>(a)));
-        } else if (dtype == KVP_BF16) KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_BF16, 3, 3><<<grid, EM_THREADS, 0, stream>>>(a)));
-        else KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_F16, 3, 3><<<grid, EM_THREADS, 0, stream>>>(a)));
-    } else if (dtype == KVP_BF16) KVP_LAUNCH("ea_qstats_mfma", stream, ea_qstats_mfma_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a));
-    else KVP_LAUNCH("ea_qstats_mfma", stream, ea_qstats_mfma_kernel<KVP_F16><<<grid, EM_THREADS, 0, stream>>>(a));
+    // ring of three 64-token tiles, three workgroups per CU (measured 211 us at 128k x 32 heads; 4 x 2: 215, 5 x 2: 230, 2 x 4: 213; 6 x 1: 256)
+    if (dtype == KVP_BF16) KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_BF16, 3, 3><<<grid, EM_THREADS, 0, stream>>>(a)));
+    else KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_F16, 3, 3><<<grid, EM_THREADS, 0, stream>>>(a)));
     const size_t sm = ((size_t)a.nchunk * 256 + 128) * 4;
     KVP_LAUNCH("ea_qstats_combine", stream, ea_qstats_combine<<<dim3(16, (uint32_t)nbh), 256, sm, stream>>>(a.s2, a.dsum, a.m0, a.Sq, a.nchunk, a.rows_per_chunk, mu, cov));
     KVP_CHECK_LAUNCH("ea_qstats_mfma");
@@ -928,8 +762,6 @@ int ea_mfma_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int 
 }
 
 bool ea_mfma_logits_eligible(const EaArgs& a, int dtype) {
-    const int off = kvp_env_int("KVP_EA_GENERIC", 0);
-    if (off) return false;
     return (dtype == KVP_BF16 || dtype == KVP_F16) && a.D == 128 && a.Sp >= 64 && (uintptr_t)a.k % 16 == 0 && aligned8(a.k_sb) &&
            aligned8(a.k_sh) && aligned8(a.k_ss) && a.G <= 65535;
 }
@@ -940,13 +772,14 @@ int ea_mfma_logits(const EaArgs& a, int dtype, float* logits, uint32_t nblk, flo
     const uint64_t units = (uint64_t)nblk * a.B * a.Hkv;
     KVP_CHECK_ARG((units + 7) / 8 * 8 * a.G < ((uint64_t)1 << 31), "ea_logits_mfma: grid too large");
     const dim3 grid((uint32_t)((units + 7) / 8 * 8 * a.G));   // (unit, head-in-group) -> linear id: see the kernel
-#define KVP_EL_LAUNCH(DTV, COV) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_kernel<DTV, COV><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)))
-    if (a.cov && kvp_env_int("KVP_EA_TRI", 1) != 0) {   // the quadratic form on the upper triangle of the covariance (2b)
+    if (a.cov) {   // the quadratic form on the doubled upper triangle of the covariance (2b): exact for any matrix, 40 instead of 64 MFMAs per tile and wave
         if (dtype == KVP_BF16) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)));
         else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_F16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)));
-    } else if (dtype == KVP_BF16) { if (a.cov) KVP_EL_LAUNCH(KVP_BF16, true); else KVP_EL_LAUNCH(KVP_BF16, false); }
-    else { if (a.cov) KVP_EL_LAUNCH(KVP_F16, true); else KVP_EL_LAUNCH(KVP_F16, false); }
-#undef KVP_EL_LAUNCH
+    } else if (dtype == KVP_BF16) {   // use_covariance = False: the mean term only
+        KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_kernel<KVP_BF16, false><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)));
+    } else {
+        KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_kernel<KVP_F16, false><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)));
+    }
     KVP_CHECK_LAUNCH("ea_logits_mfma");
     return KVP_OK;
 }

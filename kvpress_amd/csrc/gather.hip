@@ -153,16 +153,14 @@ extern "C" int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t 
     const uint32_t gpb = GA_THREADS / lpr;
     const uint64_t groups_needed = ((uint64_t)n + GA_UNROLL - 1) / GA_UNROLL;
     const uint64_t bx_full = (groups_needed + gpb - 1) / gpb;
-    const int wg_per_cu = kvp_env_int("KVP_GA_WG_PER_CU", 8);
-    const uint64_t bx_cap = std::max<uint64_t>(1, ((uint64_t)256 * wg_per_cu + BH - 1) / BH);
+    const uint64_t bx_cap = std::max<uint64_t>(1, ((uint64_t)256 * 8 + BH - 1) / BH);   // 8 workgroups of 256 threads per CU (4 / 16 measured slower)
     const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap));
     // Streaming (non-temporal) loads / stores when K + V do not fit the memory-side cache anyway (the cache is 256 MiB; the cutoff
     // chosen by measurement is 192 MiB of K + V): the copy must not
     // displace what the next kernels re-read nor leave its output behind as dirty lines -- at 128k tokens the following
     // window-attention pass pays for both (measured: its cold K stream 79 -> 50 us).  Smaller caches stay cached: there the
-    // rows just scored are still resident (32k tokens: gather 23 us cached vs 26 us streaming).  KVP_GA_NT=0/1 forces either.
-    const int nt_env = kvp_env_int("KVP_GA_NT", -1);
-    const bool nt = nt_env >= 0 ? nt_env != 0 : (uint64_t)B * H * S * a.rowbytes * 2 > (192ull << 20);
+    // rows just scored are still resident (32k tokens: gather 23 us cached vs 26 us streaming).
+    const bool nt = (uint64_t)B * H * S * a.rowbytes * 2 > (192ull << 20);
 #define KVP_GA_CASE(L)                                                                                                   \
     case L:                                                                                                              \
         if (nt) KVP_LAUNCH("gather_vec_kernel", stream, gather_vec_kernel<L, true><<<dim3(bx, BH), GA_THREADS, 0, stream>>>(a)); \

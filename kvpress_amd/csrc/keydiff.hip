@@ -250,10 +250,9 @@ KdPlan plan_for(const void* x, const KdMap& map, uint32_t BH, uint32_t D) {
         const uint64_t cap = std::max<uint64_t>(1, (256 * 8 + BH - 1) / BH);  // ~8 workgroups per CU in total
         p.nwg = (uint32_t)std::max<uint64_t>(1, std::min(full, cap));
         p.threads = KD_THREADS;
-        if (kvp_env_int("KVP_KD_SLOT", 1) != 0 && map.S >= 4096) {
-            p.threads = kvp_env_int("KVP_KD_THREADS", 1024) >= 1024 ? 1024 : 256;
-            const uint32_t per_cu = (uint32_t)std::min(8, std::max(1, kvp_env_int("KVP_KD_WGS", p.threads >= 1024 ? 1 : 8)));
-            const uint64_t want = std::max<uint64_t>(1, ((uint64_t)256 * per_cu + BH - 1) / BH);
+        if (map.S >= 4096) {   // long rows: the slot walk, one 1024-thread workgroup per CU (rownorm.hip)
+            p.threads = 1024;
+            const uint64_t want = std::max<uint64_t>(1, ((uint64_t)256 + BH - 1) / BH);
             const uint32_t step = p.threads / p.lpr * KD_UNROLL;
             uint64_t rows = ((uint64_t)map.S + want - 1) / want;
             rows = (rows + step - 1) / step * step;
@@ -273,17 +272,13 @@ int launch_keydiff(const void* x, KdMap map, uint32_t BH, uint32_t D, float* sco
     const T* xp = static_cast<const T*>(x);
     const KdPlan p = plan_for<DT>(x, map, BH, D);
     const dim3 grid(p.nwg, BH);
-    // KVP_KD_NT (bit 0 = anchor pass, bit 1 = score pass): streaming loads.  Off: inside the bench loop the gather that follows re-reads the
-    // kept K rows, and a score pass that leaves nothing of K in the memory-side cache costs it 10 us (scripts/ab_bench.sh: 195 us per step
-    // cached, 203 / 208 / 210 with mask 1 / 2 / 3) -- although the two passes alone, after a copy that left dirty lines, win 20 us with it.
-    const int ntk = std::max(0, kvp_env_int("KVP_KD_NT", 0));
-    const bool nta = (ntk & 1) != 0, ntb = (ntk & 2) != 0;
+    // Cached loads in both passes: the gather that follows re-reads the kept K rows, and a pass that leaves nothing of K in the memory-side
+    // cache costs it 10 us (streaming loads in the anchor / score / both passes: 203 / 208 / 210 us per step against 195 cached,
+    // profiles/r03_ab_bench.txt).
     if (p.vec) {
 #define KVP_KD_CASE(L)                                                                                                                 \
     case L:                                                                                                                            \
-        if (p.threads == 1024 && nta) KVP_LAUNCH("keydiff_anchor_kernel", stream, (keydiff_anchor_vec_kernel<DT, L, 1024, true><<<grid, 1024, 0, stream>>>(xp, map, p.chunks, partial, p.rows_per_wg))); \
-        else if (p.threads == 1024) KVP_LAUNCH("keydiff_anchor_kernel", stream, (keydiff_anchor_vec_kernel<DT, L, 1024, false><<<grid, 1024, 0, stream>>>(xp, map, p.chunks, partial, p.rows_per_wg))); \
-        else if (nta) KVP_LAUNCH("keydiff_anchor_kernel", stream, (keydiff_anchor_vec_kernel<DT, L, KD_THREADS, true><<<grid, KD_THREADS, 0, stream>>>(xp, map, p.chunks, partial, p.rows_per_wg))); \
+        if (p.threads == 1024) KVP_LAUNCH("keydiff_anchor_kernel", stream, (keydiff_anchor_vec_kernel<DT, L, 1024, false><<<grid, 1024, 0, stream>>>(xp, map, p.chunks, partial, p.rows_per_wg))); \
         else KVP_LAUNCH("keydiff_anchor_kernel", stream, (keydiff_anchor_vec_kernel<DT, L, KD_THREADS, false><<<grid, KD_THREADS, 0, stream>>>(xp, map, p.chunks, partial, p.rows_per_wg))); \
         break;
         switch (p.lpr) { KVP_KD_CASE(1) KVP_KD_CASE(2) KVP_KD_CASE(4) KVP_KD_CASE(8) KVP_KD_CASE(16) KVP_KD_CASE(32) KVP_KD_CASE(64) }
@@ -296,9 +291,7 @@ int launch_keydiff(const void* x, KdMap map, uint32_t BH, uint32_t D, float* sco
     if (p.vec) {
 #define KVP_KD_CASE(L)                                                                                                                      \
     case L:                                                                                                                                 \
-        if (p.threads == 1024 && ntb) KVP_LAUNCH("keydiff_score_kernel", stream, (keydiff_score_vec_kernel<DT, L, 1024, true><<<grid, 1024, 0, stream>>>(xp, map, p.chunks, anchor, scores, p.rows_per_wg))); \
-        else if (p.threads == 1024) KVP_LAUNCH("keydiff_score_kernel", stream, (keydiff_score_vec_kernel<DT, L, 1024, false><<<grid, 1024, 0, stream>>>(xp, map, p.chunks, anchor, scores, p.rows_per_wg))); \
-        else if (ntb) KVP_LAUNCH("keydiff_score_kernel", stream, (keydiff_score_vec_kernel<DT, L, KD_THREADS, true><<<grid, KD_THREADS, 0, stream>>>(xp, map, p.chunks, anchor, scores, p.rows_per_wg))); \
+        if (p.threads == 1024) KVP_LAUNCH("keydiff_score_kernel", stream, (keydiff_score_vec_kernel<DT, L, 1024, false><<<grid, 1024, 0, stream>>>(xp, map, p.chunks, anchor, scores, p.rows_per_wg))); \
         else KVP_LAUNCH("keydiff_score_kernel", stream, (keydiff_score_vec_kernel<DT, L, KD_THREADS, false><<<grid, KD_THREADS, 0, stream>>>(xp, map, p.chunks, anchor, scores, p.rows_per_wg))); \
         break;
         switch (p.lpr) { KVP_KD_CASE(1) KVP_KD_CASE(2) KVP_KD_CASE(4) KVP_KD_CASE(8) KVP_KD_CASE(16) KVP_KD_CASE(32) KVP_KD_CASE(64) }

@@ -33,14 +33,16 @@ void kvp_set_error(const char* fmt, ...);
 // A kernel that detects at RUN time that its result is invalid (the cluster select when its workgroups never become co-resident,
 // topk_cluster.hip) poisons its output AND stores a code into one process-wide, host-pinned status word; every entry point that
 // produces or consumes a selection calls kvp_async_check() first and turns a pending report into KVP_EASYNC + kvp_last_error().
+// The word holds (launch sequence number << 8) | code: all the stores of ONE failed launch make one report, however late the last of
+// them lands (a repeat of a sequence number that was already reported is dropped).
 uint32_t* kvp_async_flag();             // device-visible address of the status word (nullptr: pinned allocation failed -> poison only)
+uint32_t kvp_async_next_seq();          // sequence number (1 .. 2^24 - 1, wrapping) for the next launch that may report
 int kvp_async_check(const char* who);   // KVP_OK, or KVP_EASYNC exactly once per report
 
 // ---- opt-in per-kernel timing (kvp_prof_* in include/kvpress_hip.h; implemented in capi.hip) ----
 bool kvp_prof_enabled();
 void kvp_prof_begin(const char* name, hipStream_t stream);
 void kvp_prof_end(hipStream_t stream);
-float* kvp_prof_clock_slot();  // device float that snapkv_p1_mfma fills with its in-kernel shader clock (MHz) while profiling
 // every kernel launch of the library goes through this macro
 #define KVP_LAUNCH(name, stream, ...)                         \
     do {                                                      \

@@ -67,7 +67,6 @@ struct QprojArgs {
     int64_t cs_sb, cs_sw;  // element strides
     void* out;          // [B, Hq, 64, 128] contiguous
     uint32_t Hq, K;
-    uint32_t rotate;    // 1: workgroup j of an XCD starts its walk over the K tiles at tile j % ntiles (see the kernel)
 };
 
 // Tile rows 0..15 = the 16 weight rows (columns of the output tile), rows 16..79 = the 64 hidden-state rows; 512 B per row,
@@ -82,7 +81,7 @@ __global__ __launch_bounds__(QP_THREADS) void qproj_rope_kernel(QprojArgs a) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t l16 = lane & 15, kq = lane >> 4;  // fragment row / column, k-slot group (8 elements)
     const uint32_t ntiles = a.K / QP_KT;
-    const uint32_t rot = a.rotate ? (blockIdx.x >> 3) % ntiles : 0u;
+    const uint32_t rot = (blockIdx.x >> 3) % ntiles;
 
     // ---- LDS-DMA requests: request i of a tile moves chunks e = i * 512 + t; a wave's 64 chunks = 2 rows x 32 slots
     const char* gsrc[QP_REQ];     // global address of this thread's chunk in K tile 0
@@ -191,7 +190,6 @@ int kvp_qproj_rope_launch(const void* x, int64_t x_sb, int64_t x_sw, const void*
     a.w = static_cast<const char*>(w);
     a.cosp = cosp; a.sinp = sinp; a.cs_sb = cs_sb; a.cs_sw = cs_sw;
     a.out = out; a.Hq = (uint32_t)Hq; a.K = (uint32_t)K;
-    a.rotate = kvp_env_int("KVP_QP_ROTATE", 1) ? 1u : 0u;
     const dim3 grid((uint32_t)(Hq * 8), (uint32_t)B);
     if (dtype == KVP_BF16) KVP_LAUNCH("qproj_rope_kernel", stream, qproj_rope_kernel<KVP_BF16><<<grid, QP_THREADS, 0, stream>>>(a));
     else KVP_LAUNCH("qproj_rope_kernel", stream, qproj_rope_kernel<KVP_F16><<<grid, QP_THREADS, 0, stream>>>(a));

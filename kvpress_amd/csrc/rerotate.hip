@@ -229,7 +229,7 @@ extern "C" int kvp_gather_kv_rerotate(const void* k, int64_t k_sb, int64_t k_sh,
     const bool fused = dtype != KVP_F32 && D % 16 == 0 && B * H <= 65535 && n * D < ((int64_t)1 << 31) && S < ((int64_t)1 << 31) &&
                        al16((int64_t)(uintptr_t)k) && al16((int64_t)(uintptr_t)v) && al16((int64_t)(uintptr_t)k_out) &&
                        al16((int64_t)(uintptr_t)v_out) && al16((int64_t)(uintptr_t)inv_freq) && al16(k_sb * 2) && al16(k_sh * 2) && al16(k_ss * 2) &&
-                       al16(v_sb * 2) && al16(v_sh * 2) && al16(v_ss * 2) && kvp_env_int("KVP_GA_REROT_FUSED", 1) != 0;
+                       al16(v_sb * 2) && al16(v_sh * 2) && al16(v_ss * 2);
     if (!fused) {   // any other shape / dtype: the two kernels it replaces
         if (int rc = kvp_gather_kv(k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, H, S, D, idx, n, k_out, v_out, stream_)) return rc;
         return kvp_rerotate_keys(k_out, dtype, B, H, n, D, idx, inv_freq, stream_);
@@ -244,10 +244,9 @@ extern "C" int kvp_gather_kv_rerotate(const void* k, int64_t k_sb, int64_t k_sh,
     const uint32_t BH = (uint32_t)(B * H);
     const uint64_t total = (uint64_t)n * (uint64_t)(D / 16);
     const uint64_t bx_full = (total + 256 * GR_UNROLL - 1) / (256 * GR_UNROLL);
-    const uint64_t bx_cap = std::max<uint64_t>(1, ((uint64_t)256 * kvp_env_int("KVP_GR_WG_PER_CU", 8) + BH - 1) / BH);
+    const uint64_t bx_cap = std::max<uint64_t>(1, ((uint64_t)256 * 8 + BH - 1) / BH);
     const dim3 grid((uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap)), BH);
-    const int nt_env = kvp_env_int("KVP_GA_NT", -1);   // the same rule as kvp_gather_kv
-    const bool nt = nt_env >= 0 ? nt_env != 0 : (uint64_t)B * H * S * D * 2 * 2 > (192ull << 20);
+    const bool nt = (uint64_t)B * H * S * D * 2 * 2 > (192ull << 20);   // the same rule as kvp_gather_kv
 #define KVP_GR(DTV, NTV) KVP_LAUNCH("gather_rerotate_kernel", stream, (gather_rerotate_kernel<DTV, NTV><<<grid, 256, 0, stream>>>(a)))
     if (dtype == KVP_F16) { if (nt) KVP_GR(KVP_F16, true); else KVP_GR(KVP_F16, false); }
     else { if (nt) KVP_GR(KVP_BF16, true); else KVP_GR(KVP_BF16, false); }

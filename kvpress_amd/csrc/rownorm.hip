@@ -192,17 +192,14 @@ __global__ __launch_bounds__(RN_THREADS) void rownorm_scalar_kernel(
 // cutoff of kvp_gather_kv).  Whether that pays is decided by what runs next, so the caller says so (`read_once`), measured inside the
 // bench loops (scripts/ab_bench.sh, profiles/r03_ab_bench.txt): ExpectedAttention's ||V|| 58 -> 47 us, CUR's two energies 105 -> 91 us
 // (its gather + 7); but the stand-alone K norm of a press whose gather re-reads the kept K rows right after (Knorm through
-// KeyRerotationPress) LOSES 14 us when the stream leaves nothing of K behind -- kvp_rownorm_score stays cached.  KVP_RN_NT=0/1 forces either.
-bool rn_streaming(uint64_t bytes, bool read_once) {
-    const int e = kvp_env_int("KVP_RN_NT", -1);
-    return e >= 0 ? e != 0 : (read_once && bytes > (192ull << 20));
-}
+// KeyRerotationPress) LOSES 14 us when the stream leaves nothing of K behind -- kvp_rownorm_score stays cached.
+bool rn_streaming(uint64_t bytes, bool read_once) { return read_once && bytes > (192ull << 20); }
 
 template <int DT, int THREADS>
 void launch_rownorm_slot_t(const typename Elem<DT>::T* x0, const typename Elem<DT>::T* x1, PlaneMap m0, PlaneMap m1, uint32_t BH, uint32_t ntens,
                            uint32_t chunks, int lpr, float scale, float* o0, float* o1, hipStream_t stream, bool nt) {
     const uint32_t gpb = THREADS / lpr;
-    const uint32_t wgs_per_cu = (uint32_t)std::max(1, kvp_env_int("KVP_RN_WGS", THREADS >= 1024 ? 1 : 2048 / THREADS));
+    const uint32_t wgs_per_cu = THREADS >= 1024 ? 1 : 2048 / THREADS;
     const uint64_t want = std::max<uint64_t>(1, ((uint64_t)256 * wgs_per_cu + (uint64_t)BH * ntens - 1) / ((uint64_t)BH * ntens));
     const uint32_t step = gpb * RN_UNROLL;
     uint64_t rows = ((uint64_t)m0.S + want - 1) / want;
@@ -222,11 +219,8 @@ void launch_rownorm_slot_t(const typename Elem<DT>::T* x0, const typename Elem<D
 template <int DT>
 void launch_rownorm_slot(const typename Elem<DT>::T* x0, const typename Elem<DT>::T* x1, PlaneMap m0, PlaneMap m1, uint32_t BH, uint32_t ntens,
                          uint32_t chunks, int lpr, float scale, float* o0, float* o1, hipStream_t stream, bool nt) {
-    switch (kvp_env_int("KVP_RN_THREADS", 1024)) {
-        case 256: launch_rownorm_slot_t<DT, 256>(x0, x1, m0, m1, BH, ntens, chunks, lpr, scale, o0, o1, stream, nt); break;
-        case 512: launch_rownorm_slot_t<DT, 512>(x0, x1, m0, m1, BH, ntens, chunks, lpr, scale, o0, o1, stream, nt); break;
-        default: launch_rownorm_slot_t<DT, 1024>(x0, x1, m0, m1, BH, ntens, chunks, lpr, scale, o0, o1, stream, nt); break;
-    }
+    // one 1024-thread workgroup per CU (256 / 512 threads with 8 / 4 workgroups per CU measured slower: profiles/r03_stream_lab.txt)
+    launch_rownorm_slot_t<DT, 1024>(x0, x1, m0, m1, BH, ntens, chunks, lpr, scale, o0, o1, stream, nt);
 }
 
 // returns 1 if hist1 was requested and produced (vector path only), else 0
@@ -252,7 +246,7 @@ int launch_rownorm(const void* x, PlaneMap map, uint32_t BH, uint32_t D, float s
     const uint64_t bx_cap = std::max<uint64_t>(1, (256 * 8 + BH - 1) / BH);  // ~8 workgroups per CU in total
     const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap));
     const bool nt = rn_streaming((uint64_t)BH * map.S * rowbytes, read_once);
-    if (!hist1 && kvp_env_int("KVP_RN_SLOT", 1) != 0 && map.S >= 4096) {
+    if (!hist1 && map.S >= 4096) {   // long rows: the slot walk; short rows (and the <HIST> variant): the interleaved walk below
         launch_rownorm_slot<DT>(xp, xp, map, map, BH, 1, chunks, lpr, scale, out, out, stream, nt);
         return 0;
     }
@@ -332,7 +326,7 @@ int kvp_rowsumsq2_launch(const void* k, const void* v, int dtype, int64_t B, int
     }
     PlaneMap mk{(uint32_t)H, (uint32_t)S, k_sb, k_sh, k_ss, true}, mv{(uint32_t)H, (uint32_t)S, v_sb, v_sh, v_ss, true};
     const uint32_t BH = (uint32_t)(B * H);
-    if (kvp_env_int("KVP_RN_SLOT", 1) != 0 && S >= 4096) {
+    if (S >= 4096) {
         const bool nts = rn_streaming((uint64_t)BH * 2 * S * 256, true);
         if (dtype == KVP_BF16) launch_rownorm_slot<KVP_BF16>(static_cast<const uint16_t*>(k), static_cast<const uint16_t*>(v), mk, mv, BH, 2, 16, 16, 1.0f, out_k, out_v, stream, nts);
         else launch_rownorm_slot<KVP_F16>(static_cast<const _Float16*>(k), static_cast<const _Float16*>(v), mk, mv, BH, 2, 16, 16, 1.0f, out_k, out_v, stream, nts);

@@ -376,9 +376,9 @@ int finish_scores(const SnapWs& w, int64_t B, int64_t Hq, int64_t Hkv, int64_t S
     const uint32_t BH = (uint32_t)(B * Hkv);
     const float inv = snapkv_pool_scale(Hq, Hkv, W, kernel_size);
     // four scores per thread: kernel_size 5, aligned row starts, long rows (short ones are launch-bound either way)
-    const bool vec = kernel_size == 5 && (S - W) % 2 == 0 && S % 4 == 0 && ((uintptr_t)scores % 16) == 0 && S - W >= 8192 && kvp_env_int("KVP_SK_POOL_VEC", 1);
+    const bool vec = kernel_size == 5 && (S - W) % 2 == 0 && S % 4 == 0 && ((uintptr_t)scores % 16) == 0 && S - W >= 8192;
     const uint64_t per_wg = (uint64_t)SK_THREADS * (vec ? 4 : 1);
-    const uint64_t wg_cap = vec ? (uint64_t)std::max(1, kvp_env_int("KVP_SK_POOL_WGS", 1024)) : 2048;   // <= 4096: the size of w.bmax
+    const uint64_t wg_cap = vec ? 1024 : 2048;   // <= 4096: the size of w.bmax
     const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)(S - W) + per_wg - 1) / per_wg, std::max<uint64_t>(1, std::min<uint64_t>(wg_cap, 4096) / BH)));
     const dim3 grid(bx, BH);
     const int pad = kernel_size / 2;

@@ -539,12 +539,10 @@ extern "C" size_t kvp_topk_workspace_bytes(int64_t R, int64_t S, int64_t k) {
 // rows this short are selected by one workgroup each (topk_row_kernel); the scorers then skip their fused histogram
 // should the kernel that writes the scores accumulate the first 12-bit histogram?  Not for rows of <= 16384 scores (the plain
 // one-launch select with its own digits is faster there); longer: the (chunk, row) passes start at their second pass
-// (KVP_TK_ROW_FUSED=1: one launch that starts from it up to 32768)
 bool topk_fused_hist_wanted(int64_t S) { return S > 16384; }
 
 bool topk_row_eligible(int64_t S) {
-    const int64_t row_max = std::min<int64_t>(32768, kvp_env_int("KVP_TK_ROW_MAX", 32768));  // 1024 threads x 32 keys
-    return S >= 1 && S <= row_max;
+    return S >= 1 && S <= 32768;  // 1024 threads x 32 keys
 }
 
 int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, int64_t idx_stride,
@@ -568,14 +566,8 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
         KVP_CHECK_LAUNCH("topk(iota)");
         return KVP_OK;
     }
-    // One launch from the fused first-digit histogram: KVP_TK_ROW_FUSED=1 only.  With 1024-score chunks and the wide second pass
-    // the three (chunk, row) launches are faster even at 8 x 32768 (Knorm config 2: 0.0525 against 0.0538 ms per layer).
-    if (hist1_ready && S <= 32768 && S > 16384 && ws && kvp_env_int("KVP_TK_ROW_FUSED", 0)) {
-        KVP_LAUNCH("topk_row_kernel", stream, (topk_row_kernel<32, -1, true><<<(uint32_t)R, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w.kmask, 1.f, idx,
-                                                                                                                   idx_stride, tail_start, tail_n, nseg, seg_len, pos_base, w.hist1)));
-        KVP_CHECK_LAUNCH("topk(row, fused digit)");
-        return KVP_OK;
-    }
+    // (A one-launch variant that starts from the fused first-digit histogram up to 32768 scores was measured slower than the passes
+    // below -- Knorm config 2: 0.0538 against 0.0525 ms per layer -- and removed in round 5.)
     if (!hist1_ready && topk_row_eligible(S)) {  // short rows: one launch, no workspace
         const uint32_t km = w.kmask;
 #define KVP_TR_CASE(P)                                                                                                                   \
@@ -611,20 +603,10 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
     const dim3 grid((uint32_t)nchunks, (uint32_t)R);
     if (!hist1_ready)
         KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<1><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
-    // Second pass: 1024-thread workgroups of KVP_TK_H2_WIDE scores per thread (default 8; 0 = the narrow kernel with this pass's
-    // own (chunk, row) grid).  Measured at 8 x 131072 on flat SnapKV scores / Knorm norms: narrow 15.4-15.8 us, 4: 9.3-9.8,
-    // 8: 9.2-9.6, 16: 11.3-11.9, 32: 17.0-17.7 (too few workgroups).
-    const int wide = kvp_env_int("KVP_TK_H2_WIDE", 8);
-    const dim3 gw((uint32_t)((S + (int64_t)TR_THREADS * std::max(wide, 1) - 1) / ((int64_t)TR_THREADS * std::max(wide, 1))), (uint32_t)R);
-#define KVP_TK_WIDE(P) KVP_LAUNCH("topk_hist12_wide_kernel", stream, topk_hist12_wide_kernel<P><<<gw, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w))
-    switch (wide) {
-        case 4: KVP_TK_WIDE(4); break;
-        case 8: KVP_TK_WIDE(8); break;
-        case 16: KVP_TK_WIDE(16); break;
-        case 32: KVP_TK_WIDE(32); break;
-        default: KVP_LAUNCH("topk_hist12_kernel", stream, topk_hist12_kernel<2><<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
-    }
-#undef KVP_TK_WIDE
+    // Second pass: 1024-thread workgroups of 8 scores per thread.  Measured at 8 x 131072 on flat SnapKV scores / Knorm norms: this
+    // pass's own (chunk, row) grid 15.4-15.8 us, 4 per thread 9.3-9.8, 8: 9.2-9.6, 16: 11.3-11.9, 32: 17.0-17.7 (too few workgroups).
+    const dim3 gw((uint32_t)((S + (int64_t)TR_THREADS * 8 - 1) / ((int64_t)TR_THREADS * 8)), (uint32_t)R);
+    KVP_LAUNCH("topk_hist12_wide_kernel", stream, topk_hist12_wide_kernel<8><<<gw, TR_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, w));
     KVP_LAUNCH("topk_hist8_kernel", stream, topk_hist8_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)nchunks, w));
     KVP_LAUNCH("topk_write_kernel", stream, topk_write_kernel<<<grid, TK_THREADS, 0, stream>>>(scores, row_stride, (uint32_t)S, (uint32_t)k, (uint32_t)nchunks, w, idx, idx_stride, tail_start, tail_n, nseg, seg_len, pos_base));
     KVP_CHECK_LAUNCH("topk");

@@ -1,7 +1,8 @@
 // Cluster select: the whole radix select of long score rows (16384 < S <= 262144) in ONE launch.
 // Replaces `scores.topk(n_kept, dim=-1).indices` (kvpress/presses/scorer_press.py:95); same digits (12 + 12 + 8 bits of the
 // order-preserving key), same tie rule (lowest position first) and therefore the same indices as the (chunk, row) passes of
-// topk.hip, which stay as the fallback (other devices, rows beyond 262144 scores, more than 16 rows, KVP_TK_CLUSTER=0).
+// topk.hip, which stay as the fallback (devices with fewer than 256 CUs, rows beyond 262144 scores, more than 8 rows; KVP_TK_CLUSTER=0
+// selects them on any device).
 //
 // Structure.  The (chunk, row) passes are chains of dependent launches over an L2-resident row: load the keys, count a digit,
 // flush, kernel boundary, load the keys again ...  (4 launches of 5-7 us for ~2 us of work each).  Here a row belongs to a
@@ -17,9 +18,12 @@
 //
 // Failure is LOUD (torch.topk cannot return wrong indices silently, scorer_press.py:95).  The barrier spins are bounded
 // (KVP_TC_TIMEOUT_US, default 1 s) so that a cluster that never becomes co-resident cannot hang the GPU; a spin that times out
-// sets the cluster's flag, the workspace's flag and the process-wide host-pinned status word (kvp_async_check: the next call of
-// the library returns KVP_EASYNC), and every workgroup of that cluster writes -1 instead of indices (kvp_gather_kv* turn a
-// negative index into a NaN row).  The host launches this kernel only on a device with at least 256 CUs.
+// sets the cluster's PERSISTENT flag in the workspace and the process-wide host-pinned status word (kvp_async_check: the next call
+// of the library returns KVP_EASYNC), and every workgroup of that cluster writes -1 instead of indices (kvp_gather_kv* turn a
+// negative index into a NaN row).  A workspace that is handed in again as "clean" after such a failure without having been
+// zero-filled still carries the flag: its rows are poisoned again AND the host word is raised again (stale reuse is reported, not
+// only poisoned).  Reports carry the launch's sequence number, so the 32 stores of one failed launch make ONE report.
+// The host launches this kernel only on a device with at least 256 CUs.
 //
 // Key sources (MODE):  SCORES  the row is read from memory (kvp_topk_select, every scorer);
 //                      POOL5   SnapKV's un-pooled column sums: avg_pool1d(kernel 5) + scale in the loader, term for term the
@@ -41,28 +45,38 @@ __device__ __forceinline__ void tc_st(uint32_t* p, uint32_t v) { __hip_atomic_st
 __device__ __forceinline__ void tc_add(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_add(p, v, TC_RLX); }
 
 // Where a cluster's barrier state lives: bar + cluster * 32 (its own 128-byte line): [0] the monotonic arrival counter,
-// [1] the cluster's give-up code (0 = none).  bar[TC_CLUSTERS * 32] = the workspace-wide give-up code.
+// [1] the cluster's give-up code (0 = none; persistent: only a zero-fill of the workspace clears it).
 struct ClusterSync {
     uint32_t* ctr;
     uint32_t* cl_flag;
-    uint32_t* ws_flag;
     uint32_t* host_flag;      // process-wide pinned status word (kvp_async_flag(); may be null)
+    uint32_t report;          // launch sequence number << 8: OR-ed with the give-up code in the host word
     uint32_t timeout_ticks;   // of the 100 MHz real-time counter
-    uint32_t delay_ticks;     // TEST AID (KVP_TC_TEST_DELAY_SLOT): this workgroup arrives at its first barrier this late
+#ifdef KVP_TC_FAULT_INJECTION
+    uint32_t delay_ticks;     // fault-injection build only (tests): this workgroup arrives at its first barrier this late
+#endif
 };
+__device__ __forceinline__ void tc_report(const ClusterSync& cs, uint32_t code) {
+    tc_st(cs.cl_flag, code);
+    if (cs.host_flag) __hip_atomic_store(cs.host_flag, cs.report | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // Arrive at / wait for the cluster's next barrier.  Every wave first drains its own agent-scope stores and atomics
 // (they are what the other workgroups read after the barrier).  A spin that times out REPORTS it -- the cluster's flag (read by
-// every workgroup of the cluster before it writes indices: see the poison path of the kernel), the workspace's flag and the host's
-// status word -- and goes on, so that every workgroup still makes all its arrivals and the counter stays a multiple of TC_SLOTS.
+// every workgroup of the cluster before it writes indices: see the poison path of the kernel) and the host's status word -- and
+// goes on, so that every workgroup still makes all its arrivals and the counter stays a multiple of TC_SLOTS.
 __device__ __forceinline__ void cluster_barrier(const ClusterSync& cs, uint32_t code, uint32_t* lds_gave_up, bool first) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
+#ifdef KVP_TC_FAULT_INJECTION
         if (first && cs.delay_ticks) {
             const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
             while (__builtin_amdgcn_s_memrealtime() - t0 < cs.delay_ticks) __builtin_amdgcn_s_sleep(8);
         }
+#else
+        (void)first;
+#endif
         const uint32_t old = __hip_atomic_fetch_add(cs.ctr, 1u, TC_RLX);
         const uint32_t target = (old & ~(uint32_t)(TC_SLOTS - 1)) + TC_SLOTS;
         if ((int32_t)(tc_ld(cs.ctr) - target) < 0) {
@@ -71,9 +85,7 @@ __device__ __forceinline__ void cluster_barrier(const ClusterSync& cs, uint32_t 
                 __builtin_amdgcn_s_sleep(1);
                 if (__builtin_amdgcn_s_memrealtime() - t0 > cs.timeout_ticks) {  // the cluster is not co-resident: give up, loudly
                     *lds_gave_up = code;
-                    tc_st(cs.cl_flag, code);
-                    tc_st(cs.ws_flag, code);
-                    if (cs.host_flag) __hip_atomic_store(cs.host_flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    tc_report(cs, code);
                     break;
                 }
             }
@@ -131,10 +143,11 @@ struct ClusterArgs {
     float scale;
     // barrier protocol
     uint32_t* host_flag;
+    uint32_t report;           // launch sequence number << 8 (kvp_async_next_seq)
     uint32_t timeout_ticks;
-    int32_t test_delay_slot;   // TEST AID: slot (of cluster 0) that arrives 2 x timeout late at its first barrier; -1 = none
-    uint32_t poll;             // 1: round 1 without a counter barrier -- complete when its histogram's total says so (see the kernel)
-    uint32_t interleave;       // 1: cluster = block % 8 (the 32 workgroups of a row on ONE XCD under the observed placement, lab only)
+#ifdef KVP_TC_FAULT_INJECTION
+    int32_t test_delay_slot;   // slot (of cluster 0) that arrives 2 x timeout late at its first barrier; -1 = none
+#endif
 };
 
 #ifndef TC_KN_UNROLL
@@ -181,25 +194,27 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
     __shared__ uint32_t s_fail[2];   // [0] this workgroup gave up at a barrier, [1] the cluster's flag as read after the last barrier
     // A row's 32 workgroups are CONSECUTIVE blocks: whatever part of the grid the device can hold at once, whole clusters become
     // resident in dispatch order and finish, so a device with fewer free CUs than the grid (CU masking, a busy neighbour) makes
-    // the launch slower, not stuck.  (interleave = 1, lab: cluster = block % 8 puts a row on one XCD under the observed
-    // placement -- and deadlocks into the give-up path as soon as fewer than all 256 workgroups fit.)
-    const uint32_t cluster = a.interleave ? blockIdx.x % TC_CLUSTERS : blockIdx.x / TC_SLOTS;
-    const uint32_t slot = a.interleave ? blockIdx.x / TC_CLUSTERS : blockIdx.x % TC_SLOTS;
+    // the launch slower, not stuck.  (This leans on the dispatcher handing out blocks in index order -- observed, not promised:
+    // if it ever did not, the bounded spins turn the would-be deadlock into the loud give-up path below.)
+    const uint32_t cluster = blockIdx.x / TC_SLOTS;
+    const uint32_t slot = blockIdx.x % TC_SLOTS;
     ClusterSync cs;
     cs.ctr = a.w.bar + cluster * 32;
     cs.cl_flag = cs.ctr + 1;
-    cs.ws_flag = a.w.bar + TC_CLUSTERS * 32;
     cs.host_flag = a.host_flag;
+    cs.report = a.report;
     cs.timeout_ticks = a.timeout_ticks;
+#ifdef KVP_TC_FAULT_INJECTION
     cs.delay_ticks = (cluster == 0 && (int32_t)slot == a.test_delay_slot) ? 2u * a.timeout_ticks : 0u;
+#endif
     if (threadIdx.x < 2) s_fail[threadIdx.x] = 0;   // (ordered before its first use by the barriers of the key loaders / histograms)
-    // Round 1 without a counter barrier (a.poll; rounds that count their own first digit: not HIST1).  What the barrier buys --
+    // Round 1 without a counter barrier (rounds that count their own first digit: not HIST1).  What the barrier buys --
     // "every workgroup's atomics have landed" -- the histogram itself can say: the row's first histogram is complete exactly when
     // its total equals the row's S valid keys, so a workgroup flushes and then repeats {read the histogram, search} until the
     // total is right: no drain, no arrival atomic, no separate poll (-1.6 us, profiles/r04_select_poll_lab.txt).  Rounds 2 and 3
     // keep their counter barriers: on flat rows round 2 drains ~2400 atomics per workgroup, and pollers re-reading the
     // histogram while those are in flight slow them down (measured: +1.9 us); round 3 publishes plain tables anyway.
-    const bool poll = !HIST1 && a.poll != 0;
+    constexpr bool poll = !HIST1;
     const uint32_t max_poll = a.timeout_ticks / 100u + 8u;   // iterations: each costs >= one L2 round trip (~1 us)
     const uint32_t S = a.S, k = a.k, kmask = a.kmask;
     const uint32_t p0 = slot * L + threadIdx.x * PER;   // this thread's PER consecutive positions
@@ -315,27 +330,24 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
                 for (int j = 1; j < PER; ++j) topk_hist_add_bin(lh, keys[j] >> 20, !uni && keys[j] != 0u);
             }
             __syncthreads();
-            if (poll) {
-                if (cs.delay_ticks && threadIdx.x == 0) {                         // TEST AID: this workgroup flushes late
-                    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-                    while (__builtin_amdgcn_s_memrealtime() - t0 < 2ull * cs.delay_ticks) __builtin_amdgcn_s_sleep(8);   // (a poll round is ~1.6 us, not 1)
-                }
-                if (cs.delay_ticks) __syncthreads();
+#ifdef KVP_TC_FAULT_INJECTION
+            if (cs.delay_ticks && threadIdx.x == 0) {                         // fault injection: this workgroup flushes late
+                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+                while (__builtin_amdgcn_s_memrealtime() - t0 < 2ull * cs.delay_ticks) __builtin_amdgcn_s_sleep(8);   // (a poll round is ~1.6 us, not 1)
             }
+            if (cs.delay_ticks) __syncthreads();
+#endif
             for (int i = threadIdx.x; i < 4096; i += TR_THREADS) {
                 const uint32_t c = lh[i];
                 if (c) tc_add(&h1[i], c);
             }
-            if (!poll) cluster_barrier(cs, 1, &s_fail[0], true);
         }
         // (polling) repeat {read the row's histogram, search} until its total is `expect`; gives up like a barrier after max_poll rounds
 #define TC_POLL_GIVE_UP(code)                                                                                              \
     do {                                                                                                                   \
         if (threadIdx.x == 0) {                                                                                            \
             s_fail[0] = (code);                                                                                            \
-            tc_st(cs.cl_flag, (code));                                                                                     \
-            tc_st(cs.ws_flag, (code));                                                                                     \
-            if (cs.host_flag) __hip_atomic_store(cs.host_flag, (code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       \
+            tc_report(cs, (code));                                                                                         \
         }                                                                                                                  \
         __syncthreads();                                                                                                   \
     } while (0)
@@ -366,7 +378,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             const uint32_t c = lh[i];
             if (c) tc_add(&h2[i], c);
         }
-        cluster_barrier(cs, 2, &s_fail[0], HIST1 || poll);   // (the first counter barrier of the launch when round 1 was polled)
+        cluster_barrier(cs, 2, &s_fail[0], true);   // (the first counter barrier of the launch: round 1 is polled or was done by the scorer)
         uint32_t b2, k2;
         {
             uint32_t loc[4];
@@ -425,6 +437,8 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
         // together they fill the row's k + tail_n entries with -1 (kvp_gather_kv: a row of NaN instead of somebody else's token).
         // (A polled round 1 that timed out is one more "earlier give-up".)
         if (s_fail[0] | s_fail[1]) {
+            // (also reached with a STALE flag: a workspace reused as "clean" after a failure without a zero-fill -- report that too)
+            if (threadIdx.x == 0 && slot == 0) tc_report(cs, s_fail[0] ? s_fail[0] : s_fail[1]);
             const uint32_t tot_out = k + a.tail_n, per = (tot_out + TC_SLOTS - 1) / TC_SLOTS;
             for (uint32_t j = slot * per + threadIdx.x; j < min((slot + 1) * per, tot_out); j += TR_THREADS) out[j] = -1;
             return;
@@ -487,11 +501,13 @@ int launch_one(const ClusterArgs& a, hipStream_t stream) {
     ClusterArgs b = a;
     b.host_flag = kvp_async_flag();
     b.timeout_ticks = (uint32_t)std::min<int64_t>(std::max<int64_t>(kvp_env_int("KVP_TC_TIMEOUT_US", 1000000), 100), 20000000) * 100u;
+#ifdef KVP_TC_FAULT_INJECTION
     b.test_delay_slot = kvp_env_int("KVP_TC_TEST_DELAY_SLOT", -1);
-    b.interleave = kvp_env_int("KVP_TC_INTERLEAVE", 0) ? 1u : 0u;
-    b.poll = kvp_env_int("KVP_TC_POLL", 1) ? 1u : 0u;
-    for (b.row_base = 0; b.row_base < b.R; b.row_base += TC_CLUSTERS)
+#endif
+    for (b.row_base = 0; b.row_base < b.R; b.row_base += TC_CLUSTERS) {
+        b.report = kvp_async_next_seq() << 8;
         KVP_LAUNCH("topk_cluster_kernel", stream, (topk_cluster_kernel<PER, MODE, HIST1><<<TC_CLUSTERS * TC_SLOTS, TR_THREADS, 0, stream>>>(b)));
+    }
     return 0;
 }
 

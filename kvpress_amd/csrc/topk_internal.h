@@ -20,8 +20,8 @@ struct TopkWs {
     uint32_t* hist1;       // [R][4096]
     uint32_t* hist2;       // [R][4096]
     uint32_t* hist3;       // [R][256]
-    uint32_t* bar;         // [TC_CLUSTERS][32] cluster select: one monotonic arrival counter per row cluster (own 128-byte line);
-                           // [TC_CLUSTERS * 32] = give-up code of a barrier that timed out (0 = none)
+    uint32_t* bar;         // [TC_CLUSTERS][32] cluster select, one 128-byte line per row cluster: [0] its monotonic arrival counter,
+                           // [1] its give-up code (0 = none; persistent until the workspace is zero-filled again)
     uint32_t* sel;         // [R][4] : b1, k1, b2, k2
     uint32_t* chunk_hist;  // [R][nchunks][257] suffix counts of the last digit: [d] = #(digit >= d), [256] = 0
     uint32_t* chunk_gt;    // [R][nchunks]
@@ -42,7 +42,7 @@ inline TopkWs topk_carve_ws(void* ws, int64_t R, int64_t nchunks) {
     w.hist1 = (uint32_t*)take((size_t)R * 4096 * 4);
     w.hist2 = (uint32_t*)take((size_t)R * 4096 * 4);
     w.hist3 = (uint32_t*)take((size_t)R * 256 * 4);
-    w.bar = (uint32_t*)take((size_t)(TC_CLUSTERS * 32 + 32 + TC_SLOTS * 16) * 4);   // (+ phase time stamps of the KVP_TC_TIMING lab build)
+    w.bar = (uint32_t*)take((size_t)(TC_CLUSTERS * 32 + 32 + TC_SLOTS * 16) * 4);   // (the tail is room for the phase stamps of tools/make_tc_timing.py's lab build)
     w.zero_bytes = off;
     w.sel = (uint32_t*)take((size_t)R * 4 * 4);
     // per-chunk tables: the (chunk, row) passes index them by 1024-score chunk, the cluster select by its TC_SLOTS slots

@@ -5,8 +5,8 @@
 when they are NOT all resident at once:
   * CUs held by another stream for a while -> the select waits, the indices are right;
   * a reduced CU set (HSA_CU_MASK, own process) -> right indices or a raised KvpressHipError, never garbage;
-  * a barrier that really times out (test knobs: one workgroup arrives late) -> indices -1, gathered rows NaN, the NEXT library
-    call raises KVP_EASYNC, the workspace cache is dropped, and the call after that is correct again.
+  * a barrier that really times out (fault-injection twin of the library, child process: one workgroup arrives late) -> indices -1,
+    gathered rows NaN, the NEXT library call raises KVP_EASYNC once, the workspace cache is dropped, the call after that is correct.
 """
 import os
 import subprocess
@@ -89,61 +89,33 @@ def test_select_under_a_cu_mask_is_right_or_raises(mask):
         pytest.skip(f"child did not run under HSA_CU_MASK={mask}: {out[-300:]}")
 
 
-@pytest.mark.parametrize("poll", [1, 0])
-def test_barrier_timeout_is_loud(knobs, poll):
-    """One workgroup of cluster 0 arrives 2 x timeout late at its first barrier (test knob): the others give up.  Row 0's indices
-    are -1 (other rows: untouched clusters, correct), the gather turns them into NaN rows, the next library call raises, the
-    cached clean workspaces are gone, and then everything works again."""
+@pytest.mark.parametrize("scenario", ["barrier", "fused", "stale"])
+def test_barrier_timeout_is_loud(scenario):
+    """A barrier that REALLY times out: one workgroup of a cluster arrives 2 x timeout late.  The hook that makes it late exists only
+    in the fault-injection twin of the library (kvpress_amd/build.py: topk_cluster.hip with -DKVP_TC_FAULT_INJECTION), loaded by a child
+    process; the scenarios (tests/_fault_child.py): `barrier` -- kvp_topk_select: row 0 = -1, other rows correct, gathered rows NaN, the
+    next call raises KVP_EASYNC exactly once, cached workspaces dropped, then correct again; `fused` -- the same through
+    kvp_knorm_compress; `stale` -- a workspace reused as clean without a zero-fill is poisoned AND reported again."""
+    from kvpress_amd import build
+
+    assert os.path.exists(build.FAULT_LIB), "fault-injection twin not built (python -m kvpress_amd.build)"
+    env = dict(os.environ, KVPRESS_HIP_LIB=build.FAULT_LIB, PYTHONDONTWRITEBYTECODE="1")
+    for k in ("KVP_TC_TIMEOUT_US", "KVP_TC_TEST_DELAY_SLOT", "KVP_TK_CLUSTER"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fault_child.py"), scenario], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and f"CHILD_PASS {scenario}" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_product_library_has_no_fault_injection_hook(knobs):
+    """The same knob on the PRODUCT library does nothing: the select is correct and nothing is reported."""
     n = native()
-    sc = _scores(seed=1)
+    sc = _scores(seed=2)
     want = O.topk_select(sc.numpy(), 65472)
-    d = sc.to(DEV)
-    k = torch.randn(1, 8, 131008, 128, device=DEV, dtype=torch.bfloat16)
-    v = torch.randn(1, 8, 131008, 128, device=DEV, dtype=torch.bfloat16)
-    assert np.array_equal(n.topk_select(d, 65472).cpu().numpy(), want)   # sanity, default knobs
-    n.gather_kv(k, v, torch.from_numpy(want).to(DEV).view(1, 8, -1))       # (the allocator now holds the output blocks)
+    knobs(KVP_TC_TIMEOUT_US=20000, KVP_TC_TEST_DELAY_SLOT=5)
+    got = n.topk_select(sc.to(DEV), 65472)
     torch.cuda.synchronize()
     n.async_error_check()
-
-    knobs(KVP_TC_TIMEOUT_US=20000, KVP_TC_TEST_DELAY_SLOT=5, KVP_TC_POLL=poll)   # both protocols: polled totals / counter barriers
-    got = n.topk_select(d, 65472)            # returns KVP_OK: the failure happens on the device, later
-    ko, vo = n.gather_kv(k, v, got.view(1, 8, -1))
-    torch.cuda.synchronize()
-    g = got.cpu().numpy()
-    assert (g[0] == -1).all(), "row of the cluster that timed out must be poisoned"
-    assert np.array_equal(g[1:], want[1:]), "clusters that did not time out are unaffected"
-    assert torch.isnan(ko[0, 0].float()).all() and torch.isnan(vo[0, 0].float()).all(), "poisoned indices must gather NaN rows"
-    assert torch.equal(ko[0, 1], k[0, 1][torch.from_numpy(want[1]).long().to(DEV)])
-    knobs(KVP_TC_TIMEOUT_US=None, KVP_TC_TEST_DELAY_SLOT=None, KVP_TC_POLL=None)
-    with pytest.raises(n.KvpressHipError, match="cluster select"):
-        n.topk_select(d, 65472)
-    assert not n._TOPK_WS, "a reported failure must drop every cached 'clean' workspace"
-    for _ in range(2):
-        assert np.array_equal(n.topk_select(d, 65472).cpu().numpy(), want)
-    torch.cuda.synchronize()
-    n.async_error_check()
-
-
-def test_fused_compress_timeout_is_loud(knobs):
-    """The same through the fused Knorm compress (the cluster kernel computes the norms itself): poisoned rows come out as NaN."""
-    n = native()
-    g = torch.Generator().manual_seed(3)
-    k = torch.randn(1, 8, 32768, 128, generator=g).to(DEV, torch.bfloat16)
-    v = torch.randn(1, 8, 32768, 128, generator=g).to(DEV, torch.bfloat16)
-    ko_ref, vo_ref = n.knorm_compress(k, v, 16384)
-    torch.cuda.synchronize()
-    knobs(KVP_TC_TIMEOUT_US=20000, KVP_TC_TEST_DELAY_SLOT=0)
-    ko, vo = n.knorm_compress(k, v, 16384)
-    torch.cuda.synchronize()
-    assert torch.isnan(ko[0, 0].float()).all() and torch.isnan(vo[0, 0].float()).all()
-    assert torch.equal(ko[0, 1:], ko_ref[0, 1:]) and torch.equal(vo[0, 1:], vo_ref[0, 1:])
-    knobs(KVP_TC_TIMEOUT_US=None, KVP_TC_TEST_DELAY_SLOT=None)
-    with pytest.raises(n.KvpressHipError, match="cluster select"):
-        n.knorm_compress(k, v, 16384)
-    ko2, vo2 = n.knorm_compress(k, v, 16384)
-    torch.cuda.synchronize()
-    n.async_error_check()
-    assert torch.equal(ko2, ko_ref) and torch.equal(vo2, vo_ref)
+    assert np.array_equal(got.cpu().numpy(), want)
 
 
 def test_gather_never_reads_through_a_bad_index():

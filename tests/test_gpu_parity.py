@@ -153,18 +153,16 @@ def test_topk_heavy_ties_and_edges():
 
 @pytest.mark.parametrize("S", [32769, 49153, 65536, 100003, 131072])
 def test_topk_second_pass_variants(S, knobs):
-    """Rows beyond 32768: the cluster select (one launch; default) and, with KVP_TK_CLUSTER=0, the (chunk, row) passes whose second
-    12-bit histogram runs in 1024-thread workgroups of KVP_TK_H2_WIDE scores per thread (default 8; 4 / 16 / 32 compiled too) or in
-    the original 2048-key ones (0): the oracle's indices every time, on wide, flat (one exponent, heavy ties: half the row in
-    the threshold's first-digit bin) and constant rows, k smallest included."""
+    """Rows beyond 32768: the cluster select (one launch; default) and, with KVP_TK_CLUSTER=0, the (chunk, row) passes (what devices
+    with fewer than 256 CUs, more than 8 rows or longer rows run): the oracle's indices every time, on wide, flat (one exponent, heavy
+    ties: half the row in the threshold's first-digit bin) and constant rows, k smallest included."""
     rs = np.random.RandomState(S)
     N = native()
     wide = rs.standard_normal((3, S)).astype(np.float32)
     flat = (2.0 ** -17 * (1 + 0.05 * rs.standard_normal((3, S)))).astype(np.float32)   # pooled-attention-like: +-5 % around one value
     ties = _inputs.round_to(-np.sqrt(rs.chisquare(64, size=(3, S))).astype(np.float32), "bf16")
     const = np.full((2, S), 0.25, np.float32)
-    variants = ([dict(KVP_TK_CLUSTER=None, KVP_TK_H2_WIDE=None, KVP_TC_POLL=None), dict(KVP_TK_CLUSTER=None, KVP_TK_H2_WIDE=None, KVP_TC_POLL=0)]
-                + [dict(KVP_TK_CLUSTER=0, KVP_TK_H2_WIDE=w, KVP_TC_POLL=None) for w in (None, 4, 16, 32, 0)])
+    variants = [dict(KVP_TK_CLUSTER=None), dict(KVP_TK_CLUSTER=0)]
     for variant in variants:
         knobs(**variant)
         for sc_np in (wide, flat, ties, const):
@@ -190,11 +188,9 @@ def test_topk_cluster_select_rows_and_lengths(R, S, knobs):
     for sc_np in (flat, ties):
         t = torch.from_numpy(sc_np).to(DEV)
         for k in sorted({1, S // 2, S - 1}) * 2:
-            knobs(KVP_TK_CLUSTER=None, KVP_TC_POLL=None)
+            knobs(KVP_TK_CLUSTER=None)
             got = N.topk_select(t, k)
-            knobs(KVP_TK_CLUSTER=None, KVP_TC_POLL=0)   # counter barriers instead of polled totals: same workspace, alternating
-            assert torch.equal(N.topk_select(t, k), got), f"R={R} S={S} k={k}: polled != barriers"
-            knobs(KVP_TK_CLUSTER=0, KVP_TC_POLL=None)
+            knobs(KVP_TK_CLUSTER=0)
             legacy = N.topk_select(t, k)
             assert torch.equal(got, legacy), f"R={R} S={S} k={k}: cluster != passes"
             if R * S <= 8 * 131072:
@@ -448,34 +444,27 @@ def test_keydiff_is_deterministic_and_handles_zero_rows():
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])
-def test_streaming_walk_variants(dtype, knobs):
-    """The walk shapes of the streaming reductions (rownorm.hip / keydiff.hip / cur.hip): interleaved row groups or one contiguous slot
-    per workgroup, 256 / 512 / 1024 threads, cached or streaming loads, CUR's combine per token or staged through LDS.  The row norms
-    and CUR's scores are the same bits in every variant; KeyDiff's anchor is summed in another order (2e-6 of the oracle either way)."""
+def test_streaming_walks_agree(dtype):
+    """The two walk shapes of the streaming reductions (rownorm.hip / keydiff.hip / cur.hip): rows of >= 4096 tokens take one contiguous
+    slot per 1024-thread workgroup, shorter ones interleaved row groups.  A row's lanes, order and rounding are the same in both, so
+    the norms of the first 3000 tokens are the SAME BITS whether they are computed inside the long tensor (slot walk) or from a
+    3000-token view of it (interleaved walk); every result also matches the oracle, and CUR's combine is checked for window
+    lengths it stages through LDS (divisors of 256) and one it does not."""
     rs = np.random.RandomState(31)
     N = native()
     for B, H, S, D in ((1, 8, 5000, 128), (2, 2, 20001, 64), (1, 1, 4096, 128), (1, 3, 9000, 40)):
         kn = _inputs.round_to(rs.standard_normal((B, H, S, D)).astype(np.float32), dtype)
         vn = _inputs.round_to(rs.standard_normal((B, H, S, D)).astype(np.float32), dtype)
         k, v = to_dev(kn, dtype), to_dev(vn, dtype)
-        knobs(KVP_RN_SLOT=0, KVP_RN_NT=0, KVP_KD_SLOT=0, KVP_KD_NT=0, KVP_CUR_LDS=0)
-        rn0, cur0, kd0 = N.rownorm_score(k, -1.0), N.cur_score(k, v, "kv_product", 16, 4), N.keydiff_score(k)
-        assert_scores_close(rn0.cpu().numpy(), O.knorm_score(kn), 1e-5)
-        np.testing.assert_allclose(kd0.cpu().numpy(), O.keydiff_score(kn), rtol=0, atol=2e-6)
-        assert_scores_close(cur0.cpu().numpy(), O.cur_score(kn, vn, "kv_product", True, 16, 4), 2e-5)
-        for thr, wgs, nt in ((1024, 1, 0), (1024, 1, 1), (512, 2, 1), (256, 4, 0), (256, 8, 1), (1024, 2, 0)):
-            knobs(KVP_RN_SLOT=1, KVP_RN_THREADS=thr, KVP_RN_WGS=wgs, KVP_RN_NT=nt, KVP_KD_SLOT=1, KVP_KD_THREADS=thr, KVP_KD_WGS=wgs, KVP_KD_NT=3 * nt,
-                  KVP_CUR_LDS=nt)
-            assert torch.equal(N.rownorm_score(k, -1.0), rn0), (dtype, S, D, thr, wgs, nt)
-            assert torch.equal(N.cur_score(k, v, "kv_product", 16, 4), cur0), (dtype, S, D, thr, wgs, nt)
-            np.testing.assert_allclose(N.keydiff_score(k).cpu().numpy(), O.keydiff_score(kn), rtol=0, atol=2e-6)
-        knobs(KVP_RN_SLOT=0, KVP_RN_NT=1, KVP_KD_SLOT=0, KVP_KD_NT=3)
-        assert torch.equal(N.rownorm_score(k, -1.0), rn0) and torch.equal(N.keydiff_score(k), kd0)
-        for w in (2, 4, 64, 256, 5):   # every window length the LDS-staged combine takes (divisors of 256) and one it does not
-            knobs(KVP_CUR_LDS=0)
-            ref = N.cur_score(k, v, "kv_avg", w, 0)
-            knobs(KVP_CUR_LDS=1)
-            assert torch.equal(N.cur_score(k, v, "kv_avg", w, 0), ref), (dtype, S, D, w)
+        rn, kd = N.rownorm_score(k, -1.0), N.keydiff_score(k)
+        assert_scores_close(rn.cpu().numpy(), O.knorm_score(kn), 1e-5)
+        np.testing.assert_allclose(kd.cpu().numpy(), O.keydiff_score(kn), rtol=0, atol=2e-6)
+        short = N.rownorm_score(k[:, :, :3000], -1.0)                     # a strided view: the interleaved walk
+        assert torch.equal(short, rn[..., :3000]), (dtype, S, D)
+        np.testing.assert_allclose(N.keydiff_score(k[:, :, :3000]).cpu().numpy(), O.keydiff_score(kn[:, :, :3000]), rtol=0, atol=2e-6)
+        assert_scores_close(N.cur_score(k, v, "kv_product", 16, 4).cpu().numpy(), O.cur_score(kn, vn, "kv_product", True, 16, 4), 2e-5)
+        for w in (2, 4, 64, 256, 5):
+            assert_scores_close(N.cur_score(k, v, "kv_avg", w, 0).cpu().numpy(), O.cur_score(kn, vn, "kv_avg", True, w, 0), 2e-5)
 
 
 def test_scores_head_mean():
@@ -722,10 +711,11 @@ def test_snapkv_fused_rope_is_bit_identical_to_torch_rope(name):
         assert torch.allclose(b, c, rtol=1e-5, atol=0)
 
 
-def test_ea_logits_triangular_vs_full_form(knobs):
-    """ea_logits_mfma_tri_kernel (k^T C k on the doubled upper triangle of C, 40 instead of 64 MFMAs per tile and wave) against the full form
-    (KVP_EA_TRI=0) and the oracle: symmetric covariances as the press produces them, an ASYMMETRIC matrix (U_jc = C_jc + C_cj is exact
-    for any C), ragged lengths, one tile and many, both 16-bit dtypes."""
+def test_ea_logits_triangular_form_vs_oracle():
+    """ea_logits_mfma_tri_kernel (k^T C k on the doubled upper triangle of C, 40 instead of 64 MFMAs per tile and wave) against the
+    oracle: symmetric covariances as the press produces them, an ASYMMETRIC matrix (U_jc = C_jc + C_cj is exact for any C), ragged
+    lengths, one tile and many, both 16-bit dtypes; and the mean-only form (use_covariance=False: the full-form kernel without its
+    covariance chains)."""
     N = native()
     rs = np.random.RandomState(12)
     for dtype in ("bf16", "f16"):
@@ -737,20 +727,19 @@ def test_ea_logits_triangular_vs_full_form(knobs):
             cov = (a @ a.transpose(0, 1, 3, 2)) if sym else (a @ a.transpose(0, 1, 3, 2) + 0.01 * rs.standard_normal((B, Hq, 128, 128)).astype(np.float32))
             k, v = to_dev(kn, dtype), to_dev(vn, dtype)
             want = O.ea_score(kn, vn, mu, cov, n_sink, True, 0.0)
-            out = {}
-            for tri in (1, 0):
-                knobs(KVP_EA_TRI=tri)
-                out[tri] = N.ea_score(k, v, torch.from_numpy(mu).to(DEV), torch.from_numpy(cov).to(DEV), n_sink, True, 0.0).cpu().numpy()
-                rel = np.abs(out[tri][..., n_sink:] - want[..., n_sink:]) / np.abs(want[..., n_sink:])
-                assert rel.max() <= 1e-3, (dtype, S, sym, tri, rel.max())
-            assert (np.abs(out[1] - out[0]) <= 2e-5 * np.abs(out[0])).all(), (dtype, S, sym)
-            knobs(KVP_EA_TRI=None)
+            got = N.ea_score(k, v, torch.from_numpy(mu).to(DEV), torch.from_numpy(cov).to(DEV), n_sink, True, 0.0).cpu().numpy()
+            rel = np.abs(got[..., n_sink:] - want[..., n_sink:]) / np.abs(want[..., n_sink:])
+            assert rel.max() <= 1e-3, (dtype, S, sym, rel.max())
+            want0 = O.ea_score(kn, vn, mu, None, n_sink, True, 0.0)
+            got0 = N.ea_score(k, v, torch.from_numpy(mu).to(DEV), None, n_sink, True, 0.0).cpu().numpy()
+            rel0 = np.abs(got0[..., n_sink:] - want0[..., n_sink:]) / np.abs(want0[..., n_sink:])
+            assert rel0.max() <= 1e-3, (dtype, S, "mean only", rel0.max())
 
 
 def test_ea_fused_finalize_equals_three_kernels(knobs):
     """kvp_ea_score's one-pass ||v|| + row normalisers + finalize (ea_vnorm_finalize_kernel: 256-byte rows, >= 4096 scored keys) against
-    the three kernels it replaces (KVP_EA_FUSED_FINALIZE=0): the same bits, with and without sinks, GQA groups of 1 / 2 / 4 (one pass) and 8 (the three kernels), ragged
-    lengths, a strided V view, cached and streaming loads."""
+    the three kernels it replaces (KVP_EA_FUSED_FINALIZE=0: the generic path other shapes take): the same bits, with and without sinks, GQA
+    groups of 1 / 2 / 4 (one pass) and 8 (the three kernels), ragged lengths, a strided V view."""
     N = native()
     g = torch.Generator(device=DEV)
     g.manual_seed(5)
@@ -762,13 +751,11 @@ def test_ea_fused_finalize_equals_three_kernels(knobs):
             mu = torch.randn((B, Hq, 128), generator=g, device=DEV) * 0.3
             a = torch.randn((B, Hq, 128, 128), generator=g, device=DEV) * 0.05
             cov = a @ a.transpose(-1, -2)
-            knobs(KVP_EA_FUSED_FINALIZE=0, KVP_RN_NT=0)
+            knobs(KVP_EA_FUSED_FINALIZE=0)
             ref = N.ea_score(k, v, mu, cov, n_sink, True, 0.02)
-            for nt in (0, 1):
-                knobs(KVP_EA_FUSED_FINALIZE=1, KVP_RN_NT=nt)
-                got = N.ea_score(k, v, mu, cov, n_sink, True, 0.02)
-                assert torch.equal(got, ref), (dt, B, Hq, Hkv, S, n_sink, nt, float((got - ref).abs().max()))
-            knobs(KVP_EA_FUSED_FINALIZE=None, KVP_RN_NT=None)
+            knobs(KVP_EA_FUSED_FINALIZE=None)
+            got = N.ea_score(k, v, mu, cov, n_sink, True, 0.02)
+            assert torch.equal(got, ref), (dt, B, Hq, Hkv, S, n_sink, float((got - ref).abs().max()))
 
 
 def test_ea_qstats_mfma_multichunk():
@@ -836,16 +823,16 @@ def test_fused_knorm_compress_equals_modular(name):
     assert torch.equal(ko, wk) and torch.equal(vo, wv)
 
 
-@pytest.mark.parametrize("variant", ["cluster_knorm", "cluster", "passes", "row_fused"])
+@pytest.mark.parametrize("variant", ["cluster_knorm", "passes"])
 @pytest.mark.parametrize("S", [16384, 16385, 20000, 32768, 32769, 70001])
 def test_fused_knorm_select_variants_equal_modular(S, variant, knobs):
-    """Knorm's fused compress across the select's row-length regimes and variants: own digits <= 16384; beyond, norms + select in
-    ONE cluster launch (default), the cluster select after the norm kernel with its fused first-digit histogram
-    (KVP_TK_CLUSTER_KNORM=0), the (chunk, row) passes (KVP_TK_CLUSTER=0), one launch from that histogram up to 32768
-    (KVP_TK_ROW_FUSED=1); heavy ties included (bf16 norms): the modular sequence's bytes, twice through the same self-cleaning
-    workspace."""
-    knobs(**{"cluster_knorm": {}, "cluster": dict(KVP_TK_CLUSTER_KNORM=0), "passes": dict(KVP_TK_CLUSTER=0),
-             "row_fused": dict(KVP_TK_CLUSTER=0, KVP_TK_ROW_FUSED=1)}[variant])
+    """Knorm's fused compress across the select's row-length regimes: own digits <= 16384; beyond, norms + select in ONE cluster
+    launch (default) or -- what a device that cannot hold the cluster grid runs, KVP_TK_CLUSTER=0 -- the norm kernel with its fused
+    first-digit histogram + the (chunk, row) passes; heavy ties included (bf16 norms): the modular sequence's bytes, twice through the
+    same self-cleaning workspace."""
+    if variant != "cluster_knorm" and S <= 16384:
+        pytest.skip("the variants differ only for rows beyond 16384 scores")
+    knobs(**{"cluster_knorm": {}, "passes": dict(KVP_TK_CLUSTER=0)}[variant])
     N = native()
     g = torch.Generator(device=DEV); g.manual_seed(S)
     k = torch.randn((1, 8, S, 128), generator=g, device=DEV).to(torch.bfloat16)
@@ -885,16 +872,16 @@ def test_fused_snapkv_compress_equals_modular(name):
         assert torch.equal(ko, wk) and torch.equal(vo, wv), f"{name} n={n}"
 
 
-@pytest.mark.parametrize("variant", ["default", "cluster_hist1", "passes"])
+@pytest.mark.parametrize("variant", ["default", "passes"])
 @pytest.mark.parametrize("S", [70, 1087, 1089, 1500, 2112, 2113, 3000, 4160, 4161, 9000, 16448, 16449, 20001, 32832, 32833, 40000, 70003])
 def test_fused_snapkv_select_variants_equal_modular(S, variant, knobs):
     """The fused compress picks its select by row length (pool + select in one launch up to 4096 columns, one-launch select
-    up to 16384; beyond: pooling inside the cluster select's loader (default), the pooling kernel with its fused first-digit
-    histogram + the cluster select (KVP_TK_CLUSTER_POOL=0) or + the (chunk, row) passes (KVP_TK_CLUSTER=0)): always the modular
+    up to 16384; beyond: pooling inside the cluster select's loader (default) or -- a device that cannot hold the cluster grid,
+    KVP_TK_CLUSTER=0 -- the pooling kernel with its fused first-digit histogram + the (chunk, row) passes): always the modular
     sequence's bytes."""
     if variant != "default" and S - 64 <= 16384:
         pytest.skip("the variants differ only for rows beyond 16384 columns")
-    knobs(**{"default": {}, "cluster_hist1": dict(KVP_TK_CLUSTER_POOL=0), "passes": dict(KVP_TK_CLUSTER=0)}[variant])
+    knobs(**{"default": {}, "passes": dict(KVP_TK_CLUSTER=0)}[variant])
     N = native()
     g = torch.Generator(device=DEV); g.manual_seed(S)
     k = torch.randn((2, 2, S, 128), generator=g, device=DEV).to(torch.bfloat16)
@@ -1219,11 +1206,12 @@ def test_snapkv_mfma_group_blocks_are_deterministic(G):
 
 
 @pytest.mark.parametrize("S,W", [(8256, 64), (8260, 64), (12288 + 64, 64), (20000, 64), (40000, 64), (65600, 64), (8228, 30), (9000, 2)])
-def test_snapkv_pool_variants_identical(S, W, knobs):
-    """Long rows with kernel_size 5 are pooled four scores per thread (8-byte loads, one 16-byte store; aligned rows only): the
-    same additions in the same order as the one-score-per-thread kernel, so scores (pad value included), fused histogram and
-    the compressed cache are bit-identical with KVP_SK_POOL_VEC=0, and the scores match the oracle.  (Windows other than 64
-    take the generic attention kernels; S - W = 2 mod 4 leaves a partial last group of four.)"""
+def test_snapkv_pool_vector_and_scalar_paths(S, W, knobs):
+    """Long rows with kernel_size 5 are pooled four scores per thread (8-byte loads, one 16-byte store; aligned rows only), other
+    rows one score per thread -- the same additions in the same order.  Both shapes occur in this list (S - W = 2 mod 4 leaves a
+    partial last group of four; windows other than 64 take the generic attention kernels): the scores match the oracle, and the
+    fused compress -- through the cluster select's pooling loader (default) and through the pooling kernel with its fused
+    histogram + the (chunk, row) passes (KVP_TK_CLUSTER=0) -- returns the modular sequence's bytes."""
     g = torch.Generator().manual_seed(S)
     keys = torch.randn((1, 2, S, 128), generator=g).to(torch.bfloat16).to(DEV)
     vals = torch.randn((1, 2, S, 128), generator=g).to(torch.bfloat16).to(DEV)
@@ -1231,13 +1219,11 @@ def test_snapkv_pool_variants_identical(S, W, knobs):
     cos = torch.ones((1, W, 128), dtype=torch.bfloat16, device=DEV)
     sin = torch.zeros((1, W, 128), dtype=torch.bfloat16, device=DEV)
     N = native()
-    out = {}
-    for variant in ("1", "0"):
-        knobs(KVP_SK_POOL_VEC=variant, KVP_TK_CLUSTER_POOL=0)   # (the fused compress through the pooling kernel, not the cluster select's loader)
-        sc = N.snapkv_score(q, keys, 5)
-        ko, vo = N.snapkv_compress_rope(q, cos, sin, keys, vals, 5, S // 2)
-        out[variant] = (sc, ko, vo)
-    for a, b in zip(out["1"], out["0"]):
-        assert torch.equal(a, b)
+    sc = N.snapkv_score(q, keys, 5)
     ref = O.snapkv_score(q.float().cpu().numpy(), keys.float().cpu().numpy(), 5)
-    np.testing.assert_allclose(out["1"][0].cpu().numpy()[..., :-W], ref[..., :-W], rtol=1e-3)
+    np.testing.assert_allclose(sc.cpu().numpy()[..., :-W], ref[..., :-W], rtol=1e-3)
+    wk, wv = N.gather_kv(keys, vals, N.topk_select(sc, S // 2))
+    for cluster in (None, 0):
+        knobs(KVP_TK_CLUSTER=cluster)
+        ko, vo = N.snapkv_compress_rope(q, cos, sin, keys, vals, 5, S // 2)
+        assert torch.equal(ko, wk) and torch.equal(vo, wv), (S, W, cluster)

@@ -218,6 +218,7 @@ UB_HEAD = r'''// GENERATED by tools/gen_stage_asm.py ubench -- do not edit.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sys/time.h>
 #include <vector>
 #define ITER 400
 #define CLOB %(clob)s
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(%(threads)d, 1) void k_%(name)s(unsigned long long*
     const uint32_t m0base = __builtin_amdgcn_readfirstlane(ldsbase + (threadIdx.x >> 6) * 1024);
     const char* g = kglob + (size_t)blockIdx.x * ((size_t)400 * 3 * 32768 + 98304);
     const uint32_t voff = threadIdx.x * 16;
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     asm volatile(
 %(init)s
         "s_mov_b32 s20, 0x3e0296b3\n"   // c = log2(e) / sqrt(128)
@@ -249,10 +250,11 @@ __global__ __launch_bounds__(%(threads)d, 1) void k_%(name)s(unsigned long long*
         "s_nop 15\n"
         :: "v"(in + lane * 8), "v"(voff), "s"(m0base), "s"(g), "v"(la[0]), "v"(la[1]), "v"(la[2]), "v"(la[3]), "v"(la[4]), "v"(la[5]), "v"(la[6]), "v"(la[7])
         : CLOB%(aclob)s, "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "m0", "scc", "memory");
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float r;
     asm volatile("v_add_f32 %%0, v193, v192" : "=v"(r));
     if (lane == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+    if (lane == 0) cyc[2048 + blockIdx.x * 8 + (threadIdx.x >> 6)] = r1 - r0;   // 100 MHz real-time ticks of the same interval
     if (r == 123.456f) sink[0] = r;
 }
 '''
@@ -353,7 +355,13 @@ def gen_ubench():
         out.append(UB_KERNEL % dict(name=name, init=fmt(init), body=fmt(body), iters=400 // 1, threads=512, aclob=""))
     # host
     out.append(r'''
+static const char* g_only = nullptr;   // argv[1]: run only this variant ("all" = every one)
+static int g_loop_ms = 0;              // argv[2]: after the one-shot measurement, relaunch the variant back to back for this many ms
+                                       // (sustained clocks / power: tools/power_clock_lab.py samples amdsmi beside it)
+static int g_mode = -1;                // argv[3]: 0 = 8 workgroups / constant operands only, 1 = 256 workgroups / random operands only
+static double now_s() { timeval tv; gettimeofday(&tv, nullptr); return tv.tv_sec + tv.tv_usec * 1e-6; }
 template <typename K> void run(const char* name, K kern, int blocks, const uint32_t* in, const char* kglob, unsigned long long* d_cyc, float* sink, int threads = 512) {
+    if (g_only && strcmp(g_only, "all") && strcmp(g_only, name)) return;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipMemset(d_cyc, 0, 4096 * 8);
@@ -363,13 +371,35 @@ template <typename K> void run(const char* name, K kern, int blocks, const uint3
     kern<<<blocks, threads, 98304>>>(d_cyc, sink, in, kglob);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    std::vector<unsigned long long> h(blocks * 8);
-    hipMemcpy(h.data(), d_cyc, h.size() * 8, hipMemcpyDeviceToHost);
-    double a = 0; int nz = 0; for (auto x : h) if (x) { a += (double)x; ++nz; }
+    auto summarize = [&](double& ticks, double& mhz) {
+        std::vector<unsigned long long> h(4096);
+        hipMemcpy(h.data(), d_cyc, h.size() * 8, hipMemcpyDeviceToHost);
+        double a = 0, c = 0, r = 0; int nz = 0;
+        for (int i = 0; i < blocks * 8; ++i) if (h[i]) { a += (double)h[i]; ++nz; if (h[2048 + i]) { c += (double)h[i]; r += (double)h[2048 + i]; } }
+        ticks = a / (nz ? nz : 1);
+        mhz = r > 0 ? c / r * 100.0 : 0.0;
+    };
     const double stages = 400.0 * 12.0;
-    printf("%-22s blocks %3d: %7.1f ns per stage (%d wave%s/SIMD)   %7.1f s_memtime ticks per stage   kernel %.1f us\n", name, blocks, ms * 1e6 / stages, threads / 256, threads == 512 ? "s" : "", a / (nz ? nz : 1) / stages, ms * 1e3);
+    double ticks, mhz; summarize(ticks, mhz);
+    printf("%-22s blocks %3d: %7.1f ns per stage (%d wave%s/SIMD)   %7.1f s_memtime ticks per stage   kernel %.1f us   in-kernel clock %.0f MHz\n", name, blocks, ms * 1e6 / stages,
+           threads / 256, threads == 512 ? "s" : "", ticks / stages, ms * 1e3, mhz);
+    if (g_loop_ms > 0) {
+        const double t0 = now_s();
+        int n = 0;
+        hipEventRecord(e0);
+        while ((now_s() - t0) * 1e3 < g_loop_ms) { for (int i = 0; i < 8; ++i) kern<<<blocks, threads, 98304>>>(d_cyc, sink, in, kglob); n += 8; hipStreamSynchronize(0); }
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        const double t1 = now_s();
+        hipEventElapsedTime(&ms, e0, e1);
+        summarize(ticks, mhz);
+        printf("LOOP %s blocks %d t0 %.6f t1 %.6f launches %d ns_per_stage %.1f clock_mhz_last_launch %.0f\n", name, blocks, t0, t1, n, ms * 1e6 / n / stages, mhz);
+    }
+    fflush(stdout);
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_only = argv[1];
+    if (argc > 2) g_loop_ms = atoi(argv[2]);
+    if (argc > 3) g_mode = atoi(argv[3]);
     unsigned long long* d_cyc; float* sink; uint32_t* in_rand; uint32_t* in_const; char* kglob;
     hipMalloc(&d_cyc, 4096 * 8); hipMalloc(&sink, 64); hipMalloc(&in_rand, 512 * 4); hipMalloc(&in_const, 512 * 4);
     const size_t gbytes = (size_t)256 * ((size_t)400 * 3 * 32768 + 98304) + (1u << 20);
@@ -382,6 +412,7 @@ int main() {
     for (auto& x : h) x = 0x3c003c00u;
     hipMemcpy(in_const, h.data(), 2048, hipMemcpyHostToDevice);
     for (int mode = 0; mode < 2; ++mode) {
+        if (g_mode >= 0 && mode != g_mode) continue;
         const int blocks = mode ? 256 : 8;
         const uint32_t* in = mode ? in_rand : in_const;
         printf("== %s\n", mode ? "256 workgroups, random operands" : "8 workgroups, constant operands");
