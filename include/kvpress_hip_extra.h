@@ -2,8 +2,8 @@
  *
  * include/kvpress_hip.h is the boundary a maintainer binds for the score -> top-k -> gather path (KnormPress, SnapKVPress,
  * ExpectedAttentionPress and the section-8(f) presses that reuse its kernels).  The functions below serve presses that
- * SURVEY.md section 2 marks out of scope (ObservedAttention, LagKV, ThinK, CriticalKV); they were built in round 1, are
- * kept and tested, and live in the same shared library, but they are not part of that boundary.
+ * SURVEY.md section 2 marks out of scope (ObservedAttention, LagKV, ThinK: python package kvpress_amd.contrib); they were built in
+ * round 1, are kept and tested, and live in the same shared library, but they are not part of that boundary.
  * Conventions (return codes, dtypes, strides, streams): as in kvpress_hip.h. */
 #ifndef KVPRESS_HIP_EXTRA_H
 #define KVPRESS_HIP_EXTRA_H
@@ -43,12 +43,6 @@ int kvp_think_channel_scores(const void* q, int64_t q_sb, int64_t q_sh, int64_t 
                              float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream);
 int kvp_zero_channels(void* x, int64_t sb, int64_t sh, int64_t ss, int dtype, int64_t B, int64_t H, int64_t S, int64_t D,
                       const int32_t* idx, int64_t n, kvp_stream_t stream);
-
-/* ---- CriticalKVPress.vwl1norm: `torch.norm(head_WoV, p=1, dim=-1)` (kvpress/presses/criticalkv_press.py:70-73) ---------
- * out[r] = scale * sum_c |x[r,c]| over the rows of a 2-D view [R, N] (row_stride in elements, rows contiguous): the L1 norm of
- * every token's value vector after the head's slice of the output projection (that projection is a plain library GEMM on the
- * model's own o_proj weight and stays with the caller).  out contiguous [R] float32. */
-int kvp_rowl1_score(const void* x, int dtype, int64_t R, int64_t N, int64_t row_stride, float scale, float* out, kvp_stream_t stream);
 
 #ifdef __cplusplus
 }

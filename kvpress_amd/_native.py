@@ -39,7 +39,6 @@ SIGNATURES = {
     "kvp_think_channel_scores": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, _I64,
                                          c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_zero_channels": (c_int, [c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, c_void_p, _I64, c_void_p]),
-    "kvp_rowl1_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, c_float, c_void_p, c_void_p]),
     "kvp_rowdot_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_void_p, _I64, c_float, c_void_p, c_void_p]),
     "kvp_knorm_compress_workspace_bytes": (c_size_t, [_I64] * 4),
     "kvp_knorm_compress": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64,
@@ -255,20 +254,6 @@ def zero_channels_(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         _check(lib().kvp_zero_channels(_p(x), _st(x, 0), _st(x, 1), _st(x, 2), _DTYPES[x.dtype], B, H, S, D, _p(idx), idx.shape[2], _stream(x)),
                "kvp_zero_channels")
     return x
-
-
-def rowl1_score(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
-    """L1 norm of the rows of x [..., N] (last dim contiguous, leading dims collapsible to one stride), float32 [...]."""
-    x = _dev(x)
-    lead, N = x.shape[:-1], x.shape[-1]
-    x2 = x.reshape(-1, N)          # a view when the leading dims collapse, else a copy
-    if x2.stride(-1) != 1:
-        x2 = x2.contiguous()
-    out = torch.empty((x2.shape[0],), dtype=torch.float32, device=x.device)
-    with _on_device(x.device):
-        _check(lib().kvp_rowl1_score(_p(x2), _DTYPES[x2.dtype], x2.shape[0], N, x2.stride(0) if x2.shape[0] > 1 else N, float(scale), _p(out),
-                                     _stream(x2)), "kvp_rowl1_score")
-    return out.view(lead)
 
 
 def rowdot_score(x: torch.Tensor, filt: torch.Tensor, scale: float) -> torch.Tensor:

@@ -11,8 +11,8 @@ cut back to its post-prefill length between questions.
     pipe(context, questions=[...], press=...)["answers"]
 
 Host-side differences to the reference, none of which changes a result:
-  * FinchPress (delimiter token, :224-232), DMSPress, DecodingPress, PrefillDecodingPress and KeyRerotationPress are handled as
-    there; the RestoreKVPress special case (:243) is absent (that press is not part of this package);
+  * FinchPress (delimiter token, :224-232), DecodingPress, PrefillDecodingPress and KeyRerotationPress are handled as there; the
+    DMSPress / RestoreKVPress special cases (:230-232, :243) are absent (those presses are not part of this package);
   * ``logits_to_keep`` is the transformers >= 4.50 name of ``num_logits_to_keep`` (:288).
 """
 from __future__ import annotations
@@ -27,7 +27,6 @@ from transformers.pipelines import PIPELINE_REGISTRY
 
 from kvpress_amd.presses.base_press import BasePress
 from kvpress_amd.presses.decoding_press import DecodingPress, PrefillDecodingPress
-from kvpress_amd.presses.dms_press import DMSPress
 from kvpress_amd.presses.finch_press import FinchPress
 from kvpress_amd.presses.key_rerotation_press import KeyRerotationPress
 
@@ -92,7 +91,7 @@ class KVPressTextGenerationPipeline(Pipeline):
                  cache: Optional[Cache] = None):
         """Prefill the context under the press, then one greedy answer per question (pipeline.py:173-246)."""
         is_decoding_press = isinstance(press, (DecodingPress, PrefillDecodingPress))
-        decoding = is_decoding_press or (isinstance(press, DMSPress) and press.decoding)   # pipeline.py:230-232
+        decoding = is_decoding_press   # pipeline.py:230-232 (the reference also counts a decoding DMSPress: not part of this package)
         if is_decoding_press and len(input_tensors["questions_ids"]) > 1:
             raise ValueError("DecodingPress is not compatible with multiple questions. Please specify a single question.")
         device = self.model.device

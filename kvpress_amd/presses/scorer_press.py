@@ -32,6 +32,50 @@ from kvpress_amd.presses.base_press import BasePress
 
 logger = logging.getLogger(__name__)
 
+_ORDER_WARNED = False
+
+
+def _wrapped(press):
+    """`press` and every press it wraps (ChunkPress.press, DecodingPress.base_press, ComposedPress.presses, ...)"""
+    out, todo = [], [press]
+    while todo:
+        p = todo.pop()
+        if not isinstance(p, BasePress) or any(p is q for q in out):
+            continue
+        out.append(p)
+        for name in ("press", "base_press", "prefilling_press", "decoding_press"):
+            todo.append(getattr(p, name, None))
+        todo += list(getattr(p, "presses", None) or [])
+    return out
+
+
+def warn_if_chain_depends_on_kept_order(first, later, where: str) -> bool:
+    """One-time ``logger.warning`` when a press that looks at token ORDER (anything but the order-blind row scorers Knorm / KeyDiff /
+    QFilter / CUR-without-sinks is treated as order-dependent: "last W tokens", sinks, chunks, re-rotation, recency) runs on a cache that
+    an earlier ScorerPress pruned with ``kept_order = "position"``: the reference hands that press the survivors in descending SCORE
+    order (scorer_press.py:95-100), this package in ascending position order, so the chain keeps different tokens than the reference
+    unless ``kept_order = "score"`` is set on the earlier press (composed_press.py:56-62).  Returns whether the
+    situation was detected (tests)."""
+    global _ORDER_WARNED
+    from kvpress_amd.presses.keydiff_press import KeyDiffPress
+    from kvpress_amd.presses.knorm_press import KnormPress
+    from kvpress_amd.presses.qfilter_press import QFilterPress
+
+    order_blind = (KnormPress, KeyDiffPress, QFilterPress)
+    pruners = [p for p in _wrapped(first) if isinstance(p, ScorerPress) and p.kept_order == "position" and p.compression_ratio != 0]
+    dependents = [p for q in later for p in _wrapped(q)]
+    dependents = [p for p in dependents if not isinstance(p, order_blind) and type(p).__name__ not in ("ComposedPress", "PerLayerCompressionPress", "DecodingPress")]
+    if not pruners or not dependents:
+        return False
+    if not _ORDER_WARNED:
+        _ORDER_WARNED = True
+        logger.warning(
+            "%s: %s runs on a cache that %s has already pruned with kept_order='position' (survivors in ascending position order). The "
+            "reference stores them in descending score order, so this order-dependent press sees different 'last' / 'first' tokens than "
+            "in NVIDIA/kvpress; set kept_order='score' on the earlier press for reference-identical chains. (Shown once.)",
+            where, type(dependents[0]).__name__, type(pruners[0]).__name__)
+    return True
+
 
 @dataclass
 class ScorerPress(BasePress):

@@ -63,11 +63,7 @@ __all__ = [
     "think_channel_scores",
     "think_prune",
     "qfilter_score",
-    "simlayer_lazy_score",
     "chunkkv_indices",
-    "vwl1norm",
-    "critical_scores",
-    "criticalada_pruned",
 ]
 
 
@@ -452,13 +448,6 @@ def qfilter_score(keys: np.ndarray, q_filter: np.ndarray, ctype=np.float64) -> n
     return (-(f[None, :, None, :] * k).sum(-1)).astype(np.float32)
 
 
-def simlayer_lazy_score(q_win, keys, n_initial: int, n_recent: int, ctype=np.float64) -> float:
-    """SimLayerKVPress.is_lazy's statistic (simlayerkv_press.py:49-56): window attention of the last queries (as SnapKV),
-    mean over batch, heads and window rows, then the mass on the first ``n_initial`` and the last ``n_recent`` keys."""
-    w = snapkv_window_attention(q_win, keys, ctype).mean(axis=(0, 1, 2))
-    return float(w[:n_initial].sum() + w[-n_recent:].sum())
-
-
 def tova_score(q_last, keys, ctype=np.float64) -> np.ndarray:
     """TOVAPress.score with ``attentions=None`` (tova_press.py:45-59) from the RoPE'd query of the LAST token
     ``q_last [B,Hq,1,D]``: window attention with window 1 (SnapKVPress.compute_window_attention, snapkv_press.py:41-69),
@@ -571,62 +560,6 @@ def adakv_pruned(scores: np.ndarray, compression_ratio: float, alpha_safeguard: 
         np.put_along_axis(sc, top.astype(np.int64), np.finfo(np.float32).max, axis=-1)
     n_pruned = H * (S - n_kept)
     return topk_select(-sc.reshape(B, H * S), n_pruned).astype(np.int64)
-
-
-def vwl1norm(values, wo, num_heads: int, ctype=np.float64) -> np.ndarray:
-    """``CriticalKVPress.vwl1norm`` (criticalkv_press.py:57-77): per q-head the L1 norm of ``v @ Wo_head`` (Wo = o_proj.weight^T
-    viewed [Hq, D, hidden]), mean over the kv-head's group.  values [B,H,S,D], wo = o_proj.weight [hidden, Hq*D] -> [B,H,S]."""
-    v = np.asarray(values).astype(ctype)
-    B, H, S, D = v.shape
-    G = num_heads // H
-    Wo = np.asarray(wo).astype(ctype).T.reshape(num_heads, D, -1)
-    out = np.zeros((B, H, S), ctype)
-    for hq in range(num_heads):
-        out[:, hq // G] += np.abs(v[:, hq // G] @ Wo[hq]).sum(-1) / G
-    return out
-
-
-_F32MAX = float(np.finfo(np.float32).max)
-
-
-def critical_scores(scores, values, wo, num_heads: int, compression_ratio: float, epsilon: float = 1e-4, first_stage_ratio: float = 0.5):
-    """CriticalKVPress.score (criticalkv_press.py:79-93) from the wrapped press's scores [B,H,S]."""
-    sc = np.asarray(scores, np.float64)
-    S = sc.shape[-1]
-    first = topk_select(sc.astype(np.float32), int((1 - compression_ratio) * S * first_stage_ratio))
-    out = (sc + epsilon) * vwl1norm(values, wo, num_heads)
-    np.put_along_axis(out, first.astype(np.int64), _F32MAX, axis=-1)
-    return out.astype(np.float32)
-
-
-def criticalada_pruned(scores, values, wo, num_heads: int, compression_ratio: float, alpha_safeguard: float = 0.2, epsilon: float = 1e-4,
-                       first_stage_ratio: float = 0.5) -> np.ndarray:
-    """CriticalAdaKVPress.compress (criticalkv_press.py:128-183), batch size 1: the pruned (head, position) pairs as sorted
-    flat indices ``head * S + position``."""
-    sc = np.array(scores, np.float64)
-    B, H, S = sc.shape
-    assert B == 1
-    n_kept = int(S * (1 - compression_ratio))
-    n_safe = int(n_kept * alpha_safeguard)
-    def f32(a):
-        with np.errstate(over="ignore"):   # float32 max times a norm overflows to +inf, as in the reference's float32 tensors
-            return a.astype(np.float32)
-    np.put_along_axis(sc, topk_select(f32(sc), n_safe).astype(np.int64), _F32MAX, axis=-1)
-    flat_top = topk_select(f32(sc.reshape(B, -1)), n_kept * H)
-    budgets = np.bincount((flat_top // S).reshape(-1), minlength=H)
-    stage1 = (budgets * first_stage_ratio).astype(np.int64)
-    order = topk_select_by_score(f32(sc), int(stage1.max())) if stage1.max() > 0 else None
-    for h in range(H):
-        if stage1[h]:
-            sc[:, h, order[:, h, : stage1[h]].reshape(-1)] = _F32MAX
-    sc = (f32(sc).astype(np.float64) + epsilon) * vwl1norm(values, wo, num_heads)
-    sc = f32(sc).astype(np.float64)   # +inf where the protected float32 maxima were rescaled: they stay on top either way
-    order = topk_select_by_score(f32(sc), int(budgets.max())) if budgets.max() > 0 else None
-    for h in range(H):
-        if budgets[h]:
-            sc[:, h, order[:, h, : budgets[h]].reshape(-1)] = _F32MAX
-    n_pruned = H * (S - n_kept)
-    return np.sort(topk_select(f32(-sc.reshape(B, -1)), n_pruned), axis=-1).astype(np.int64)
 
 
 def cur_score(keys, values, leverage_type="kv_product", use_local_approximation=True, local_window_size=16, num_sinks=4, ctype=np.float64):

@@ -312,30 +312,13 @@ def tiny_context(n_words: int, seed: int = 0) -> str:
     return " ".join(TINY_WORDS[i] for i in rng.integers(0, len(TINY_WORDS), n_words))
 
 
-def make_duo_press(ns, head_compression_ratio: float):
-    """DuoAttentionPress with seeded head scores instead of the published patterns (network), the way the reference's own
-    tests do it (tests/default_presses.py:38-42); works for the reference package and for this one."""
-    class OfflineDuoAttentionPress(ns.DuoAttentionPress):
-        @staticmethod
-        def load_attention_pattern(model):
-            n_layers, n_heads = model.config.num_hidden_layers, model.config.num_key_value_heads
-            return 2, 2, np.random.RandomState(7).rand(n_layers, n_heads)
+def press_class(ns, name):
+    """class `name` of namespace `ns`; for this package also its contrib sub-package (presses outside SURVEY §8)"""
+    if hasattr(ns, name):
+        return getattr(ns, name)
+    import importlib
 
-    return OfflineDuoAttentionPress(head_compression_ratio=head_compression_ratio)
-
-
-def make_ea_stats_press(ns, model_config=None, **kw):
-    """ExpectedAttentionStatsPress with seeded statistics assigned directly (the published ones need the hub): mean ~ N(0, 0.3),
-    covariance = A A^T / D + 0.1 I per (layer, head), for the tiny Llama geometry (2 layers, 4 heads, head_dim 6)."""
-    import torch
-
-    L, Hq, D = 2, 4, 6
-    g = torch.Generator().manual_seed(11)
-    A = torch.randn(L, Hq, D, D, generator=g)
-    press = ns.ExpectedAttentionStatsPress(**kw)
-    press.mu = 0.3 * torch.randn(L, Hq, D, generator=g)
-    press.cov = A @ A.transpose(-1, -2) / D + 0.1 * torch.eye(D)
-    return press
+    return getattr(importlib.import_module(ns.__name__ + ".contrib"), name)
 
 
 def build_press(ns, spec):
@@ -346,13 +329,9 @@ def build_press(ns, spec):
     if isinstance(spec, list):
         return [build_press(ns, x) for x in spec]
     cls, kw = spec
-    if cls == "DuoAttentionPress":
-        return make_duo_press(ns, **kw)
-    if cls == "ExpectedAttentionStatsPress":
-        return make_ea_stats_press(ns, **kw)
     is_spec = lambda v: (isinstance(v, tuple) and len(v) == 2 and isinstance(v[0], str) and isinstance(v[1], dict)) or \
         (isinstance(v, list) and v and isinstance(v[0], tuple))
-    return getattr(ns, cls)(**{k: (build_press(ns, v) if is_spec(v) else v) for k, v in kw.items()})
+    return press_class(ns, cls)(**{k: (build_press(ns, v) if is_spec(v) else v) for k, v in kw.items()})
 
 
 _KN = lambda r=0.0: ("KnormPress", dict(compression_ratio=r))
@@ -375,13 +354,6 @@ PIPELINE_CASES = {
         prefilling_press=_KN(0.5),
         decoding_press=("DecodingPress", dict(base_press=_KN(), compression_interval=4, target_size=36, hidden_states_buffer_size=2)))),
         80, ["w5 w6 w7"], 16),
-    "pipe_simlayer_lazy": (("SimLayerKVPress", dict(lazy_threshold=0.05, n_last=1, n_recent=16, n_initial=4)), 120, ["w2 w3"], 6),
-    "pipe_simlayer_busy": (("SimLayerKVPress", dict(lazy_threshold=0.9, n_last=2, n_recent=16, n_initial=4)), 120, ["w2 w3"], 6),
-    "pipe_dms": (("DMSPress", dict(press=_KN(), threshold=-0.21, sliding_window_size=16)), 100, ["w2 w3", "w5"], 6),
-    "pipe_dms_decoding": (("DMSPress", dict(press=_KN(), threshold=-0.21, sliding_window_size=8, decoding=True)), 60, ["w2 w3"], 14),
-    "pipe_duo": (("DuoAttentionPress", dict(head_compression_ratio=0.5)), 80, ["w2 w3", "w9"], 6),
-    "pipe_ea_stats": (("ExpectedAttentionStatsPress", dict(compression_ratio=0.5, n_sink=2, n_future_positions=64)), 90, ["w2 w3", "w7"], 6),
-    "pipe_ea_stats_nocov": (("ExpectedAttentionStatsPress", dict(compression_ratio=0.3, use_covariance=False, use_vnorm=False)), 50, ["w1"], 6),
     "pipe_ratio_decoding": (("CompressionRatioDecodingPress", dict(base_press=_KN(), target_compression_ratio=0.5, compression_interval=3,
                                                                     hidden_states_buffer_size=4)), 70, ["w2 w3 w4"], 13),
     # QuantizedCache write-back of the hook (base_press.py:152-157) and the pipeline's answer removal
@@ -466,14 +438,6 @@ WRAP_CASES = {
                                      chunk_length=64, W=8, ks=5, ratios=(0.5, 0.97)),
     "wrap_chunkkv_short": dict(wrapper="chunkkv", kind="knorm", B=1, H=2, G=1, S=15, D=16, dtype="f32", data="A", seed=96,
                                chunk_length=20, ratios=(0.5,)),
-    "wrap_critical_knorm": dict(wrapper="critical", kind="knorm", B=2, H=2, G=2, S=300, D=16, dtype="f32", data="B", seed=97,
-                                ratios=(0.25, 0.5, 0.9)),
-    "wrap_critical_snapkv_bf16": dict(wrapper="critical", kind="snapkv", B=1, H=2, G=4, S=700, D=128, dtype="bf16", data="B", seed=98,
-                                      W=64, ks=5, ratios=(0.5,)),
-    "wrap_criticalada_knorm": dict(wrapper="criticalada", kind="knorm", B=1, H=4, G=1, S=300, D=16, dtype="f32", data="B", seed=99,
-                                   alpha=0.2, ratios=(0.25, 0.5, 0.9)),
-    "wrap_criticalada_snapkv": dict(wrapper="criticalada", kind="snapkv", B=1, H=2, G=4, S=700, D=128, dtype="f32", data="B", seed=100,
-                                    alpha=0.5, W=64, ks=5, ratios=(0.5,)),
     "wrap_adakv_knorm": dict(wrapper="adakv", kind="knorm", B=2, H=4, G=1, S=300, D=16, dtype="f32", data="B", seed=88, alpha=0.2,
                              ratios=(0.25, 0.5, 0.9)),
     "wrap_adakv_snapkv": dict(wrapper="adakv", kind="snapkv", B=1, H=2, G=4, S=700, D=128, dtype="f32", data="B", seed=89, alpha=0.5,

@@ -11,6 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import kvpress_amd.contrib  # noqa: F401  (tests reach the out-of-scope presses as kvpress_amd.contrib.X)
 
 
 def _has_gpu():
@@ -125,9 +126,6 @@ def fake_native(monkeypatch):
         x.scatter_(-1, idx.long().unsqueeze(2).expand(-1, -1, x.shape[2], -1), 0)
         return x
 
-    def rowl1_score(x, scale=1.0):
-        return torch.from_numpy((np.abs(x.double().numpy()).sum(-1) * scale).astype(np.float32))
-
     def rowdot_score(x, filt, scale):
         return torch.from_numpy(np.float32(-scale) * O.qfilter_score(x.float().numpy(), filt.float().numpy()))
 
@@ -173,7 +171,7 @@ def fake_native(monkeypatch):
 
     for name, fn in dict(rownorm_score=rownorm_score, topk_select=topk_select, gather_kv=gather_kv,
                          snapkv_score=snapkv_score, snapkv_score_rope=snapkv_score_rope, finch_score=finch_score, snapkv_score_from_attn=snapkv_score_from_attn,
-                         keydiff_score=keydiff_score, rowdot_score=rowdot_score, rowl1_score=rowl1_score, think_channel_scores=think_channel_scores, zero_channels_=zero_channels_, lagkv_score=lagkv_score, observed_attention_score=observed_attention_score, cur_score=cur_score, scores_head_mean_=scores_head_mean_, knorm_compress=knorm_compress, qproj_rope_supported=qproj_rope_supported, scores_fill_at_=scores_fill_at_, topk_select_segmented=topk_select_segmented, rerotate_keys_=rerotate_keys_, gather_kv_rerotate=gather_kv_rerotate,
+                         keydiff_score=keydiff_score, rowdot_score=rowdot_score, think_channel_scores=think_channel_scores, zero_channels_=zero_channels_, lagkv_score=lagkv_score, observed_attention_score=observed_attention_score, cur_score=cur_score, scores_head_mean_=scores_head_mean_, knorm_compress=knorm_compress, qproj_rope_supported=qproj_rope_supported, scores_fill_at_=scores_fill_at_, topk_select_segmented=topk_select_segmented, rerotate_keys_=rerotate_keys_, gather_kv_rerotate=gather_kv_rerotate,
                          snapkv_compress_rope=snapkv_compress_rope, ea_qstats=ea_qstats, ea_score=ea_score).items():
         monkeypatch.setattr(_native, name, fn)
     return _native

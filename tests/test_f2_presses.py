@@ -24,9 +24,9 @@ def make_press(s, ratio):
     if k == "keydiff":
         return P.KeyDiffPress(compression_ratio=ratio)
     if k == "lagkv":
-        return P.LagKVPress(compression_ratio=ratio, n_sink=s["n_sink"], lag_size=s["lag"], cross_scoring=s.get("cross", False))
+        return P.contrib.LagKVPress(compression_ratio=ratio, n_sink=s["n_sink"], lag_size=s["lag"], cross_scoring=s.get("cross", False))
     if k == "observed":
-        return P.ObservedAttentionPress(compression_ratio=ratio)
+        return P.contrib.ObservedAttentionPress(compression_ratio=ratio)
     if k == "qfilter":
         p = P.QFilterPress(compression_ratio=ratio)
         p.q_filters = torch.from_numpy(_inputs.make_qfilters(s))

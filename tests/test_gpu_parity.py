@@ -537,9 +537,9 @@ def make_press(s, ratio):
         return P.CURPress(compression_ratio=ratio, num_sinks=s.get("sinks", 4), leverage_type=s["leverage"],
                           use_local_approximation=s.get("local", True), local_window_size=s.get("window", 16))
     if s["kind"] == "lagkv":
-        return P.LagKVPress(compression_ratio=ratio, n_sink=s["n_sink"], lag_size=s["lag"], cross_scoring=s.get("cross", False))
+        return P.contrib.LagKVPress(compression_ratio=ratio, n_sink=s["n_sink"], lag_size=s["lag"], cross_scoring=s.get("cross", False))
     if s["kind"] == "observed":
-        return P.ObservedAttentionPress(compression_ratio=ratio)
+        return P.contrib.ObservedAttentionPress(compression_ratio=ratio)
     if s["kind"] == "qfilter":
         p = P.QFilterPress(compression_ratio=ratio)
         p.q_filters = torch.from_numpy(_inputs.make_qfilters(s)).to(DEV)   # the press casts per call to the key dtype

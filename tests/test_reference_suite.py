@@ -34,11 +34,11 @@ def _presses_run(device, dtype):
     from transformers import DynamicCache
 
     import kvpress_amd as P
+    from kvpress_amd import contrib as C
 
     model = _inputs.make_tiny_llama(dtype=dtype, device=device)
     ids = torch.randint(3, 59, (1, 128), generator=torch.Generator().manual_seed(0)).to(device)
-    for wrapper in (None, P.ComposedPress, P.KeyRerotationPress, P.AdaKVPress, P.ChunkPress, P.BlockPress, P.ChunkKVPress, P.CriticalKVPress,
-                    P.CriticalAdaKVPress, P.DMSPress):
+    for wrapper in (None, P.ComposedPress, P.KeyRerotationPress, P.AdaKVPress, P.ChunkPress, C.BlockPress, C.ChunkKVPress):
         for cls, kw_list in _scorer_configs(P):
             for kwargs in kw_list:
                 press = _make(P, cls, kwargs, model)
@@ -46,10 +46,8 @@ def _presses_run(device, dtype):
                     press = P.ComposedPress(presses=[press])
                 elif wrapper is P.ChunkPress:
                     press = P.ChunkPress(press=press, chunk_length=24)
-                elif wrapper is P.BlockPress:
-                    press = P.BlockPress(press=press, block_size=32)
-                elif wrapper is P.DMSPress:
-                    press = P.DMSPress(press=press, threshold=-0.5, sliding_window_size=32)      # the reference's setting (:100)
+                elif wrapper is C.BlockPress:
+                    press = C.BlockPress(press=press, block_size=32)
                 elif wrapper is not None:
                     press = wrapper(press=press)
                 press.post_init_from_model(model)
@@ -58,45 +56,14 @@ def _presses_run(device, dtype):
                     model(ids, past_key_values=cache)
                 assert hasattr(press, "compression_ratio")
                 n = cache.get_seq_length()
-                if wrapper in (P.AdaKVPress, P.CriticalAdaKVPress, P.DMSPress):
+                if wrapper is P.AdaKVPress:
                     assert n == 128                                # head-wise pruning masks, nothing is removed
                     for layer in model.model.layers:
                         layer.self_attn.masked_key_indices = None
-                elif wrapper in (None, P.KeyRerotationPress, P.BlockPress, P.CriticalKVPress) and cls is not P.PyramidKVPress:
+                elif wrapper in (None, P.KeyRerotationPress, C.BlockPress) and cls is not P.PyramidKVPress:
                     assert n == int(128 * (1 - kwargs["compression_ratio"])), (cls.__name__, wrapper, n)
                 else:
                     assert 0 < n < 128
-
-
-def test_duo_attention_press(fake_native):
-    """tests/presses/test_duo_attention_press.py + the DuoAttention entry of test_presses_run: masks and bookkeeping."""
-    from transformers import DynamicCache
-
-    import kvpress_amd as P
-
-    model = _inputs.make_tiny_llama()
-    ids = torch.randint(3, 59, (2, 40), generator=torch.Generator().manual_seed(0))
-    for ratio in (0.2, 0.8):
-        press = _inputs.make_duo_press(P, ratio)
-        with pytest.raises(AssertionError):
-            press.compression_ratio
-        cache = DynamicCache()
-        with torch.no_grad(), press(model):
-            model(ids, past_key_values=cache)
-        n_stream = int(press.streaming_mask.sum())
-        assert n_stream == round(2 * 2 * ratio) and (press.sink_size, press.recent_size) == (2, 2)
-        assert cache.get_seq_length() == 40                                      # nothing is removed, streaming heads are masked
-        assert press.compression_ratio == pytest.approx(press.streaming_mask.float().mean().item() * (1 - 4 / 40))
-        for i, layer in enumerate(model.model.layers):
-            b, h, s_ = layer.self_attn.masked_key_indices
-            heads = torch.nonzero(press.streaming_mask[i]).flatten().tolist()
-            assert sorted(set(h.tolist())) == heads and len(b) == 2 * len(heads) * 36
-            assert int(s_.min()) == 2 and int(s_.max()) == 37 if len(heads) else True
-            layer.self_attn.masked_key_indices = None
-        with pytest.raises(AttributeError):
-            press.compression_ratio = 0.3
-    with pytest.raises(ValueError):
-        P.DuoAttentionPress(0.5).compress(model.model.layers[0].self_attn, None, torch.zeros(1, 2, 8, 6), None, None, {})
 
 
 def test_presses_run_cpu(fake_native):

@@ -38,7 +38,7 @@ def _run(s, dev, dt):
     out = []
     with torch.no_grad():
         for i, r in enumerate(s["ratios"]):
-            press = P.ThinKPress(key_channel_compression_ratio=r, window_size=s["W"])
+            press = P.contrib.ThinKPress(key_channel_compression_ratio=r, window_size=s["W"])
             assert press.compression_ratio == r / 2
             keys = torch.from_numpy(s["keys"]).to(device=dev, dtype=dt).clone()
             ko, vo = press.compress(att, hidden, keys, values, None, kwargs)
@@ -52,10 +52,10 @@ def _run(s, dev, dt):
             assert torch.equal(ko[keep], torch.from_numpy(s["keys"]).to(device=dev, dtype=dt)[keep])
             out.append((i, r, pruned))
         k0 = torch.from_numpy(s["keys"]).to(device=dev, dtype=dt)
-        a, b = P.ThinKPress(0.0).compress(att, hidden, k0, values, None, kwargs)
+        a, b = P.contrib.ThinKPress(0.0).compress(att, hidden, k0, values, None, kwargs)
         assert a is k0 and b is values
         with pytest.raises(AttributeError):
-            P.ThinKPress(0.5).compression_ratio = 0.1
+            P.contrib.ThinKPress(0.5).compression_ratio = 0.1
     return out
 
 
@@ -76,7 +76,7 @@ def test_composed_with_token_press(fake_native):
     model = _inputs.make_tiny_llama()
     ids = torch.randint(3, 59, (1, 64), generator=torch.Generator().manual_seed(0))
     cache = DynamicCache()
-    with torch.no_grad(), P.ComposedPress([P.KnormPress(compression_ratio=0.5), P.ThinKPress(key_channel_compression_ratio=0.5, window_size=2)])(model):
+    with torch.no_grad(), P.ComposedPress([P.KnormPress(compression_ratio=0.5), P.contrib.ThinKPress(key_channel_compression_ratio=0.5, window_size=2)])(model):
         model(ids, past_key_values=cache)
     assert cache.get_seq_length() == 32
     for layer in cache.layers:

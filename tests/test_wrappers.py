@@ -15,8 +15,6 @@ ADAKV = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "adakv"]
 BLOCK = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "block"]
 CHUNK = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "chunk"]
 CHUNKKV = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "chunkkv"]
-CRITICAL = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "critical"]
-CRITICALADA = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "criticalada"]
 REROT = [n for n, c in _inputs.WRAP_CASES.items() if c["wrapper"] == "rerot"]
 DEV = "cuda:0"
 
@@ -57,13 +55,9 @@ def wrapped(s, ratio):
     if s["wrapper"] == "adakv":
         return P.AdaKVPress(inner_press(s, ratio), alpha_safeguard=s["alpha"])
     if s["wrapper"] == "block":
-        return P.BlockPress(inner_press(s, ratio), block_size=s["block_size"])
-    if s["wrapper"] == "critical":
-        return P.CriticalKVPress(inner_press(s, ratio))
-    if s["wrapper"] == "criticalada":
-        return P.CriticalAdaKVPress(inner_press(s, ratio), alpha_safeguard=s["alpha"])
+        return P.contrib.BlockPress(inner_press(s, ratio), block_size=s["block_size"])
     if s["wrapper"] == "chunkkv":
-        return P.ChunkKVPress(inner_press(s, ratio), chunk_length=s["chunk_length"])
+        return P.contrib.ChunkKVPress(inner_press(s, ratio), chunk_length=s["chunk_length"])
     return P.ChunkPress(inner_press(s, ratio), chunk_length=s["chunk_length"]) if s["wrapper"] == "chunk" else P.KeyRerotationPress(inner_press(s, ratio))
 
 
@@ -91,67 +85,6 @@ def test_oracle_chunk_indices_match_reference(name):
     for i, r in enumerate(s["ratios"]):
         idx = np.sort(O.chunk_press_indices(fn, s["S"], s["chunk_length"], r), axis=-1)
         assert np.array_equal(idx, g[f"pos_{i}"]), f"{name} r={r}"
-
-
-def _wo(s, dt=torch.float32):
-    att, *_ = _inputs.build_llama_attention(s, dt)
-    return att.o_proj.weight.detach().float().numpy()
-
-
-def _critical_close(got, ref, name):
-    """CriticalKV scores: the protected entries are the float32 maximum in both, the others compare numerically."""
-    big = ref > 1e37
-    assert np.array_equal(got > 1e37, big), f"{name}: first-stage sets differ"
-    np.testing.assert_allclose(got[~big], ref[~big], rtol=1e-3, atol=1e-30, err_msg=name)
-
-
-@pytest.mark.parametrize("name", CRITICAL)
-def test_oracle_critical_scores_match_reference(name):
-    s = _inputs.make_wrap_case(name)
-    g = gold(name)
-    sc = _oracle_scores_full(s)
-    for i, r in enumerate(s["ratios"]):
-        got = O.critical_scores(sc, s["values"], _wo(s), s["Hq"], r)
-        _critical_close(got, g[f"scores_{i}"], f"{name} r={r}")
-        assert np.array_equal(O.topk_select(got, O.n_kept(s["S"], r)), g[f"pos_{i}"])
-
-
-@pytest.mark.parametrize("name", CRITICALADA)
-def test_oracle_criticalada_matches_reference(name):
-    s = _inputs.make_wrap_case(name)
-    g = gold(name)
-    sc = _oracle_scores_full(s)
-    for i, r in enumerate(s["ratios"]):
-        assert np.array_equal(O.criticalada_pruned(sc, s["values"], _wo(s), s["Hq"], r, s["alpha"]), g[f"masked_{i}"]), f"{name} r={r}"
-
-
-def _check_critical(s, name, dev, rtol_dt=torch.float32):
-    g = gold(name)
-    att, rot, hidden, pe = _inputs.build_llama_attention(s, rtol_dt, dev)
-    keys = torch.from_numpy(s["keys"]).to(device=dev, dtype=rtol_dt)
-    values = torch.from_numpy(s["values"]).to(device=dev, dtype=rtol_dt)
-    kwargs = {"position_embeddings": pe}
-    with torch.no_grad():
-        for i, r in enumerate(s["ratios"]):
-            p = wrapped(s, r)
-            sc = p.score(att, hidden, keys, values, None, kwargs).cpu().numpy()
-            _critical_close(sc, g[f"scores_{i}"], f"{name} r={r}")
-            ko, vo = p.compress(att, hidden, keys, values, None, kwargs)
-            wk, wv = O.gather_kv(s["keys"], s["values"], g[f"pos_{i}"])
-            assert np.array_equal(ko.float().cpu().numpy(), wk) and np.array_equal(vo.float().cpu().numpy(), wv)
-        p = wrapped(s, 0.5)
-        p.compression_ratio = 0.25
-        assert p.press.compression_ratio == 0.25
-
-
-@pytest.mark.parametrize("name", CRITICAL)
-def test_critical_matches_reference_cpu(name, fake_native):
-    _check_critical(_inputs.make_wrap_case(name), name, "cpu")
-
-
-@pytest.mark.parametrize("name", CRITICALADA)
-def test_criticalada_matches_reference_cpu(name, fake_native):
-    _run_adakv(_inputs.make_wrap_case(name), name, "cpu")
 
 
 @pytest.mark.parametrize("name", CHUNKKV)
@@ -348,7 +281,7 @@ def test_block_press_is_streaming_top_k(fake_native):
     model = _inputs.make_tiny_llama()
     ids = torch.randint(3, 59, (1, 256), generator=torch.Generator().manual_seed(0))
     sums = []
-    for press in [P.BlockPress(press=HiddenStatesPress(0.5), block_size=b) for b in (2, 4, 8, 128, 256)] + [HiddenStatesPress(0.5)]:
+    for press in [P.contrib.BlockPress(press=HiddenStatesPress(0.5), block_size=b) for b in (2, 4, 8, 128, 256)] + [HiddenStatesPress(0.5)]:
         cache = DynamicCache()
         with torch.no_grad(), press(model):
             model(ids, past_key_values=cache)
@@ -384,31 +317,6 @@ def test_wrappers_match_reference_gpu_fp32(name):
         else:
             wk, _ = O.gather_kv(s["keys"], s["values"], pos)
             assert np.array_equal(ko, wk)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("name", CRITICAL)
-def test_critical_matches_reference_gpu(name):
-    _check_critical(_inputs.make_wrap_case(name), name, DEV)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("name", CRITICALADA)
-def test_criticalada_matches_reference_gpu(name):
-    _run_adakv(_inputs.make_wrap_case(name), name, DEV)
-
-
-@pytest.mark.gpu
-def test_rowl1_kernel():
-    from kvpress_amd import _native
-
-    rs = np.random.RandomState(1)
-    for shape, dt in (((3, 7, 4096), "bf16"), ((5, 515), "f16"), ((2, 3, 100), "f32"), ((4, 8200), "bf16")):
-        x = _inputs.round_to(rs.standard_normal(shape).astype(np.float32), dt)
-        t = torch.from_numpy(x).to(device=DEV, dtype=_inputs.torch_dtype(dt))
-        np.testing.assert_allclose(_native.rowl1_score(t, 0.5).cpu().numpy(), 0.5 * np.abs(x.astype(np.float64)).sum(-1), rtol=2e-6)
-        v = t[..., 1:]                                     # unaligned rows: the scalar path
-        np.testing.assert_allclose(_native.rowl1_score(v).cpu().numpy(), np.abs(x[..., 1:].astype(np.float64)).sum(-1), rtol=2e-6)
 
 
 @pytest.mark.gpu

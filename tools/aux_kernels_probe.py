@@ -45,8 +45,6 @@ for S in (32768, 131072):
 # ||Wo v||_1 rows: [S, 4096] bf16 projected values of one q-head
 for S in (32768,):
     x = torch.randn((S, 4096), device=dev).to(torch.bfloat16)
-    us = timed(lambda: N.rowl1_score(x))
-    print(f"S={S:6d} {'rowl1 over [S,4096]':26s} {us:8.1f} us  {x.numel() * 2 / us / 1e3:7.0f} GB/s", flush=True)
 # observed attention: [1, 32, 4096, 4096] bf16 eager weights
 a = torch.rand((1, 32, 4096, 4096), device=dev).to(torch.bfloat16)
 us = timed(lambda: N.observed_attention_score(a, 8), 5)
