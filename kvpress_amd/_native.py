@@ -591,13 +591,15 @@ def topk_select(scores: torch.Tensor, k: int, order: int = ORDER_POSITION) -> to
     idx = torch.empty((R, k), dtype=torch.int32, device=s.device)
     if R and k:
         with _on_device(s.device):
+            stream = torch.cuda.current_stream(s.device)
             if (int(order) & 0xFF) == ORDER_SCORE:
-                # descending-score order: select + sort, in a workspace of its own (zero-filled: the select's histograms)
-                ws = torch.zeros(max(int(lib().kvp_topk_order_workspace_bytes(R, S, k)), 256), dtype=torch.uint8, device=s.device)
+                # descending-score order: the select's self-cleaning region first, then the sort's tiles and samples (never read before
+                # they are written): one cached workspace per (device, stream, shape), zero-filled once like the plain select's
+                nws = lib().kvp_topk_order_workspace_bytes(R, S, k)
+                ws = _cached_ws(("order", s.device.index, stream.cuda_stream, R, S, int(k)), nws, s.device)
             else:
                 nws = lib().kvp_topk_workspace_bytes(R, S, k)
                 # self-cleaning workspace: zeroed once per (device, stream, size), reused with KVP_TOPK_WS_CLEAN
-                stream = torch.cuda.current_stream(s.device)
                 key = (s.device.index, stream.cuda_stream, R, S)  # the layout (hence the clean region) depends on R and S
                 ws = _cached_ws(key, nws, s.device)
             try:

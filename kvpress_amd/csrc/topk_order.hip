@@ -1,100 +1,355 @@
 // KVP_ORDER_SCORE: the retained indices in DESCENDING SCORE order (what `scores.topk(n_kept).indices` returns with
-// sorted=True, kvpress/presses/scorer_press.py:95), ties in ascending position.
+// sorted=True, kvpress/presses/scorer_press.py:95), ties in ascending position.  This is the order in which the reference stores
+// K' / V' (scorer_press.py:96-100): `press.kept_order = "score"` reproduces its tensors.
 //
-// Not on the hot path (no press of this package asks for it: attention is permutation-invariant over the kept tokens and the
-// position order makes the gather a monotone stream), so it is built from parts: kvp_topk_select's position-ordered
-// result, one kernel that fetches each kept score as a 64-bit key (row << 32 | descending-order score key), and ONE device-wide
-// rocPRIM radix sort over all R * k pairs (stable: equal scores stay in ascending position; the row bits keep the rows apart).
-// (Round 3 used rocPRIM's SEGMENTED sort: with 8 segments of 65536 it ran 1.3 ms -- one workgroup per segment; the device-wide
-// sort of the same 524288 pairs takes tens of microseconds.)  rocPRIM ships with ROCm as HIP headers.
+// A hand-written segmented sort (round 5; rounds 3-4 called rocPRIM's device-wide radix sort: 138 us for 8 x 65536 pairs).
+// Input: kvp_topk_select's position-ordered selection idx[R][k].  Every kept index becomes ONE 64-bit composite
+//     (~order_key(score) << 32) | position          -- ascending composite = descending score, ties by ascending position --
+// (a poisoned index, -1 from a select that reported a failure, becomes (0 << 32) | 0x80000000 | slot: first in its row, written
+// back as -1; padding slots are (0xFFFFFFFF << 32) | 0x80000000 | slot: last).  Composites are UNIQUE within a row, which is what
+// bounds the bucket sizes below whatever the score distribution is (flat rows put half of their scores into one 12-bit radix bin).
+//
+// Sort by regular sampling (PSRS), two launches for up to 32 tiles per row:
+//   order_tiles_kernel   grid (tiles, rows), 1024 threads: a tile of T = 1024 E composites (E = 2 or 4 per thread) is fetched
+//                        (index -> score -> key), sorted by a bitonic network that lives in registers (strides inside a thread: plain
+//                        compare-exchange; inside a wave: shuffles; across waves: one LDS exchange per step), and written back sorted
+//                        together with 64 regular samples (every T/64-th element).  One tile per row: the indices are written directly.
+//   order_buckets_kernel grid (tiles, rows): workgroup b sorts the row's <= 2048 samples itself (32 x 64; every workgroup of a row
+//                        does the same 5 us of work instead of a third launch + hop), takes the samples of rank 64 b - 1 and
+//                        64 (b + 1) - 1 as its two pivots, finds per tile -- ballot over the tile's 64 samples, then ONE coalesced load
+//                        of the T/64 elements between two samples -- how many elements lie below each pivot, gathers those
+//                        <= T (1 + tiles/64) <= 1.5 T composites (the PSRS bound; capacity 2 T) into LDS, sorts them with the same
+//                        network at 2 E per thread and writes the positions at the bucket's offset (= the sum of its lower counts).
+// More than 32 tiles of 4096 (k > 131072): a plain global merge network over sorted 2048-tiles (log^2 launches; correct for any k,
+// used by no configuration of this package's benchmarks).
 #include "kvp_common.h"
+#include "topk_block.h"
 #include "topk_internal.h"
-
-#include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
-struct OrderWs {
-    uint64_t* keys_in;
-    uint64_t* keys_out;
-    int32_t* idx_in;
-    void* tmp;
-    size_t tmp_bytes, total_bytes;
+typedef unsigned long long u64;
+constexpr u64 OS_PAD_HI = 0xFFFFFFFFull << 32;
+constexpr int OS_SAMPLES = 64;      // regular samples per tile
+constexpr int OS_MAX_TILES = 32;    // tiles per row on the two-launch path: 32 x 64 samples = one 2048-element sort
+
+__device__ __forceinline__ u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
+__device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a < b ? b : a; }
+__device__ __forceinline__ u64 shfl_xor64(u64 v, int d) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
+    return ((u64)hi << 32) | lo;
+}
+
+// Bitonic sort of the 1024 * E composites of a 1024-thread workgroup, ascending; thread t holds elements E t .. E t + E - 1 before and
+// after.  xch: LDS, 1024 * E words of 8 bytes (used only by the steps whose partner sits in another wave).
+template <int E>
+__device__ __forceinline__ void bitonic_sort_block(u64 (&v)[E], u64* xch) {
+    constexpr uint32_t N = 1024u * E;
+    const uint32_t t = threadIdx.x;
+#pragma unroll 1
+    for (uint32_t size = 2; size <= N; size <<= 1) {
+#pragma unroll 1
+        for (uint32_t stride = size >> 1; stride >= (uint32_t)E; stride >>= 1) {
+            const uint32_t d = stride / E;                      // partner thread = t ^ d, same slot
+            const bool lower = (t & d) == 0;                    // this thread holds the lower-indexed element of every pair
+            const bool asc = ((E * t) & size) == 0;             // size >= 2 E here: the direction bit lies in the thread index
+            const bool keep_min = lower == asc;
+            if (d < 64) {
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const u64 p = shfl_xor64(v[i], (int)d);
+                    v[i] = keep_min ? umin64(v[i], p) : umax64(v[i], p);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < E; ++i) xch[E * t + i] = v[i];
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const u64 p = xch[E * (t ^ d) + i];
+                    v[i] = keep_min ? umin64(v[i], p) : umax64(v[i], p);
+                }
+                __syncthreads();
+            }
+        }
+        // strides inside a thread (compile-time slots; the direction bit may be a slot bit while size <= E)
+#pragma unroll
+        for (int s = E / 2; s >= 1; s >>= 1) {
+            if ((uint32_t)s < size) {
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    if ((i & s) == 0) {
+                        const bool asc = ((E * t + i) & size) == 0;
+                        const u64 a = v[i], b = v[i | s];
+                        const u64 lo = umin64(a, b), hi = umax64(a, b);
+                        v[i] = asc ? lo : hi;
+                        v[i | s] = asc ? hi : lo;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ u64 order_composite(const float* __restrict__ row, int32_t p, uint32_t S, uint32_t kmask, uint32_t slot) {
+    if ((uint32_t)p < S) return ((u64)(~(float_to_key(row[p]) ^ kmask)) << 32) | (uint32_t)p;
+    return (u64)(0x80000000u | slot);                       // poisoned: sorts first, written back as -1
+}
+__device__ __forceinline__ int32_t order_position(u64 c) { return (c & 0x80000000ull) ? -1 : (int32_t)(uint32_t)c; }
+
+struct OrderArgs {
+    const float* scores;
+    int64_t row_stride;
+    int32_t* idx;          // [R][k] in: ascending positions; out: descending score
+    uint32_t S, k, kmask, ntiles;
+    u64* tiles;            // [R][ntiles * T] sorted tiles
+    u64* samples;          // [R][ntiles][OS_SAMPLES]; nullptr: none wanted (the global network)
 };
 
-unsigned row_bits(int64_t R) {
-    unsigned b = 0;
-    while (((int64_t)1 << b) < R) ++b;
-    return b;
-}
-
-size_t sort_tmp_bytes(int64_t R, int64_t k) {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr,
-                                    (size_t)(R * k), 0u, 32u + row_bits(R), (hipStream_t)0);
-    return bytes;
-}
-
-OrderWs carve(void* ws, int64_t R, int64_t k) {
-    OrderWs w;
-    size_t off = 0;
-    char* base = static_cast<char*>(ws);
-    auto take = [&](size_t bytes) {
-        void* p = base ? base + off : nullptr;
-        off += kvp_align_up(bytes, 256);
-        return p;
-    };
-    const size_t n = (size_t)std::max<int64_t>(1, R * k);
-    w.keys_in = (uint64_t*)take(n * 8);
-    w.keys_out = (uint64_t*)take(n * 8);
-    w.idx_in = (int32_t*)take(n * 4);
-    w.tmp_bytes = sort_tmp_bytes(R, k);
-    w.tmp = take(w.tmp_bytes);
-    w.total_bytes = off;
-    return w;
-}
-
-// keys_in[r * k + j] = r << 32 | ~(order-preserving key of scores[r, idx[r, j]])  (ascending sort = rows in order, descending scores).
-// A poisoned index (-1: a select that reported a failure) sorts first in its row and stays -1.
-__global__ __launch_bounds__(256) void order_keys_kernel(const float* __restrict__ scores, int64_t row_stride, const int32_t* __restrict__ idx,
-                                                         uint32_t k, uint32_t S, uint32_t kmask, uint64_t* __restrict__ keys,
-                                                         int32_t* __restrict__ idx_copy) {
-    const uint32_t r = blockIdx.y;
-    const float* row = scores + (int64_t)r * row_stride;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < k; j += gridDim.x * blockDim.x) {
-        const int32_t p = idx[(size_t)r * k + j];
-        const uint32_t sk = (uint32_t)p < S ? ~(float_to_key(row[p]) ^ kmask) : 0u;
-        keys[(size_t)r * k + j] = ((uint64_t)r << 32) | sk;
-        idx_copy[(size_t)r * k + j] = p;
+// ---- launch 1: sort the tiles ---------------------------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(1024) void order_tiles_kernel(OrderArgs a) {
+    constexpr uint32_t T = 1024u * E;
+    __shared__ __attribute__((aligned(16))) u64 xch[T];
+    const uint32_t tile = blockIdx.x, r = blockIdx.y, t = threadIdx.x;
+    const float* row = a.scores + (int64_t)r * a.row_stride;
+    int32_t* ir = a.idx + (size_t)r * a.k;
+    u64 v[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const uint32_t j = tile * T + E * t + i;
+        v[i] = j < a.k ? order_composite(row, ir[j], a.S, a.kmask, j) : (OS_PAD_HI | 0x80000000u | j);
     }
+    bitonic_sort_block<E>(v, xch);
+    if (a.ntiles == 1) {                                        // the whole row: done
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const uint32_t j = E * t + i;
+            if (j < a.k) ir[j] = order_position(v[i]);
+        }
+        return;
+    }
+    u64* out = a.tiles + ((size_t)r * a.ntiles + tile) * T;
+#pragma unroll
+    for (int i = 0; i < E; ++i) out[E * t + i] = v[i];
+    // sample m = element (T / 64) m + T / 64 - 1: the last slot of every (T / 64 / E)-th thread
+    constexpr uint32_t G = T / OS_SAMPLES;                      // 32 (E = 2) or 64 (E = 4) elements between samples = G / E threads
+    if (a.samples && (t % (G / E)) == (G / E) - 1) a.samples[((size_t)r * a.ntiles + tile) * OS_SAMPLES + t / (G / E)] = v[E - 1];
+}
+
+// ---- launch 2: one bucket per workgroup -----------------------------------------------------------------------------------------
+template <int E>   // E = composites per thread of launch 1; this kernel sorts 2 E per thread
+__global__ __launch_bounds__(1024) void order_buckets_kernel(OrderArgs a) {
+    constexpr uint32_t T = 1024u * E, G = T / OS_SAMPLES, CAP = 2 * T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char os_lds[];
+    u64* stage = reinterpret_cast<u64*>(os_lds);                               // [CAP]: sample sort, then the bucket
+    u64* smp = stage + CAP;                                                    // [OS_MAX_TILES][OS_SAMPLES] the tiles' samples, unsorted
+    __shared__ uint32_t cnt[2][OS_MAX_TILES];                                  // per tile: elements <= lower pivot / <= upper pivot
+    __shared__ uint32_t pre[OS_MAX_TILES + 2];                                 // exclusive scan of the piece sizes; [nt] = bucket size; [nt + 1] = output offset
+    const uint32_t b = blockIdx.x, r = blockIdx.y, t = threadIdx.x, nt = a.ntiles;
+    const uint32_t lane = t & 63, wv = t >> 6;
+    const u64* tiles = a.tiles + (size_t)r * nt * T;
+    const u64* sg = a.samples + (size_t)r * nt * OS_SAMPLES;
+
+    // (1) the row's samples: registers (two per thread) for the sort, an unsorted copy in LDS for the per-tile searches
+    u64 sv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t j = 2 * t + i;
+        sv[i] = j < nt * OS_SAMPLES ? sg[j] : (OS_PAD_HI | 0xC0000000u | j);   // (above every real composite and every tile pad)
+        if (j < nt * OS_SAMPLES) smp[j] = sv[i];
+    }
+    bitonic_sort_block<2>(sv, stage);
+    stage[2 * t] = sv[0];
+    stage[2 * t + 1] = sv[1];
+    __syncthreads();
+    // (2) pivots of bucket b: samples of rank 64 b - 1 (exclusive lower bound) and 64 (b + 1) - 1 (inclusive upper bound)
+    const bool has_lo = b > 0, has_hi = b + 1 < nt;
+    const u64 plo = has_lo ? stage[OS_SAMPLES * b - 1] : 0ull;
+    const u64 phi = has_hi ? stage[OS_SAMPLES * (b + 1) - 1] : ~0ull;
+    __syncthreads();                                                           // stage is reused below
+    // (3) per tile and pivot: number of elements <= pivot.  A wave per search: ballot over the tile's 64 samples, then the G elements
+    //     between the last sample <= pivot and the next one.
+    for (uint32_t q = wv; q < 2 * nt; q += TR_WAVES) {
+        const uint32_t tile = q >> 1, which = q & 1;
+        uint32_t count;
+        if (which == 0 && !has_lo) count = 0;
+        else if (which == 1 && !has_hi) count = T;
+        else {
+            const u64 piv = which ? phi : plo;
+            const uint32_t c = (uint32_t)__popcll(__ballot(smp[tile * OS_SAMPLES + lane] <= piv));   // samples are ascending: the first c
+            count = T;
+            if (c < OS_SAMPLES) {
+                const bool in = lane < G;
+                const u64 x = in ? tiles[(size_t)tile * T + G * c + lane] : ~0ull;
+                count = G * c + (uint32_t)__popcll(__ballot(in && x <= piv));
+            }
+        }
+        if (lane == 0) cnt[which][tile] = count;
+    }
+    __syncthreads();
+    // (4) piece sizes -> offsets inside the bucket, bucket size, output offset (wave 0; nt <= 32 <= 64 lanes)
+    if (wv == 0) {
+        const uint32_t lo = lane < nt ? cnt[0][lane] : 0u, hi = lane < nt ? cnt[1][lane] : 0u;
+        const uint32_t n = hi - lo;
+        const uint32_t inc = wave_incl_scan(n), inclo = wave_incl_scan(lo);
+        if (lane < nt) pre[lane] = inc - n;
+        if (lane == 63) {
+            pre[nt] = inc;
+            pre[nt + 1] = inclo;
+        }
+    }
+    __syncthreads();
+    const uint32_t total = pre[nt], gofs = pre[nt + 1];
+    // (5) gather the pieces (each a contiguous range of a sorted tile) into LDS; pad to the capacity
+    for (uint32_t tile = wv; tile < nt; tile += TR_WAVES) {
+        const uint32_t lo = cnt[0][tile], n = cnt[1][tile] - lo, o = pre[tile];
+        for (uint32_t j = lane; j < n && o + j < CAP; j += 64) stage[o + j] = tiles[(size_t)tile * T + lo + j];   // (o + n <= 1.5 T by the PSRS bound)
+    }
+    for (uint32_t j = total + t; j < CAP; j += 1024) stage[j] = OS_PAD_HI | 0xC0000000u | j;
+    __syncthreads();
+    u64 v[2 * E];
+#pragma unroll
+    for (int i = 0; i < 2 * E; ++i) v[i] = stage[2 * E * t + i];
+    __syncthreads();
+    // (6) sort the bucket, write the positions
+    bitonic_sort_block<2 * E>(v, stage);
+    int32_t* out = a.idx + (size_t)r * a.k;
+#pragma unroll
+    for (int i = 0; i < 2 * E; ++i) {
+        const uint32_t j = 2 * E * t + i;
+        if (j < total && gofs + j < a.k) out[gofs + j] = order_position(v[i]);
+    }
+}
+
+// ---- any k: global merge network over sorted 2048-tiles ---------------------------------------------------------------------------
+// tiles: [R][npad] with npad = a power of two >= k, pads last, every `size / 2`-long run ascending.  Merging two ascending runs into
+// one of length `size`: ONE mirrored compare-exchange (element i of the left run against element size - 1 - i of the pair) leaves
+// every left element <= every right element and both halves bitonic; half-cleaners of stride size / 4 .. 1, all ascending, finish.
+__global__ __launch_bounds__(256) void order_global_mirror_kernel(u64* __restrict__ tiles, uint32_t npad, uint32_t size) {
+    u64* row = tiles + (size_t)blockIdx.y * npad;
+    const uint32_t half = size / 2;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npad / 2; i += gridDim.x * blockDim.x) {
+        const uint32_t blk = i / half, off = i % half;
+        const uint32_t e = blk * size + off, f = blk * size + size - 1 - off;
+        const u64 x = row[e], y = row[f];
+        row[e] = umin64(x, y);
+        row[f] = umax64(x, y);
+    }
+}
+__global__ __launch_bounds__(256) void order_global_step_kernel(u64* __restrict__ tiles, uint32_t npad, uint32_t stride) {
+    u64* row = tiles + (size_t)blockIdx.y * npad;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npad / 2; i += gridDim.x * blockDim.x) {
+        const uint32_t e = ((i / stride) * 2 * stride) + (i % stride);        // lower element of pair i
+        const u64 x = row[e], y = row[e + stride];
+        row[e] = umin64(x, y);
+        row[e + stride] = umax64(x, y);
+    }
+}
+// half-cleaners of stride 1024 .. 1 inside a 2048-tile, ascending; last = 1: the positions go to idx instead
+__global__ __launch_bounds__(1024) void order_global_tail_kernel(u64* __restrict__ tiles, uint32_t npad, int32_t* __restrict__ idx, uint32_t k, uint32_t last) {
+    __shared__ __attribute__((aligned(16))) u64 xch[2048];
+    u64* row = tiles + (size_t)blockIdx.y * npad;
+    const uint32_t t = threadIdx.x, base = blockIdx.x * 2048u;
+    xch[t] = row[base + t];
+    xch[t + 1024] = row[base + t + 1024];
+    __syncthreads();
+    for (uint32_t stride = 1024; stride >= 1; stride >>= 1) {
+        const uint32_t e = ((t / stride) * 2 * stride) + (t % stride);
+        const u64 x = xch[e], y = xch[e + stride];
+        xch[e] = umin64(x, y);
+        xch[e + stride] = umax64(x, y);
+        __syncthreads();
+    }
+    if (last) {
+        int32_t* out = idx + (size_t)blockIdx.y * k;
+        if (base + t < k) out[base + t] = order_position(xch[t]);
+        if (base + t + 1024 < k) out[base + t + 1024] = order_position(xch[t + 1024]);
+    } else {
+        row[base + t] = xch[t];
+        row[base + t + 1024] = xch[t + 1024];
+    }
+}
+
+struct OrderPlan {
+    int e;               // composites per thread of launch 1 (2 or 4); 0 = the global network
+    uint32_t T, ntiles;
+    size_t tiles_bytes, samples_bytes, total_bytes;
+};
+OrderPlan order_plan(int64_t R, int64_t k) {
+    OrderPlan p{};
+    const size_t rows = (size_t)std::max<int64_t>(1, R);
+    if (k <= 2048 * OS_MAX_TILES) p.e = 2;
+    else if (k <= 4096 * OS_MAX_TILES) p.e = 4;
+    if (p.e) {
+        p.T = 1024u * p.e;
+        p.ntiles = (uint32_t)std::max<int64_t>(1, (k + p.T - 1) / p.T);
+        p.tiles_bytes = kvp_align_up(rows * p.ntiles * p.T * 8, 256);
+        p.samples_bytes = kvp_align_up(rows * p.ntiles * OS_SAMPLES * 8, 256);
+    } else {
+        uint64_t npad = 4096;
+        while ((int64_t)npad < k) npad <<= 1;
+        p.T = 2048;
+        p.ntiles = (uint32_t)(npad / 2048);
+        p.tiles_bytes = kvp_align_up(rows * npad * 8, 256);
+        p.samples_bytes = 256;
+    }
+    p.total_bytes = p.tiles_bytes + p.samples_bytes;
+    return p;
+}
+
+template <int E>
+int launch_psrs(const OrderArgs& a, int64_t R, hipStream_t stream) {
+    const dim3 grid(a.ntiles, (uint32_t)R);
+    KVP_LAUNCH("order_tiles_kernel", stream, (order_tiles_kernel<E><<<grid, 1024, 0, stream>>>(a)));
+    KVP_CHECK_LAUNCH("topk(order: tiles)");
+    if (a.ntiles == 1) return KVP_OK;
+    const size_t lds = (size_t)(2 * 1024 * E + OS_MAX_TILES * OS_SAMPLES) * 8;
+    static bool raised[2] = {false, false};                      // (per instantiation; the attribute is per function, set once)
+    if (lds > 48 * 1024 && !raised[E / 4]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(order_buckets_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            kvp_set_error("topk(order): cannot raise the dynamic LDS limit to %zu bytes", lds);
+            return KVP_EHIP;
+        }
+        raised[E / 4] = true;
+    }
+    KVP_LAUNCH("order_buckets_kernel", stream, (order_buckets_kernel<E><<<grid, 1024, lds, stream>>>(a)));
+    KVP_CHECK_LAUNCH("topk(order: buckets)");
+    return KVP_OK;
 }
 
 }  // namespace
 
-size_t topk_order_workspace_bytes(int64_t R, int64_t k) { return (R <= 0 || k <= 0) ? 0 : carve(nullptr, R, k).total_bytes; }
+size_t topk_order_workspace_bytes(int64_t R, int64_t k) { return (R <= 0 || k <= 0) ? 0 : order_plan(R, k).total_bytes; }
 
 // idx [R, k] (contiguous, ascending positions from the select) is rewritten in descending-score order
 int topk_order_by_score(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, bool smallest, void* ws,
                         size_t ws_bytes, hipStream_t stream) {
     if (R == 0 || k == 0) return KVP_OK;
-    KVP_CHECK_ARG(R * k < ((int64_t)1 << 31), "topk(order): too many indices");
-    OrderWs w = carve(ws, R, k);
-    if (!ws || ws_bytes < w.total_bytes) {
-        kvp_set_error("topk(order): workspace too small (%zu < %zu)", ws_bytes, w.total_bytes);
+    KVP_CHECK_ARG(R <= 65535 && k < ((int64_t)1 << 30) && S < ((int64_t)1 << 31), "topk(order): shape too large (R=%ld k=%ld)", (long)R, (long)k);
+    const OrderPlan p = order_plan(R, k);
+    if (!ws || ws_bytes < p.total_bytes) {
+        kvp_set_error("topk(order): workspace too small (%zu < %zu)", ws_bytes, p.total_bytes);
         return KVP_EWORKSPACE;
     }
-    const uint32_t bx = (uint32_t)std::max<int64_t>(1, std::min<int64_t>((k + 255) / 256, 256));
-    KVP_LAUNCH("order_keys_kernel", stream, order_keys_kernel<<<dim3(bx, (uint32_t)R), 256, 0, stream>>>(
-        scores, row_stride, idx, (uint32_t)k, (uint32_t)S, smallest ? 0xFFFFFFFFu : 0u, w.keys_in, w.idx_in));
-    KVP_CHECK_LAUNCH("topk(order keys)");
-    size_t tmp_bytes = w.tmp_bytes;
-    hipError_t e = hipSuccess;
-    KVP_LAUNCH("rocprim_radix_sort_pairs", stream, (e = rocprim::radix_sort_pairs(w.tmp, tmp_bytes, (const uint64_t*)w.keys_in, w.keys_out, (const int32_t*)w.idx_in,
-                                                                                idx, (size_t)(R * k), 0u, 32u + row_bits(R), stream)));
-    if (e != hipSuccess) {
-        kvp_set_error("topk(order): sort failed: %s", hipGetErrorString(e));
-        return KVP_EHIP;
+    OrderArgs a;
+    a.scores = scores; a.row_stride = row_stride; a.idx = idx;
+    a.S = (uint32_t)S; a.k = (uint32_t)k; a.kmask = smallest ? 0xFFFFFFFFu : 0u; a.ntiles = p.ntiles;
+    a.tiles = static_cast<u64*>(ws);
+    a.samples = reinterpret_cast<u64*>(static_cast<char*>(ws) + p.tiles_bytes);
+    if (p.e == 2) return launch_psrs<2>(a, R, stream);
+    if (p.e == 4) return launch_psrs<4>(a, R, stream);
+    // any k: sorted 2048-tiles (launch 1 with padding tiles, no samples), then the global merge network
+    const uint32_t npad = p.ntiles * 2048u;
+    a.samples = nullptr;
+    const dim3 gs(std::min<uint32_t>(npad / 512, 2048), (uint32_t)R), gt(p.ntiles, (uint32_t)R);
+    KVP_LAUNCH("order_tiles_kernel", stream, (order_tiles_kernel<2><<<gt, 1024, 0, stream>>>(a)));
+    for (uint32_t size = 4096; size <= npad; size <<= 1) {
+        KVP_LAUNCH("order_global_mirror_kernel", stream, (order_global_mirror_kernel<<<gs, 256, 0, stream>>>(a.tiles, npad, size)));
+        for (uint32_t stride = size / 4; stride >= 2048; stride >>= 1)
+            KVP_LAUNCH("order_global_step_kernel", stream, (order_global_step_kernel<<<gs, 256, 0, stream>>>(a.tiles, npad, stride)));
+        KVP_LAUNCH("order_global_tail_kernel", stream, (order_global_tail_kernel<<<gt, 1024, 0, stream>>>(a.tiles, npad, idx, a.k, size == npad ? 1u : 0u)));
     }
+    KVP_CHECK_LAUNCH("topk(order: global network)");
     return KVP_OK;
 }

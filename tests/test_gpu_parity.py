@@ -151,6 +151,31 @@ def test_topk_heavy_ties_and_edges():
     assert np.array_equal(got, O.topk_select(base[:, 100:20100], 777))
 
 
+@pytest.mark.parametrize("R,S,k", [(1, 5, 3), (2, 64, 64), (3, 3000, 2048), (3, 3000, 2049), (2, 9000, 4097), (5, 40000, 13001), (8, 131072, 65536),
+                                   (8, 131008, 65472), (2, 200000, 65537), (2, 200000, 91750), (1, 262144, 131072), (1, 300000, 131073), (2, 300000, 140000)])
+def test_score_order_sort_shapes(R, S, k):
+    """KVP_ORDER_SCORE's hand-written segmented sort (topk_order.hip) over its three regimes -- one tile per row (k <= 2048), tiles +
+    sampled buckets with 2 or 4 composites per thread (k <= 65536 / <= 131072), the global merge network beyond -- on wide scores,
+    flat ones (half a row in one radix bin), heavy ties (bf16-rounded values: equal scores keep ascending positions) and constant
+    rows; descending score with ties by position, k smallest included: the oracle's element order exactly."""
+    rs = np.random.RandomState(R * 7919 + S + k)
+    N = native()
+    wide = rs.standard_normal((R, S)).astype(np.float32)
+    flat = (2.0 ** -17 * (1 + 0.05 * rs.standard_normal((R, S)))).astype(np.float32)
+    ties = _inputs.round_to(rs.standard_normal((R, S)).astype(np.float32), "bf16")
+    const = np.full((R, S), -0.5, np.float32)
+    for name, sc_np in (("wide", wide), ("flat", flat), ("ties", ties), ("const", const)):
+        t = torch.from_numpy(sc_np).to(DEV)
+        got = N.topk_select(t, k, N.ORDER_SCORE).cpu().numpy()
+        assert np.array_equal(got, O.topk_select_by_score(sc_np, k)), f"{name} R={R} S={S} k={k}"
+    got = N.topk_select(torch.from_numpy(ties).to(DEV), k, N.ORDER_SCORE | N.TOPK_SMALLEST).cpu().numpy()
+    assert np.array_equal(got, O.topk_select_by_score(-ties, k)), f"smallest R={R} S={S} k={k}"
+    view = torch.from_numpy(wide).to(DEV)[:, 1:S - 1] if S > 4 else None          # strided, unaligned rows
+    if view is not None and k <= S - 2:
+        got = N.topk_select(view, k, N.ORDER_SCORE).cpu().numpy()
+        assert np.array_equal(got, O.topk_select_by_score(wide[:, 1:S - 1], k))
+
+
 @pytest.mark.parametrize("S", [32769, 49153, 65536, 100003, 131072])
 def test_topk_second_pass_variants(S, knobs):
     """Rows beyond 32768: the cluster select (one launch; default) and, with KVP_TK_CLUSTER=0, the (chunk, row) passes (what devices
