@@ -354,6 +354,94 @@ def timed_steps(step, steps: int, warmup: int, world: int, sync) -> float:
     return time.perf_counter() - t0
 
 
+def event_timed_steps(step, n: int = 20, warmup: int = 3) -> dict:
+    """SURVEY §8(d)'s timing method beside the contract's host-clock mean: `warmup` untimed steps, then `n` steps each bracketed by a
+    HIP event pair on the launch stream (torch's current stream = the stream the library launches on); median and min in ms.  An
+    event-bracketed step carries the event floor (~6 us) and starts on a drained queue, so its median sits a little above
+    `ms_per_step` (back-to-back steps overlap their launch ramps); the min / median pair shows how much of a box-to-box spread is
+    clock ramp rather than the kernels."""
+    import torch
+
+    for _ in range(warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for e0, e1 in ev:
+        e0.record()
+        step()
+        e1.record()
+    torch.cuda.synchronize()
+    t = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    med = t[n // 2] if n % 2 else 0.5 * (t[n // 2 - 1] + t[n // 2])
+    return {"method": "hipEvent pair per step on the launch stream", "warmup": warmup, "n": n, "median_ms": round(med, 4), "min_ms": round(t[0], 4),
+            "max_ms": round(t[-1], 4)}
+
+
+def roofline_block(avg: dict, workload: str, B: int, t_step: float, world: int, live_pmc: str):
+    """The `roofline` object of the bench line from the per-kernel table avg = {kernel: (mean ms, launches per step)} (HIP events,
+    library profiling on).  Needs no GPU: for N > 1 (and under a profiler) `traffic` falls back to the committed PMC summary of this
+    build (pmc_traffic).  None when no kernel of the table moves algorithmic bytes."""
+    kind, S, ratio = WORKLOADS[workload]
+    cand = {k: a for k, (a, _) in avg.items() if kernel_bytes(k, kind, S, ratio) > 0}
+    if not cand:
+        return None
+    ab = algorithmic_bytes(kind, S, ratio)
+    dom = max(cand, key=cand.get)
+    kb = kernel_bytes(dom, kind, S, ratio) * B
+    ach = kb / (cand[dom] * 1e-3) / 1e9
+    model = path_model(avg, kind, S, ratio, B)
+    path_frac = ab["total"] * B / t_step / 1e9 / HBM_PEAK_GBS
+
+    def kfrac(prefix):   # HBM fraction of one kernel family (None if the workload does not launch it)
+        ks = [k for k in avg if k.startswith(prefix)]
+        return round(kernel_bytes(ks[0], kind, S, ratio) * B / (avg[ks[0]][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ks else None
+
+    traffic, traffic_source = (None, "not requested" if live_pmc == "off" else f"no live pass with {world} ranks")
+    if world == 1 and live_pmc != "off":
+        try:
+            traffic, traffic_source = live_pmc_traffic(dom, workload)
+        except Exception as e:   # noqa: BLE001 -- the bench line must never die in its optional profiler pass
+            traffic, traffic_source = None, f"live PMC pass raised {type(e).__name__}: {e}"
+    if traffic is None:   # no profiler here (or a child / profiled run / N > 1): the committed summary of this same build, if there is one
+        live_note = traffic_source
+        traffic, traffic_source = pmc_traffic(dom, workload)
+        traffic_source = f"{traffic_source} [{live_note}]"
+    roofline = {
+        # THE number the north-star target of 0.70 is about comes first: the whole compress() against SURVEY §8(d)'s bytes
+        "path_frac": round(path_frac, 4),
+        "path_model_us": model["total_us"], "path_frac_of_model": round(model["total_us"] * 1e-6 / t_step, 4),
+        "p1_frac": kfrac("snapkv_p1"), "p2_frac": kfrac("snapkv_p2"),
+        # the dominant kernel (contract fields)
+        "kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+        "algorithmic_bytes_per_launch": kb, "avg_launch_us": round(cand[dom] * 1e3, 2),
+        # secondary bound of the same kernel (SURVEY §8d): the window-attention passes are matrix-core / VALU work
+        "mfma": ({"achieved": round(kernel_flops(dom, S) * B / (cand[dom] * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS,
+                  "unit": "TFLOP/s", "frac": round(kernel_flops(dom, S) * B / (cand[dom] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+                 if kernel_flops(dom, S) else None),
+        "path": {
+            "algorithmic_bytes_per_layer": ab["total"] * B,
+            "achieved": round(ab["total"] * B / t_step / 1e9, 1),
+            "frac": round(path_frac, 4),
+            "kernels_us": {k: round(a * 1e3 * c, 2) for k, (a, c) in sorted(avg.items())},
+            "kernels_sum_us": round(sum(a * c for a, c in avg.values()) * 1e3, 2),
+            "model": model,
+        },
+    }
+    m = roofline["mfma"]
+    if m and m["frac"] > roofline["frac"]:   # the matrix-core roof is the nearer one (ExpectedAttention's quadratic form)
+        roofline["hbm"] = {k: roofline[k] for k in ("achieved", "peak", "unit", "frac")}
+        roofline.update(bound="mfma", achieved=m["achieved"], peak=m["peak"], unit=m["unit"], frac=m["frac"])
+    return roofline
+
+
+def bench_config(workload: str, world: int, B: int, n_kept: int, prewarm_ms: float, inputs: str, kept_order: str, library_qproj: bool) -> dict:
+    """`config` of the bench line: the same keys whatever the number of ranks (tests/test_dist_gloo.py pins that)."""
+    kind, S, ratio = WORKLOADS[workload]
+    return {"workload": workload, "press": kind, "compression_ratio": ratio, "batch_per_gpu": B, "seq_len": S, "n_kept": n_kept,
+            "h_q": H_Q, "h_kv": H_KV, "head_dim": D, "layers_for_tok_s": LAYERS, "parallelism": f"batch-sharded x{world}, no collective",
+            "prewarm_ms": prewarm_ms, "inputs": inputs, "kept_order": kept_order, "library_qproj": library_qproj}
+
+
 def result_line(args, world: int, B: int, S: int, t_step: float, config: dict, roofline, cpu, metric: str, dtype: str = "bf16") -> dict:
     assert world == args.gpus
     return {"metric": metric, "value": round(world * B * S / (LAYERS * t_step), 1), "unit": "tok/s", "n_gpus": world, "steps": args.steps,
@@ -463,11 +551,19 @@ def stub_main(args, world: int, rank: int):
     kind, S, ratio = WORKLOADS[args.workload]
     lo, hi = shard_batch(world, world, rank)
     B = hi - lo
-    local = timed_steps(lambda: time.sleep(args.stub_step * 1e-3 * (1 + rank)), args.steps, args.warmup, world, lambda: None)
+    calls = [0]
+
+    def step():
+        calls[0] += 1
+        if args.stub_fail_rank == rank and calls[0] > args.warmup + 1:
+            raise RuntimeError(f"stub failure on rank {rank} (tests: a rank that dies mid-run must take the job down, not hang it)")
+        time.sleep(args.stub_step * 1e-3 * (1 + rank))
+
+    local = timed_steps(step, args.steps, args.warmup, world, lambda: None)
     t_step = aggregate_time(local, world) / args.steps
     if rank == 0:
-        cfg = {"workload": args.workload, "press": kind, "batch_per_gpu": B, "seq_len": S, "stub_step_ms": args.stub_step,
-               "parallelism": f"batch-sharded x{world}, no collective"}
+        cfg = bench_config(args.workload, world, B, n_kept_of(kind, S, ratio), args.prewarm_ms, "none (stub)", "position", False)
+        cfg["stub_step_ms"] = args.stub_step
         print(json.dumps(result_line(args, world, B, S, t_step, cfg, None, None, "stub (launcher test)", dtype="none")), flush=True)
     if world > 1:
         import torch.distributed as dist
@@ -495,6 +591,10 @@ def main():
                     help="process-group backend for N > 1 (nccl = RCCL); gloo + --stub-step exercises the launcher on CPU (tests)")
     ap.add_argument("--stub-step", type=float, default=None, metavar="MS",
                     help="(tests) replace the press by a host sleep of MS milliseconds: launcher / sharding / timing path without a GPU")
+    ap.add_argument("--stub-fail-rank", type=int, default=-1, help="(tests, with --stub-step) this rank raises in the timed region")
+    ap.add_argument("--dist-timeout", type=float, default=600.0,
+                    help="seconds after which a collective (the barriers around the timed region, the MAX-reduce of the step time) gives up: "
+                         "a rank that died must end the job, not leave the others waiting at a barrier")
     args = ap.parse_args()
 
     # ---- `python bench.py --gpus N`, no launcher around it: become N ranks (one process per GPU, torch.distributed.run) ----
@@ -524,11 +624,30 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tmo = datetime.timedelta(seconds=args.dist_timeout)
         if args.backend == "nccl" and not stub:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=tmo)
+    try:
+        return run(args, world, rank, device, stub)
+    except BaseException as e:   # noqa: BLE001 -- any rank's failure (a shape assert, KVP_EASYNC, an OOM ...) ends the WHOLE job
+        if world > 1 and not isinstance(e, SystemExit):
+            import traceback
+
+            traceback.print_exc()
+            print(f"bench.py: rank {rank} failed ({type(e).__name__}); aborting the {world}-rank job", file=sys.stderr, flush=True)
+            # no destroy_process_group(): it may wait for peers that sit in a barrier.  A non-zero exit makes the launcher
+            # (torch.distributed.run) terminate the other ranks; --dist-timeout bounds their wait if it does not.
+            os._exit(3)
+        raise
+
+
+def run(args, world: int, rank: int, device, stub: bool):
+    """Everything after the process group exists (split from main() so that main() can turn any rank's failure into the job's)."""
     if stub:
         return stub_main(args, world, rank)
 
@@ -556,7 +675,7 @@ def main():
                                                   if path.get("kernels_sum_us") else None),
                              "path_model_us": rf.get("path_model_us"), "path_frac_of_model": rf.get("path_frac_of_model"),
                              "dominant_kernel": rf.get("kernel"), "dominant_frac": rf.get("frac"), "bound": rf.get("bound"),
-                             "kernels_us": path.get("kernels_us"), "parity": r["parity"]}
+                             "kernels_us": path.get("kernels_us"), "parity": r["parity"], "step_events": r["step_events"]}
             except Exception as e:   # noqa: BLE001 -- the headline line must never die in an extra
                 extra[wl] = {"error": f"{type(e).__name__}: {e}"}
 
@@ -564,11 +683,10 @@ def main():
         kind, S, ratio = WORKLOADS[args.workload]
         metric = ("press ms/layer + prefill tok/s, Llama-3.1-8B 128k ctx, SnapKV ratio=0.5" if args.workload == "snapkv128k"
                   else f"press ms/layer + prefill tok/s, Llama-3.1-8B, {args.workload}")
-        cfg = {"workload": args.workload, "press": kind, "compression_ratio": ratio, "batch_per_gpu": head["B"], "seq_len": S, "n_kept": head["n_kept"],
-               "h_q": H_Q, "h_kv": H_KV, "head_dim": D, "layers_for_tok_s": LAYERS, "parallelism": f"batch-sharded x{world}, no collective",
-               "prewarm_ms": args.prewarm_ms, "inputs": head["inputs"], "kept_order": head["kept_order"], "library_qproj": bool(_native.USE_LIBRARY_QPROJ)}
+        cfg = bench_config(args.workload, world, head["B"], head["n_kept"], args.prewarm_ms, head["inputs"], head["kept_order"], bool(_native.USE_LIBRARY_QPROJ))
         line = result_line(args, world, head["B"], S, head["t_step"], cfg, head["roofline"], head["cpu"], metric)
         line["parity"] = head["parity"]
+        line["step_events"] = head["step_events"]   # hipEvent median / min per step; ms_per_step above stays the host-clock mean
         if extra is not None:
             line["extra"] = extra
         print(json.dumps(line), flush=True)
@@ -652,6 +770,7 @@ def measure(workload, steps, warmup, prewarm_ms, world, rank, lo, hi, device, li
     out = step()
     torch.cuda.synchronize()
     _native.async_error_check()   # a select kernel that gave up during the timed region would have poisoned its result: fail, loudly
+    ev_stats = event_timed_steps(step) if rank == 0 else None   # median / min of event-bracketed steps, beside the mean
     total = aggregate_time(local, world)
     t_step = total / steps
     n_kept = n_kept_of(kind, S, ratio)
@@ -669,55 +788,7 @@ def measure(workload, steps, warmup, prewarm_ms, world, rank, lo, hi, device, li
             kern_table.setdefault(name, []).append(ms)
         _native.prof_enable(False)
         avg = {k: (sum(v) / len(v), len(v) / nprof) for k, v in kern_table.items()}
-        cand = {k: a for k, (a, _) in avg.items() if kernel_bytes(k, kind, S, ratio) > 0}
-        ab = algorithmic_bytes(kind, S, ratio)
-        if cand:
-            dom = max(cand, key=cand.get)
-            kb = kernel_bytes(dom, kind, S, ratio) * B
-            ach = kb / (cand[dom] * 1e-3) / 1e9
-            model = path_model(avg, kind, S, ratio, B)
-            path_frac = ab["total"] * B / t_step / 1e9 / HBM_PEAK_GBS
-
-            def kfrac(prefix):   # HBM fraction of one kernel family (None if the workload does not launch it)
-                ks = [k for k in avg if k.startswith(prefix)]
-                return round(kernel_bytes(ks[0], kind, S, ratio) * B / (avg[ks[0]][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ks else None
-
-            traffic, traffic_source = (None, "not requested")
-            if world == 1 and live_pmc != "off":
-                try:
-                    traffic, traffic_source = live_pmc_traffic(dom, workload)
-                except Exception as e:   # noqa: BLE001 -- the bench line must never die in its optional profiler pass
-                    traffic, traffic_source = None, f"live PMC pass raised {type(e).__name__}: {e}"
-            if traffic is None:   # no profiler here (or a child / profiled run): the committed summary of this same build, if there is one
-                live_note = traffic_source
-                traffic, traffic_source = pmc_traffic(dom, workload)
-                traffic_source = f"{traffic_source} [{live_note}]"
-            roofline = {
-                # THE number the north-star target of 0.70 is about comes first: the whole compress() against SURVEY §8(d)'s bytes
-                "path_frac": round(path_frac, 4),
-                "path_model_us": model["total_us"], "path_frac_of_model": round(model["total_us"] * 1e-6 / t_step, 4),
-                "p1_frac": kfrac("snapkv_p1"), "p2_frac": kfrac("snapkv_p2"),
-                # the dominant kernel (contract fields)
-                "kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": kb, "avg_launch_us": round(cand[dom] * 1e3, 2),
-                # secondary bound of the same kernel: the window-attention passes are matrix-core / VALU work
-                "mfma": ({"achieved": round(kernel_flops(dom, S) * B / (cand[dom] * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS,
-                          "unit": "TFLOP/s", "frac": round(kernel_flops(dom, S) * B / (cand[dom] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
-                         if kernel_flops(dom, S) else None),
-                "path": {
-                    "algorithmic_bytes_per_layer": ab["total"] * B,
-                    "achieved": round(ab["total"] * B / t_step / 1e9, 1),
-                    "frac": round(path_frac, 4),
-                    "kernels_us": {k: round(a * 1e3 * c, 2) for k, (a, c) in sorted(avg.items())},
-                    "kernels_sum_us": round(sum(a * c for a, c in avg.values()) * 1e3, 2),
-                    "model": model,
-                },
-            }
-            m = roofline["mfma"]
-            if m and m["frac"] > roofline["frac"]:   # the matrix-core roof is the nearer one (ExpectedAttention's quadratic form)
-                roofline["hbm"] = {k: roofline[k] for k in ("achieved", "peak", "unit", "frac")}
-                roofline.update(bound="mfma", achieved=m["achieved"], peak=m["peak"], unit=m["unit"], frac=m["frac"])
+        roofline = roofline_block(avg, workload, B, t_step, world, live_pmc)
         if profile_json:
             with open(profile_json, "w") as f:
                 json.dump({"workload": workload, "ms_per_step": t_step * 1e3,
@@ -731,7 +802,7 @@ def measure(workload, steps, warmup, prewarm_ms, world, rank, lo, hi, device, li
     # ---- CPU baseline (rank 0, N=1 only): the reference's op sequence in plain PyTorch on this box's host cores -------------
     cpu_res = cpu_baseline(workload, press, att, rot, hidden, keys, values, kwargs, n_kept) if cpu else None
     res = {"t_step": t_step, "B": B, "n_kept": n_kept, "roofline": roofline, "cpu": cpu_res, "parity": par, "inputs": inputs_note,
-           "kept_order": getattr(press, "kept_order", "position")}
+           "kept_order": getattr(press, "kept_order", "position"), "step_events": ev_stats}
     del keys, values, hidden, out
     torch.cuda.empty_cache()
     return res

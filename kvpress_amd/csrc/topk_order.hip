@@ -13,12 +13,13 @@
 //   order_tiles_kernel   grid (tiles, rows), 1024 threads: a tile of T = 1024 E composites (E = 2 or 4 per thread) is fetched
 //                        (index -> score -> key), sorted by a bitonic network that lives in registers (strides inside a thread: plain
 //                        compare-exchange; inside a wave: shuffles; across waves: one LDS exchange per step), and written back sorted
-//                        together with 64 regular samples (every T/64-th element).  One tile per row: the indices are written directly.
-//   order_buckets_kernel grid (tiles, rows): workgroup b sorts the row's <= 2048 samples itself (32 x 64; every workgroup of a row
-//                        does the same 5 us of work instead of a third launch + hop), takes the samples of rank 64 b - 1 and
-//                        64 (b + 1) - 1 as its two pivots, finds per tile -- ballot over the tile's 64 samples, then ONE coalesced load
-//                        of the T/64 elements between two samples -- how many elements lie below each pivot, gathers those
-//                        <= T (1 + tiles/64) <= 1.5 T composites (the PSRS bound; capacity 2 T) into LDS, sorts them with the same
+//                        together with its regular samples (every 64th element: NS = 32 or 64 per tile).  One tile per row: the indices
+//                        are written directly.
+//   order_buckets_kernel grid (tiles, rows): workgroup b sorts the row's <= 32 NS samples itself (every workgroup of a row does the
+//                        same few microseconds of work instead of a third launch + hop), takes the samples of rank NS b - 1 and
+//                        NS (b + 1) - 1 as its two pivots, finds per tile -- ballot over the tile's samples, then ONE coalesced load
+//                        of the 64 elements between two samples -- how many elements lie below each pivot, gathers those
+//                        < 2 T composites (the PSRS bound; typically 1.2 T) into LDS, sorts them with the same
 //                        network at 2 E per thread and writes the positions at the bucket's offset (= the sum of its lower counts).
 // More than 32 tiles of 4096 (k > 131072): a plain global merge network over sorted 2048-tiles (log^2 launches; correct for any k,
 // used by no configuration of this package's benchmarks).
@@ -30,65 +31,75 @@ namespace {
 
 typedef unsigned long long u64;
 constexpr u64 OS_PAD_HI = 0xFFFFFFFFull << 32;
-constexpr int OS_SAMPLES = 64;      // regular samples per tile
-constexpr int OS_MAX_TILES = 32;    // tiles per row on the two-launch path: 32 x 64 samples = one 2048-element sort
+constexpr int OS_GROUP = 64;        // elements between two regular samples of a sorted tile: T / 64 samples per tile (32 or 64)
+constexpr int OS_MAX_TILES = 32;    // tiles per row on the two-launch path: 32 tiles x T / 64 samples = one 1024- / 2048-element sort
 
 __device__ __forceinline__ u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
 __device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a < b ? b : a; }
-__device__ __forceinline__ u64 shfl_xor64(u64 v, int d) {
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d);
-    return ((u64)hi << 32) | lo;
+// value of lane (lane ^ D) for a compile-time lane distance: quad permutes (VALU speed) for 1 / 2, the LDS crossbar's bit-mode swizzle
+// for 4 / 8 / 16 (no address register), ds_bpermute for 32
+template <int D> __device__ __forceinline__ uint32_t xor_lane32(uint32_t x) {
+    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false);         // quad_perm [1,0,3,2]
+    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+    else if constexpr (D <= 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, (D << 10) | 0x1F);           // xor mask D, and mask 0x1f
+    else return (uint32_t)__shfl_xor((int)x, D);
+}
+template <int D> __device__ __forceinline__ u64 xor_lane64(u64 v) {
+    return ((u64)xor_lane32<D>((uint32_t)(v >> 32)) << 32) | xor_lane32<D>((uint32_t)v);
 }
 
 // Bitonic sort of the 1024 * E composites of a 1024-thread workgroup, ascending; thread t holds elements E t .. E t + E - 1 before and
-// after.  xch: LDS, 1024 * E words of 8 bytes (used only by the steps whose partner sits in another wave).
-template <int E>
-__device__ __forceinline__ void bitonic_sort_block(u64 (&v)[E], u64* xch) {
-    constexpr uint32_t N = 1024u * E;
-    const uint32_t t = threadIdx.x;
-#pragma unroll 1
-    for (uint32_t size = 2; size <= N; size <<= 1) {
-#pragma unroll 1
-        for (uint32_t stride = size >> 1; stride >= (uint32_t)E; stride >>= 1) {
-            const uint32_t d = stride / E;                      // partner thread = t ^ d, same slot
-            const bool lower = (t & d) == 0;                    // this thread holds the lower-indexed element of every pair
-            const bool asc = ((E * t) & size) == 0;             // size >= 2 E here: the direction bit lies in the thread index
-            const bool keep_min = lower == asc;
-            if (d < 64) {
+// after.  xch: LDS, 1024 * E words of 8 bytes (used only by the steps whose partner sits in another wave).  Composites are unique,
+// so ONE 64-bit compare decides a compare-exchange: keep the partner's value iff (partner < mine) == (I keep the minimum).
+// Every (size, stride) step is its own template instance: lane distances are compile-time (DPP / swizzle instead of ds_bpermute).
+template <int E, uint32_t SIZE, uint32_t STRIDE>
+__device__ __forceinline__ void bitonic_step(u64 (&v)[E], u64* xch, uint32_t t_) {
+    // (opaque copy of the thread index per step: otherwise the compiler hoists every step's lane masks out of the network and
+    // keeps ~80 of them alive in scalar registers -- spills)
+    uint32_t t = t_;
+    asm volatile("" : "+v"(t));
+    if constexpr (STRIDE >= (uint32_t)E) {
+        constexpr uint32_t D = STRIDE / E;                   // partner thread = t ^ D, same slot
+        const bool keep_min = ((t & D) == 0) == (((E * t) & SIZE) == 0);   // (lower element of the pair) == (ascending block); SIZE >= 2 E here
+        if constexpr (D < 64) {
 #pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    const u64 p = shfl_xor64(v[i], (int)d);
-                    v[i] = keep_min ? umin64(v[i], p) : umax64(v[i], p);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < E; ++i) xch[E * t + i] = v[i];
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    const u64 p = xch[E * (t ^ d) + i];
-                    v[i] = keep_min ? umin64(v[i], p) : umax64(v[i], p);
-                }
-                __syncthreads();
+            for (int i = 0; i < E; ++i) {
+                const u64 p = xor_lane64<(int)D>(v[i]);
+                v[i] = ((p < v[i]) == keep_min) ? p : v[i];
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i) xch[E * t + i] = v[i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const u64 p = xch[E * (t ^ D) + i];
+                v[i] = ((p < v[i]) == keep_min) ? p : v[i];
+            }
+            __syncthreads();
         }
-        // strides inside a thread (compile-time slots; the direction bit may be a slot bit while size <= E)
+    } else {                                                 // both elements in this thread's registers
 #pragma unroll
-        for (int s = E / 2; s >= 1; s >>= 1) {
-            if ((uint32_t)s < size) {
-#pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    if ((i & s) == 0) {
-                        const bool asc = ((E * t + i) & size) == 0;
-                        const u64 a = v[i], b = v[i | s];
-                        const u64 lo = umin64(a, b), hi = umax64(a, b);
-                        v[i] = asc ? lo : hi;
-                        v[i | s] = asc ? hi : lo;
-                    }
-                }
+        for (int i = 0; i < E; ++i) {
+            if ((i & STRIDE) == 0) {
+                const bool asc = ((E * t + i) & SIZE) == 0;
+                const u64 a = v[i], b = v[i | STRIDE];
+                const bool swap = (b < a) == asc;
+                v[i] = swap ? b : a;
+                v[i | STRIDE] = swap ? a : b;
             }
         }
     }
+    if constexpr (STRIDE > 1) bitonic_step<E, SIZE, STRIDE / 2>(v, xch, t_);
+}
+template <int E, uint32_t SIZE>
+__device__ __forceinline__ void bitonic_phase(u64 (&v)[E], u64* xch, uint32_t t) {
+    bitonic_step<E, SIZE, SIZE / 2>(v, xch, t);
+    if constexpr (SIZE < 1024u * E) bitonic_phase<E, SIZE * 2>(v, xch, t);
+}
+template <int E>
+__device__ __forceinline__ void bitonic_sort_block(u64 (&v)[E], u64* xch) {
+    bitonic_phase<E, 2>(v, xch, threadIdx.x);
 }
 
 __device__ __forceinline__ u64 order_composite(const float* __restrict__ row, int32_t p, uint32_t S, uint32_t kmask, uint32_t slot) {
@@ -103,7 +114,7 @@ struct OrderArgs {
     int32_t* idx;          // [R][k] in: ascending positions; out: descending score
     uint32_t S, k, kmask, ntiles;
     u64* tiles;            // [R][ntiles * T] sorted tiles
-    u64* samples;          // [R][ntiles][OS_SAMPLES]; nullptr: none wanted (the global network)
+    u64* samples;          // [R][ntiles][T / OS_GROUP]; nullptr: none wanted (the global network)
 };
 
 // ---- launch 1: sort the tiles ---------------------------------------------------------------------------------------------------
@@ -132,44 +143,47 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(OrderArgs a) {
     u64* out = a.tiles + ((size_t)r * a.ntiles + tile) * T;
 #pragma unroll
     for (int i = 0; i < E; ++i) out[E * t + i] = v[i];
-    // sample m = element (T / 64) m + T / 64 - 1: the last slot of every (T / 64 / E)-th thread
-    constexpr uint32_t G = T / OS_SAMPLES;                      // 32 (E = 2) or 64 (E = 4) elements between samples = G / E threads
-    if (a.samples && (t % (G / E)) == (G / E) - 1) a.samples[((size_t)r * a.ntiles + tile) * OS_SAMPLES + t / (G / E)] = v[E - 1];
+    // sample m = element 64 m + 63: the last slot of every (64 / E)-th thread
+    constexpr uint32_t G = OS_GROUP, NS = T / G;
+    if (a.samples && (t % (G / E)) == (G / E) - 1) a.samples[((size_t)r * a.ntiles + tile) * NS + t / (G / E)] = v[E - 1];
 }
 
 // ---- launch 2: one bucket per workgroup -----------------------------------------------------------------------------------------
+// Bucket sizes: pivot j is the sample of rank NS j - 1, so between j T and j T + tiles (G - 1) elements of the row are <= pivot j
+// (a tile with c samples <= pivot has between G c and G c + G - 1 such elements): a bucket holds at most T + 32 * 63 < 2 T = CAP.
 template <int E>   // E = composites per thread of launch 1; this kernel sorts 2 E per thread
 __global__ __launch_bounds__(1024) void order_buckets_kernel(OrderArgs a) {
-    constexpr uint32_t T = 1024u * E, G = T / OS_SAMPLES, CAP = 2 * T;
+    constexpr uint32_t T = 1024u * E, G = OS_GROUP, NS = T / G, CAP = 2 * T;
+    constexpr int ES = (int)(OS_MAX_TILES * NS / 1024);                        // samples per thread of the sample sort: 1 (E = 2) or 2 (E = 4)
     extern __shared__ __attribute__((aligned(16))) unsigned char os_lds[];
     u64* stage = reinterpret_cast<u64*>(os_lds);                               // [CAP]: sample sort, then the bucket
-    u64* smp = stage + CAP;                                                    // [OS_MAX_TILES][OS_SAMPLES] the tiles' samples, unsorted
+    u64* smp = stage + CAP;                                                    // [OS_MAX_TILES][NS] the tiles' samples, unsorted
     __shared__ uint32_t cnt[2][OS_MAX_TILES];                                  // per tile: elements <= lower pivot / <= upper pivot
     __shared__ uint32_t pre[OS_MAX_TILES + 2];                                 // exclusive scan of the piece sizes; [nt] = bucket size; [nt + 1] = output offset
     const uint32_t b = blockIdx.x, r = blockIdx.y, t = threadIdx.x, nt = a.ntiles;
     const uint32_t lane = t & 63, wv = t >> 6;
     const u64* tiles = a.tiles + (size_t)r * nt * T;
-    const u64* sg = a.samples + (size_t)r * nt * OS_SAMPLES;
+    const u64* sg = a.samples + (size_t)r * nt * NS;
 
-    // (1) the row's samples: registers (two per thread) for the sort, an unsorted copy in LDS for the per-tile searches
-    u64 sv[2];
+    // (1) the row's samples: registers for the sort, an unsorted copy in LDS for the per-tile searches
+    u64 sv[ES];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const uint32_t j = 2 * t + i;
-        sv[i] = j < nt * OS_SAMPLES ? sg[j] : (OS_PAD_HI | 0xC0000000u | j);   // (above every real composite and every tile pad)
-        if (j < nt * OS_SAMPLES) smp[j] = sv[i];
+    for (int i = 0; i < ES; ++i) {
+        const uint32_t j = ES * t + i;
+        sv[i] = j < nt * NS ? sg[j] : (OS_PAD_HI | 0xC0000000u | j);           // (above every real composite and every tile pad)
+        if (j < nt * NS) smp[j] = sv[i];
     }
-    bitonic_sort_block<2>(sv, stage);
-    stage[2 * t] = sv[0];
-    stage[2 * t + 1] = sv[1];
+    bitonic_sort_block<ES>(sv, stage);
+#pragma unroll
+    for (int i = 0; i < ES; ++i) stage[ES * t + i] = sv[i];
     __syncthreads();
-    // (2) pivots of bucket b: samples of rank 64 b - 1 (exclusive lower bound) and 64 (b + 1) - 1 (inclusive upper bound)
+    // (2) pivots of bucket b: samples of rank NS b - 1 (exclusive lower bound) and NS (b + 1) - 1 (inclusive upper bound)
     const bool has_lo = b > 0, has_hi = b + 1 < nt;
-    const u64 plo = has_lo ? stage[OS_SAMPLES * b - 1] : 0ull;
-    const u64 phi = has_hi ? stage[OS_SAMPLES * (b + 1) - 1] : ~0ull;
+    const u64 plo = has_lo ? stage[NS * b - 1] : 0ull;
+    const u64 phi = has_hi ? stage[NS * (b + 1) - 1] : ~0ull;
     __syncthreads();                                                           // stage is reused below
-    // (3) per tile and pivot: number of elements <= pivot.  A wave per search: ballot over the tile's 64 samples, then the G elements
-    //     between the last sample <= pivot and the next one.
+    // (3) per tile and pivot: number of elements <= pivot.  A wave per search: ballot over the tile's NS samples, then the G = 64
+    //     elements between the last sample <= pivot and the next one (one coalesced 512-byte load).
     for (uint32_t q = wv; q < 2 * nt; q += TR_WAVES) {
         const uint32_t tile = q >> 1, which = q & 1;
         uint32_t count;
@@ -177,12 +191,11 @@ __global__ __launch_bounds__(1024) void order_buckets_kernel(OrderArgs a) {
         else if (which == 1 && !has_hi) count = T;
         else {
             const u64 piv = which ? phi : plo;
-            const uint32_t c = (uint32_t)__popcll(__ballot(smp[tile * OS_SAMPLES + lane] <= piv));   // samples are ascending: the first c
+            const uint32_t c = (uint32_t)__popcll(__ballot(lane < NS && smp[tile * NS + (lane & (NS - 1))] <= piv));   // samples ascend: the first c
             count = T;
-            if (c < OS_SAMPLES) {
-                const bool in = lane < G;
-                const u64 x = in ? tiles[(size_t)tile * T + G * c + lane] : ~0ull;
-                count = G * c + (uint32_t)__popcll(__ballot(in && x <= piv));
+            if (c < NS) {
+                const u64 x = tiles[(size_t)tile * T + G * c + lane];
+                count = G * c + (uint32_t)__popcll(__ballot(x <= piv));
             }
         }
         if (lane == 0) cnt[which][tile] = count;
@@ -285,7 +298,7 @@ OrderPlan order_plan(int64_t R, int64_t k) {
         p.T = 1024u * p.e;
         p.ntiles = (uint32_t)std::max<int64_t>(1, (k + p.T - 1) / p.T);
         p.tiles_bytes = kvp_align_up(rows * p.ntiles * p.T * 8, 256);
-        p.samples_bytes = kvp_align_up(rows * p.ntiles * OS_SAMPLES * 8, 256);
+        p.samples_bytes = kvp_align_up(rows * p.ntiles * (p.T / OS_GROUP) * 8, 256);
     } else {
         uint64_t npad = 4096;
         while ((int64_t)npad < k) npad <<= 1;
@@ -304,7 +317,7 @@ int launch_psrs(const OrderArgs& a, int64_t R, hipStream_t stream) {
     KVP_LAUNCH("order_tiles_kernel", stream, (order_tiles_kernel<E><<<grid, 1024, 0, stream>>>(a)));
     KVP_CHECK_LAUNCH("topk(order: tiles)");
     if (a.ntiles == 1) return KVP_OK;
-    const size_t lds = (size_t)(2 * 1024 * E + OS_MAX_TILES * OS_SAMPLES) * 8;
+    const size_t lds = (size_t)(2 * 1024 * E + OS_MAX_TILES * (1024 * E / OS_GROUP)) * 8;
     static bool raised[2] = {false, false};                      // (per instantiation; the attribute is per function, set once)
     if (lds > 48 * 1024 && !raised[E / 4]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(order_buckets_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {

@@ -181,3 +181,56 @@ def test_bench_refuses_a_rank_count_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-step", "1"], capture_output=True, text=True,
                        timeout=120, env=env, cwd=ROOT)
     assert r.returncode != 0 and "one rank per GPU" in r.stderr
+
+
+def test_rank_failure_aborts_the_job():
+    """VERDICT r4 #8b: a rank that raises inside the timed region (stub: rank 1 raises after the warm-up) must end the job with a
+    non-zero exit instead of leaving rank 0 at the barrier -- through the self-launcher and under an external torchrun."""
+    import subprocess
+    import time
+
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for cmd in ([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-step", "2", "--steps", "50", "--warmup", "1",
+                 "--stub-fail-rank", "1", "--dist-timeout", "60"],
+                [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                 str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-step", "2", "--steps", "50", "--warmup", "1",
+                 "--stub-fail-rank", "0", "--dist-timeout", "60"]):
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+        assert r.returncode != 0, "a failed rank must fail the job"
+        assert time.time() - t0 < 120, "the job must end promptly, not at a collective's default 30-minute timeout"
+        assert "aborting the 2-rank job" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")], r.stderr[-800:]
+
+
+def test_n_rank_line_has_the_same_shape_as_the_single_rank_line():
+    """VERDICT r4 #8a: the line of an N-rank run (rank 0: per-kernel table by HIP events, no live PMC pass) carries `roofline` with the
+    contract fields -- `traffic` from the committed PMC summary of this build or null with the reason -- and `config` has the same keys
+    for 1 and 8 ranks (and in the stub line the launcher tests print).  Uses the committed per-kernel table of the headline."""
+    import glob
+    import json
+
+    import bench
+
+    tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_kernels_snapkv128k.json")))
+    assert tables
+    d = json.load(open(tables[-1]))
+    avg = {k: (v, d["launches_per_step"][k]) for k, v in d["kernels_avg_ms"].items()}
+    t_step = d["ms_per_step"] * 1e-3
+    lines = {}
+    for world in (1, 8):
+        rf = bench.roofline_block(avg, "snapkv128k", 1, t_step, world, "off" if world == 1 else "auto")
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "path_frac", "kernel"):
+            assert key in rf, (world, key)
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and 0 < rf["frac"] <= 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+        if world == 8:
+            assert "8 ranks" in rf["traffic_source"]            # no live profiler pass with N > 1: the committed summary (digest-guarded) or null
+        lines[world] = (rf, bench.bench_config("snapkv128k", world, 1, 65536, 60.0, "x", "position", True))
+    assert set(lines[1][0]) == set(lines[8][0]) and set(lines[1][1]) == set(lines[8][1])
+    assert lines[8][1]["parallelism"] == "batch-sharded x8, no collective" and lines[8][1]["batch_per_gpu"] == 1
+    stub = _run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--stub-step", "1", "--steps", "2", "--warmup", "1"])
+    assert set(stub["config"]) - {"stub_step_ms"} == set(lines[8][1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in stub, key
