@@ -71,7 +71,7 @@ ROUND = "r04"   # prefix of the committed profiles/ this build's fallbacks read
 # config 2 use the seeds of their full-size parity fixtures (tests/_fullsize.py FULL_CASES), so the timed tensors ARE the tensors
 # whose retained sets are pinned to the real reference (tests/golden/full_snapkv128k.npz, full_knorm32k.npz)
 SEEDS = {"snapkv128k": 103, "snapkv128k_scoreorder": 103, "knorm32k": 102, "ea128k": 104}
-FIXTURES = {"snapkv128k": "full_snapkv128k", "knorm32k": "full_knorm32k"}
+FIXTURES = {"snapkv128k": "full_snapkv128k", "knorm32k": "full_knorm32k", "ea128k": "full_ea128k_A"}   # reference outputs for exactly the timed tensors
 
 
 def shard_batch(global_batch: int, world: int, rank: int):

@@ -192,7 +192,9 @@ int kvp_gather_kv_rerotate(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_
  * also accumulates the select's first histogram, and SnapKV's window columns are appended to the selection instead of
  * being scored with max + 1 (snapkv_press.py:103), which removes the global max and the pad fill.
  * flags: KVP_TOPK_WS_CLEAN if the first kvp_topk_workspace_bytes(R, S, n_kept) bytes of ws were zero-filled once and
- * the workspace has only been used by these calls on ONE stream since (they leave it clean), else 0. */
+ * the workspace has only been used by these calls on ONE stream since (they leave it clean), else 0;
+ * | KVP_ORDER_SCORE: the rows of k_out / v_out in descending score order, ties by ascending position (SnapKV: the window tokens
+ * first) -- the order in which the reference stores them (scorer_press.py:95-100); default: ascending position. */
 size_t kvp_knorm_compress_workspace_bytes(int64_t B, int64_t H, int64_t S, int64_t n_kept);
 int kvp_knorm_compress(const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
                        const void* v, int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype,

@@ -408,7 +408,9 @@ def qproj_rope_eligible(module, hidden_states: torch.Tensor, window: int) -> boo
     lin = module.__dict__.get("_modules", {}).get("q_proj")
     if type(lin) is torch.nn.Linear and hidden_states.is_cuda and hidden_states.stride(-1) == 1:
         w = lin._parameters.get("weight")
-        if w is not None:   # (the module-side checks are remembered per weight tensor: they cost more than the rest of the call's Python)
+        if _linear_is_hooked(lin):   # (never remembered: hooks come and go)
+            return False
+        if type(w) in (torch.Tensor, torch.nn.Parameter):   # (the module-side checks are remembered per weight tensor: they cost more than the rest of the call's Python)
             key = (id(module), w.data_ptr(), w._version, hidden_states.dtype, window, lin._parameters.get("bias") is None,
                    "q_norm" in module.__dict__["_modules"])
             hit = _QP_ELIGIBLE.get(key)
@@ -422,11 +424,20 @@ def qproj_rope_eligible(module, hidden_states: torch.Tensor, window: int) -> boo
     return _qproj_rope_eligible_slow(module, hidden_states, window)
 
 
+def _linear_is_hooked(lin) -> bool:
+    """The library reads ``q_proj.weight`` directly instead of CALLING q_proj: anything that rides on the call -- forward (pre-)hooks of
+    steering / tracing tools, accelerate's ``_hf_hook`` (offloading, device alignment) -- would be skipped, so such a module keeps
+    the model's own call."""
+    return bool(lin._forward_hooks) or bool(lin._forward_pre_hooks) or hasattr(lin, "_hf_hook")
+
+
 def _qproj_rope_eligible_slow(module, hidden_states: torch.Tensor, window: int) -> bool:
     lin = getattr(module, "q_proj", None)
-    if type(lin) is not torch.nn.Linear or lin.bias is not None or hasattr(module, "q_norm"):
+    if type(lin) is not torch.nn.Linear or lin.bias is not None or hasattr(module, "q_norm") or _linear_is_hooked(lin):
         return False
     w = lin.weight
+    if type(w) not in (torch.Tensor, torch.nn.Parameter):   # tensor subclasses (torchao-quantised, DTensor-sharded ...) keep the nn.Linear type and
+        return False                                        # report the plain dtype, but their data_ptr() is not the [out, in] matrix
     return (hidden_states.is_cuda and w.is_cuda and w.dtype == hidden_states.dtype and w.dtype in (torch.bfloat16, torch.float16)
             and w.is_contiguous() and window == 64 and getattr(module, "head_dim", 0) == 128 and w.shape[1] % 256 == 0
             and hidden_states.stride(-1) == 1 and w.shape[0] == module.config.num_attention_heads * 128)
@@ -477,8 +488,8 @@ def snapkv_score_hidden(hidden_win: torch.Tensor, wq: torch.Tensor, cos: torch.T
 
 
 def snapkv_compress_hidden(hidden_win: torch.Tensor, wq: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, keys: torch.Tensor,
-                           values: torch.Tensor, kernel_size: int, n_kept: int):
-    """SnapKVPress.compress (attentions=None) in one library call from the window's hidden states."""
+                           values: torch.Tensor, kernel_size: int, n_kept: int, order: int = ORDER_POSITION):
+    """SnapKVPress.compress (attentions=None) in one library call from the window's hidden states (order: see snapkv_compress_rope)."""
     keys = _rows_last_contig(_dev(keys))
     values = _rows_last_contig(_dev(values))
     dt = keys.dtype
@@ -498,7 +509,7 @@ def snapkv_compress_hidden(hidden_win: torch.Tensor, wq: torch.Tensor, cos: torc
             rc = lib().kvp_snapkv_compress_hidden(_p(hidden_win), _st(hidden_win, 0), _st(hidden_win, 1), _p(wq), K, _p(cos), _p(sin),
                                                   _st(cos, 0), _st(cos, 1), _p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2),
                                                   _p(values), _st(values, 0), _st(values, 1), _st(values, 2), _DTYPES[dt], B, Hq, Hkv, S,
-                                                  W, D, int(kernel_size), n, _p(ko), _p(vo), _p(ws), ws.numel(), TOPK_WS_CLEAN, st)
+                                                  W, D, int(kernel_size), n, _p(ko), _p(vo), _p(ws), ws.numel(), TOPK_WS_CLEAN | (int(order) & ORDER_SCORE), st)
             if rc != 0:
                 _drop_ws(ws)
             _check(rc, "kvp_snapkv_compress_hidden")
@@ -689,8 +700,9 @@ def _drop_ws(ws: torch.Tensor):
             del _TOPK_WS[key]
 
 
-def knorm_compress(keys: torch.Tensor, values: torch.Tensor, n_kept: int):
-    """KnormPress.compress in one library call: (K', V') contiguous [B,H,n_kept,D]."""
+def knorm_compress(keys: torch.Tensor, values: torch.Tensor, n_kept: int, order: int = ORDER_POSITION):
+    """KnormPress.compress in one library call: (K', V') contiguous [B,H,n_kept,D]; order = ORDER_SCORE stores the rows in descending
+    score order (the reference's layout)."""
     keys = _rows_last_contig(_dev(keys))
     values = _rows_last_contig(_dev(values))
     assert keys.dtype == values.dtype and keys.shape == values.shape
@@ -704,7 +716,7 @@ def knorm_compress(keys: torch.Tensor, values: torch.Tensor, n_kept: int):
             ws = _clean_ws("knorm", (B, H, S, n), _ws_bytes("kvp_knorm_compress_workspace_bytes", B, H, S, n), keys, st)
             rc = lib().kvp_knorm_compress(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _p(values), _st(values, 0), _st(values, 1),
                                           _st(values, 2), _DTYPES[keys.dtype], B, H, S, D, n, _p(ko), _p(vo), _p(ws), ws.numel(),
-                                          TOPK_WS_CLEAN, st)
+                                          TOPK_WS_CLEAN | (int(order) & ORDER_SCORE), st)
             if rc != 0:
                 _drop_ws(ws)
             _check(rc, "kvp_knorm_compress")
@@ -712,8 +724,9 @@ def knorm_compress(keys: torch.Tensor, values: torch.Tensor, n_kept: int):
 
 
 def snapkv_compress_rope(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, keys: torch.Tensor, values: torch.Tensor,
-                         kernel_size: int, n_kept: int):
-    """SnapKVPress.compress (attentions=None) in one library call from the pre-RoPE window queries."""
+                         kernel_size: int, n_kept: int, order: int = ORDER_POSITION):
+    """SnapKVPress.compress (attentions=None) in one library call from the pre-RoPE window queries; order = ORDER_SCORE stores the rows
+    in descending score order (window tokens first: the reference's layout)."""
     keys = _rows_last_contig(_dev(keys))
     values = _rows_last_contig(_dev(values))
     q_pre = _rows_last_contig(_dev(q_pre))
@@ -737,7 +750,7 @@ def snapkv_compress_rope(q_pre: torch.Tensor, cos: torch.Tensor, sin: torch.Tens
             rc = lib().kvp_snapkv_compress_rope(_p(q_pre), _st(q_pre, 0), _st(q_pre, 1), _st(q_pre, 2), _p(cos), _p(sin), _st(cos, 0),
                                                 _st(cos, 1), _p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _p(values),
                                                 _st(values, 0), _st(values, 1), _st(values, 2), _DTYPES[dt], B, Hq, Hkv, S, W, D,
-                                                int(kernel_size), n, _p(ko), _p(vo), _p(ws), ws.numel(), TOPK_WS_CLEAN, st)
+                                                int(kernel_size), n, _p(ko), _p(vo), _p(ws), ws.numel(), TOPK_WS_CLEAN | (int(order) & ORDER_SCORE), st)
             if rc != 0:
                 _drop_ws(ws)
             _check(rc, "kvp_snapkv_compress_rope")

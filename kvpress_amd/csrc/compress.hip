@@ -31,6 +31,8 @@ struct CompressWs {
     int32_t* idx;     // [R][n_kept]
     void* scorer;     // scorer-specific scratch
     size_t scorer_bytes;
+    void* order;      // KVP_ORDER_SCORE: the sort's tiles and samples (topk_order.hip)
+    size_t order_bytes;
     size_t total_bytes;
 };
 
@@ -50,6 +52,8 @@ CompressWs carve(void* ws, int64_t R, int64_t S_select, int64_t S, int64_t n_kep
     w.idx = (int32_t*)take((size_t)std::max<int64_t>(1, R * n_kept) * 4);
     w.scorer_bytes = scorer_bytes;
     w.scorer = take(scorer_bytes);
+    w.order_bytes = topk_order_workspace_bytes(R, n_kept);
+    w.order = take(w.order_bytes);
     w.total_bytes = off;
     return w;
 }
@@ -88,7 +92,8 @@ extern "C" int kvp_knorm_compress(const void* k, int64_t k_sb, int64_t k_sh, int
     }
     // long rows of 256-byte keys (Llama: D = 128, bf16 / f16): norms, select digits and compaction in ONE launch, the scores stay
     // in registers (topk_cluster.hip); other shapes / a device that cannot hold the grid / KVP_TK_CLUSTER=0: the sequence below
-    if (n_kept < S && topk_cluster_eligible(R, S) && (dtype == KVP_BF16 || dtype == KVP_F16) && D == 128 && ((uintptr_t)k % 16) == 0 &&
+    const bool by_score = (flags & KVP_ORDER_SCORE) != 0;   // K' / V' rows in descending-score order (the reference's layout, scorer_press.py:95-100)
+    if (!by_score && n_kept < S && topk_cluster_eligible(R, S) && (dtype == KVP_BF16 || dtype == KVP_F16) && D == 128 && ((uintptr_t)k % 16) == 0 &&
         (k_sb * 2) % 16 == 0 && (k_sh * 2) % 16 == 0 && (k_ss * 2) % 16 == 0) {
         TopkWs tw = topk_carve_ws(w.topk, R, (S + TK_CHUNK - 1) / TK_CHUNK);
         const int rc = topk_cluster_select(TOPK_CLUSTER_KNORM, nullptr, 0, 1.f, k, dtype, k_sb, k_sh, k_ss, H, -1.0f, R, S, n_kept, w.idx, n_kept, 0, 0, tw,
@@ -101,6 +106,8 @@ extern "C" int kvp_knorm_compress(const void* k, int64_t k_sb, int64_t k_sh, int
     uint32_t* hist1 = (n_kept < S && topk_fused_hist_wanted(S)) ? topk_carve_ws(w.topk, R, 1).hist1 : nullptr;  // short rows: one-launch select with its own digits
     if (int rc = kvp_rownorm_launch(k, dtype, B, H, S, D, k_sb, k_sh, k_ss, -1.0f, w.scores, stream, hist1, &hist1_done)) return rc;
     if (int rc = topk_select_impl(w.scores, R, S, S, n_kept, w.idx, n_kept, 0, 0, w.topk, w.topk_bytes, true, hist1_done, stream)) return rc;
+    if (by_score)   // (the norms are in w.scores: the one-launch path that keeps them in registers is not taken with this flag)
+        if (int rc = topk_order_by_score(w.scores, R, S, S, n_kept, w.idx, false, w.order, w.order_bytes, stream)) return rc;
     return kvp_gather_kv(k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, H, S, D, w.idx, n_kept, k_out, v_out, stream_);
 }
 
@@ -118,7 +125,7 @@ static bool snapkv_cluster_pooled(int64_t R, int64_t Sm, int kernel_size) {
 // select + gather after a SnapKV scorer has run (fused: hist1 holds the first pass over the S - W non-window columns)
 static int snapkv_select_gather(const CompressWs& w, bool fused, const float* colsum, float inv, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, const void* v,
                                 int64_t v_sb, int64_t v_sh, int64_t v_ss, int dtype, int64_t B, int64_t Hkv, int64_t S, int64_t W, int64_t D,
-                                int64_t n_kept, void* k_out, void* v_out, hipStream_t stream) {
+                                int64_t n_kept, void* k_out, void* v_out, hipStream_t stream, bool by_score) {
     const int64_t R = B * Hkv;
     int rc;
     if (fused && colsum && !topk_pooled_rows_eligible(S - W, 5)) {  // long rows, kernel_size 5: pooling inside the cluster select's loader
@@ -137,6 +144,13 @@ static int snapkv_select_gather(const CompressWs& w, bool fused, const float* co
     else
         rc = topk_select_impl(w.scores, R, S, S, n_kept, w.idx, n_kept, 0, 0, w.topk, w.topk_bytes, true, false, stream);
     if (rc) return rc;
+    if (by_score) {
+        // descending score: the window columns first (the reference's pad = max + 1, ties by position), then the scored ones.  Keys come
+        // from the pooled scores where they were written, else from the un-pooled column sums (pooled again per kept position)
+        if (fused && colsum) rc = topk_order_by_score(colsum, R, S, S - W, n_kept, w.idx, false, w.order, w.order_bytes, stream, 1, S - W, inv);
+        else rc = topk_order_by_score(w.scores, R, S, S, n_kept, w.idx, false, w.order, w.order_bytes, stream, 0, fused ? S - W : -1);
+        if (rc) return rc;
+    }
     return kvp_gather_kv(k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, D, w.idx, n_kept, k_out, v_out, stream);
 }
 
@@ -168,7 +182,7 @@ extern "C" int kvp_snapkv_compress_hidden(const void* hidden_win, int64_t x_sb, 
                                           Hkv, S, W, D, kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1,
                                           pooled ? SNAP_FINISH_COLSUM : fused ? SNAP_FINISH_NO_PAD : SNAP_FINISH_FULL))
         return rc;
-    return snapkv_select_gather(w, fused, pooled ? snapkv_ws_colsum(w.scorer, B, Hq, Hkv, S, W, D) : nullptr, snapkv_pool_scale(Hq, Hkv, W, kernel_size), k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, W, D, n_kept, k_out, v_out, stream);
+    return snapkv_select_gather(w, fused, pooled ? snapkv_ws_colsum(w.scorer, B, Hq, Hkv, S, W, D) : nullptr, snapkv_pool_scale(Hq, Hkv, W, kernel_size), k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, W, D, n_kept, k_out, v_out, stream, (flags & KVP_ORDER_SCORE) != 0);
 }
 
 extern "C" int kvp_snapkv_compress_rope(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, const void* cosp, const void* sinp,
@@ -198,5 +212,5 @@ extern "C" int kvp_snapkv_compress_rope(const void* q, int64_t q_sb, int64_t q_s
                                         kernel_size, w.scores, w.scorer, w.scorer_bytes, stream, hist1, false,
                                         pooled ? SNAP_FINISH_COLSUM : fused ? SNAP_FINISH_NO_PAD : SNAP_FINISH_FULL))
         return rc;
-    return snapkv_select_gather(w, fused, pooled ? snapkv_ws_colsum(w.scorer, B, Hq, Hkv, S, W, D) : nullptr, snapkv_pool_scale(Hq, Hkv, W, kernel_size), k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, W, D, n_kept, k_out, v_out, stream);
+    return snapkv_select_gather(w, fused, pooled ? snapkv_ws_colsum(w.scorer, B, Hq, Hkv, S, W, D) : nullptr, snapkv_pool_scale(Hq, Hkv, W, kernel_size), k, k_sb, k_sh, k_ss, v, v_sb, v_sh, v_ss, dtype, B, Hkv, S, W, D, n_kept, k_out, v_out, stream, (flags & KVP_ORDER_SCORE) != 0);
 }

@@ -520,10 +520,6 @@ __global__ void topk_iota_kernel(int32_t* __restrict__ idx, int64_t idx_stride, 
 
 }  // namespace
 
-// ordering step (topk_order.hip)
-size_t topk_order_workspace_bytes(int64_t R, int64_t k);
-int topk_order_by_score(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, bool smallest, void* ws,
-                        size_t ws_bytes, hipStream_t stream);
 
 extern "C" size_t kvp_topk_order_workspace_bytes(int64_t R, int64_t S, int64_t k) {
     return kvp_topk_workspace_bytes(R, S, k) + topk_order_workspace_bytes(R, k);

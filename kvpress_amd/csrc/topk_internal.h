@@ -111,3 +111,11 @@ bool topk_pooled_rows_eligible(int64_t Sm, int kernel_size);
 int topk_select_pooled_rows(const float* colsum, int64_t R, int64_t Sm, float inv, int64_t k, int32_t* idx, int64_t idx_stride,
                             uint32_t tail_start, uint32_t tail_n, hipStream_t stream);
 // nseg > 1: rows are (outer row, segment) pairs and every reported position gets (row % nseg) * seg_len + pos_base added
+
+// ---- KVP_ORDER_SCORE: the selection in descending-score order (topk_order.hip: a hand-written segmented sort) -------------------------
+// idx [R][k] holds a select's ascending positions and is rewritten in place.  mode 0: `scores` are score rows of S columns
+// (row_stride); mode 1: SnapKV's un-pooled column sums [R][ncols] (row_stride = ncols; 5-tap average * inv recomputed per kept
+// position).  Positions ncols .. S - 1 (ncols < 0: none) count as the largest scores, by position.
+size_t topk_order_workspace_bytes(int64_t R, int64_t k);
+int topk_order_by_score(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, bool smallest, void* ws,
+                        size_t ws_bytes, hipStream_t stream, int mode = 0, int64_t ncols = -1, float inv = 1.f);

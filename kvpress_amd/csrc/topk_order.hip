@@ -102,9 +102,29 @@ __device__ __forceinline__ void bitonic_sort_block(u64 (&v)[E], u64* xch) {
     bitonic_phase<E, 2>(v, xch, threadIdx.x);
 }
 
-__device__ __forceinline__ u64 order_composite(const float* __restrict__ row, int32_t p, uint32_t S, uint32_t kmask, uint32_t slot) {
-    if ((uint32_t)p < S) return ((u64)(~(float_to_key(row[p]) ^ kmask)) << 32) | (uint32_t)p;
-    return (u64)(0x80000000u | slot);                       // poisoned: sorts first, written back as -1
+// Where a kept position's score comes from.  ORDER_SCORES: the score row.  ORDER_POOL5: SnapKV's un-pooled column sums -- the fused
+// compress never writes its pooled scores, so the 5-tap zero-padded average is recomputed here with the additions and the scale of
+// the select's loader (topk_cluster.hip TC_POOL5, snapkv_pool_kernel: the same bits, hence the order the modular sequence gives).
+// Positions >= ncols are the window columns the reference pads with max + 1 (snapkv_press.py:103): they sort first, by position.
+enum { ORDER_SCORES = 0, ORDER_POOL5 = 1 };
+template <int MODE>
+__device__ __forceinline__ u64 order_composite(const float* __restrict__ row, int32_t p, uint32_t S, uint32_t ncols, float inv, uint32_t kmask,
+                                               uint32_t slot) {
+    if ((uint32_t)p >= S) return (u64)(0x80000000u | slot);                    // poisoned: sorts first, written back as -1
+    if ((uint32_t)p >= ncols) return (u64)(uint32_t)p;                         // kept by construction: ahead of every scored position
+    float sc;
+    if (MODE == ORDER_POOL5) {
+        float sum = 0.f;
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+            const int32_t q = p - 2 + d;
+            sum += (q >= 0 && (uint32_t)q < ncols) ? row[q] : 0.f;
+        }
+        sc = sum * inv;
+    } else {
+        sc = row[p];
+    }
+    return ((u64)(~(float_to_key(sc) ^ kmask)) << 32) | (uint32_t)p;
 }
 __device__ __forceinline__ int32_t order_position(u64 c) { return (c & 0x80000000ull) ? -1 : (int32_t)(uint32_t)c; }
 
@@ -113,12 +133,14 @@ struct OrderArgs {
     int64_t row_stride;
     int32_t* idx;          // [R][k] in: ascending positions; out: descending score
     uint32_t S, k, kmask, ntiles;
+    uint32_t ncols;        // scored columns of a row (positions ncols .. S - 1 are kept by construction); ORDER_SCORES callers pass S
+    float inv;             // ORDER_POOL5: 1 / (G * W * kernel_size)
     u64* tiles;            // [R][ntiles * T] sorted tiles
     u64* samples;          // [R][ntiles][T / OS_GROUP]; nullptr: none wanted (the global network)
 };
 
 // ---- launch 1: sort the tiles ---------------------------------------------------------------------------------------------------
-template <int E>
+template <int E, int MODE>
 __global__ __launch_bounds__(1024) void order_tiles_kernel(OrderArgs a) {
     constexpr uint32_t T = 1024u * E;
     __shared__ __attribute__((aligned(16))) u64 xch[T];
@@ -129,7 +151,7 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(OrderArgs a) {
 #pragma unroll
     for (int i = 0; i < E; ++i) {
         const uint32_t j = tile * T + E * t + i;
-        v[i] = j < a.k ? order_composite(row, ir[j], a.S, a.kmask, j) : (OS_PAD_HI | 0x80000000u | j);
+        v[i] = j < a.k ? order_composite<MODE>(row, ir[j], a.S, a.ncols, a.inv, a.kmask, j) : (OS_PAD_HI | 0x80000000u | j);
     }
     bitonic_sort_block<E>(v, xch);
     if (a.ntiles == 1) {                                        // the whole row: done
@@ -312,9 +334,10 @@ OrderPlan order_plan(int64_t R, int64_t k) {
 }
 
 template <int E>
-int launch_psrs(const OrderArgs& a, int64_t R, hipStream_t stream) {
+int launch_psrs(const OrderArgs& a, int mode, int64_t R, hipStream_t stream) {
     const dim3 grid(a.ntiles, (uint32_t)R);
-    KVP_LAUNCH("order_tiles_kernel", stream, (order_tiles_kernel<E><<<grid, 1024, 0, stream>>>(a)));
+    if (mode == ORDER_POOL5) KVP_LAUNCH("order_tiles_kernel", stream, (order_tiles_kernel<E, ORDER_POOL5><<<grid, 1024, 0, stream>>>(a)));
+    else KVP_LAUNCH("order_tiles_kernel", stream, (order_tiles_kernel<E, ORDER_SCORES><<<grid, 1024, 0, stream>>>(a)));
     KVP_CHECK_LAUNCH("topk(order: tiles)");
     if (a.ntiles == 1) return KVP_OK;
     const size_t lds = (size_t)(2 * 1024 * E + OS_MAX_TILES * (1024 * E / OS_GROUP)) * 8;
@@ -335,9 +358,10 @@ int launch_psrs(const OrderArgs& a, int64_t R, hipStream_t stream) {
 
 size_t topk_order_workspace_bytes(int64_t R, int64_t k) { return (R <= 0 || k <= 0) ? 0 : order_plan(R, k).total_bytes; }
 
-// idx [R, k] (contiguous, ascending positions from the select) is rewritten in descending-score order
+// idx [R, k] (contiguous, ascending positions from the select) is rewritten in descending-score order.  mode / ncols / inv: see
+// order_composite (defaults: plain score rows of S columns).
 int topk_order_by_score(const float* scores, int64_t R, int64_t S, int64_t row_stride, int64_t k, int32_t* idx, bool smallest, void* ws,
-                        size_t ws_bytes, hipStream_t stream) {
+                        size_t ws_bytes, hipStream_t stream, int mode, int64_t ncols, float inv) {
     if (R == 0 || k == 0) return KVP_OK;
     KVP_CHECK_ARG(R <= 65535 && k < ((int64_t)1 << 30) && S < ((int64_t)1 << 31), "topk(order): shape too large (R=%ld k=%ld)", (long)R, (long)k);
     const OrderPlan p = order_plan(R, k);
@@ -348,15 +372,17 @@ int topk_order_by_score(const float* scores, int64_t R, int64_t S, int64_t row_s
     OrderArgs a;
     a.scores = scores; a.row_stride = row_stride; a.idx = idx;
     a.S = (uint32_t)S; a.k = (uint32_t)k; a.kmask = smallest ? 0xFFFFFFFFu : 0u; a.ntiles = p.ntiles;
+    a.ncols = (uint32_t)(ncols < 0 ? S : ncols); a.inv = inv;
     a.tiles = static_cast<u64*>(ws);
     a.samples = reinterpret_cast<u64*>(static_cast<char*>(ws) + p.tiles_bytes);
-    if (p.e == 2) return launch_psrs<2>(a, R, stream);
-    if (p.e == 4) return launch_psrs<4>(a, R, stream);
+    if (p.e == 2) return launch_psrs<2>(a, mode, R, stream);
+    if (p.e == 4) return launch_psrs<4>(a, mode, R, stream);
     // any k: sorted 2048-tiles (launch 1 with padding tiles, no samples), then the global merge network
     const uint32_t npad = p.ntiles * 2048u;
     a.samples = nullptr;
     const dim3 gs(std::min<uint32_t>(npad / 512, 2048), (uint32_t)R), gt(p.ntiles, (uint32_t)R);
-    KVP_LAUNCH("order_tiles_kernel", stream, (order_tiles_kernel<2><<<gt, 1024, 0, stream>>>(a)));
+    if (mode == ORDER_POOL5) KVP_LAUNCH("order_tiles_kernel", stream, (order_tiles_kernel<2, ORDER_POOL5><<<gt, 1024, 0, stream>>>(a)));
+    else KVP_LAUNCH("order_tiles_kernel", stream, (order_tiles_kernel<2, ORDER_SCORES><<<gt, 1024, 0, stream>>>(a)));
     for (uint32_t size = 4096; size <= npad; size <<= 1) {
         KVP_LAUNCH("order_global_mirror_kernel", stream, (order_global_mirror_kernel<<<gs, 256, 0, stream>>>(a.tiles, npad, size)));
         for (uint32_t stride = size / 4; stride >= 2048; stride >>= 1)

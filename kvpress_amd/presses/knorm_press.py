@@ -31,6 +31,7 @@ class KnormPress(ScorerPress):
         A subclass that overrides ``score`` gets the generic three-call sequence."""
         if self.compression_ratio == 0:
             return keys, values
-        if type(self).score is not KnormPress.score or self.kept_order != "position":
+        if type(self).score is not KnormPress.score:
             return super().compress(module, hidden_states, keys, values, attentions, kwargs)
-        return _native.knorm_compress(keys, values, self.n_kept(module, keys.shape[2]))
+        order = _native.ORDER_SCORE if self.kept_order == "score" else _native.ORDER_POSITION   # "score": the reference's row order
+        return _native.knorm_compress(keys, values, self.n_kept(module, keys.shape[2]), order)

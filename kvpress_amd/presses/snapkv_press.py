@@ -70,8 +70,9 @@ class SnapKVPress(ScorerPress):
         subclass with its own ``score``, the generic three-call sequence runs."""
         if self.compression_ratio == 0:
             return keys, values
-        if attentions is not None or type(self).score is not SnapKVPress.score or self.kept_order != "position":
+        if attentions is not None or type(self).score is not SnapKVPress.score:
             return super().compress(module, hidden_states, keys, values, attentions, kwargs)
+        order = _native.ORDER_SCORE if self.kept_order == "score" else _native.ORDER_POSITION   # "score": the reference's row order
         assert (
             hidden_states.shape[1] > self.window_size
         ), f"Query length {hidden_states.shape[1]} should be greater than the window size {self.window_size}"
@@ -80,6 +81,6 @@ class SnapKVPress(ScorerPress):
         n_kept = self.n_kept(module, keys.shape[2])
         if _native.qproj_rope_supported(module, hidden_states, self.window_size):
             return _native.snapkv_compress_hidden(hidden_states[:, -self.window_size:], module.q_proj.weight, cos, sin, keys, values,
-                                                  self.kernel_size, n_kept)
+                                                  self.kernel_size, n_kept, order)
         q_pre = get_prerope_query_states(module, hidden_states[:, -self.window_size:])
-        return _native.snapkv_compress_rope(q_pre, cos, sin, keys, values, self.kernel_size, n_kept)
+        return _native.snapkv_compress_rope(q_pre, cos, sin, keys, values, self.kernel_size, n_kept, order)

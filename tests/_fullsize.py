@@ -18,6 +18,7 @@ FULL_CASES = {
     "full_snapkv128k": dict(kind="snapkv", S=131072, ratio=0.5, data="A", seed=103),               # BASELINE config 3 (the bench workload)
     "full_snapkv128k_B": dict(kind="snapkv", S=131072 - 1000 + 37, ratio=0.5, data="B", seed=113),  # ragged length, structured keys
     "full_ea128k": dict(kind="ea", S=131072, ratio=0.7, data="B", seed=104),                       # BASELINE config 4
+    "full_ea128k_A": dict(kind="ea", S=131072, ratio=0.7, data="A", seed=104),                     # config 4 on bench.py's timed tensors (set A)
     # SURVEY §8(f-2) scorers at the BASELINE size (round 3: the kernels they run on were reshaped for this size)
     "full_keydiff128k": dict(kind="keydiff", S=131072, ratio=0.5, data="B", seed=105),
     "full_cur128k": dict(kind="cur", S=131072, ratio=0.5, data="B", seed=106),

@@ -136,11 +136,11 @@ def fake_native(monkeypatch):
         scores.copy_(scores.mean(dim=1, keepdim=True).expand_as(scores).clone())
         return scores
 
-    def knorm_compress(keys, values, n_kept):
-        return gather_kv(keys, values, topk_select(rownorm_score(keys, -1.0), n_kept))
+    def knorm_compress(keys, values, n_kept, order=0):
+        return gather_kv(keys, values, topk_select(rownorm_score(keys, -1.0), n_kept, order))
 
-    def snapkv_compress_rope(q_pre, cos, sin, keys, values, kernel_size, n_kept):
-        return gather_kv(keys, values, topk_select(snapkv_score_rope(q_pre, cos, sin, keys, kernel_size), n_kept))
+    def snapkv_compress_rope(q_pre, cos, sin, keys, values, kernel_size, n_kept, order=0):
+        return gather_kv(keys, values, topk_select(snapkv_score_rope(q_pre, cos, sin, keys, kernel_size), n_kept, order))
 
     def topk_select_segmented(scores, seg_len, k, pos_base=0):
         sc = scores.float().numpy()
