@@ -40,11 +40,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 LAYERS = 32  # Llama-3.1-8B
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md); with real operands the chip power-limits to ~1.44 GHz
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md); with real operands the chip sits at its 1.4 kW power limit at ~1.75 GHz
 # measured ceilings the path model is built from:
 COPY_CEILING_GBS = 6290.0       # float4 copy ceiling, MI355X_MICROARCH.md "HBM": what a pure streaming kernel reaches
-MFMA_SUSTAINED_TFLOPS = 1459.0  # v_mfma_f32_32x32x16_bf16 back to back on all 256 CUs with RANDOM operands: 367.9 ns per 524 288-flop
-                                # SIMD stage (profiles/r02_ubench_stage.txt, "mfma_only", 256 workgroups) -- the chip power-limits to ~1.4 GHz
+MFMA_SUSTAINED_TFLOPS = 1752.0  # v_mfma_f32_32x32x16_bf16 back to back on all 256 CUs with RANDOM operands, SUSTAINED: 306.4 ns per stage of
+                                # 536.9 MFLOP (profiles/r05_clock_power.txt, "ubench:mfma_only:256wg_random": 1305 W, 1.75 GHz in-kernel).  Rounds 2-4
+                                # used the one-shot launch of the same micro-benchmark (367.9 ns = 1459: the first launch after idle clocks lower)
 BOUNDARY_US = 1.7               # one dependent kernel boundary / all-to-all hop (MI355X_MICROARCH.md price list "boundary"; the cluster
                                 # select's in-launch hops measure ~2 us each, profiles/r03_select_cluster_lab.txt)
 
@@ -63,10 +64,10 @@ WORKLOADS = {
     "rerotate128k": ("rerotate", 131072, 0.5),           # key_rerotation_press.py:101-152 around KnormPress
     "decode_snapkv2k": ("snapkv", 2048, 0.5),            # decoding_press.py:113-179's regime: a 2k-token cache, latency-bound
     # the headline workload with K' / V' stored in the REFERENCE's tensor layout (descending score, scorer_press.py:95-100:
-    # press.kept_order = "score"): modular score -> select -> sort -> gather of rows in random order
+    # press.kept_order = "score"): the fused compress call + the hand-written sort (topk_order.hip) + a gather of rows in score order
     "snapkv128k_scoreorder": ("snapkv", 131072, 0.5),
 }
-ROUND = "r04"   # prefix of the committed profiles/ this build's fallbacks read
+ROUND = "r05"   # prefix of the committed profiles/ this build's fallbacks read
 # CPU seeds of the timed tensors (SURVEY §8d set A: N(0,1) from a CPU torch.Generator, rounded to bf16 once): the headline and
 # config 2 use the seeds of their full-size parity fixtures (tests/_fullsize.py FULL_CASES), so the timed tensors ARE the tensors
 # whose retained sets are pinned to the real reference (tests/golden/full_snapkv128k.npz, full_knorm32k.npz)
@@ -125,7 +126,7 @@ def kernel_bytes(name: str, kind: str, S: int, ratio: float) -> float:
         return kbytes   # one pass over K (or V)
     if name.startswith("ea_qstats_mfma"):
         return S * H_Q * D * 2  # Q [B, S, H_q * D] read once for the statistics
-    if name.startswith("qproj_rope"):
+    if name.startswith("qproj_rope_splitk"):
         return HIDDEN * H_Q * D * 2   # the q_proj weight, streamed once (the 512 KiB hidden window is re-read from L2)
     if name.startswith("rerotate"):
         return 2 * ab["n_kept"] * H_KV * D * 2
