@@ -126,7 +126,7 @@ def kernel_bytes(name: str, kind: str, S: int, ratio: float) -> float:
         return kbytes   # one pass over K (or V)
     if name.startswith("ea_qstats_mfma"):
         return S * H_Q * D * 2  # Q [B, S, H_q * D] read once for the statistics
-    if name.startswith("qproj_rope_splitk"):
+    if name.startswith("qproj_rope"):
         return HIDDEN * H_Q * D * 2   # the q_proj weight, streamed once (the 512 KiB hidden window is re-read from L2)
     if name.startswith("rerotate"):
         return 2 * ab["n_kept"] * H_KV * D * 2

@@ -239,13 +239,11 @@ int kvp_scores_head_mean(float* scores, int64_t B, int64_t H, int64_t S, int64_t
  * [Hq * D, hidden] contiguous, no bias; cos/sin: the window's rotary tables [1 or B, W, D].  bf16 / f16, W = 64, D = 128,
  * hidden % 256 == 0, else KVP_EUNSUPPORTED (the caller then runs its own q_proj and kvp_snapkv_*_rope).
  * kvp_snapkv_qproj_rope writes the RoPE'd window queries q_rot [B, Hq, W, D] (contiguous, input dtype): fp32 accumulation
- * in a fixed order (the hidden dimension is split over workgroups; the partial products go through `ws` and are added in
- * split order by a second kernel), rounded to the dtype like a GEMM output, then rotated with torch's per-op rounding.
+ * in a fixed order, rounded to the dtype like a GEMM output, then rotated with torch's per-op rounding.
  * kvp_snapkv_score_hidden / kvp_snapkv_compress_hidden = kvp_snapkv_score_rope / kvp_snapkv_compress_rope from there. */
-size_t kvp_snapkv_qproj_rope_workspace_bytes(int64_t B, int64_t Hq);   /* float32 partial products of the split over `hidden` */
 int kvp_snapkv_qproj_rope(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, const void* cos, const void* sin,
                           int64_t cs_sb, int64_t cs_sw, int dtype, int64_t B, int64_t Hq, int64_t W, int64_t D, int64_t hidden,
-                          void* q_rot, void* ws, size_t ws_bytes, kvp_stream_t stream);
+                          void* q_rot, kvp_stream_t stream);
 int kvp_snapkv_score_hidden(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, int64_t hidden,
                             const void* cos, const void* sin, int64_t cs_sb, int64_t cs_sw,
                             const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss, int dtype,

@@ -60,9 +60,8 @@ SIGNATURES = {
                                       _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_finch_score": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, c_void_p, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int,
                                 _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "kvp_snapkv_qproj_rope_workspace_bytes": (c_size_t, [_I64] * 2),
     "kvp_snapkv_qproj_rope": (c_int, [c_void_p, _I64, _I64, c_void_p, c_void_p, c_void_p, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64,
-                                      c_void_p, c_void_p, c_size_t, c_void_p]),
+                                      c_void_p, c_void_p]),
     "kvp_snapkv_score_hidden": (c_int, [c_void_p, _I64, _I64, c_void_p, _I64, c_void_p, c_void_p, _I64, _I64, c_void_p, _I64, _I64, _I64,
                                         c_int, _I64, _I64, _I64, _I64, _I64, _I64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvp_snapkv_compress_hidden": (c_int, [c_void_p, _I64, _I64, c_void_p, _I64, c_void_p, c_void_p, _I64, _I64, c_void_p, _I64, _I64, _I64,
@@ -462,9 +461,8 @@ def snapkv_qproj_rope(hidden_win: torch.Tensor, wq: torch.Tensor, cos: torch.Ten
     Hq = wq.shape[0] // head_dim
     out = torch.empty((B, Hq, W, head_dim), dtype=dt, device=hidden_win.device)
     with _on_device(hidden_win.device):
-        ws = _ws(lib().kvp_snapkv_qproj_rope_workspace_bytes(B, Hq), hidden_win)
         _check(lib().kvp_snapkv_qproj_rope(_p(hidden_win), _st(hidden_win, 0), _st(hidden_win, 1), _p(wq), _p(cos), _p(sin), _st(cos, 0),
-                                           _st(cos, 1), _DTYPES[dt], B, Hq, W, head_dim, K, _p(out), _p(ws), ws.numel(), _stream(hidden_win)),
+                                           _st(cos, 1), _DTYPES[dt], B, Hq, W, head_dim, K, _p(out), _stream(hidden_win)),
                "kvp_snapkv_qproj_rope")
     return out
 

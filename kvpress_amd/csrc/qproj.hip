@@ -2,26 +2,31 @@
 // Replaces `get_prerope_query_states(module, hidden_states[:, -W:])` (kvpress/utils.py:43-46: q_proj, view, transpose) followed
 // by `q * cos + rotate_half(q) * sin` (snapkv_press.py:53-58) for a plain nn.Linear q_proj without bias.
 //
-// A 64 x hidden by hidden x (H_q * 128) product: 32 MiB of bf16 weights for Llama-3.1-8B, 2 GFLOP -- a pure streaming problem whose
-// bound is NOT HBM but what each CU has to pull through its L2 port (~40 GB/s per CU with 256 CUs pulling: round 4, R4.1).  Rounds 1-4
-// gave every workgroup 16 output columns over the WHOLE hidden dimension: 128 KiB of weights + the whole 512 KiB hidden window per CU =
-// 160 MiB in flight chip-wide, 15 us (the library GEMM's 16 x 64 tiling moves the same bytes in the same time).  Round 5 splits the
-// hidden dimension instead:
-//   qproj_splitk_kernel   workgroup = (64 output columns -- 32 dims of a head and their rotate_half partners --, one of NS = 4 ranges of
-//                         the hidden dimension): 128 KiB of weights + 128 KiB of the window per CU (64 MiB chip-wide).  K is walked
-//                         in tiles of 128 elements: 64 weight rows + 64 hidden rows (32 KiB) by LDS-DMA into a ring of four buffers
-//                         (XOR-swizzled on the global side); wave w multiplies k-step w & 3 of the tile for column blocks 2 (w >> 2),
-//                         2 (w >> 2) + 1 and all four row blocks (v_mfma_f32_16x16x32, 8 per tile and wave).  The four k-step partials
-//                         of a workgroup are added in a fixed order through LDS and written as float32 partial products
-//                         [b][split][column block][64 rows][64 columns] (workspace).  Workgroups of one split share an XCD (block
-//                         index % 4 = split), so an L2 sees one quarter of the window.
-//   qproj_reduce_rope_kernel  adds the NS partials in split order (fixed: deterministic), rounds to the model dtype like a GEMM
-//                         output, applies RoPE with torch's per-op rounding (rope_elem) and writes [B, H_q, W, D].
-// Two launches instead of an in-launch seam: a last-arriver ticket would need zeroed tickets in a caller-owned workspace (no such
-// contract on kvp_snapkv_score_hidden) and a cluster barrier a failure path; the second launch costs ~3 us on the chain.
-// History of the single-launch kernel (16 columns x whole K per workgroup; rounds 1-4, profiles/r04_qproj_lab.txt): 20 us in isolation,
-// 17.3 with a rotated tile walk; weights in registers / deeper rings / register staging did not help (tools/lab_patches/qproj_v2_v3.diff)
-// -- every variant moved the same 640 KiB per CU.
+// A 64 x hidden by hidden x (H_q * 128) product: 32 MiB of bf16 weights for Llama-3.1-8B.  One workgroup per 16 output
+// columns -- the 8 dims d0..d0+7 of a head AND their rotate_half partners d0+64..d0+71, so the RoPE pairs meet in the same
+// workgroup -- 256 workgroups for 32 heads.  K is walked in tiles of 256 elements: the 16 weight rows and the 64
+// hidden-state rows of a tile (40 KiB) land in LDS by LDS-DMA (coalesced 512-byte row segments, ring of three buffers);
+// each of the 8 waves multiplies one 32-element k-step of the tile (v_mfma_f32_16x16x32: 4 row blocks x 1 column block,
+// fragments by ds_read_b128 from XOR-swizzled rows).  The eight k-step partials are summed in a fixed order through LDS
+// (deterministic), rounded to the model dtype like a GEMM output, rotated with torch's per-op rounding (rope_elem) and
+// written as [B, H_q, W, D].
+//
+// Measured (Llama-3.1-8B window, MI355X).  Round 1, in isolation: 20 us, on par with the library GEMM + RoPE launch it replaces
+// (17.6 + 5 us).  Round 4, inside bench.py's loop (two boxes, alternating runs, profiles/r04_qproj_lab.txt): the step is 3-4 us
+// SHORTER with this kernel (271.3 / 271.6 / 268.7 us against 274.5 / 275.9 / 273.0 / 272.0 with hipBLASLt 15.1 + RoPE 4.8), so the
+// presses now project the window here by default (kvpress_amd/_native.py USE_LIBRARY_QPROJ).  A rotated tile walk (workgroup j of an
+// XCD starts at K tile j % 16, so the 32 CUs of an XCD do not ask their L2 for the same hidden-window lines at the same moment)
+// is worth another ~0.8 us of the kernel, 1.6 us of the step (three alternating A/B pairs: 271.9 against 273.5 us; KVP_QP_ROTATE=0).
+// What bounds it is the traffic between the L2s and the CUs, not HBM and not the matrix pipe: every workgroup pulls the whole hidden
+// window (512 KiB) next to its 128 KiB weight slice, 160 MiB in total, and that path delivers ~10 TB/s chip-wide when all CUs read
+// the same lines -- the library GEMM's 16 x 64 tiles move the same 160 MiB and take the same ~15 us.  Round 4 tried to hide it and
+// could not (same file history, tools/lab_patches/qproj_v2_v3.diff): the weight slice in registers with ALL of it in flight from the first
+// microsecond + the hidden window through a 4-deep LDS-DMA ring fed by 8 loader waves: 21.6 us (18.4 for this kernel, same run); the
+// same with the window staged through registers (global_load_dwordx4 -> ds_write_b128, 12 loads per lane in flight): 26 us.  Deeper
+// prefetch does not help a stream that is bandwidth-bound where it enters the CU.  Earlier variants: fragments straight from
+// global memory (16-byte pieces of 16 rows per instruction: address-path bound, 27 us); 64-column tiles on 64 workgroups (64 MiB of
+// traffic but 1 MiB per CU: 28 us); a fourth buffer (no change); split-K with a second reduction pass (18.4 against 15.4 us in
+// isolation).  Fewer bytes per CU need 32 x 32 output tiles (128 MiB) or an in-launch split-K seam (5-13 us per seam): not pursued.
 #include "kvp_common.h"
 
 namespace {
@@ -31,14 +36,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int QP_THREADS = 512;
+constexpr int QP_WAVES = QP_THREADS / 64;  // one 32-element k-step of every K tile per wave
 constexpr int QP_ROWS = 64;     // window
-constexpr int QP_COLS = 64;     // output columns per workgroup: dims d0 .. d0 + 31 of a head and d0 + 64 .. d0 + 95
-constexpr int QP_KT = 128;      // K elements per tile = 4 k-steps of 32
-constexpr int QP_ROWB = QP_KT * 2;                         // 256 B per tile row = 16 chunks of 16 B
-constexpr int QP_TILEB = (QP_COLS + QP_ROWS) * QP_ROWB;    // 16 KiB of weights + 16 KiB of hidden states
-constexpr int QP_REQ = QP_TILEB / 16 / QP_THREADS;         // LDS-DMA requests per thread and tile (4)
-constexpr int QP_NBUF = 4;      // three tiles (96 KiB) in flight per CU: the walk is only 8 tiles long
-constexpr int QP_MAXSPLIT = 4;
+constexpr int QP_COLS = 16;     // 8 dims + their 8 rotate_half partners
+constexpr int QP_KT = 256;      // K elements per tile = QP_WAVES k-steps of 32
+constexpr int QP_ROWB = QP_KT * 2;                         // 512 B per tile row = 32 chunks of 16 B
+constexpr int QP_TILEB = (QP_COLS + QP_ROWS) * QP_ROWB;    // 8 KiB of weights + 32 KiB of hidden states
+constexpr int QP_REQ = QP_TILEB / 16 / QP_THREADS;         // LDS-DMA requests per thread and tile (5)
+constexpr int QP_NBUF = 3;
 static_assert(QP_TILEB % (16 * QP_THREADS) == 0, "whole requests");
 
 template <int DT> __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 c);
@@ -61,41 +66,45 @@ struct QprojArgs {
     const void* sinp;
     int64_t cs_sb, cs_sw;  // element strides
     void* out;          // [B, Hq, 64, 128] contiguous
-    float* part;        // [B][nsplit][Hq * 2][64 rows][64 cols] float32 partial products
-    uint32_t Hq, K, nsplit;
+    uint32_t Hq, K;
 };
 
-// Tile rows 0..63 = the 64 weight rows (columns of the output block), rows 64..127 = the 64 hidden-state rows; 256 B per row,
+// Tile rows 0..15 = the 16 weight rows (columns of the output tile), rows 16..79 = the 64 hidden-state rows; 512 B per row,
 // 16-byte slot p of row r holds chunk p ^ (r & 15) (XOR swizzle applied on the global side of the DMA): the 16 lanes of a
-// fragment read (16 consecutive rows, same chunk) hit 16 distinct slots.
+// fragment read (16 rows, same chunk) hit 16 distinct slots.
 template <int DT>
-__global__ __launch_bounds__(QP_THREADS) void qproj_splitk_kernel(QprojArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // QP_NBUF * QP_TILEB; reused for the k-step partials
-    const uint32_t split = blockIdx.x % a.nsplit, cb = blockIdx.x / a.nsplit, b = blockIdx.y;
-    const uint32_t h = cb >> 1, d0 = (cb & 1) * 32;   // output columns: dims d0 .. d0 + 31 of head h, then d0 + 64 .. d0 + 95
+__global__ __launch_bounds__(QP_THREADS) void qproj_rope_kernel(QprojArgs a) {
+    using T = typename Elem<DT>::T;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[QP_NBUF * QP_TILEB];
+    const uint32_t nt = blockIdx.x, b = blockIdx.y;
+    const uint32_t h = nt >> 3, d0 = (nt & 7) * 8;  // output columns: dims d0..d0+7 of head h, then d0+64..d0+71
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t l16 = lane & 15, kq = lane >> 4;   // fragment row / column, k-slot group (8 elements)
-    const uint32_t kstep = wv & 3, chalf = wv >> 2;   // this wave: k-step of every tile, column blocks 2 chalf and 2 chalf + 1
-    const uint32_t ktiles = a.K / a.nsplit / QP_KT;   // tiles of this workgroup's range of the hidden dimension
-    const int64_t kbase = (int64_t)split * ktiles * QP_ROWB;   // byte offset of the range inside a row
+    const uint32_t l16 = lane & 15, kq = lane >> 4;  // fragment row / column, k-slot group (8 elements)
+    const uint32_t ntiles = a.K / QP_KT;
+    const uint32_t rot = (blockIdx.x >> 3) % ntiles;
 
-    // ---- LDS-DMA requests: request i of a tile moves chunks e = i * 512 + t; a wave's 64 chunks = 4 rows x 16 slots
-    const char* gsrc[QP_REQ];
+    // ---- LDS-DMA requests: request i of a tile moves chunks e = i * 512 + t; a wave's 64 chunks = 2 rows x 32 slots
+    const char* gsrc[QP_REQ];     // global address of this thread's chunk in K tile 0
 #pragma unroll
     for (int i = 0; i < QP_REQ; ++i) {
-        const uint32_t e = i * QP_THREADS + threadIdx.x, row = e >> 4, slot = e & 15;
+        const uint32_t e = i * QP_THREADS + threadIdx.x, row = e >> 5, slot = e & 31;
         const uint32_t chunk = slot ^ (row & 15);
         const char* rowp;
         if (row < QP_COLS) {
-            const uint32_t wrow = h * 128 + (row < 32 ? d0 + row : d0 + 64 + (row - 32));
+            const uint32_t wrow = h * 128 + (row < 8 ? d0 + row : d0 + 64 + (row - 8));
             rowp = a.w + (int64_t)wrow * a.K * 2;
         } else {
             rowp = a.x + (int64_t)b * a.x_sb + (int64_t)(row - QP_COLS) * a.x_sw;
         }
-        gsrc[i] = rowp + kbase + chunk * 16;
+        gsrc[i] = rowp + chunk * 16;
     }
     auto request_tile = [&](uint32_t t, uint32_t buf) {
-        const uint32_t tt = min(t, ktiles - 1);   // past the end: re-fetch the last tile (never read)
+        // Every workgroup reads the SAME hidden window; walking it in lockstep makes the 32 CUs of an XCD ask their L2 for the same
+        // lines at the same moment.  A rotated walk (workgroup j of an XCD starts at tile j % ntiles; blocks b, b + 8, ... share an
+        // XCD) spreads them over the window.  The sum over the tiles then runs in a rotated order per workgroup: still a fixed order.
+        uint32_t tt = min(t, ntiles - 1);  // past the end: re-fetch the last tile (never read)
+        tt += rot;
+        tt -= tt >= ntiles ? ntiles : 0u;
 #pragma unroll
         for (int i = 0; i < QP_REQ; ++i) {
             const char* g = gsrc[i] + (int64_t)tt * QP_ROWB;
@@ -106,147 +115,97 @@ __global__ __launch_bounds__(QP_THREADS) void qproj_splitk_kernel(QprojArgs a) {
     };
 #pragma unroll
     for (int p = 0; p < QP_NBUF - 1; ++p) request_tile(p, p);
-    __builtin_amdgcn_s_waitcnt(0x0F70 | ((QP_NBUF - 2) * QP_REQ));  // tile 0 landed (the newer tile may still be in flight)
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((QP_NBUF - 2) * QP_REQ));  // tile 0 landed (the newer tiles may still be in flight)
     __syncthreads();
 
-    f32x4 acc[2][4];
+    f32x4 acc[4];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) acc[c][m] = {0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < 4; ++m) acc[m] = {0.f, 0.f, 0.f, 0.f};
     uint32_t bc = 0;
-    for (uint32_t t = 0; t < ktiles; ++t) {
+    for (uint32_t t = 0; t < ntiles; ++t) {
         const unsigned char* buf = lds + bc * QP_TILEB;
         request_tile(t + QP_NBUF - 1, bc == 0 ? QP_NBUF - 1 : bc - 1);  // into the buffer tile t-1 just left
-        const uint32_t sl = ((kstep * 4 + kq) ^ l16) << 4;   // this wave's k-step: chunk kstep * 4 + kq, swizzled by the row's low bits
-        uint4 bfrag[2], afrag[4];
+        const uint32_t sl = ((wv * 4 + kq) ^ l16) << 4;  // this wave's k-step: chunk wv * 4 + kq, swizzled by the row's low bits
+        const uint4 bfrag = *reinterpret_cast<const uint4*>(buf + l16 * QP_ROWB + sl);
+        uint4 afrag[4];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)   // weight rows (output columns) 16 (2 chalf + c) + l16
-            bfrag[c] = *reinterpret_cast<const uint4*>(buf + ((2 * chalf + c) * 16 + l16) * QP_ROWB + sl);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)   // hidden rows 16 m + l16
+        for (int m = 0; m < 4; ++m)   // row 16 + 16 m + l16: (row & 15) == l16
             afrag[m] = *reinterpret_cast<const uint4*>(buf + (QP_COLS + 16 * m + l16) * QP_ROWB + sl);
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[c][m] = mma16<DT>(afrag[m], bfrag[c], acc[c][m]);  // C[row 16 m + 4 kq + r][col 16 (2 chalf + c) + l16]
+        for (int m = 0; m < 4; ++m) acc[m] = mma16<DT>(afrag[m], bfrag, acc[m]);  // C[row 16 m + 4 kq + r][col l16]
         __builtin_amdgcn_s_waitcnt(0x0070 | ((QP_NBUF - 2) * QP_REQ));  // lgkmcnt(0) + tile t+1 landed
         __syncthreads();
         bc = bc + 1 == QP_NBUF ? 0 : bc + 1;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the DMA before the buffers are reused for the partial sums
-    __syncthreads();
 
-    float (*kp)[QP_ROWS][QP_COLS + 1] = reinterpret_cast<float (*)[QP_ROWS][QP_COLS + 1]>(lds);  // [k-step][row][col] 66.5 KiB
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) kp[kstep][m * 16 + kq * 4 + r][(2 * chalf + c) * 16 + l16] = acc[c][m][r];
+    float (*part)[QP_ROWS][QP_COLS + 1] = reinterpret_cast<float (*)[QP_ROWS][QP_COLS + 1]>(lds);  // [k-step][row][col]
     __syncthreads();
-    // the four k-step partials in a fixed order -> this workgroup's partial product (coalesced: 64 columns of a row per 64 threads)
-    float* pout = a.part + ((((size_t)b * a.nsplit + split) * (a.Hq * 2) + cb) * QP_ROWS) * QP_COLS;
-    for (uint32_t e = threadIdx.x; e < QP_ROWS * QP_COLS; e += QP_THREADS) {
-        const uint32_t row = e >> 6, col = e & 63;
-        pout[e] = ((kp[0][row][col] + kp[1][row][col]) + kp[2][row][col]) + kp[3][row][col];
-    }
-}
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wv][m * 16 + kq * 4 + r][l16] = acc[m][r];
+    __syncthreads();
+    if (threadIdx.x >= 256) return;
 
-// One thread per RoPE pair (b, head, window row, dim d < 64 and its partner d + 64).
-template <int DT>
-__global__ __launch_bounds__(256) void qproj_reduce_rope_kernel(QprojArgs a, uint32_t B) {
-    using T = typename Elem<DT>::T;
-    const uint32_t total = B * a.Hq * QP_ROWS * 64;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const uint32_t d = i & 63, row = (i >> 6) & 63, h = (i >> 12) % a.Hq, b = (i >> 12) / a.Hq;
-        const uint32_t cb = h * 2 + (d >> 5), c = d & 31;
-        float a0 = 0.f, a1 = 0.f;
-        for (uint32_t s = 0; s < a.nsplit; ++s) {   // fixed order over the splits; the first add to 0.f is exact
-            const float* pp = a.part + ((((size_t)b * a.nsplit + s) * (a.Hq * 2) + cb) * QP_ROWS + row) * QP_COLS;
-            a0 += pp[c];
-            a1 += pp[32 + c];
+    // epilogue: thread t -> row t / 4, pairs p = (t % 4) * 2 + {0, 1}
+    const uint32_t row = threadIdx.x >> 2;
+    const T* cr = static_cast<const T*>(a.cosp) + (int64_t)b * a.cs_sb + (int64_t)row * a.cs_sw;
+    const T* sr = static_cast<const T*>(a.sinp) + (int64_t)b * a.cs_sb + (int64_t)row * a.cs_sw;
+    T* orow = static_cast<T*>(a.out) + (((size_t)b * a.Hq + h) * QP_ROWS + row) * 128;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t p = (threadIdx.x & 3) * 2 + i;
+        // fixed summation order over the eight k-step slices, then the GEMM's output rounding
+        float a0 = part[0][row][p], a1 = part[0][row][p + 8];
+#pragma unroll
+        for (int w = 1; w < QP_WAVES; ++w) {
+            a0 += part[w][row][p];
+            a1 += part[w][row][p + 8];
         }
-        const float q0 = round_dt<DT>(a0), q1 = round_dt<DT>(a1);   // the GEMM's output rounding
-        const T* cr = static_cast<const T*>(a.cosp) + (int64_t)b * a.cs_sb + (int64_t)row * a.cs_sw;
-        const T* sr = static_cast<const T*>(a.sinp) + (int64_t)b * a.cs_sb + (int64_t)row * a.cs_sw;
-        T* orow = static_cast<T*>(a.out) + (((size_t)b * a.Hq + h) * QP_ROWS + row) * 128;
+        const float q0 = round_dt<DT>(a0), q1 = round_dt<DT>(a1);
+        const uint32_t d = d0 + p;
         st_dt<DT>(orow + d, rope_elem<DT>(q0, Elem<DT>::ld(cr + d), -q1, Elem<DT>::ld(sr + d)));
         st_dt<DT>(orow + d + 64, rope_elem<DT>(q1, Elem<DT>::ld(cr + d + 64), q0, Elem<DT>::ld(sr + d + 64)));
     }
 }
 
-uint32_t qproj_nsplit(int64_t K) {   // the largest split whose ranges are whole 128-element tiles
-    for (uint32_t n = QP_MAXSPLIT; n > 1; n >>= 1)
-        if (K % ((int64_t)n * QP_KT) == 0) return n;
-    return 1;
-}
 
 }  // namespace
-
-size_t kvp_qproj_rope_ws_bytes(int64_t B, int64_t Hq) {   // partial products of the largest split
-    return kvp_align_up((size_t)std::max<int64_t>(1, B) * QP_MAXSPLIT * (size_t)std::max<int64_t>(1, Hq) * 2 * QP_ROWS * QP_COLS * 4, 256);
-}
 
 bool kvp_qproj_rope_eligible(int dtype, int64_t W, int64_t D, int64_t K, const void* x, int64_t x_sb, int64_t x_sw, const void* w,
                              const void* cosp, const void* sinp, int64_t cs_sb, int64_t cs_sw) {
     if (dtype != KVP_BF16 && dtype != KVP_F16) return false;
-    if (W != QP_ROWS || D != 128 || K < 256 || K % 256 != 0) return false;
+    if (W != QP_ROWS || D != 128 || K < QP_KT || K % QP_KT != 0) return false;
     auto al8 = [](int64_t v) { return v % 8 == 0; };
     if (((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)cosp % 2) || ((uintptr_t)sinp % 2)) return false;
     return al8(x_sb) && al8(x_sw) && cs_sb >= 0 && cs_sw >= 0;
 }
 
-// out: [B, Hq, 64, 128] contiguous in the input dtype.  Strides in elements.  part: kvp_qproj_rope_ws_bytes(B, Hq) bytes of scratch.
+// out: [B, Hq, 64, 128] contiguous in the input dtype.  Strides in elements.
 int kvp_qproj_rope_launch(const void* x, int64_t x_sb, int64_t x_sw, const void* w, const void* cosp, const void* sinp, int64_t cs_sb,
-                          int64_t cs_sw, int dtype, int64_t B, int64_t Hq, int64_t K, void* out, void* part, hipStream_t stream) {
+                          int64_t cs_sw, int dtype, int64_t B, int64_t Hq, int64_t K, void* out, hipStream_t stream) {
     QprojArgs a;
     a.x = static_cast<const char*>(x); a.x_sb = x_sb * 2; a.x_sw = x_sw * 2;
     a.w = static_cast<const char*>(w);
     a.cosp = cosp; a.sinp = sinp; a.cs_sb = cs_sb; a.cs_sw = cs_sw;
-    a.out = out; a.part = static_cast<float*>(part);
-    a.Hq = (uint32_t)Hq; a.K = (uint32_t)K; a.nsplit = qproj_nsplit(K);
-    const size_t lds = (size_t)QP_NBUF * QP_TILEB;   // 128 KiB (>= the 66.5 KiB of the k-step partials that reuse it)
-    static_assert(QP_NBUF * QP_TILEB >= 4 * QP_ROWS * (QP_COLS + 1) * 4, "the k-step partials reuse the ring");
-    static bool raised[2] = {false, false};
-    const int di = dtype == KVP_BF16 ? 0 : 1;
-    if (!raised[di]) {
-        const void* fn = dtype == KVP_BF16 ? reinterpret_cast<const void*>(qproj_splitk_kernel<KVP_BF16>) : reinterpret_cast<const void*>(qproj_splitk_kernel<KVP_F16>);
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            kvp_set_error("qproj_rope: cannot raise the dynamic LDS limit to %zu bytes", lds);
-            return KVP_EHIP;
-        }
-        raised[di] = true;
-    }
-    const dim3 grid((uint32_t)(Hq * 2 * a.nsplit), (uint32_t)B);
-    const uint32_t pairs = (uint32_t)(B * Hq * QP_ROWS * 64);
-    const uint32_t rblocks = std::min<uint32_t>((pairs + 255) / 256, 2048);
-    if (dtype == KVP_BF16) {
-        KVP_LAUNCH("qproj_rope_splitk_kernel", stream, qproj_splitk_kernel<KVP_BF16><<<grid, QP_THREADS, lds, stream>>>(a));
-        KVP_LAUNCH("qproj_rope_reduce_kernel", stream, qproj_reduce_rope_kernel<KVP_BF16><<<rblocks, 256, 0, stream>>>(a, (uint32_t)B));
-    } else {
-        KVP_LAUNCH("qproj_rope_splitk_kernel", stream, qproj_splitk_kernel<KVP_F16><<<grid, QP_THREADS, lds, stream>>>(a));
-        KVP_LAUNCH("qproj_rope_reduce_kernel", stream, qproj_reduce_rope_kernel<KVP_F16><<<rblocks, 256, 0, stream>>>(a, (uint32_t)B));
-    }
+    a.out = out; a.Hq = (uint32_t)Hq; a.K = (uint32_t)K;
+    const dim3 grid((uint32_t)(Hq * 8), (uint32_t)B);
+    if (dtype == KVP_BF16) KVP_LAUNCH("qproj_rope_kernel", stream, qproj_rope_kernel<KVP_BF16><<<grid, QP_THREADS, 0, stream>>>(a));
+    else KVP_LAUNCH("qproj_rope_kernel", stream, qproj_rope_kernel<KVP_F16><<<grid, QP_THREADS, 0, stream>>>(a));
     KVP_CHECK_LAUNCH("qproj_rope");
     return KVP_OK;
 }
 
-extern "C" size_t kvp_snapkv_qproj_rope_workspace_bytes(int64_t B, int64_t Hq) { return kvp_qproj_rope_ws_bytes(B, Hq); }
-
 extern "C" int kvp_snapkv_qproj_rope(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, const void* cosp,
                                      const void* sinp, int64_t cs_sb, int64_t cs_sw, int dtype, int64_t B, int64_t Hq, int64_t W,
-                                     int64_t D, int64_t hidden, void* q_rot, void* ws, size_t ws_bytes, kvp_stream_t stream_) {
-    KVP_CHECK_ARG(B >= 1 && Hq >= 1 && B <= 65535 && Hq * 8 < ((int64_t)1 << 28), "qproj_rope: bad shape B=%ld Hq=%ld", (long)B, (long)Hq);
+                                     int64_t D, int64_t hidden, void* q_rot, kvp_stream_t stream_) {
+    KVP_CHECK_ARG(B >= 1 && Hq >= 1 && B <= 65535 && Hq * 8 < ((int64_t)1 << 31), "qproj_rope: bad shape B=%ld Hq=%ld", (long)B, (long)Hq);
     KVP_CHECK_ARG(hidden_win && wq && cosp && sinp && q_rot, "qproj_rope: null pointer");
     if (!kvp_qproj_rope_eligible(dtype, W, D, hidden, hidden_win, x_sb, x_sw, wq, cosp, sinp, cs_sb, cs_sw)) {
         kvp_set_error("qproj_rope: needs bf16/f16, W = 64, D = 128, hidden %% 256 == 0 and 16-byte aligned rows");
         return KVP_EUNSUPPORTED;
     }
-    if (!ws || ws_bytes < kvp_qproj_rope_ws_bytes(B, Hq)) {
-        kvp_set_error("qproj_rope: workspace too small (%zu < %zu)", ws_bytes, kvp_qproj_rope_ws_bytes(B, Hq));
-        return KVP_EWORKSPACE;
-    }
-    return kvp_qproj_rope_launch(hidden_win, x_sb, x_sw, wq, cosp, sinp, cs_sb, cs_sw, dtype, B, Hq, hidden, q_rot, ws,
+    return kvp_qproj_rope_launch(hidden_win, x_sb, x_sw, wq, cosp, sinp, cs_sb, cs_sw, dtype, B, Hq, hidden, q_rot,
                                  static_cast<hipStream_t>(stream_));
 }

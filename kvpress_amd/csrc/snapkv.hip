@@ -25,8 +25,6 @@
 #include "snapkv_internal.h"
 #include "topk_internal.h"
 
-size_t kvp_qproj_rope_ws_bytes(int64_t B, int64_t Hq);   // qproj.hip: scratch of the split-K window projection
-
 namespace {
 
 constexpr int SK_THREADS = 256;
@@ -342,7 +340,6 @@ struct SnapWs {
     float* colsum2;  // G > 4 (two group-blocks per kv-head in the MFMA pass 2): the second block's column sums, added in a fixed order
     float* bmax;  // per-workgroup maxima of the pool kernel (<= 4096)
     void* qrot;   // [B,Hq,W,D] RoPE'd window queries (kvp_snapkv_score_rope)
-    void* qpart;  // float32 partial products of the split-K window projection (qproj.hip; kvp_snapkv_score_hidden only)
     size_t total_bytes;
 };
 
@@ -365,7 +362,6 @@ SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, in
     w.colsum = (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4);
     w.colsum2 = Hq / std::max<int64_t>(1, Hkv) > 4 ? (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4) : nullptr;
     w.qrot = take((size_t)B * Hq * W * D * 4);
-    w.qpart = take(kvp_qproj_rope_ws_bytes(B, Hq));
     w.total_bytes = off;
     return w;
 }
@@ -529,7 +525,7 @@ int snapkv_score_rope_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
 bool kvp_qproj_rope_eligible(int dtype, int64_t W, int64_t D, int64_t K, const void* x, int64_t x_sb, int64_t x_sw, const void* w,
                              const void* cosp, const void* sinp, int64_t cs_sb, int64_t cs_sw);
 int kvp_qproj_rope_launch(const void* x, int64_t x_sb, int64_t x_sw, const void* w, const void* cosp, const void* sinp, int64_t cs_sb,
-                          int64_t cs_sw, int dtype, int64_t B, int64_t Hq, int64_t K, void* out, void* part, hipStream_t stream);
+                          int64_t cs_sw, int dtype, int64_t B, int64_t Hq, int64_t K, void* out, hipStream_t stream);
 
 int snapkv_score_hidden_impl(const void* hidden_win, int64_t x_sb, int64_t x_sw, const void* wq, int64_t hidden, const void* cosp,
                              const void* sinp, int64_t cs_sb, int64_t cs_sw, const void* k, int64_t k_sb, int64_t k_sh, int64_t k_ss,
@@ -547,7 +543,7 @@ int snapkv_score_hidden_impl(const void* hidden_win, int64_t x_sb, int64_t x_sw,
         kvp_set_error("snapkv: workspace too small (%zu < %zu)", ws_bytes, w.total_bytes);
         return KVP_EWORKSPACE;
     }
-    if (int rc = kvp_qproj_rope_launch(hidden_win, x_sb, x_sw, wq, cosp, sinp, cs_sb, cs_sw, dtype, B, Hq, hidden, w.qrot, w.qpart, stream)) return rc;
+    if (int rc = kvp_qproj_rope_launch(hidden_win, x_sb, x_sw, wq, cosp, sinp, cs_sb, cs_sw, dtype, B, Hq, hidden, w.qrot, stream)) return rc;
     return snapkv_score_impl(w.qrot, Hq * W * D, W * D, D, k, k_sb, k_sh, k_ss, dtype, B, Hq, Hkv, S, W, D, kernel_size, scores, ws,
                              ws_bytes, stream, hist1, false, finish);
 }
