@@ -16,7 +16,7 @@
 // SHORTER with this kernel (271.3 / 271.6 / 268.7 us against 274.5 / 275.9 / 273.0 / 272.0 with hipBLASLt 15.1 + RoPE 4.8), so the
 // presses now project the window here by default (kvpress_amd/_native.py USE_LIBRARY_QPROJ).  A rotated tile walk (workgroup j of an
 // XCD starts at K tile j % 16, so the 32 CUs of an XCD do not ask their L2 for the same hidden-window lines at the same moment)
-// is worth another ~0.8 us of the kernel, 1.6 us of the step (three alternating A/B pairs: 271.9 against 273.5 us; KVP_QP_ROTATE=0).
+// is worth another ~0.8 us of the kernel, 1.6 us of the step (three alternating A/B pairs: 271.9 against 273.5 us).
 // What bounds it is the traffic between the L2s and the CUs, not HBM and not the matrix pipe: every workgroup pulls the whole hidden
 // window (512 KiB) next to its 128 KiB weight slice, 160 MiB in total, and that path delivers ~10 TB/s chip-wide when all CUs read
 // the same lines -- the library GEMM's 16 x 64 tiles move the same 160 MiB and take the same ~15 us.  Round 4 tried to hide it and
@@ -26,7 +26,9 @@
 // prefetch does not help a stream that is bandwidth-bound where it enters the CU.  Earlier variants: fragments straight from
 // global memory (16-byte pieces of 16 rows per instruction: address-path bound, 27 us); 64-column tiles on 64 workgroups (64 MiB of
 // traffic but 1 MiB per CU: 28 us); a fourth buffer (no change); split-K with a second reduction pass (18.4 against 15.4 us in
-// isolation).  Fewer bytes per CU need 32 x 32 output tiles (128 MiB) or an in-launch split-K seam (5-13 us per seam): not pursued.
+// isolation).  Round 5 built the split over the hidden dimension properly (64 columns x K/4 per workgroup: 64 MiB of traffic, float32
+// partials + a reduce / RoPE kernel; tools/lab_patches/qproj_splitk.diff): same step time on the same box (0.2705 vs 0.2695 ms,
+// profiles/r05_ab_qproj.txt) and +3 us on short caches -- the fixed cost of 256 short-lived streaming workgroups, not the L2 -> CU bytes, is what is left.
 #include "kvp_common.h"
 
 namespace {

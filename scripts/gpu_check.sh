@@ -1,12 +1,12 @@
 #!/bin/bash
 # One GPU-box session: build check, parity tests by group, smoke, bench lines.  Logs -> gpurun_out/.
-# usage: scripts/gpu_check.sh [tests] [bench] [prof]
+# usage: scripts/gpu_check.sh [tests] [bench] [frows] [prof] [timeline] [pmc] [e2e] [power]
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
 WHAT="${*:-tests bench}"
-R="${ROUND_TAG:-r04}"
+R="${ROUND_TAG:-r05}"
 python __graft_entry__.py > gpurun_out/build.log 2>&1; echo "build rc=$?"
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
 if [[ "$WHAT" == *tests* ]]; then
@@ -23,18 +23,10 @@ if [[ "$WHAT" == *bench* ]]; then
 fi
 if [[ "$WHAT" == *frows* ]]; then
   # SURVEY section 8(f) workloads (no CPU baseline: the four BASELINE configs above carry it)
-  for wl in keydiff128k cur128k finch128k chunk_snapkv128k rerotate128k decode_snapkv2k; do
+  for wl in snapkv128k_scoreorder keydiff128k cur128k finch128k chunk_snapkv128k rerotate128k decode_snapkv2k; do
     timeout 600 python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline --live-pmc off > gpurun_out/bench_$wl.log 2>&1
     echo "bench[$wl] rc=$? $(tail -1 gpurun_out/bench_$wl.log | cut -c1-200)"
     tail -1 gpurun_out/bench_$wl.log > gpurun_out/${R}_bench_$wl.json
-  done
-fi
-if [[ "$WHAT" == *ab* ]]; then
-  # A/B knobs: non-temporal loads/stores in the streaming kernels, workgroups per CU in the gather
-  for cfg in "KVP_GA_NT=0 KVP_RN_NT=0" "KVP_GA_NT=1 KVP_RN_NT=1" "KVP_GA_NT=0 KVP_GA_WG_PER_CU=4" "KVP_GA_NT=0 KVP_GA_WG_PER_CU=16" "KVP_GA_NT=1 KVP_GA_WG_PER_CU=16"; do
-    tag=$(echo "$cfg" | tr ' =' '__')
-    env $cfg timeout 300 python bench.py --workload knorm128k --steps 20 --warmup 3 --no-cpu-baseline --live-pmc off --profile-json gpurun_out/ab_$tag.json > gpurun_out/ab_$tag.log 2>&1
-    echo "ab[$cfg] rc=$? $(python -c "import json;d=json.load(open('gpurun_out/ab_$tag.json'));print(round(d['ms_per_step']*1e3,1),'us/step', {k:round(v*1e3,1) for k,v in d['kernels_avg_ms'].items()})" 2>&1)"
   done
 fi
 if [[ "$WHAT" == *pmc* ]]; then
@@ -82,4 +74,10 @@ if [[ "$WHAT" == *prof* ]]; then
     rm -rf "$GRAFT_REPO_ROOT/gpurun_out/prof_$wl"
   done
   cd "$GRAFT_REPO_ROOT"
+fi
+if [[ "$WHAT" == *power* ]]; then
+  # socket power / clocks per kernel (amdsmi + in-kernel stamps of a lab build): profiles/rNN_clock_power.txt
+  python tools/gen_stage_asm.py ubench > /dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench_stage.hip -o tools/ubench_stage 2>/dev/null
+  python tools/make_clock_lab.py > /dev/null 2>&1; echo "clocklab rc=$?"
+  timeout 900 python tools/power_clock_lab.py > gpurun_out/${R}_clock_power_raw.txt 2> gpurun_out/pcl.err; echo "power rc=$?"
 fi

@@ -87,7 +87,7 @@ def main():
         return
     g = torch.Generator(device=DEV)
     g.manual_seed(0)
-    ALL = dict(KVP_TK_CLUSTER=None, KVP_TK_CLUSTER_KNORM=None, KVP_TK_CLUSTER_POOL=None)
+    ALL = dict(KVP_TK_CLUSTER=None)
     # ---- stand-alone select ----
     for R, S in ((8, 131008), (8, 32768), (8, 65536), (1, 131072), (16, 131072)):
         flat = (2.0 ** -17 * (1 + 0.05 * torch.randn((R, S), generator=g, device=DEV))).float()
@@ -107,7 +107,7 @@ def main():
         k = torch.randn((1, 8, S, 128), generator=g, device=DEV).to(torch.bfloat16)
         v = torch.randn((1, 8, S, 128), generator=g, device=DEV).to(torch.bfloat16)
         res = {}
-        for var, kv in (("cluster_knorm", {}), ("cluster_hist1", dict(KVP_TK_CLUSTER_KNORM=0)), ("passes", dict(KVP_TK_CLUSTER=0))):
+        for var, kv in (("cluster_knorm", {}), ("passes", dict(KVP_TK_CLUSTER=0))):
             knobs(**ALL)
             knobs(**kv)
             ko, vo = N.knorm_compress(k, v, S // 2)
@@ -122,7 +122,7 @@ def main():
     ang = torch.rand((1, 64, 128), generator=g, device=DEV)
     c, si = torch.cos(ang).to(torch.bfloat16), torch.sin(ang).to(torch.bfloat16)
     res = {}
-    for var, kv in (("cluster_pool", {}), ("cluster_hist1", dict(KVP_TK_CLUSTER_POOL=0)), ("passes", dict(KVP_TK_CLUSTER=0))):
+    for var, kv in (("cluster_pool", {}), ("passes", dict(KVP_TK_CLUSTER=0))):
         knobs(**ALL)
         knobs(**kv)
         ko, vo = N.snapkv_compress_rope(q, c, si, k, v, 5, S // 2)

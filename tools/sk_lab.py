@@ -3,7 +3,7 @@
 stream, kvp_prof_*) under environment-selected variants on the BASELINE shape (B=1, H_q=32, H_kv=8, S=131072, D=128,
 W=64, bf16, random data) and checks every variant's scores against variant 0.
 
-    python tools/sk_lab.py "KVP_SK_ASM=1" "KVP_SK_ASM=0" ...
+    python tools/sk_lab.py "" "KVP_SK_SLOTS=128" ...
     KVPRESS_HIP_LIB=kvpress_amd/lib/variants/nodma.so python tools/sk_lab.py      (ablated builds: tools/build_variants.sh)
 
 Each argument is one configuration: space-separated NAME=VALUE pairs put into the environment for that run (the
@@ -21,7 +21,7 @@ from kvpress_amd import _native  # noqa: E402
 
 
 def stamps():
-    """Cycle breakdown of pass 1's waves (lab build: tools/build_variants.sh "stamp=GEN_STAMP=1 KVP_VARIANT_CFLAGS=-DKVP_SK_STAMP",
+    """Cycle breakdown of pass 1's waves (lab build: apply tools/lab_patches/sk_stamp.diff, then tools/build_variants.sh "stamp=GEN_STAMP=1 KVP_VARIANT_CFLAGS=-DKVP_SK_STAMP",
     run with KVPRESS_HIP_LIB=kvpress_amd/lib/variants/stamp.so): the asm loop returns, per wave, the shader cycles of the whole loop,
     those between the two s_memtime stamps around every stage head's `s_waitcnt lgkmcnt(0)` (K fragments), around every tile's
     `s_waitcnt vmcnt` (K stream) and around every tile's `s_barrier`."""
@@ -70,7 +70,7 @@ def stamps():
 def main():
     if "--stamps" in sys.argv:
         return stamps()
-    cfgs = sys.argv[1:] or ["KVP_SK_ASM=1"]
+    cfgs = sys.argv[1:] or [""]
     S = int(os.environ.get("SK_LAB_S", 131072))
     reps = int(os.environ.get("SK_LAB_REPS", 12))
     dev = torch.device("cuda", 0)
