@@ -134,6 +134,11 @@ class BasePress:
         finally:
             for hook in hooks:
                 hook.remove()
-        # a select kernel that found at RUN time that it could not produce valid indices (include/kvpress_hip.h, KVP_EASYNC) must
-        # not pass silently: poll the library's status word on the way out (no sync; reached only when the body did not raise)
+        # A select kernel that found at RUN time that it could not produce valid indices (include/kvpress_hip.h, KVP_EASYNC) must not
+        # pass silently: poll the library's status word on the way out (reached only when the body did not raise).  The poll never
+        # waits for the GPU -- a prefill's kernels may still be running here -- so it is BEST EFFORT for the last layers: a failure
+        # they report later surfaces at the next library call (every select / compress / gather entry point checks first), or at
+        # ``kvpress_amd._native.async_error_check()`` after the caller's own synchronisation.  What it always catches is everything
+        # that has already run -- in particular all but the last layers of a long prefill -- and a poisoned cache cannot be USED
+        # silently either way: its rows are NaN.
         _native.async_error_check()
