@@ -116,6 +116,13 @@ def child():
         loop("gather", lambda: _native.gather_kv(keys, values, idx), ga)
         loop("compress_step", lambda: press.compress(att, hidden, keys, values, None, kw), sk + ga)
         loop("knorm_stream", lambda: _native.rownorm_score(keys, -1.0))
+        if not lab and os.environ.get("PCL_EA", "1") != "0":
+            # ExpectedAttention's kernels (is the quadratic form power-limited like the SnapKV passes?)
+            qg = torch.randn((1, S, 32 * 128), generator=gen, device=dev, dtype=torch.float32).to(bf).view(1, S, 32, 128).transpose(1, 2)
+            mu, cov = _native.ea_qstats(qg, True)
+            loop("ea_qstats(1 GiB of Q)", lambda: _native.ea_qstats(qg, True))
+            loop("ea_score(logits + |v| + finalize)", lambda: _native.ea_score(keys, values, mu, cov, 4, True, 0.0))
+            loop("knorm_compress(128k)", lambda: _native.knorm_compress(keys, values, S // 2))
 
 
 def ubench(variant, mode, loop_ms):
