@@ -204,6 +204,37 @@ def w1_stage(s, opts, lds_imm=None, dma=None):
     return [l for l in lines if l]
 
 
+def mfma_reuse_body(kind, dt="bf16"):
+    """96 MFMAs (= 12 stages of 8) with a chosen operand-reuse pattern between CONSECUTIVE matrix instructions (lab: does the matrix
+    pipe draw less when an operand repeats?  the chip is power-limited in these loops, so time ~ energy).
+      afix / bfix / abfix   every instruction names the same A / B / both registers (bound of the effect)
+      bpair / bquad         k-step outer, 2 / 4 sub-tiles inner: B (the Q fragment of pass 1) repeats 2 / 4 times, A always differs
+      apair / aquad         the same with the roles swapped (pass 2: A = Q fragment)
+    accumulators: v128.. (4 x 16; the softmax temporaries are unused here)."""
+    accs = [128, 144, 160, 176]
+    kregs = [KF0, KF1]
+    L = []
+    if kind in ("afix", "bfix", "abfix"):
+        for s_ in range(12):
+            kfu = kregs[s_ % 2]
+            for k in range(8):
+                a = kfu if kind in ("afix", "abfix") else kfu + 4 * k
+                b = QF if kind in ("bfix", "abfix") else QF + 4 * k
+                L.append(mfma(accs[s_ % 3], a, b, k == 0, dt))
+        return L
+    nsub = 2 if kind.endswith("pair") else 4
+    shared_b = kind.startswith("b")
+    for g in range(12 // nsub):
+        for k in range(8):
+            for sub in range(nsub):
+                # the streaming operand: a different register set per sub-tile (values differ: ub_init permutes 8 random dwords)
+                stream = kregs[sub % 2] + 4 * ((k + 3 * (sub // 2)) % 8)
+                shared = QF + 4 * k
+                a, b = (stream, shared) if shared_b else (shared, stream)
+                L.append(mfma(accs[sub], a, b, k == 0, dt))
+    return L
+
+
 def clobbers(lo=32, hi=LAST_V):
     return ", ".join(f'"v{i}"' for i in range(lo, hi))
 
@@ -301,6 +332,8 @@ def gen_ubench():
         "m16_math_lds_bar_dma": dict(m16=True, lds=True, bar=True, dma=True),
         "valu_lds": dict(mfma=False, lds=True),
     }
+    for kind in ("afix", "bfix", "abfix", "bpair", "bquad", "apair", "aquad"):
+        variants["mfma_" + kind] = dict(reuse=kind)
     for n_, o_ in (("w1_mfma_only", dict(softmax=False)), ("w1_valu_only", dict(mfma=False)), ("w1_math", dict()), ("w1_math_lds", dict(lds=True)),
                    ("w1_math_lds_bar", dict(lds=True, bar=True)), ("w1_math_lds_bar_dma", dict(lds=True, bar=True, dma=True))):
         variants[n_] = dict(o_, w1=True)
@@ -330,6 +363,9 @@ def gen_ubench():
                 init += [f"v_add_u32 v{DMAV + i}, {i * 8192}, %1" for i in range(4)]
             out.append(UB_KERNEL % dict(name=name, init=fmt(init), body=fmt(body), iters=400, threads=256,
                                         aclob=", " + ", ".join(f'"a{i}"' for i in range(64))))
+            continue
+        if o.get("reuse"):
+            out.append(UB_KERNEL % dict(name=name, init=fmt(ub_init()), body=fmt(mfma_reuse_body(o["reuse"])), iters=400, threads=512, aclob=""))
             continue
         # 12 stages = 3 tiles (ring of three buffers), accumulators rotate with period 3, fragments with period 2
         for s in range(12):
