@@ -135,7 +135,8 @@ struct ClusterArgs {
     int32_t* idx;
     int64_t idx_stride;
     uint32_t tail_start, tail_n, nseg, seg_len, pos_base;
-    TopkWs w;
+    uint32_t* ws0;             // workspace base; regions by topk_ws_layout(wsR, ws_ntab) at the point of use (TCW)
+    uint32_t wsR, ws_ntab;
     // KNORM
     const void* x;         // [B,H,S,D], 256-byte rows
     int64_t x_sb, x_sh, x_ss;  // element strides
@@ -154,6 +155,7 @@ struct ClusterArgs {
 #define TC_KN_UNROLL 4   // 64-row steps of the Knorm stream in flight per workgroup (L = 1024 PER is a multiple of 64 * 8)
 #endif
 enum { TC_SCORES = 0, TC_POOL5 = 1, TC_KNORM_BF16 = 2, TC_KNORM_F16 = 3 };
+constexpr int TC_NS = 128;   // sampled keys per row (two-hop form)
 
 template <int DT>
 __device__ __forceinline__ float tc_sumsq16(const uint4& v) {   // = rownorm.hip's sumsq16 (same fma chain)
@@ -183,14 +185,19 @@ __device__ __forceinline__ void tc_hist_add_weighted(uint32_t* lds_hist, uint32_
     if (valid) atomicAdd(&lds_hist[bin], heavy ? w : 1u);
 }
 
+// a value that every lane holds identically, moved to a scalar register: branches on it are scalar branches (no saved exec masks)
+__device__ __forceinline__ uint32_t tc_uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
 // out-of-range positions carry key 0; real keys are >= 1 (as in topk_row_kernel)
 __device__ __forceinline__ uint32_t tc_key(float f, uint32_t kmask) { return max(float_to_key(f) ^ kmask, 1u); }
 
+#define TCW(field) (a.ws0 + topk_ws_layout(a.wsR, a.ws_ntab).field)
 template <int PER, int MODE, bool HIST1>
 __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a) {
     constexpr uint32_t L = TR_THREADS * PER;   // keys per workgroup
     __shared__ __attribute__((aligned(16))) uint32_t lh[L > 4096 ? L : 4096];   // histogram; KNORM: first the staged scores; last the staged output
     __shared__ uint32_t scr[TR_WAVES + 3];
+    __shared__ uint32_t fh[HIST1 ? 1 : 4096];   // two-hop form: the local rounds' histogram (<= 12 bits per round)
     __shared__ uint32_t s_fail[2];   // [0] this workgroup gave up at a barrier, [1] the cluster's flag as read after the last barrier
     // A row's 32 workgroups are CONSECUTIVE blocks: whatever part of the grid the device can hold at once, whole clusters become
     // resident in dispatch order and finish, so a device with fewer free CUs than the grid (CU masking, a busy neighbour) makes
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
     const uint32_t cluster = blockIdx.x / TC_SLOTS;
     const uint32_t slot = blockIdx.x % TC_SLOTS;
     ClusterSync cs;
-    cs.ctr = a.w.bar + cluster * 32;
+    cs.ctr = TCW(bar) + cluster * 32;
     cs.cl_flag = cs.ctr + 1;
     cs.host_flag = a.host_flag;
     cs.report = a.report;
@@ -224,23 +231,115 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
     const uint32_t row = a.row_base + cluster;
     if (row >= a.R) return;
     {
+        // ---- sample (two-hop form, not HIST1): TC_NS scores of the row at fixed positions, requested BEFORE the workgroup's own keys
+        // so that their latency hides behind the key loads / the Knorm stream.  Every workgroup of the row reads the same positions.
+        constexpr bool KN = MODE == TC_KNORM_BF16 || MODE == TC_KNORM_F16;
+        // wave-uniform conditions (scalar branches) instead of thread-index comparisons: the compiler hoists the latter into lane
+        // masks that live across the whole kernel and overflow the scalar register file
+        const uint32_t wvu = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        float smp_f = 0.f;          // SCORES / POOL5: thread t < TC_NS holds sample t
+        uint4 smp_v[KN ? TC_NS / 64 : 1];   // KNORM: 16 lanes per sampled row, 64 rows per step
+        const uint32_t smp_stride = S / TC_NS;   // S > 16384: >= 64
+        if (!HIST1) {
+            if (KN) {
+                constexpr int DT = MODE == TC_KNORM_BF16 ? KVP_BF16 : KVP_F16;
+                using T = typename Elem<DT>::T;
+                const uint32_t b = row / a.H, h = row - b * a.H;
+                const T* __restrict__ base = static_cast<const T*>(a.x) + (int64_t)b * a.x_sb + (int64_t)h * a.x_sh;
+#pragma unroll
+                for (int u = 0; u < TC_NS / 64; ++u) {
+                    const uint32_t sp = min((u * 64 + (threadIdx.x >> 4)) * smp_stride + smp_stride / 2, S - 1);
+                    smp_v[u] = *reinterpret_cast<const uint4*>(base + (int64_t)sp * a.x_ss + (size_t)(threadIdx.x & 15u) * 8);
+                }
+            } else if (wvu < (uint32_t)(TC_NS / 64)) {
+                const float* rp = a.scores + (int64_t)row * a.row_stride;
+                const uint32_t sp = min(threadIdx.x * smp_stride + smp_stride / 2, S - 1);
+                if (MODE == TC_POOL5) {
+#pragma unroll
+                    for (int d = 0; d < 5; ++d) {
+                        const int32_t pos = (int32_t)sp + d - 2;
+                        const uint32_t inside = (uint32_t)(((pos - (int32_t)S) >> 31) & ~(pos >> 31));
+                        smp_f += __uint_as_float(__float_as_uint(rp[min(max(pos, 0), (int32_t)S - 1)]) & inside);
+                    }
+                    smp_f *= a.inv;
+                } else {
+                    smp_f = rp[sp];
+                }
+            }
+        }
+        // ---- window of the two-hop form from the sample (see below); runs while this workgroup's own key loads are in flight ----
+        uint32_t sft = 0, wbase = 0;
+        auto window_setup = [&]() {
+            uint32_t* smp = fh;                 // [TC_NS] sampled keys
+            uint32_t* swin = fh + TC_NS;        // [2] Lk, Hk
+            uint32_t* whist = fh + 2 * TC_NS;   // [TC_WB] this workgroup's window histogram
+            static_assert(TC_NS <= 256 && TC_NS % 64 == 0 && TC_WB % 64 == 0 && TC_WB <= TR_THREADS, "sample ranking / one window bin per thread");
+            if (KN) {
+                constexpr int DT = MODE == TC_KNORM_BF16 ? KVP_BF16 : KVP_F16;
+#pragma unroll
+                for (int u = 0; u < (KN ? TC_NS / 64 : 1); ++u) {
+                    float acc = tc_sumsq16<DT>(smp_v[u]);
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+                    const uint32_t si = u * 64 + (threadIdx.x >> 4);
+                    if ((threadIdx.x & 15u) == 0) smp[si] = tc_key(a.scale * sqrtf(acc), kmask);
+                }
+            } else if (wvu < (uint32_t)(TC_NS / 64)) {
+                smp[threadIdx.x] = tc_key(smp_f, kmask);
+            }
+            if (wvu < (uint32_t)(TC_WB / 64)) whist[threadIdx.x] = 0;
+            __syncthreads();
+            {
+                // descending rank of sample i = number of samples that are larger, or equal with a lower index (a permutation): LPS lanes
+                // share a sample and split the 16-byte chunks of the sample array (chunk LPS t + q: the lanes' reads are contiguous)
+                constexpr uint32_t LPS = TR_THREADS / TC_NS, NCH = TC_NS / 4;
+                const uint32_t i = threadIdx.x / LPS, q = threadIdx.x % LPS;
+                const uint32_t xi = smp[i];
+                const uint4* s4 = reinterpret_cast<const uint4*>(smp);
+                uint32_t c = 0;
+#pragma unroll
+                for (uint32_t t = 0; t < NCH / LPS; ++t) {
+                    const uint4 x = s4[LPS * t + q];
+                    const uint32_t j0 = (LPS * t + q) * 4u;
+                    c += (x.x > xi || (x.x == xi && j0 + 0u < i)) ? 1u : 0u;
+                    c += (x.y > xi || (x.y == xi && j0 + 1u < i)) ? 1u : 0u;
+                    c += (x.z > xi || (x.z == xi && j0 + 2u < i)) ? 1u : 0u;
+                    c += (x.w > xi || (x.w == xi && j0 + 3u < i)) ? 1u : 0u;
+                }
+#pragma unroll
+                for (uint32_t o = 1; o < LPS; o <<= 1) c += __shfl_xor(c, o);
+                const float pq = (float)k / (float)S;
+                const int32_t rstar = min((int32_t)(pq * (float)TC_NS), TC_NS - 1);
+                const int32_t delta = (int32_t)(4.5f * sqrtf((float)TC_NS * pq * (1.f - pq))) + 3;
+                const uint32_t r_hi = (uint32_t)max(rstar - delta, 0), r_lo = (uint32_t)min(rstar + delta, TC_NS - 1);
+                if (q == 0 && c == r_lo) swin[0] = xi;
+                if (q == 0 && c == r_hi) swin[1] = xi;
+            }
+            __syncthreads();
+            const uint32_t Lk = tc_uni(swin[0]), Hk = tc_uni(swin[1]);
+            while (((Hk >> sft) - (Lk >> sft)) > (uint32_t)(TC_WB - 3)) ++sft;
+            wbase = Lk >> sft;
+        };
         // ---- keys ------------------------------------------------------------------------------------------------
         uint32_t keys[PER];
         if (MODE == TC_SCORES) {
             const float* rp = a.scores + (int64_t)row * a.row_stride;
+            float raw[PER];
             if (PER % 4 == 0 && p0 + PER <= S && ((((uintptr_t)(rp + p0)) & 15u) == 0)) {
 #pragma unroll
                 for (int q = 0; q < PER / 4; ++q) {
                     const float4 v = *reinterpret_cast<const float4*>(rp + p0 + 4 * q);
-                    keys[4 * q + 0] = tc_key(v.x, kmask); keys[4 * q + 1] = tc_key(v.y, kmask);
-                    keys[4 * q + 2] = tc_key(v.z, kmask); keys[4 * q + 3] = tc_key(v.w, kmask);
+                    raw[4 * q + 0] = v.x; raw[4 * q + 1] = v.y; raw[4 * q + 2] = v.z; raw[4 * q + 3] = v.w;
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < PER; ++j) {
-                    const uint32_t inside = (uint32_t)((int32_t)(p0 + j - S) >> 31);  // all ones iff p0 + j < S
-                    keys[j] = tc_key(rp[min(p0 + j, S - 1)], kmask) & inside;
-                }
+                for (int j = 0; j < PER; ++j) raw[j] = rp[min(p0 + j, S - 1)];
+            }
+            if (!HIST1) window_setup();
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const uint32_t inside = (uint32_t)((int32_t)(p0 + j - S) >> 31);  // all ones iff p0 + j < S
+                keys[j] = tc_key(raw[j], kmask) & inside;
             }
         } else if (MODE == TC_POOL5) {
             const float* rp = a.scores + (int64_t)row * a.row_stride;
@@ -260,6 +359,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
                     in[i] = __uint_as_float(__float_as_uint(rp[min(max(pos, 0), (int32_t)S - 1)]) & inside);
                 }
             }
+            if (!HIST1) window_setup();
 #pragma unroll
             for (int j = 0; j < PER; ++j) {
                 float sum = 0.f;
@@ -288,6 +388,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
                     v[u] = make_uint4(0, 0, 0, 0);
                     if (s < S) v[u] = *reinterpret_cast<const uint4*>(base + (int64_t)s * a.x_ss + (size_t)lir * 8);
                 }
+                if (!HIST1 && it == 0) window_setup();   // (the sample's loads are older than this step's: they have landed or land first)
 #pragma unroll
                 for (int u = 0; u < TC_KN_UNROLL; ++u) {
                     float acc = tc_sumsq16<DT>(v[u]);
@@ -312,9 +413,198 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
         }
         const bool full = kmin != 0u;   // all PER positions inside the row
 
-        uint32_t* h1 = a.w.hist1 + (size_t)row * 4096;
-        uint32_t* h2 = a.w.hist2 + (size_t)row * 4096;
-        uint32_t* h3 = a.w.hist3 + (size_t)row * 256;
+        // (polling) repeat {read the row's histogram, search} until its total is `expect`; gives up like a barrier after max_poll rounds
+#define TC_POLL_GIVE_UP(code)                                                                                              \
+    do {                                                                                                                   \
+        if (threadIdx.x == 0) {                                                                                            \
+            s_fail[0] = (code);                                                                                            \
+            tc_report(cs, (code));                                                                                         \
+        }                                                                                                                  \
+        __syncthreads();                                                                                                   \
+    } while (0)
+        // results of either form of the select: the threshold key, how many keys equal to it are kept, and the kept keys in the
+        // slots before this one
+        uint32_t T = 0, quota = 0, gt_before = 0, eq_before = 0;
+        bool done = false;
+        // ==== two-hop form ==============================================================================================
+        // The 12 + 12 + 8-bit digits below cost three all-to-all rounds, and on the flat rows of a real layer the first digit (sign,
+        // exponent, 3 mantissa bits) separates nothing: 60 % of a row share the threshold's bin (LAB R4.2).  Here the FIRST digit is
+        // steered by a sample: the TC_NS sampled keys bracket the k-th largest between two of them (+- 4.5 sigma of the sample
+        // quantile), the bracket [Lk, Hk] is cut into TC_WB - 2 bins of 2^s keys (s = the smallest shift that fits), everything below /
+        // above lands in bin 0 / TC_WB - 1.  Any such binning is monotone in the key, so the digit search is as exact as before; what
+        // the sample buys is that the threshold's bin now holds a few dozen keys of the row instead of most of it.  Those CANDIDATES are
+        // published per slot (plain stores, no atomics), ONE cluster barrier later every workgroup holds all of them and finishes the
+        // select locally (rounds of <= 12 bits in LDS over <= 4032 keys, no further hop).  Same threshold, same tie rule, same indices.
+        // Whenever the sample misleads (threshold outside the bracket, a slot with more candidates than its record holds: rows of
+        // mostly equal scores) every workgroup of the row sees that in the same words and all of them take the three-round form below.
+        if (!HIST1) {
+            uint32_t* whist = fh + 2 * TC_NS;   // (zeroed by window_setup)
+            uint32_t* hw = TCW(histw) + (size_t)row * TC_WB;
+            auto wbin = [&](uint32_t key) -> uint32_t {
+                const uint32_t v = key >> sft;
+                return v < wbase ? 0u : min(v - wbase + 1u, (uint32_t)(TC_WB - 1));
+            };
+            {
+                // most keys lie outside the bracket (bins 0 and TC_WB - 1): those are counted in registers and added once per wave;
+                // the keys inside spread over the bins in between (plain LDS atomics)
+                uint32_t nout = 0;   // below in bits 0-15, above in bits 16-31 (<= 64 * PER per wave)
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    const uint32_t bj = wbin(keys[j]);
+                    if (keys[j] != 0u) {
+                        if (bj == 0u) nout += 1u;
+                        else if (bj == (uint32_t)(TC_WB - 1)) nout += 1u << 16;
+                        else atomicAdd(&whist[bj], 1u);
+                    }
+                }
+                const uint32_t ws_ = wave_incl_scan(nout);
+                if ((threadIdx.x & 63u) == 63u) {
+                    if (ws_ & 0xFFFFu) atomicAdd(&whist[0], ws_ & 0xFFFFu);
+                    if (ws_ >> 16) atomicAdd(&whist[TC_WB - 1], ws_ >> 16);
+                }
+            }
+            __syncthreads();
+#ifdef KVP_TC_FAULT_INJECTION
+            if (cs.delay_ticks && threadIdx.x == 0) {                         // fault injection: this workgroup flushes late
+                const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+                while (__builtin_amdgcn_s_memrealtime() - t0 < 2ull * cs.delay_ticks) __builtin_amdgcn_s_sleep(8);
+            }
+            if (cs.delay_ticks) __syncthreads();
+#endif
+            if (wvu < (uint32_t)(TC_WB / 64)) {
+                const uint32_t c = whist[threadIdx.x];
+                if (c) tc_add(&hw[threadIdx.x], c);
+            }
+            // complete when the histogram's total is the row's S keys (the polling protocol of round 1, see above)
+            // (the search runs in ONE wave -- lane l holds the TC_WB / 64 bins below bin TC_WB - 1 - l * (TC_WB / 64), the prefix over
+            // the lanes is a DPP scan -- and costs two block barriers per poll instead of the five of the 1024-thread search)
+            uint32_t d1, k1;
+            for (uint32_t it = 0;; ++it) {
+                if (wvu == 0u) {
+                    constexpr int PB = TC_WB / 64;
+                    const uint32_t lane = threadIdx.x & 63u, top = (63u - lane) * PB;   // this lane's bins: top + PB - 1 .. top (descending)
+                    uint32_t loc[PB], sum = 0;
+#pragma unroll
+                    for (int i = 0; i < PB; ++i) loc[i] = tc_ld(&hw[top + i]);
+#pragma unroll
+                    for (int i = 0; i < PB; ++i) sum += loc[i];
+                    const uint32_t inc = wave_incl_scan(sum), excl = inc - sum;
+                    if (excl < k && k <= inc) {
+                        uint32_t c = excl;
+#pragma unroll
+                        for (int i = PB - 1; i >= 0; --i) {
+                            if (k > c && k <= c + loc[i]) {
+                                scr[0] = top + i;
+                                scr[1] = k - c;
+                            }
+                            c += loc[i];
+                        }
+                    }
+                    if (lane == 63u) scr[2] = inc;
+                }
+                __syncthreads();
+                d1 = scr[0];
+                k1 = scr[1];
+                const uint32_t total = tc_uni(scr[2]);
+                __syncthreads();
+                if (total == S) break;
+                if (it >= max_poll) { TC_POLL_GIVE_UP(1u); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            d1 = tc_uni(d1);
+            k1 = tc_uni(k1);
+            // (a poll that gave up: straight to the poison branch -- the workgroups that did see the complete histogram time out at
+            // the candidates' barrier, which this one never reaches, and end there too)
+            if (tc_uni(s_fail[0]) != 0) {
+                done = true;
+            } else if (d1 >= 1u && d1 <= (uint32_t)(TC_WB - 2)) {
+                // ---- candidates of this slot: keys in bin d1; ngt: keys in higher bins ----------------------------------------
+                uint32_t ncand = 0, ngt = 0;
+#pragma unroll
+                for (int j = 0; j < PER; ++j) {
+                    const uint32_t bj = wbin(keys[j]);
+                    ncand += (keys[j] && bj == d1) ? 1u : 0u;
+                    ngt += (keys[j] && bj > d1) ? 1u : 0u;
+                }
+                uint32_t tot;
+                const uint32_t ex = row_excl_scan(ncand | (ngt << 16), scr, &tot);   // L <= 8192: both fields < 65536
+                const uint32_t cand_tot = tot & 0xFFFFu;
+                uint32_t* rec = TCW(cand) + ((size_t)row * TC_SLOTS + slot) * TC_REC;
+                if (cand_tot <= (uint32_t)(TC_REC - 2)) {
+                    uint32_t o = 2u + (ex & 0xFFFFu);
+#pragma unroll
+                    for (int j = 0; j < PER; ++j)
+                        if (keys[j] && wbin(keys[j]) == d1) tc_st(&rec[o++], keys[j]);
+                }
+                if (threadIdx.x == 0) {
+                    tc_st(&rec[0], cand_tot <= (uint32_t)(TC_REC - 2) ? cand_tot : 0xFFFFFFFFu);
+                    tc_st(&rec[1], tot >> 16);
+                }
+                cluster_barrier(cs, 2, &s_fail[0], true);
+                // ---- the row's 32 records: 4096 words, 4 per thread (kept in registers: the rounds below run on them); the headers
+                // (count, keys above) also go through LDS --------------------------------------------------------------------------
+                uint32_t v[4];
+                {
+                    const uint32_t* rr = TCW(cand) + (size_t)row * TC_SLOTS * TC_REC;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = tc_ld(&rr[threadIdx.x * 4 + i]);
+                    if (threadIdx.x == 0) s_fail[1] = tc_ld(cs.cl_flag);   // rides on the same round trip
+                }
+                static_assert(TC_REC == 128 && TC_SLOTS * TC_REC == 4 * TR_THREADS, "a thread's 4 words lie in one record");
+                const uint32_t wrec = threadIdx.x >> 5, pos0 = (threadIdx.x & 31u) * 4u;   // record (= slot) and first word of this thread
+                uint32_t* hdr = lh;   // [TC_SLOTS][2]
+                if (pos0 == 0) {
+                    hdr[wrec * 2] = v[0];
+                    hdr[wrec * 2 + 1] = v[1];
+                }
+                __syncthreads();
+                const bool ovf = hdr[(threadIdx.x & (TC_SLOTS - 1)) * 2] == 0xFFFFFFFFu;   // (every wave looks at all 32 records)
+                const bool any_ovf = tc_uni((uint32_t)__syncthreads_or(ovf)) != 0u;
+                if (tc_uni(s_fail[0] | s_fail[1])) {
+                    done = true;   // poisoned below
+                } else if (!any_ovf) {
+                    const uint32_t cnt = hdr[wrec * 2];
+                    bool cv[4];    // word i of this thread is a candidate key
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cv[i] = pos0 + i >= 2u && pos0 + i - 2u < cnt;
+                    // ---- finish locally: the k1-th largest candidate.  Bits >= sft are the bin's; rounds of <= 12 bits over the rest ---
+                    uint32_t Tpre = (wbase + d1 - 1u) << sft, krem = k1, hi = sft;
+                    while (hi > 0u) {
+                        const uint32_t wd = min(hi, 12u), lo = hi - wd;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) fh[threadIdx.x * 4 + i] = 0;
+                        __syncthreads();
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (cv[i] && (v[i] >> hi) == (Tpre >> hi)) atomicAdd(&fh[(v[i] >> lo) & ((1u << wd) - 1u)], 1u);
+                        __syncthreads();
+                        uint32_t bb, kr;
+                        row_find_bin<4096>(fh, krem, scr, bb, kr);
+                        Tpre |= tc_uni(bb) << lo;
+                        krem = tc_uni(kr);
+                        hi = lo;
+                    }
+                    T = Tpre;
+                    quota = krem;
+                    // kept keys in the slots before this one: gt in bits 0-19 (<= 262144), eq in bits 20-31 (<= 4032)
+                    uint32_t part = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (cv[i] && wrec < slot) part += (v[i] > T ? 1u : 0u) + (v[i] == T ? (1u << 20) : 0u);
+                    if (threadIdx.x < slot) part += hdr[threadIdx.x * 2 + 1];
+                    uint32_t tot;
+                    row_excl_scan(part, scr, &tot);
+                    gt_before = tot & 0xFFFFFu;
+                    eq_before = tot >> 20;
+                    done = true;
+                }
+            }
+        }
+        // ==== three-round form (HIST1, or the two-hop form declined) =========================================================
+        if (!done) {
+        uint32_t* h1 = TCW(hist1) + (size_t)row * 4096;
+        uint32_t* h2 = TCW(hist2) + (size_t)row * 4096;
+        uint32_t* h3 = TCW(hist3) + (size_t)row * 256;
         // ---- digit 1: key >> 20 ----------------------------------------------------------------------------------
         if (!HIST1) {
             for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
@@ -342,15 +632,6 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
                 if (c) tc_add(&h1[i], c);
             }
         }
-        // (polling) repeat {read the row's histogram, search} until its total is `expect`; gives up like a barrier after max_poll rounds
-#define TC_POLL_GIVE_UP(code)                                                                                              \
-    do {                                                                                                                   \
-        if (threadIdx.x == 0) {                                                                                            \
-            s_fail[0] = (code);                                                                                            \
-            tc_report(cs, (code));                                                                                         \
-        }                                                                                                                  \
-        __syncthreads();                                                                                                   \
-    } while (0)
         uint32_t b1, k1, c1;
         for (uint32_t it = 0;; ++it) {
             uint32_t loc[4];
@@ -361,7 +642,6 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             if (it >= max_poll) { TC_POLL_GIVE_UP(1u); break; }
             __builtin_amdgcn_s_sleep(2);
         }
-#undef TC_POLL_GIVE_UP
         // ---- digit 2: (key >> 8) & 0xFFF among key >> 20 == b1 -----------------------------------------------------
         if (slot == 0 && threadIdx.x < 256) tc_st(&h3[threadIdx.x], 0u);   // self-cleaning: filled below, read after the last barrier
         for (int i = threadIdx.x; i < 4096; i += TR_THREADS) lh[i] = 0;
@@ -410,18 +690,18 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             const uint32_t c = threadIdx.x < 256 ? lh[d & 255u] : 0u;
             uint32_t tot2;
             const uint32_t above = row_excl_scan(c, scr, &tot2);
-            uint32_t* tab = a.w.chunk_hist + ((size_t)row * TC_SLOTS + slot) * 257;
+            uint32_t* tab = TCW(chunk_hist) + ((size_t)row * TC_SLOTS + slot) * 257;
             if (threadIdx.x < 256) {
                 tc_st(&tab[d], above + c);   // suffix[d] = #(digit >= d)
                 if (c) tc_add(&h3[d], c);
             }
             if (threadIdx.x == 0) {
                 tc_st(&tab[256], 0u);
-                tc_st(&a.w.chunk_gt[(size_t)row * TC_SLOTS + slot], ngt_tot);
+                tc_st(&TCW(chunk_gt)[(size_t)row * TC_SLOTS + slot], ngt_tot);
             }
         }
         cluster_barrier(cs, 3, &s_fail[0], false);
-        uint32_t b3, quota;
+        uint32_t b3;
         {
             uint32_t loc[1];
             loc[0] = threadIdx.x < 256 ? tc_ld(&h3[255u - threadIdx.x]) : 0u;
@@ -429,6 +709,25 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             if (threadIdx.x == 256) s_fail[1] = tc_ld(cs.cl_flag);
             row_find_bin_regs<1>(loc, 256, k2, scr, b3, quota);   // (its barriers publish s_fail[1])
         }
+        if ((s_fail[0] | s_fail[1]) == 0) {
+            T = (prefix << 8) | b3;
+            // kept elements in the slots before this one
+            uint32_t gt_part = 0, eq_part = 0;
+            if (threadIdx.x < slot) {
+                const uint32_t* sf = TCW(chunk_hist) + ((size_t)row * TC_SLOTS + threadIdx.x) * 257;
+                const uint32_t ge = tc_ld(&sf[b3]), gt = tc_ld(&sf[b3 + 1]);
+                gt_part = tc_ld(&TCW(chunk_gt)[(size_t)row * TC_SLOTS + threadIdx.x]) + gt;
+                eq_part = ge - gt;
+            }
+            row_excl_scan(gt_part, scr, &gt_before);
+            row_excl_scan(eq_part, scr, &eq_before);
+            // self-cleaning: this row's hist1 / hist2 are dead (every workgroup read them before the last barrier)
+            for (uint32_t i = slot * TR_THREADS + threadIdx.x; i < 4096; i += TC_SLOTS * TR_THREADS) {
+                tc_st(&h1[i], 0u);
+                tc_st(&h2[i], 0u);
+            }
+        }
+        }   // three-round form
         int32_t* out = a.idx + (int64_t)row * a.idx_stride;
         // ---- a barrier of this cluster timed out: NO index of this row is trustworthy ------------------------------------------
         // Every give-up of a cluster happens before any of its workgroups gets past the last barrier legitimately (that takes all
@@ -443,23 +742,14 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             for (uint32_t j = slot * per + threadIdx.x; j < min((slot + 1) * per, tot_out); j += TR_THREADS) out[j] = -1;
             return;
         }
-        const uint32_t T = (prefix << 8) | b3;
-        // kept elements in the slots before this one
-        uint32_t gt_part = 0, eq_part = 0;
-        if (threadIdx.x < slot) {
-            const uint32_t* sf = a.w.chunk_hist + ((size_t)row * TC_SLOTS + threadIdx.x) * 257;
-            const uint32_t ge = tc_ld(&sf[b3]), gt = tc_ld(&sf[b3 + 1]);
-            gt_part = tc_ld(&a.w.chunk_gt[(size_t)row * TC_SLOTS + threadIdx.x]) + gt;
-            eq_part = ge - gt;
-        }
-        uint32_t gt_before, eq_before;
-        row_excl_scan(gt_part, scr, &gt_before);
-        row_excl_scan(eq_part, scr, &eq_before);
-        // self-cleaning: this row's hist1 / hist2 are dead (every workgroup read them before the last barrier)
-        for (uint32_t i = slot * TR_THREADS + threadIdx.x; i < 4096; i += TC_SLOTS * TR_THREADS) {
-            tc_st(&h1[i], 0u);
-            tc_st(&h2[i], 0u);
-        }
+#ifdef KVP_TC_FAULT_INJECTION
+        // test twin only (tests/_fault_child.py "paths"): which form finished this (cluster, slot) -- 2 = two-hop, 1 = three rounds --
+        // in the spare words behind the barrier lines
+        if (threadIdx.x == 0) tc_st(&TCW(bar)[TC_CLUSTERS * 32 + 32 + slot * 16 + cluster], done ? 2u : 1u);
+#endif
+        // self-cleaning: the window histogram is dead -- every workgroup of the row searched its COMPLETE state before it arrived at
+        // the barrier(s) this workgroup has passed since (the candidates' barrier, or barriers 2 and 3 of the three-round form)
+        if (!HIST1 && slot == 0 && wvu < (uint32_t)(TC_WB / 64)) tc_st(&(TCW(histw) + (size_t)row * TC_WB)[threadIdx.x], 0u);
         // ---- ordered compaction: keys > T, and the first `quota` keys == T ---------------------------------------------
         uint32_t cg = 0, ce = 0;
 #pragma unroll
@@ -492,6 +782,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < nmine; i += TR_THREADS)
             if (rank0 + i < k) out[rank0 + i] = ob[i];
+#undef TC_POLL_GIVE_UP
     }
 }
 
@@ -553,7 +844,7 @@ int topk_cluster_select(int mode, const float* scores, int64_t row_stride, float
     a.inv = inv;
     a.idx = idx; a.idx_stride = idx_stride;
     a.tail_start = tail_start; a.tail_n = tail_n; a.nseg = nseg; a.seg_len = seg_len; a.pos_base = pos_base;
-    a.w = w;
+    a.ws0 = w.base; a.wsR = w.lay_R; a.ws_ntab = w.lay_ntab;
     a.x = x; a.x_sb = x_sb; a.x_sh = x_sh; a.x_ss = x_ss; a.H = (uint32_t)std::max<int64_t>(1, H); a.scale = scale;
     int rc;
     switch (mode) {

@@ -15,6 +15,9 @@ constexpr int TK_CHUNK = TK_THREADS * TK_PER;
 // cluster select (topk_cluster.hip): TC_CLUSTERS row clusters of TC_SLOTS workgroups each, one launch per select
 constexpr int TC_CLUSTERS = 8;
 constexpr int TC_SLOTS = 32;
+// two-hop form of the cluster select (topk_cluster.hip): bins of the sample-steered first digit, words per candidate record
+constexpr int TC_WB = 256;
+constexpr int TC_REC = 128;
 
 struct TopkWs {
     uint32_t* hist1;       // [R][4096]
@@ -22,35 +25,69 @@ struct TopkWs {
     uint32_t* hist3;       // [R][256]
     uint32_t* bar;         // [TC_CLUSTERS][32] cluster select, one 128-byte line per row cluster: [0] its monotonic arrival counter,
                            // [1] its give-up code (0 = none; persistent until the workspace is zero-filled again)
+    uint32_t* histw;       // [R][TC_WB] cluster select: histogram of the sample-steered window digit (zeroed region, self-cleaning)
+    uint32_t* cand;        // [R][TC_SLOTS][TC_REC] cluster select: per-slot candidate records (count, keys above the bin, candidate keys)
     uint32_t* sel;         // [R][4] : b1, k1, b2, k2
     uint32_t* chunk_hist;  // [R][nchunks][257] suffix counts of the last digit: [d] = #(digit >= d), [256] = 0
     uint32_t* chunk_gt;    // [R][nchunks]
     size_t zero_bytes;     // leading bytes that must be zeroed per call (hist1..hist3)
     uint32_t kmask;        // XOR-ed into every key: 0 = k largest, 0xFFFFFFFF = k smallest
     size_t total_bytes;
+    uint32_t* base;        // the workspace itself and the (R, ntab) its layout was computed for (topk_ws_layout)
+    uint32_t lay_R, lay_ntab;
 };
+
+// The workspace layout in 4-byte words from its base (every region starts on a 256-byte boundary).  __host__ __device__: the
+// cluster select carries only the base and (R, ntab) and derives a region's address where it uses it -- nine pointers in scalar
+// registers for the whole kernel were what pushed it over the scalar register file.
+struct TopkWsLayout {
+    uint32_t hist1, hist2, hist3, bar, histw, sel, chunk_hist, chunk_gt, cand;
+    uint32_t zero_words, total_words;
+};
+__host__ __device__ inline TopkWsLayout topk_ws_layout(uint32_t R, uint32_t ntab) {
+    TopkWsLayout l;
+    uint32_t off = 0;
+    auto take = [&](uint32_t words) {
+        const uint32_t at = off;
+        off += (words + 63u) / 64u * 64u;
+        return at;
+    };
+    l.hist1 = take(R * 4096u);
+    l.hist2 = take(R * 4096u);
+    l.hist3 = take(R * 256u);
+    l.bar = take((uint32_t)(TC_CLUSTERS * 32 + 32 + TC_SLOTS * 16));   // (the tail is room for the phase stamps of tools/make_tc_timing.py's lab build)
+    l.histw = take(R * (uint32_t)TC_WB);
+    l.zero_words = off;
+    l.sel = take(R * 4u);
+    // per-chunk tables: the (chunk, row) passes index them by 1024-score chunk, the cluster select by its TC_SLOTS slots
+    l.chunk_hist = take(R * ntab * 257u);
+    l.chunk_gt = take(R * ntab);
+    l.cand = take(R * (uint32_t)(TC_SLOTS * TC_REC));
+    l.total_words = off;
+    return l;
+}
 
 inline TopkWs topk_carve_ws(void* ws, int64_t R, int64_t nchunks) {
     TopkWs w;
-    size_t off = 0;
-    char* base = static_cast<char*>(ws);
-    auto take = [&](size_t bytes) {
-        void* p = base ? base + off : nullptr;
-        off += kvp_align_up(bytes, 256);
-        return p;
-    };
-    w.hist1 = (uint32_t*)take((size_t)R * 4096 * 4);
-    w.hist2 = (uint32_t*)take((size_t)R * 4096 * 4);
-    w.hist3 = (uint32_t*)take((size_t)R * 256 * 4);
-    w.bar = (uint32_t*)take((size_t)(TC_CLUSTERS * 32 + 32 + TC_SLOTS * 16) * 4);   // (the tail is room for the phase stamps of tools/make_tc_timing.py's lab build)
-    w.zero_bytes = off;
-    w.sel = (uint32_t*)take((size_t)R * 4 * 4);
-    // per-chunk tables: the (chunk, row) passes index them by 1024-score chunk, the cluster select by its TC_SLOTS slots
-    const int64_t ntab = std::max<int64_t>(nchunks, TC_SLOTS);
-    w.chunk_hist = (uint32_t*)take((size_t)R * ntab * 257 * 4);
-    w.chunk_gt = (uint32_t*)take((size_t)R * ntab * 4);
-    w.total_bytes = off;
+    const uint32_t ntab = (uint32_t)std::max<int64_t>(nchunks, TC_SLOTS);
+    const TopkWsLayout l = topk_ws_layout((uint32_t)R, ntab);
+    uint32_t* base = static_cast<uint32_t*>(ws);
+    auto at = [&](uint32_t words) { return base ? base + words : nullptr; };
+    w.hist1 = at(l.hist1);
+    w.hist2 = at(l.hist2);
+    w.hist3 = at(l.hist3);
+    w.bar = at(l.bar);
+    w.histw = at(l.histw);
+    w.zero_bytes = (size_t)l.zero_words * 4;
+    w.sel = at(l.sel);
+    w.chunk_hist = at(l.chunk_hist);
+    w.chunk_gt = at(l.chunk_gt);
+    w.cand = at(l.cand);
+    w.total_bytes = (size_t)l.total_words * 4;
     w.kmask = 0;
+    w.base = base;
+    w.lay_R = (uint32_t)R;
+    w.lay_ntab = ntab;
     return w;
 }
 

@@ -2,7 +2,7 @@
 (kvpress_amd/lib/libkvpress_hip_faultinject.so: topk_cluster.hip compiled with -DKVP_TC_FAULT_INJECTION, kvpress_amd/build.py), in which
 KVP_TC_TEST_DELAY_SLOT makes one workgroup of cluster 0 arrive 2 x timeout late.  The product library has no such hook.
 
-    python tests/_fault_child.py barrier | fused        -> prints CHILD_PASS on success, raises otherwise
+    python tests/_fault_child.py barrier | fused | stale | paths   -> prints CHILD_PASS on success, raises otherwise
 """
 import os
 import sys
@@ -128,7 +128,78 @@ def stale():
     assert L.kvp_async_error_check() == 0
 
 
+def paths():
+    """Which form of the cluster select finishes which kind of row (the test twin leaves a marker per (cluster, slot) in the workspace):
+    the two-hop form (sample-steered first digit, candidates, local finish) on rows whose threshold the sample brackets -- with ties at
+    the threshold across slots, with single-key bins (no local round), with keys spread over every exponent (several local rounds) --
+    and the three-round form where the sample must mislead (k at an extreme, rows of few distinct values, sorted rows).  Indices
+    against the oracle in every case."""
+    import ctypes
+
+    rs = np.random.RandomState(11)
+    R, S = 8, 131008
+    L = n.lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    al = lambda x: (x + 255) // 256 * 256
+    bar_off = (2 * al(R * 4096 * 4) + al(R * 256 * 4)) // 4 + 8 * 32 + 32   # topk_ws_layout: hist1, hist2, hist3, bar (+ 8 lines + 1)
+
+    def run(x, k, flags=0):
+        sc = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+        nws = L.kvp_topk_workspace_bytes(R, x.shape[1], k)
+        ws = torch.zeros(nws, dtype=torch.uint8, device=DEV)
+        idx = torch.empty((R, k), dtype=torch.int32, device=DEV)
+        for _ in range(2):   # twice through the same self-cleaning workspace
+            rc = L.kvp_topk_select(P(sc), R, x.shape[1], x.shape[1], k, n.ORDER_POSITION | n.TOPK_WS_CLEAN | flags, P(idx), P(ws), nws, st)
+            assert rc == 0, L.kvp_last_error()
+            torch.cuda.synchronize()
+        m = ws.view(torch.int32).cpu().numpy()[bar_off:bar_off + 32 * 16].reshape(32, 16)[:, :R]
+        assert L.kvp_async_error_check() == 0
+        return idx.cpu().numpy(), m
+
+    def check(name, x, k, want_form, smallest=False):
+        got, m = run(x, k, n.TOPK_SMALLEST if smallest else 0)
+        want = O.topk_select(-x if smallest else x, k)
+        assert np.array_equal(got, want), f"{name}: wrong indices"
+        forms = sorted(set(m.reshape(-1).tolist()))
+        # want_form 2 / 1: every row must finish in that form; 0: rows may differ (a row whose extreme happens to lie inside the
+        # sample's bracket finishes in the two-hop form), but each row's 32 slots agree
+        assert forms == [want_form] or (want_form == 0 and set(forms) <= {1, 2}), f"{name}: form markers {forms}, expected {want_form} (2 = two-hop, 1 = three rounds)"
+        assert all(len(set(m[:, r].tolist())) == 1 for r in range(R)), f"{name}: the slots of a row disagree about the form: {m.T.tolist()}"
+        print(f"paths {name}: forms {forms} ok", flush=True)
+
+    flat = (2.0 ** -17 * (1 + 0.05 * rs.standard_normal((R, S)))).astype(np.float32)
+    for frac in (0.5, 0.1, 0.3, 0.7, 0.9):
+        check(f"flat k/S={frac}", flat, int(S * frac), 2)
+    check("flat smallest", flat, S // 3, 2, smallest=True)
+    # ties AT the threshold, spread over the slots: 48 positions whose score is below the threshold get the threshold's value
+    k = S // 2
+    x = flat.copy()
+    for r in range(R):
+        order = np.argsort(-x[r], kind="stable")
+        v = x[r, order[k - 1]]
+        below = order[k + 100:]
+        x[r, rs.choice(below, 48, replace=False)] = v
+    check("ties at the threshold", x, k, 2)
+    # consecutive keys: 200 distinct values, ~650 each -- every window bin is ONE key (no local round), the quota cuts inside a value
+    x = (np.float32(1.0).view(np.uint32) + rs.randint(0, 200, size=(R, S)).astype(np.uint32)).view(np.float32)
+    check("consecutive keys", x, S // 2, 2)
+    # keys over every exponent and both signs: a wide bracket, several local rounds
+    x = (np.exp(12 * rs.standard_normal((R, S))) * rs.choice([-1.0, 1.0], size=(R, S))).astype(np.float32)
+    check("all exponents", x, S // 2, 2)
+    x = flat.copy()
+    x[:, ::97] = np.inf
+    x[:, 5::89] = -np.inf
+    check("infinities", x, S // 2, 2)
+    # --- rows on which the sample must mislead: the three-round form takes over, same indices
+    check("k = 1", flat, 1, 0)
+    check("k = S - 1", flat, S - 1, 0)
+    check("20 distinct values", rs.randint(0, 20, size=(R, S)).astype(np.float32), S // 2, 1)
+    check("sorted rows", np.sort(flat, axis=1), S // 2, 1)
+    check("constant rows", np.full((R, S), 0.25, np.float32), S // 2, 1)
+
+
 if __name__ == "__main__":
     assert os.environ.get("KVPRESS_HIP_LIB", "").endswith("faultinject.so"), "run me with the fault-injection library"
-    {"barrier": barrier, "fused": fused, "stale": stale}[sys.argv[1]]()
+    {"barrier": barrier, "fused": fused, "stale": stale, "paths": paths}[sys.argv[1]]()
     print("CHILD_PASS", sys.argv[1])

@@ -106,6 +106,22 @@ def test_barrier_timeout_is_loud(scenario):
     assert r.returncode == 0 and f"CHILD_PASS {scenario}" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
+def test_both_forms_of_the_cluster_select_are_exercised():
+    """Round 5: the cluster select has a two-hop form (sample-steered first digit, per-slot candidate records, local finish) and keeps
+    the three-round form for rows on which the sample misleads.  The test twin of the library marks which form finished each
+    (cluster, slot); tests/_fault_child.py `paths` runs rows built for each form -- flat BASELINE rows at five keep ratios, ties at
+    the threshold across slots, single-key bins, keys over every exponent, infinities / k at an extreme, few distinct values, sorted
+    and constant rows -- and checks the markers AND the indices (oracle) of every case."""
+    from kvpress_amd import build
+
+    assert os.path.exists(build.FAULT_LIB), "fault-injection twin not built (python -m kvpress_amd.build)"
+    env = dict(os.environ, KVPRESS_HIP_LIB=build.FAULT_LIB, PYTHONDONTWRITEBYTECODE="1")
+    for k in ("KVP_TC_TIMEOUT_US", "KVP_TC_TEST_DELAY_SLOT", "KVP_TK_CLUSTER"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_fault_child.py"), "paths"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CHILD_PASS paths" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_product_library_has_no_fault_injection_hook(knobs):
     """The same knob on the PRODUCT library does nothing: the select is correct and nothing is reported."""
     n = native()

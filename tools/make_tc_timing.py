@@ -9,22 +9,21 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MACRO = '''#define TC_STAMP(i) do { if (threadIdx.x == 0 && cluster == 0) a.w.bar[TC_CLUSTERS * 32 + 32 + slot * 16 + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
+MACRO = '''#define TC_STAMP(i) do { if (threadIdx.x == 0 && cluster == 0) TCW(bar)[TC_CLUSTERS * 32 + 32 + slot * 16 + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
     TC_STAMP(0);
 '''
-# (anchor line fragment, stamp index, "before" | "after")
+# (anchor line fragment, stamp index, "before" | "after"); the two-hop form (round 5).  Stamp 11 = 1 if the two-hop form finished the
+# select (0: it declined -- threshold outside the sample bracket or a full candidate record -- and the three rounds ran).
 ANCHORS = [
-    ("        const bool full = kmin != 0u;", 1, "after"),                                   # keys loaded
-    ("            if (!poll) cluster_barrier(cs, 1, &s_fail[0], true);", 2, "before"),      # first histogram flushed
-    ("            if (!poll) cluster_barrier(cs, 1, &s_fail[0], true);", 3, "after"),       # (counter barrier 1 passed)
-    ("        // ---- digit 2: (key >> 8) & 0xFFF among key >> 20 == b1", 4, "before"),      # first digit found
-    ("        cluster_barrier(cs, 2, &s_fail[0], HIST1 || poll);", 5, "before"),          # second histogram flushed
-    ("        cluster_barrier(cs, 2, &s_fail[0], HIST1 || poll);", 6, "after"),
-    ("        const uint32_t prefix = (b1 << 12) | b2;", 7, "after"),                        # second digit found
-    ("        cluster_barrier(cs, 3, &s_fail[0], false);", 8, "before"),          # third histogram + suffix table
-    ("        cluster_barrier(cs, 3, &s_fail[0], false);", 9, "after"),
-    ("        const uint32_t T = (prefix << 8) | b3;", 10, "after"),                          # threshold known
-    ("        // ---- ordered compaction: keys > T", 11, "before"),                           # offsets of the earlier slots, histograms zeroed
+    ("        const bool full = kmin != 0u;", 1, "after"),                                       # keys loaded
+    ("            uint32_t* whist = fh + 2 * TC_NS;   // (zeroed by window_setup)", 2, "before"),  # (the window is set up inside the key phase)
+    ("            // complete when the histogram's total is the row's S keys", 3, "before"),     # window histogram flushed
+    ("            d1 = tc_uni(d1);", 4, "before"),                                               # window digit found (poll complete)
+    ("                cluster_barrier(cs, 2, &s_fail[0], true);", 5, "before"),                  # candidate record written
+    ("                cluster_barrier(cs, 2, &s_fail[0], true);", 6, "after"),
+    ("                const bool ovf = ", 7, "before"),                                          # the row's records in LDS
+    ("                    T = Tpre;", 8, "before"),                                              # threshold known (local rounds)
+    ("        // ---- ordered compaction: keys > T", 9, "before"),                               # offsets of the earlier slots
 ]
 
 
@@ -49,9 +48,9 @@ def main(out):
     text = "\n".join(res)
     tail = "            if (rank0 + i < k) out[rank0 + i] = ob[i];\n"
     assert text.count(tail) == 1, "anchor for the final stamp moved"
-    text = text.replace(tail, tail + "        TC_STAMP(12);\n")
-    used.add(12)
-    missing = sorted(set(range(13)) - used)
+    text = text.replace(tail, tail + "        TC_STAMP(10);\n        if (threadIdx.x == 0 && cluster == 0) TCW(bar)[TC_CLUSTERS * 32 + 32 + slot * 16 + 11] = done ? 1u : 0u;\n")
+    used.add(10)
+    missing = sorted(set(range(11)) - used)
     assert not missing, f"anchors moved: stamps {missing} not placed"
     open(out, "w").write(text)
 

@@ -61,15 +61,16 @@ def stamps(R, S, flat=True):
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     al = lambda x: (x + 255) // 256 * 256
     bar_off = (2 * al(R * 4096 * 4) + al(R * 256 * 4)) // 4 + 8 * 32 + 32
-    names = ["start", "keys", "h1 flushed", "B1", "digit1", "h2 flushed", "B2", "digit2", "h3+table", "B3", "T", "offsets", "end"]
+    names = ["start", "keys", "window", "hw flushed", "digit", "records", "barrier", "rec in LDS", "T", "offsets", "end"]
     for it in range(6):
         rc = L.kvp_topk_select(P(sc), R, S, S, S // 2, N.TOPK_WS_CLEAN, P(idx), P(ws), nws, st)
         assert rc == 0, L.kvp_last_error()
         torch.cuda.synchronize()
-    w = ws.view(torch.int32).cpu().numpy().astype(np.int64)[bar_off:bar_off + 32 * 16].reshape(32, 16)[:, :13]
+    w = ws.view(torch.int32).cpu().numpy().astype(np.int64)[bar_off:bar_off + 32 * 16].reshape(32, 16)[:, :12]
     t0 = w[:, 0].min()
     rel = (w - t0) * 0.01   # us
     print(f"cluster kernel phase stamps, R={R} S={S} {'flat' if flat else 'wide'} (us since the first workgroup of cluster 0 started; min / median / max over its 32 slots)")
+    print(f"  two-hop form finished the select in {int(w[:, 11].sum())} of 32 slots")
     for i, n in enumerate(names):
         col = rel[:, i]
         print(f"  {n:12s} {col.min():7.2f} {np.median(col):7.2f} {col.max():7.2f}")
