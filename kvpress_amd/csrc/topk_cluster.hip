@@ -197,7 +197,9 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
     constexpr uint32_t L = TR_THREADS * PER;   // keys per workgroup
     __shared__ __attribute__((aligned(16))) uint32_t lh[L > 4096 ? L : 4096];   // histogram; KNORM: first the staged scores; last the staged output
     __shared__ uint32_t scr[TR_WAVES + 3];
-    __shared__ uint32_t fh[HIST1 ? 1 : 4096];   // two-hop form: the local rounds' histogram (<= 12 bits per round)
+    __shared__ uint32_t fh[HIST1 ? 1 : 4096];   // two-hop form: the local rounds' histogram (<= 12 bits per round); first the sample
+    __shared__ uint32_t fg[64];                 // ... and its sums over groups of 64 bins
+    __shared__ uint32_t res2[2];                // verdict of a one-wave search (its own words: scr belongs to the block scans)
     __shared__ uint32_t s_fail[2];   // [0] this workgroup gave up at a barrier, [1] the cluster's flag as read after the last barrier
     // A row's 32 workgroups are CONSECUTIVE blocks: whatever part of the grid the device can hold at once, whole clusters become
     // resident in dispatch order and finish, so a device with fewer free CUs than the grid (CU masking, a busy neighbour) makes
@@ -320,6 +322,10 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             while (((Hk >> sft) - (Lk >> sft)) > (uint32_t)(TC_WB - 3)) ++sft;
             wbase = Lk >> sft;
         };
+        auto wbin = [&](uint32_t key) -> uint32_t {   // the window digit of a key (valid after window_setup)
+            const uint32_t v = key >> sft;
+            return v < wbase ? 0u : min(v - wbase + 1u, (uint32_t)(TC_WB - 1));
+        };
         // ---- keys ------------------------------------------------------------------------------------------------
         uint32_t keys[PER];
         if (MODE == TC_SCORES) {
@@ -394,7 +400,13 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
                     float acc = tc_sumsq16<DT>(v[u]);
 #pragma unroll
                     for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-                    if (lir == 0) st[it + u * 64 + g] = a.scale * sqrtf(acc);
+                    if (lir == 0) {
+                        const float sc = a.scale * sqrtf(acc);
+                        st[it + u * 64 + g] = sc;
+                        // two-hop form: the window is known since step 0, so the norm is counted where it is produced (4 lanes per
+                        // wave and step: no aggregation needed) instead of in a pass over the finished keys
+                        if (!HIST1 && r0 + it + u * 64 + g < S) atomicAdd(&fh[2 * TC_NS + wbin(tc_key(sc, kmask))], 1u);
+                    }
                 }
             }
             __syncthreads();
@@ -440,11 +452,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
         if (!HIST1) {
             uint32_t* whist = fh + 2 * TC_NS;   // (zeroed by window_setup)
             uint32_t* hw = TCW(histw) + (size_t)row * TC_WB;
-            auto wbin = [&](uint32_t key) -> uint32_t {
-                const uint32_t v = key >> sft;
-                return v < wbase ? 0u : min(v - wbase + 1u, (uint32_t)(TC_WB - 1));
-            };
-            {
+            if (!KN) {   // (Knorm: the producing lanes counted their norms while they streamed K)
                 // most keys lie outside the bracket (bins 0 and TC_WB - 1): those are counted in registers and added once per wave;
                 // the keys inside spread over the bins in between (plain LDS atomics)
                 uint32_t nout = 0;   // below in bits 0-15, above in bits 16-31 (<= 64 * PER per wave)
@@ -476,41 +484,44 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
                 if (c) tc_add(&hw[threadIdx.x], c);
             }
             // complete when the histogram's total is the row's S keys (the polling protocol of round 1, see above)
-            // (the search runs in ONE wave -- lane l holds the TC_WB / 64 bins below bin TC_WB - 1 - l * (TC_WB / 64), the prefix over
-            // the lanes is a DPP scan -- and costs two block barriers per poll instead of the five of the 1024-thread search)
-            uint32_t d1, k1;
-            for (uint32_t it = 0;; ++it) {
-                if (wvu == 0u) {
-                    constexpr int PB = TC_WB / 64;
-                    const uint32_t lane = threadIdx.x & 63u, top = (63u - lane) * PB;   // this lane's bins: top + PB - 1 .. top (descending)
+            // (the search runs in ONE wave, which polls on its own -- lane l holds the TC_WB / 64 bins below bin TC_WB - 1 - l * (TC_WB / 64),
+            // the prefix over the lanes is a DPP scan -- ; the other waves wait at ONE block barrier for its verdict)
+            if (wvu == 0u) {
+                constexpr int PB = TC_WB / 64;
+                const uint32_t lane = threadIdx.x & 63u, top = (63u - lane) * PB;   // this lane's bins: top + PB - 1 .. top (descending)
+                for (uint32_t it = 0;; ++it) {
                     uint32_t loc[PB], sum = 0;
 #pragma unroll
                     for (int i = 0; i < PB; ++i) loc[i] = tc_ld(&hw[top + i]);
 #pragma unroll
                     for (int i = 0; i < PB; ++i) sum += loc[i];
                     const uint32_t inc = wave_incl_scan(sum), excl = inc - sum;
-                    if (excl < k && k <= inc) {
-                        uint32_t c = excl;
+                    if (tc_uni((uint32_t)__builtin_amdgcn_readlane((int)inc, 63)) == S) {
+                        if (excl < k && k <= inc) {
+                            uint32_t c = excl;
 #pragma unroll
-                        for (int i = PB - 1; i >= 0; --i) {
-                            if (k > c && k <= c + loc[i]) {
-                                scr[0] = top + i;
-                                scr[1] = k - c;
+                            for (int i = PB - 1; i >= 0; --i) {
+                                if (k > c && k <= c + loc[i]) {
+                                    res2[0] = top + i;
+                                    res2[1] = k - c;
+                                }
+                                c += loc[i];
                             }
-                            c += loc[i];
                         }
+                        break;
                     }
-                    if (lane == 63u) scr[2] = inc;
+                    if (it >= max_poll) {   // gives up like a barrier
+                        if (lane == 0u) {
+                            s_fail[0] = 1u;
+                            tc_report(cs, 1u);
+                        }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
                 }
-                __syncthreads();
-                d1 = scr[0];
-                k1 = scr[1];
-                const uint32_t total = tc_uni(scr[2]);
-                __syncthreads();
-                if (total == S) break;
-                if (it >= max_poll) { TC_POLL_GIVE_UP(1u); break; }
-                __builtin_amdgcn_s_sleep(2);
             }
+            __syncthreads();
+            uint32_t d1 = res2[0], k1 = res2[1];
             d1 = tc_uni(d1);
             k1 = tc_uni(k1);
             // (a poll that gave up: straight to the poison branch -- the workgroups that did see the complete histogram time out at
@@ -573,15 +584,36 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
                         const uint32_t wd = min(hi, 12u), lo = hi - wd;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) fh[threadIdx.x * 4 + i] = 0;
+                        if (wvu == 0u) fg[threadIdx.x] = 0;
                         __syncthreads();
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            if (cv[i] && (v[i] >> hi) == (Tpre >> hi)) atomicAdd(&fh[(v[i] >> lo) & ((1u << wd) - 1u)], 1u);
+                            if (cv[i] && (v[i] >> hi) == (Tpre >> hi)) {
+                                const uint32_t dg = (v[i] >> lo) & ((1u << wd) - 1u);
+                                atomicAdd(&fh[dg], 1u);
+                                atomicAdd(&fg[dg >> 6], 1u);   // the 64 groups of 64 bins
+                            }
                         __syncthreads();
-                        uint32_t bb, kr;
-                        row_find_bin<4096>(fh, krem, scr, bb, kr);
-                        Tpre |= tc_uni(bb) << lo;
-                        krem = tc_uni(kr);
+                        // two-level search in ONE wave (group, then bin inside the group: one value per lane, DPP scans): three block
+                        // barriers per round where the 1024-thread search takes six
+                        if (wvu == 0u) {
+                            const uint32_t lane = threadIdx.x & 63u;
+                            const uint32_t cgp = fg[63u - lane];
+                            const uint32_t ig = wave_incl_scan(cgp);
+                            const uint64_t hg = __ballot(ig - cgp < krem && krem <= ig);   // exactly one lane: krem <= the candidates' count
+                            const int lg = __ffsll((unsigned long long)hg) - 1;
+                            const uint32_t grp = 63u - (uint32_t)lg;
+                            const uint32_t kr2 = krem - (uint32_t)__builtin_amdgcn_readlane((int)(ig - cgp), lg);
+                            const uint32_t cb = fh[grp * 64u + (63u - lane)];
+                            const uint32_t ib = wave_incl_scan(cb);
+                            if (ib - cb < kr2 && kr2 <= ib) {
+                                res2[0] = grp * 64u + (63u - lane);
+                                res2[1] = kr2 - (ib - cb);
+                            }
+                        }
+                        __syncthreads();
+                        Tpre |= tc_uni(res2[0]) << lo;
+                        krem = tc_uni(res2[1]);
                         hi = lo;
                     }
                     T = Tpre;
