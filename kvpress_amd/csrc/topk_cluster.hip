@@ -1,18 +1,28 @@
 // Cluster select: the whole radix select of long score rows (16384 < S <= 262144) in ONE launch.
-// Replaces `scores.topk(n_kept, dim=-1).indices` (kvpress/presses/scorer_press.py:95); same digits (12 + 12 + 8 bits of the
-// order-preserving key), same tie rule (lowest position first) and therefore the same indices as the (chunk, row) passes of
+// Replaces `scores.topk(n_kept, dim=-1).indices` (kvpress/presses/scorer_press.py:95); an exact radix select on the
+// order-preserving key with the same tie rule (lowest position first), hence the same indices as the (chunk, row) passes of
 // topk.hip, which stay as the fallback (devices with fewer than 256 CUs, rows beyond 262144 scores, more than 8 rows; KVP_TK_CLUSTER=0
 // selects them on any device).
 //
 // Structure.  The (chunk, row) passes are chains of dependent launches over an L2-resident row: load the keys, count a digit,
 // flush, kernel boundary, load the keys again ...  (4 launches of 5-7 us for ~2 us of work each).  Here a row belongs to a
 // CLUSTER of TC_SLOTS = 32 workgroups of 1024 threads; a workgroup keeps its 1024 * PER keys in registers from the first
-// load to the compaction, and the three digit steps are separated by cluster barriers (one monotonic arrival counter per
-// cluster, 32 arrivals) instead of kernel boundaries.  256 workgroups = 8 clusters; a row's 32 workgroups are CONSECUTIVE blocks
+// load to the compaction, and the steps of the select are separated by in-kernel synchronisation instead of kernel boundaries.
+// Two forms, same indices:
+//   * two-hop (round 5; rows whose keys this kernel loads itself): a SAMPLE of 128 keys of the row brackets the k-th largest; the
+//     first digit is cut out of that bracket (256 bins of 2^s keys, everything outside in the two end bins), counted into the row's
+//     histogram (complete when its total is S: polled, no barrier); the threshold bin's few dozen keys -- the candidates -- are
+//     published per slot with plain stores, ONE cluster barrier later every workgroup reads them all and finishes locally (rounds of
+//     <= 12 bits in LDS).  Hop 1 = the histogram, hop 2 = the candidates;
+//   * three rounds (12 + 12 + 8 bits of the key: hop per digit; cluster barriers = one monotonic arrival counter per cluster) when
+//     the scorer already accumulated the first digit (HIST1), and whenever the two-hop form DECLINES: the threshold lies outside the
+//     sample's bracket (k at an extreme of the row) or a slot has more candidates than its record holds (rows of few distinct
+//     values).  Every workgroup of the row takes that decision from the same words, so all of them switch together.
+// 256 workgroups = 8 clusters; a row's 32 workgroups are CONSECUTIVE blocks
 // (block / 32 = cluster), i.e. spread over all XCDs -- measured, a hop costs the same ~0.8 us round trip from anywhere
 // (profiles/r03_select_cluster_lab.txt), and consecutive blocks make partial residency harmless (see the kernel).  Correctness is
-// placement-independent: every word another workgroup reads -- the row histograms, the per-slot suffix tables, the
-// counter -- is written AND read with agent-scope (sc1) atomics / loads / stores, every wave drains its vector-memory
+// placement-independent: every word another workgroup reads -- the row histograms, the candidate records, the per-slot suffix
+// tables, the counter -- is written AND read with agent-scope (sc1) atomics / loads / stores, every wave drains its vector-memory
 // counter before the arrival, no fences, nothing relies on two workgroups sharing an L2 (cdna_hip_programming.md
 // Guideline 16, the "agent atomics on both sides" form).  One launch selects up to 8 rows; more rows take the (chunk, row) passes.
 //
@@ -846,7 +856,7 @@ int launch_per(const ClusterArgs& a, hipStream_t stream) {
 }  // namespace
 
 // All TC_CLUSTERS * TC_SLOTS workgroups must be resident at once (the barriers spin).  Every instantiation fits an empty CU
-// (1024 threads, <= 128 VGPRs, <= 66 KB of LDS), so the question is whether the current device has that many CUs.
+// (1024 threads, <= 128 VGPRs, <= 50 KB of LDS), so the question is whether the current device has that many CUs.
 bool topk_cluster_launchable() {
     static int ok[64] = {0};   // per device: 0 unknown, 1 yes, -1 no
     int dev = 0;
