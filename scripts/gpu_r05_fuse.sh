@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: pass 2 folds pass 1's partials itself (no softmax_combine launch): parity + A/B through KVP_SK_FUSE_COMBINE on one box
+# round 5 LAB R5.7 (apply tools/lab_patches/p2_fused_combine.diff first: the product has no KVP_SK_FUSE_COMBINE): pass 2 folds pass 1's partials itself (no softmax_combine launch): parity + A/B through the knob on one box
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
