@@ -118,7 +118,7 @@ int kvp_snapkv_score_from_attn(const void* attn, int64_t a_sb, int64_t a_sh, int
                                int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int kernel_size,
                                float* scores, void* ws, size_t ws_bytes, kvp_stream_t stream);
 
-/* ---- ExpectedAttentionPress (kvpress/presses/expected_attention_press.py) -------------------
+/* ---- ExpectedAttentionPress.get_query_statistics (kvpress/presses/expected_attention_press.py:62-86) ----
  * kvp_ea_qstats: mean and covariance of the pre-RoPE queries q [B,Hq,Sq,D] (sinks already
  * stripped by the host, :70-71): mu[b,h,:] = mean_s q; cov = (q-mu)^T (q-mu) / Sq (:74-80).
  * mu [B,Hq,D], cov [B,Hq,D,D] float32 contiguous; cov may be NULL (use_covariance=False).
@@ -128,7 +128,8 @@ int kvp_ea_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int d
                   int64_t B, int64_t Hq, int64_t Sq, int64_t D,
                   float* mu, float* cov, void* ws, size_t ws_bytes, kvp_stream_t stream);
 
-/* kvp_ea_score (:137-163): with the post-RoPE mu [B,Hq,D] / cov [B,Hq,D,D] (float32, cov may be
+/* ---- ExpectedAttentionPress.score (kvpress/presses/expected_attention_press.py:126-165) ----
+ * kvp_ea_score (:137-163): with the post-RoPE mu [B,Hq,D] / cov [B,Hq,D,D] (float32, cov may be
  * NULL): for keys/values [B,Hkv,S,D] drop the first n_sink positions; logits = k.mu/sqrt(D) +
  * k^T cov k / (2D) per q-head; softmax over the S-n_sink keys; mean over the group;
  * (s + epsilon) * ||v||_2 if use_vnorm; positions < n_sink get max(scores)+1 (global max).
@@ -256,26 +257,6 @@ int kvp_snapkv_compress_hidden(const void* hidden_win, int64_t x_sb, int64_t x_s
                                int64_t B, int64_t Hq, int64_t Hkv, int64_t S, int64_t W, int64_t D, int kernel_size,
                                int64_t n_kept, void* k_out, void* v_out, void* ws, size_t ws_bytes, int flags,
                                kvp_stream_t stream);
-
-/* ---- measurement aid (not part of the reference boundary) ------------------------------------
- * kvp_prof_enable(1) makes every kernel launch of the calling thread record a HIP event pair on
- * its launch stream; after synchronising, kvp_prof_get(i) returns kernel i's name and duration.
- * kvp_prof_enable(0) turns it off and drops the records.  Used by bench.py for roofline.achieved. */
-int kvp_prof_enable(int on);
-int kvp_prof_count(void);
-int kvp_prof_get(int i, const char** name, float* ms);
-/* kvp_clock_probe: enqueue a one-wave kernel that spins spin_us microseconds and writes the shader clock (MHz, float, device
- * memory) it saw: s_memtime ticks per 100 MHz s_memrealtime tick.  Enqueued right behind a kernel it shows the clock that
- * kernel ran at (the governor is slow compared with a kernel). */
-int kvp_clock_probe(float* mhz_out, int spin_us, kvp_stream_t stream);
-/* kvp_occupy_cus (test aid): enqueue `blocks` workgroups of `threads` threads (a multiple of 64, <= 1024) that hold `lds_bytes`
- * of LDS each and spin spin_us microseconds (<= 200000) -- CUs that some other stream cannot use meanwhile.  The tests of the
- * one-launch select's residency behaviour run it beside kvp_topk_select (tests/test_gpu_cluster_failure.py). */
-int kvp_occupy_cus(int blocks, int threads, int lds_bytes, int spin_us, kvp_stream_t stream);
-/* kvp_tuning_reload: the library's tuning knobs (KVP_* environment variables: launch geometries and kernel-variant switches
- * for A/B runs) are read from the environment once, at first use, and cached; this drops the cache so that the next use of
- * every knob re-reads the environment.  Not needed in production; tests and lab scripts call it after changing a variable. */
-int kvp_tuning_reload(void);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,8 @@
  * include/kvpress_hip.h is the boundary a maintainer binds for the score -> top-k -> gather path (KnormPress, SnapKVPress,
  * ExpectedAttentionPress and the section-8(f) presses that reuse its kernels).  The functions below serve presses that
  * SURVEY.md section 2 marks out of scope (ObservedAttention, LagKV, ThinK: python package kvpress_amd.contrib); they were built in
- * round 1, are kept and tested, and live in the same shared library, but they are not part of that boundary.
+ * round 1, are kept and tested, and are built into their OWN shared library (libkvpress_hip_contrib.so, sources
+ * kvpress_amd/csrc/contrib/), which resolves its error / launch plumbing against libkvpress_hip.so.
  * Conventions (return codes, dtypes, strides, streams): as in kvpress_hip.h. */
 #ifndef KVPRESS_HIP_EXTRA_H
 #define KVPRESS_HIP_EXTRA_H

@@ -35,5 +35,35 @@ __all__ = ["BasePress", "ScorerPress", "KnormPress", "SnapKVPress", "ExpectedAtt
            "ComposedPress", "PerLayerCompressionPress", "RandomPress", "StreamingLLMPress", "KVPressTextGenerationPipeline"]
 
 
+# The reference exports every press at top level (kvpress/__init__.py:7-49).  The five out-of-scope presses that exist here resolve
+# lazily to kvpress_amd.contrib (so `from kvpress_amd import ThinKPress` works like `from kvpress import ThinKPress` without the hot-path
+# package importing its contrib sub-package); the reference's other presses are NOT part of this package and say so.
+_CONTRIB = ("BlockPress", "ChunkKVPress", "LagKVPress", "ObservedAttentionPress", "ThinKPress")
+_NOT_BUILT = ("CAMPress", "CapPress", "CompactorPress", "CriticalAdaKVPress", "CriticalKVPress", "DMSPress", "DuoAttentionPress",
+              "ExpectedAttentionStatsPress", "FastKVzipPress", "KVComposePress", "KVzapPress", "KVzipPress", "LeverageScorePress", "LUKVPress",
+              "MergingPress", "NonCausalAttnPress", "RestoreKVPress", "SimLayerKVPress")
+
+
+def __getattr__(name):
+    if name in _CONTRIB:
+        import importlib
+
+        return getattr(importlib.import_module("kvpress_amd.contrib"), name)
+    if name == "SUPPORTED_MODELS":     # kvpress/presses/base_press.py:26-33 (model classes; here the names are matched, resolved on demand)
+        import transformers
+
+        from kvpress_amd.presses.base_press import SUPPORTED_MODEL_NAMES
+
+        return tuple(getattr(transformers, n) for n in SUPPORTED_MODEL_NAMES)
+    if name in _NOT_BUILT:
+        raise AttributeError(f"kvpress_amd has no {name}: it is outside the hot-path scope of this package (SURVEY.md section 8, DESIGN.md "
+                             f"section 9); use NVIDIA/kvpress's {name}")
+    raise AttributeError(f"module 'kvpress_amd' has no attribute {name!r}")
+
+
+def __dir__():
+    return sorted(list(globals()) + list(_CONTRIB))
+
+
 # importing the package registers the "kv-press-text-generation" task, as `import kvpress` does (kvpress/__init__.py, pipeline.py:326-331)
 from kvpress_amd.pipeline import KVPressTextGenerationPipeline  # noqa: E402

@@ -17,6 +17,7 @@ import torch  # must be imported before the .so so that it binds to torch's liba
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # KVPRESS_HIP_LIB: an alternative build of the same library (kernel labs under tools/); unset in production
 LIB_PATH = os.environ.get("KVPRESS_HIP_LIB") or os.path.join(_HERE, "lib", "libkvpress_hip.so")
+CONTRIB_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libkvpress_hip_contrib.so")
 
 KVP_F32, KVP_F16, KVP_BF16 = 0, 1, 2
 ORDER_POSITION, ORDER_SCORE = 0, 1
@@ -32,13 +33,6 @@ SIGNATURES = {
     "kvp_last_error": (c_char_p, []),
     "kvp_async_error_check": (c_int, []),
     "kvp_rownorm_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_float, c_void_p, c_void_p]),
-    "kvp_observed_attention_score": (c_int, [c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, c_void_p, c_void_p]),
-    "kvp_lagkv_score": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, _I64, c_int,
-                                c_void_p, c_void_p]),
-    "kvp_think_workspace_bytes": (c_size_t, [_I64] * 4),
-    "kvp_think_channel_scores": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, _I64,
-                                         c_void_p, c_void_p, c_size_t, c_void_p]),
-    "kvp_zero_channels": (c_int, [c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, c_void_p, _I64, c_void_p]),
     "kvp_rowdot_score": (c_int, [c_void_p, c_int, _I64, _I64, _I64, _I64, _I64, _I64, _I64, c_void_p, _I64, c_float, c_void_p, c_void_p]),
     "kvp_knorm_compress_workspace_bytes": (c_size_t, [_I64] * 4),
     "kvp_knorm_compress": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64,
@@ -86,6 +80,9 @@ SIGNATURES = {
                               c_void_p, _I64, c_void_p, c_void_p, c_void_p]),
     "kvp_gather_kv_rerotate": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64,
                                        c_void_p, _I64, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+# include/kvpress_hip_lab.h: measurement / test aids of the same library (bench.py, tools/, the select's residency tests)
+LAB_SIGNATURES = {
     "kvp_prof_enable": (c_int, [c_int]),
     "kvp_prof_count": (c_int, []),
     "kvp_prof_get": (c_int, [c_int, ctypes.POINTER(c_char_p), ctypes.POINTER(c_float)]),
@@ -93,8 +90,19 @@ SIGNATURES = {
     "kvp_occupy_cus": (c_int, [c_int, c_int, c_int, c_int, c_void_p]),
     "kvp_tuning_reload": (c_int, []),
 }
+# include/kvpress_hip_extra.h: kernels of the presses outside SURVEY section 8 (kvpress_amd.contrib), their own shared library
+CONTRIB_SIGNATURES = {
+    "kvp_observed_attention_score": (c_int, [c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, c_void_p, c_void_p]),
+    "kvp_lagkv_score": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, _I64, c_int,
+                                c_void_p, c_void_p]),
+    "kvp_think_workspace_bytes": (c_size_t, [_I64] * 4),
+    "kvp_think_channel_scores": (c_int, [c_void_p, _I64, _I64, _I64, c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, _I64, _I64,
+                                         c_void_p, c_void_p, c_size_t, c_void_p]),
+    "kvp_zero_channels": (c_int, [c_void_p, _I64, _I64, _I64, c_int, _I64, _I64, _I64, _I64, c_void_p, _I64, c_void_p]),
+}
 
 _lib = None
+_contrib_lib = None
 
 
 class KvpressHipError(RuntimeError):
@@ -110,11 +118,27 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} not found: build it with `python -m kvpress_amd.build` (hipcc, gfx950). "
                 "kvpress_amd has no CPU / pure-PyTorch fallback.")
         handle = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in {**SIGNATURES, **LAB_SIGNATURES}.items():
             fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
             fn.restype, fn.argtypes = res, args
         _lib = handle
     return _lib
+
+
+def contrib_lib() -> ctypes.CDLL:
+    """Load libkvpress_hip_contrib.so (once): LagKV / ThinK / ObservedAttention kernels (kvpress_amd.contrib).  It resolves the
+    error / launch plumbing against libkvpress_hip.so, which is loaded first."""
+    global _contrib_lib
+    if _contrib_lib is None:
+        lib()
+        if not os.path.exists(CONTRIB_LIB_PATH):
+            raise KvpressHipError(f"{CONTRIB_LIB_PATH} not found: build it with `python -m kvpress_amd.build` (hipcc, gfx950).")
+        handle = ctypes.CDLL(CONTRIB_LIB_PATH)
+        for name, (res, args) in CONTRIB_SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _contrib_lib = handle
+    return _contrib_lib
 
 
 KVP_EASYNC = -5
@@ -206,7 +230,7 @@ def observed_attention_score(attentions: torch.Tensor, num_kv_heads: int) -> tor
     assert Hq % num_kv_heads == 0, (a.shape, num_kv_heads)
     out = torch.empty((B, num_kv_heads, S), dtype=torch.float32, device=a.device)
     with _on_device(a.device):
-        _check(lib().kvp_observed_attention_score(_p(a), _st(a, 0), _st(a, 1), _st(a, 2), _DTYPES[a.dtype], B, Hq, num_kv_heads, Sq, S,
+        _check(contrib_lib().kvp_observed_attention_score(_p(a), _st(a, 0), _st(a, 1), _st(a, 2), _DTYPES[a.dtype], B, Hq, num_kv_heads, Sq, S,
                                                   _p(out), _stream(a)), "kvp_observed_attention_score")
     return out
 
@@ -219,7 +243,7 @@ def lagkv_score(keys: torch.Tensor, values: torch.Tensor, n_sink: int, lag_size:
     B, H, S, D = keys.shape
     out = torch.empty((B, H, S), dtype=torch.float32, device=keys.device)
     with _on_device(keys.device):
-        _check(lib().kvp_lagkv_score(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _p(values), _st(values, 0), _st(values, 1),
+        _check(contrib_lib().kvp_lagkv_score(_p(keys), _st(keys, 0), _st(keys, 1), _st(keys, 2), _p(values), _st(values, 0), _st(values, 1),
                                      _st(values, 2), _DTYPES[keys.dtype], B, H, S, D, int(n_sink), int(lag_size), int(bool(cross_scoring)),
                                      _p(out), _stream(keys)), "kvp_lagkv_score")
     return out
@@ -236,9 +260,9 @@ def think_channel_scores(q_win: torch.Tensor, keys: torch.Tensor) -> torch.Tenso
     assert B == Bk and D == Dk and Hq % Hkv == 0, (q_win.shape, keys.shape)
     out = torch.empty((B, Hkv, D), dtype=torch.float32, device=keys.device)
     with _on_device(keys.device):
-        nws = lib().kvp_think_workspace_bytes(B, Hkv, S, D)
+        nws = contrib_lib().kvp_think_workspace_bytes(B, Hkv, S, D)
         ws = _ws(nws, keys)
-        _check(lib().kvp_think_channel_scores(_p(q_win), _st(q_win, 0), _st(q_win, 1), _st(q_win, 2), _p(keys), _st(keys, 0), _st(keys, 1),
+        _check(contrib_lib().kvp_think_channel_scores(_p(q_win), _st(q_win, 0), _st(q_win, 1), _st(q_win, 2), _p(keys), _st(keys, 0), _st(keys, 1),
                                               _st(keys, 2), _DTYPES[keys.dtype], B, Hq, Hkv, S, W, D, _p(out), _p(ws), ws.numel(), _stream(keys)),
                "kvp_think_channel_scores")
     return out
@@ -251,7 +275,7 @@ def zero_channels_(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     assert idx.is_cuda and idx.device == x.device and tuple(idx.shape[:2]) == (B, H), (idx.shape, x.shape)
     idx = idx.to(torch.int32).contiguous()
     with _on_device(x.device):
-        _check(lib().kvp_zero_channels(_p(x), _st(x, 0), _st(x, 1), _st(x, 2), _DTYPES[x.dtype], B, H, S, D, _p(idx), idx.shape[2], _stream(x)),
+        _check(contrib_lib().kvp_zero_channels(_p(x), _st(x, 0), _st(x, 1), _st(x, 2), _DTYPES[x.dtype], B, H, S, D, _p(idx), idx.shape[2], _stream(x)),
                "kvp_zero_channels")
     return x
 

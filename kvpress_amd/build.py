@@ -21,6 +21,10 @@ LIB = os.path.join(LIBDIR, "libkvpress_hip.so")
 # cluster select can be made to arrive late at its barrier: tests/test_gpu_cluster_failure.py loads it in a child process through
 # KVPRESS_HIP_LIB).  The product library carries no test hooks.
 FAULT_LIB = os.path.join(LIBDIR, "libkvpress_hip_faultinject.so")
+# Kernels of the presses OUTSIDE SURVEY section 8 (kvpress_amd.contrib: LagKV, ThinK, ObservedAttention; csrc/contrib/*.hip,
+# include/kvpress_hip_extra.h): their own shared library, linked against the product library for its error / launch plumbing.
+CONTRIB_LIB = os.path.join(LIBDIR, "libkvpress_hip_contrib.so")
+CONTRIB_SRC = os.path.join(CSRC, "contrib")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -44,6 +48,10 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def contrib_sources():
+    return sorted(os.path.join(CONTRIB_SRC, f) for f in os.listdir(CONTRIB_SRC) if f.endswith(".hip"))
+
+
 def _deps():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
@@ -51,10 +59,10 @@ def _deps():
 
 
 def up_to_date() -> bool:
-    if not os.path.exists(LIB) or not os.path.exists(FAULT_LIB):
+    if not os.path.exists(LIB) or not os.path.exists(FAULT_LIB) or not os.path.exists(CONTRIB_LIB):
         return False
-    t = min(os.path.getmtime(LIB), os.path.getmtime(FAULT_LIB))
-    return all(os.path.getmtime(p) <= t for p in sources() + _deps() + [os.path.abspath(__file__)])
+    t = min(os.path.getmtime(LIB), os.path.getmtime(FAULT_LIB), os.path.getmtime(CONTRIB_LIB))
+    return all(os.path.getmtime(p) <= t for p in sources() + contrib_sources() + _deps() + [os.path.abspath(__file__)])
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -66,7 +74,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hdr_t = max(os.path.getmtime(p) for p in _deps())
 
     def compile_one(src):
-        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(OBJDIR, ("contrib_" if os.path.dirname(src) == CONTRIB_SRC else "") + os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
             return obj
         cmd = [hipcc, *flags_for(src), "-c", src, "-o", obj]
@@ -80,7 +88,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
-        objs = list(ex.map(compile_one, sources()))
+        all_objs = list(ex.map(compile_one, sources() + contrib_sources()))
+    objs, cobjs = all_objs[:len(sources())], all_objs[len(sources()):]
     cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -88,6 +97,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     os.replace(LIB + ".tmp", LIB)
+    # the out-of-scope presses' kernels: resolved against the product library next to it ($ORIGIN)
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", CONTRIB_LIB + ".tmp", *cobjs,
+           "-L" + LIBDIR, "-l:libkvpress_hip.so", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed (contrib):\n{r.stdout}\n{r.stderr}")
+    os.replace(CONTRIB_LIB + ".tmp", CONTRIB_LIB)
     # the fault-injection twin (tests only)
     src = os.path.join(CSRC, "topk_cluster.hip")
     fobj = os.path.join(OBJDIR, "topk_cluster.faultinject.obj")

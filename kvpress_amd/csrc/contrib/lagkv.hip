@@ -13,7 +13,8 @@
 // min / max of the reference partition in registers -> LDS, two-pass standard deviation in registers, softmax and ranking
 // over the <= 1024 tokens of the partition in LDS.  K and V are each read twice (as reference and as data): HBM / L2 bound.
 // Ranks are exact integers; equal scores rank by position (torch.argsort leaves their order open).
-#include "kvp_common.h"
+#include "../kvp_common.h"
+#include "../../../include/kvpress_hip_extra.h"
 
 namespace {
 

@@ -5,7 +5,8 @@
 // HBM-bound column sums over a B*Hq*Sq*S matrix that the eager attention has just written: one thread per (b, h, column),
 // consecutive threads on consecutive columns (coalesced rows), four independent accumulators per thread over the query
 // rows; fp32 sums in a fixed order (no float atomics: deterministic).
-#include "kvp_common.h"
+#include "../kvp_common.h"
+#include "../../../include/kvpress_hip_extra.h"
 
 namespace {
 

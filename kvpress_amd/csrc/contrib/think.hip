@@ -5,7 +5,8 @@
 //
 // Both are single streaming passes over K (HBM-bound): column sums of squares per (b, h) through per-workgroup partials
 // (fixed summation order, no float atomics), and a masked rewrite of the rows that carry a pruned channel.
-#include "kvp_common.h"
+#include "../kvp_common.h"
+#include "../../../include/kvpress_hip_extra.h"
 
 namespace {
 

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void ea_qstats_combine(const float* __restrict
 
 // Partials per head: about two workgroups per CU over all heads (32 heads: 16 chunks of 8192 rows), at least 4096 rows each.  Fewer
 // partials are less to write, re-read and merge (32 per head: 67 MB), and a workgroup that walks more consecutive rows keeps its ring full
-// for longer; below one workgroup per CU the stream starves.  Inside the ExpectedAttention bench loop (scripts/ab_bench.sh,
+// for longer; below one workgroup per CU the stream starves.  Inside the ExpectedAttention bench loop (round 3 A/B, record
 // profiles/r03_ab_bench.txt; statistics + combine, streaming loads): 32 per head 207 + 23 us, 16: 175 + 13, 8: 207 + 10.
 void qstats_plan(int64_t Sq, int64_t nbh, uint32_t& nchunk, uint32_t& rows) {
     const int64_t target = std::max<int64_t>(1, 512 / std::max<int64_t>(1, nbh));

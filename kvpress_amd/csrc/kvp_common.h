@@ -7,7 +7,7 @@
 #include <algorithm>
 
 #include "../../include/kvpress_hip.h"
-#include "../../include/kvpress_hip_extra.h"
+#include "../../include/kvpress_hip_lab.h"
 
 // ---- error reporting (thread-local last message; defined in capi.hip) ------------------------
 void kvp_set_error(const char* fmt, ...);

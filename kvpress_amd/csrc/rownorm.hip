@@ -190,7 +190,7 @@ __global__ __launch_bounds__(RN_THREADS) void rownorm_scalar_kernel(
 
 // Streaming (non-temporal) loads for a tensor that is read ONCE on this path and cannot stay in the 256 MiB memory-side cache anyway (the
 // cutoff of kvp_gather_kv).  Whether that pays is decided by what runs next, so the caller says so (`read_once`), measured inside the
-// bench loops (scripts/ab_bench.sh, profiles/r03_ab_bench.txt): ExpectedAttention's ||V|| 58 -> 47 us, CUR's two energies 105 -> 91 us
+// bench loops (round 3 A/B of the bench loops, record: profiles/r03_ab_bench.txt; the script that made it was retired with the knobs in round 5): ExpectedAttention's ||V|| 58 -> 47 us, CUR's two energies 105 -> 91 us
 // (its gather + 7); but the stand-alone K norm of a press whose gather re-reads the kept K rows right after (Knorm through
 // KeyRerotationPress) LOSES 14 us when the stream leaves nothing of K behind -- kvp_rownorm_score stays cached.
 bool rn_streaming(uint64_t bytes, bool read_once) { return read_once && bytes > (192ull << 20); }

@@ -550,6 +550,9 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
     KVP_CHECK_ARG(row_stride >= S && idx_stride >= k + tail_n, "topk: row_stride %ld < S %ld or idx_stride %ld too small", (long)row_stride,
                   (long)S, (long)idx_stride);
     const int64_t nchunks = (S + TK_CHUNK - 1) / TK_CHUNK;
+    // the device-side layout is computed in 32-bit words (topk_ws_layout): refuse shapes whose workspace does not fit it
+    KVP_CHECK_ARG(topk_ws_total_words64((uint64_t)R, (uint64_t)std::max<int64_t>(nchunks, TC_SLOTS)) < ((uint64_t)1 << 32),
+                  "topk: R=%ld x S=%ld needs a workspace beyond 16 GiB (32-bit word offsets)", (long)R, (long)S);
     TopkWs w = topk_carve_ws(ws, R, nchunks);
     w.kmask = smallest ? 0xFFFFFFFFu : 0u;  // the k SMALLEST = the k largest of the complemented order-preserving keys
     if (k == S || k == 0) {  // every position / only the tail is kept: no selection needed

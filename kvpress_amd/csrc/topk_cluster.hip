@@ -1,7 +1,7 @@
 // Cluster select: the whole radix select of long score rows (16384 < S <= 262144) in ONE launch.
 // Replaces `scores.topk(n_kept, dim=-1).indices` (kvpress/presses/scorer_press.py:95); an exact radix select on the
 // order-preserving key with the same tie rule (lowest position first), hence the same indices as the (chunk, row) passes of
-// topk.hip, which stay as the fallback (devices with fewer than 256 CUs, rows beyond 262144 scores, more than 8 rows; KVP_TK_CLUSTER=0
+// topk.hip, which stay as the fallback (devices with fewer than 256 CUs, rows beyond 262144 scores, more than 32 rows; KVP_TK_CLUSTER=0
 // selects them on any device).
 //
 // Structure.  The (chunk, row) passes are chains of dependent launches over an L2-resident row: load the keys, count a digit,
@@ -18,13 +18,13 @@
 //     the scorer already accumulated the first digit (HIST1), and whenever the two-hop form DECLINES: the threshold lies outside the
 //     sample's bracket (k at an extreme of the row) or a slot has more candidates than its record holds (rows of few distinct
 //     values).  Every workgroup of the row takes that decision from the same words, so all of them switch together.
-// 256 workgroups = 8 clusters; a row's 32 workgroups are CONSECUTIVE blocks
+// 256 resident workgroups = 8 clusters (a launch may carry up to 32: batches > 1); a row's 32 workgroups are CONSECUTIVE blocks
 // (block / 32 = cluster), i.e. spread over all XCDs -- measured, a hop costs the same ~0.8 us round trip from anywhere
 // (profiles/r03_select_cluster_lab.txt), and consecutive blocks make partial residency harmless (see the kernel).  Correctness is
 // placement-independent: every word another workgroup reads -- the row histograms, the candidate records, the per-slot suffix
 // tables, the counter -- is written AND read with agent-scope (sc1) atomics / loads / stores, every wave drains its vector-memory
 // counter before the arrival, no fences, nothing relies on two workgroups sharing an L2 (cdna_hip_programming.md
-// Guideline 16, the "agent atomics on both sides" form).  One launch selects up to 8 rows; more rows take the (chunk, row) passes.
+// Guideline 16, the "agent atomics on both sides" form).  One launch selects up to 32 rows (8 resident at a time); more take the (chunk, row) passes.
 //
 // Failure is LOUD (torch.topk cannot return wrong indices silently, scorer_press.py:95).  The barrier spins are bounded
 // (KVP_TC_TIMEOUT_US, default 1 s) so that a cluster that never becomes co-resident cannot hang the GPU; a spin that times out
@@ -74,7 +74,7 @@ __device__ __forceinline__ void tc_report(const ClusterSync& cs, uint32_t code) 
 // Arrive at / wait for the cluster's next barrier.  Every wave first drains its own agent-scope stores and atomics
 // (they are what the other workgroups read after the barrier).  A spin that times out REPORTS it -- the cluster's flag (read by
 // every workgroup of the cluster before it writes indices: see the poison path of the kernel) and the host's status word -- and
-// goes on, so that every workgroup still makes all its arrivals and the counter stays a multiple of TC_SLOTS.
+// goes on, so that every workgroup that reaches a barrier still makes all its arrivals.
 __device__ __forceinline__ void cluster_barrier(const ClusterSync& cs, uint32_t code, uint32_t* lds_gave_up, bool first) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -91,8 +91,15 @@ __device__ __forceinline__ void cluster_barrier(const ClusterSync& cs, uint32_t 
         const uint32_t target = (old & ~(uint32_t)(TC_SLOTS - 1)) + TC_SLOTS;
         if ((int32_t)(tc_ld(cs.ctr) - target) < 0) {
             const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-            while ((int32_t)(tc_ld(cs.ctr) - target) < 0) {
+            for (uint32_t it = 1; (int32_t)(tc_ld(cs.ctr) - target) < 0; ++it) {
                 __builtin_amdgcn_s_sleep(1);
+                // A sibling that gave up BEFORE it reached this barrier (a polled round that timed out) never arrives here: its report is
+                // in the cluster's flag, looked at every 32 spins (~25 us), so that the others end now instead of after the full timeout
+                // (the counter is then off by its missing arrivals -- a failed workspace has to be zero-filled anyway).
+                if ((it & 31u) == 0u && tc_ld(cs.cl_flag) != 0u) {
+                    *lds_gave_up = code;
+                    break;
+                }
                 if (__builtin_amdgcn_s_memrealtime() - t0 > cs.timeout_ticks) {  // the cluster is not co-resident: give up, loudly
                     *lds_gave_up = code;
                     tc_report(cs, code);
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
     const uint32_t p0 = slot * L + threadIdx.x * PER;   // this thread's PER consecutive positions
 
     // (one row per cluster and launch: a row loop in here makes the compiler hoist every thread-index comparison of the body
-    // into lane masks that overflow the scalar register file; the host launches once per 8 rows instead)
+    // into lane masks that overflow the scalar register file; more rows = more clusters in the launch instead)
     const uint32_t row = a.row_base + cluster;
     if (row >= a.R) return;
     {
@@ -534,8 +541,8 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
             uint32_t d1 = res2[0], k1 = res2[1];
             d1 = tc_uni(d1);
             k1 = tc_uni(k1);
-            // (a poll that gave up: straight to the poison branch -- the workgroups that did see the complete histogram time out at
-            // the candidates' barrier, which this one never reaches, and end there too)
+            // (a poll that gave up: straight to the poison branch -- the workgroups that did see the complete histogram find this one's
+            // report in the cluster's flag while they spin at the candidates' barrier, which this one never reaches, and end there too)
             if (tc_uni(s_fail[0]) != 0) {
                 done = true;
             } else if (d1 >= 1u && d1 <= (uint32_t)(TC_WB - 2)) {
@@ -787,7 +794,7 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
 #ifdef KVP_TC_FAULT_INJECTION
         // test twin only (tests/_fault_child.py "paths"): which form finished this (cluster, slot) -- 2 = two-hop, 1 = three rounds --
         // in the spare words behind the barrier lines
-        if (threadIdx.x == 0) tc_st(&TCW(bar)[TC_CLUSTERS * 32 + 32 + slot * 16 + cluster], done ? 2u : 1u);
+        if (threadIdx.x == 0) tc_st(&TCW(bar)[TC_MAXC * 32 + 32 + slot * 32 + cluster], done ? 2u : 1u);
 #endif
         // self-cleaning: the window histogram is dead -- every workgroup of the row searched its COMPLETE state before it arrived at
         // the barrier(s) this workgroup has passed since (the candidates' barrier, or barriers 2 and 3 of the three-round form)
@@ -837,9 +844,12 @@ int launch_one(const ClusterArgs& a, hipStream_t stream) {
 #ifdef KVP_TC_FAULT_INJECTION
     b.test_delay_slot = kvp_env_int("KVP_TC_TEST_DELAY_SLOT", -1);
 #endif
-    for (b.row_base = 0; b.row_base < b.R; b.row_base += TC_CLUSTERS) {
+    // one launch carries up to TC_MAXC rows: TC_CLUSTERS clusters fit the device at once, the others start in dispatch order as the
+    // first retire (a row's workgroups are consecutive blocks: see the kernel)
+    for (b.row_base = 0; b.row_base < b.R; b.row_base += TC_MAXC) {
         b.report = kvp_async_next_seq() << 8;
-        KVP_LAUNCH("topk_cluster_kernel", stream, (topk_cluster_kernel<PER, MODE, HIST1><<<TC_CLUSTERS * TC_SLOTS, TR_THREADS, 0, stream>>>(b)));
+        const uint32_t nclusters = std::min<uint32_t>(b.R - b.row_base, (uint32_t)TC_MAXC);
+        KVP_LAUNCH("topk_cluster_kernel", stream, (topk_cluster_kernel<PER, MODE, HIST1><<<nclusters * TC_SLOTS, TR_THREADS, 0, stream>>>(b)));
     }
     return 0;
 }
@@ -868,11 +878,12 @@ bool topk_cluster_launchable() {
     return ok[dev] > 0;
 }
 
-// (few long rows: the structure buys latency, not throughput.  Measured on MI355X, profiles/r03_select_cluster_lab.txt: 8 x 131008
-// flat scores 22.5 us = the four (chunk, row) launches; 1 row 18 against 24 us; 16 rows (two launches) 44 against 29 us -- so up to
-// 8 rows.  What it saves is SnapKV's pooling launch (POOL5 loader: -3 us per compress) and Knorm's score round trip.)
+// (few long rows: the structure buys latency, not throughput.  Round 3, three-round form, profiles/r03_select_cluster_lab.txt: 8 x 131008
+// flat scores 22.5 us = the four (chunk, row) launches; 1 row 18 against 24 us; 16 rows (two launches) 44 against 29 us -- hence 8 rows
+// then.  Round 6: with the two-hop form (13.6 us per 8 rows) and all rows in ONE launch, batches of 2 - 4 elements (R = 16 .. 32) take
+// it too: what it saves there is SnapKV's pooling launch / score round trip (POOL5 loader) and Knorm's norms never leaving the chip.)
 bool topk_cluster_eligible(int64_t R, int64_t S) {
-    return R <= TC_CLUSTERS && S > 16384 && S <= (int64_t)TC_SLOTS * TR_THREADS * 8 && kvp_env_int("KVP_TK_CLUSTER", 1) != 0;
+    return R <= TC_MAXC && S > 16384 && S <= (int64_t)TC_SLOTS * TR_THREADS * 8 && kvp_env_int("KVP_TK_CLUSTER", 1) != 0;
 }
 
 // returns KVP_OK, an error, or 1 = "not launched" (the device cannot hold the grid: the caller takes the (chunk, row) passes)

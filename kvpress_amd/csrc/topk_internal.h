@@ -12,8 +12,11 @@ constexpr int TK_PER = KVP_TK_PER;
 // workgroups beat few large ones (8 x 131072, last two passes: 8.2 + 7.6 us with 4 scores per thread, 9.6 + 8.2 with 8,
 // 11.0 + 9.1 with 16)
 constexpr int TK_CHUNK = TK_THREADS * TK_PER;
-// cluster select (topk_cluster.hip): TC_CLUSTERS row clusters of TC_SLOTS workgroups each, one launch per select
+// cluster select (topk_cluster.hip): one row cluster of TC_SLOTS workgroups per row, one launch per select.  TC_CLUSTERS clusters (256
+// workgroups, one per CU) are resident at once; a launch carries up to TC_MAXC of them (round 6: rows 9 .. 32 of a batch > 1 ride in
+// the same launch and become resident in dispatch order as the first clusters retire).
 constexpr int TC_CLUSTERS = 8;
+constexpr int TC_MAXC = 32;
 constexpr int TC_SLOTS = 32;
 // two-hop form of the cluster select (topk_cluster.hip): bins of the sample-steered first digit, words per candidate record
 constexpr int TC_WB = 256;
@@ -23,10 +26,11 @@ struct TopkWs {
     uint32_t* hist1;       // [R][4096]
     uint32_t* hist2;       // [R][4096]
     uint32_t* hist3;       // [R][256]
-    uint32_t* bar;         // [TC_CLUSTERS][32] cluster select, one 128-byte line per row cluster: [0] its monotonic arrival counter,
+    uint32_t* bar;         // [TC_MAXC][32] cluster select, one 128-byte line per row cluster: [0] its monotonic arrival counter,
                            // [1] its give-up code (0 = none; persistent until the workspace is zero-filled again)
     uint32_t* histw;       // [R][TC_WB] cluster select: histogram of the sample-steered window digit (zeroed region, self-cleaning)
     uint32_t* cand;        // [R][TC_SLOTS][TC_REC] cluster select: per-slot candidate records (count, keys above the bin, candidate keys)
+                           // (both only for row counts the cluster select takes: topk_ws_has_cluster)
     uint32_t* sel;         // [R][4] : b1, k1, b2, k2
     uint32_t* chunk_hist;  // [R][nchunks][257] suffix counts of the last digit: [d] = #(digit >= d), [256] = 0
     uint32_t* chunk_gt;    // [R][nchunks]
@@ -44,6 +48,17 @@ struct TopkWsLayout {
     uint32_t hist1, hist2, hist3, bar, histw, sel, chunk_hist, chunk_gt, cand;
     uint32_t zero_words, total_words;
 };
+// the cluster select's own regions (window histograms, candidate records) exist only for row counts it can run on: the segmented /
+// per-chunk selects hand over thousands of short rows and would zero-fill and carry them for nothing.  A function of R
+// alone: the leading zero-filled part of the layout must not depend on the row length (compress.hip sizes it before it knows ntab).
+__host__ __device__ inline bool topk_ws_has_cluster(uint32_t R) { return R <= (uint32_t)TC_MAXC; }
+// the layout in 64-bit arithmetic: the same regions as topk_ws_layout below, only the total (host side: size queries, range check)
+inline uint64_t topk_ws_total_words64(uint64_t R, uint64_t ntab) {
+    auto up = [](uint64_t w) { return (w + 63u) / 64u * 64u; };
+    const bool cl = R <= (uint64_t)TC_MAXC;
+    return 2 * up(R * 4096u) + up(R * 256u) + up((uint64_t)(TC_MAXC * 32 + 32 + TC_SLOTS * 32)) + (cl ? up(R * TC_WB) : 0) + up(R * 4u) +
+           up(R * ntab * 257u) + up(R * ntab) + (cl ? up(R * (uint64_t)(TC_SLOTS * TC_REC)) : 0);
+}
 __host__ __device__ inline TopkWsLayout topk_ws_layout(uint32_t R, uint32_t ntab) {
     TopkWsLayout l;
     uint32_t off = 0;
@@ -52,17 +67,18 @@ __host__ __device__ inline TopkWsLayout topk_ws_layout(uint32_t R, uint32_t ntab
         off += (words + 63u) / 64u * 64u;
         return at;
     };
+    const bool cl = topk_ws_has_cluster(R);
     l.hist1 = take(R * 4096u);
     l.hist2 = take(R * 4096u);
     l.hist3 = take(R * 256u);
-    l.bar = take((uint32_t)(TC_CLUSTERS * 32 + 32 + TC_SLOTS * 16));   // (the tail is room for the phase stamps of tools/make_tc_timing.py's lab build)
-    l.histw = take(R * (uint32_t)TC_WB);
+    l.bar = take((uint32_t)(TC_MAXC * 32 + 32 + TC_SLOTS * 32));   // (the tail: form markers of the test twin / phase stamps of tools/make_tc_timing.py's lab build)
+    l.histw = take(cl ? R * (uint32_t)TC_WB : 0u);
     l.zero_words = off;
     l.sel = take(R * 4u);
     // per-chunk tables: the (chunk, row) passes index them by 1024-score chunk, the cluster select by its TC_SLOTS slots
     l.chunk_hist = take(R * ntab * 257u);
     l.chunk_gt = take(R * ntab);
-    l.cand = take(R * (uint32_t)(TC_SLOTS * TC_REC));
+    l.cand = take(cl ? R * (uint32_t)(TC_SLOTS * TC_REC) : 0u);
     l.total_words = off;
     return l;
 }
@@ -70,6 +86,7 @@ __host__ __device__ inline TopkWsLayout topk_ws_layout(uint32_t R, uint32_t ntab
 inline TopkWs topk_carve_ws(void* ws, int64_t R, int64_t nchunks) {
     TopkWs w;
     const uint32_t ntab = (uint32_t)std::max<int64_t>(nchunks, TC_SLOTS);
+    // (callers check topk_ws_total_words64(R, ntab) < 2^32 before they LAUNCH on a carved workspace: topk_select_impl)
     const TopkWsLayout l = topk_ws_layout((uint32_t)R, ntab);
     uint32_t* base = static_cast<uint32_t*>(ws);
     auto at = [&](uint32_t words) { return base ? base + words : nullptr; };
@@ -83,7 +100,7 @@ inline TopkWs topk_carve_ws(void* ws, int64_t R, int64_t nchunks) {
     w.chunk_hist = at(l.chunk_hist);
     w.chunk_gt = at(l.chunk_gt);
     w.cand = at(l.cand);
-    w.total_bytes = (size_t)l.total_words * 4;
+    w.total_bytes = (size_t)topk_ws_total_words64((uint64_t)R, ntab) * 4;   // 64-bit: a size query never wraps
     w.kmask = 0;
     w.base = base;
     w.lay_R = (uint32_t)R;
@@ -130,7 +147,7 @@ int topk_select_impl(const float* scores, int64_t R, int64_t S, int64_t row_stri
                      hipStream_t stream, uint32_t nseg = 1, uint32_t seg_len = 0, uint32_t pos_base = 0, bool smallest = false);
 // S this short: one launch, one workgroup per row, no workspace
 bool topk_row_eligible(int64_t S);
-// Cluster select (topk_cluster.hip): the whole select of up to 8 rows of 16385 .. 262144 scores in ONE launch.  mode: where the keys
+// Cluster select (topk_cluster.hip): the whole select of up to 32 rows of 16385 .. 262144 scores in ONE launch (8 rows resident at once).  mode: where the keys
 // come from -- the score rows, SnapKV's un-pooled column sums (avg_pool1d of width 5 + scale `inv` in the loader), or
 // -||x[b,h,s,:]|| computed from 256-byte rows of a 2-byte dtype (fused Knorm compress).  Returns KVP_OK, an error code, or
 // 1 = not launched (the device cannot hold the 256 workgroups at once): the caller falls back to the (chunk, row) passes.

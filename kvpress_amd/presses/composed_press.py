@@ -27,14 +27,13 @@ class ComposedPress(BasePress):
         self._order_checked = False
 
     def _check_kept_order(self):
-        # once per ComposedPress, at its first hook call (ratios / kept_order may be set after construction): an order-dependent press
-        # behind a position-ordered ScorerPress diverges from the reference (scorer_press.warn_if_chain_depends_on_kept_order)
-        from kvpress_amd.presses.scorer_press import warn_if_chain_depends_on_kept_order
+        # once per ComposedPress, at its first hook call (ratios / kept_order may be set after construction): a ScorerPress in front
+        # of an order-dependent press hands over its survivors in the reference's order (scorer_press.resolve_chain_kept_order)
+        from kvpress_amd.presses.scorer_press import resolve_chain_kept_order
 
         self._order_checked = True
         for i, press in enumerate(self.presses[:-1]):
-            if warn_if_chain_depends_on_kept_order(press, self.presses[i + 1:], "ComposedPress"):
-                break
+            resolve_chain_kept_order(press, self.presses[i + 1:], "ComposedPress")
 
     def post_init_from_model(self, model):
         for press in self.presses:

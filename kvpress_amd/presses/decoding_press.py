@@ -200,12 +200,11 @@ class PrefillDecodingPress(BasePress):
 
     def forward_hook(self, module: nn.Module, input: list[torch.Tensor], kwargs: dict, output: list):
         if not getattr(self, "_order_checked", False) and self.prefilling_press is not None and self.decoding_press is not None:
-            # the decoding press works on what the prefill press left: order-dependent scorers see position order here, score order in
-            # the reference, unless the prefill press has kept_order = "score"
-            from kvpress_amd.presses.scorer_press import warn_if_chain_depends_on_kept_order
+            # the decoding press works on what the prefill press left: an order-dependent one must see the reference's score order
+            from kvpress_amd.presses.scorer_press import resolve_chain_kept_order
 
             self._order_checked = True
-            warn_if_chain_depends_on_kept_order(self.prefilling_press, [self.decoding_press], "PrefillDecodingPress")
+            resolve_chain_kept_order(self.prefilling_press, [self.decoding_press], "PrefillDecodingPress")
         press = self._phase_press(_kv_len(kwargs["past_key_values"], module.layer_idx), kwargs["hidden_states"].shape[1])
         return output if press is None else press.forward_hook(module, input, kwargs, output)
 

@@ -14,10 +14,11 @@ Defined deviations (DESIGN.md "Parity contract"):
     score order, which no reference test observes.  CONSEQUENCE for chains: a position-dependent press running AFTER a
     ScorerPress on the already-pruned cache (ComposedPress([Knorm, SnapKV / StreamingLLM / ExpectedAttention]),
     PrefillDecodingPress with such a decoding press) sees the survivors in position order here and in score order in the
-    reference, so its "last W tokens" / sinks are different tokens: such chains are NOT reference-equivalent by default.
+    reference, so its "last W tokens" / sinks would be different tokens.
     ``kept_order = "score"`` (class attribute, settable per instance) stores the survivors in the reference's order
-    (descending score, ties by position: ``KVP_ORDER_SCORE``) for reference-exact chaining; pinned by
-    tests/test_host_hook.py::test_kept_order_switch.
+    (descending score, ties by position: ``KVP_ORDER_SCORE``); pinned by tests/test_host_hook.py::test_kept_order_switch.
+    ComposedPress / PrefillDecodingPress switch the earlier presses of such a chain to it automatically (round 6:
+    ``resolve_chain_kept_order``), so chains ARE reference-equivalent unless an instance was explicitly set to "position".
 """
 from __future__ import annotations
 
@@ -31,9 +32,6 @@ from kvpress_amd import _native
 from kvpress_amd.presses.base_press import BasePress
 
 logger = logging.getLogger(__name__)
-
-_ORDER_WARNED = False
-
 
 def _wrapped(press):
     """`press` and every press it wraps (ChunkPress.press, DecodingPress.base_press, ComposedPress.presses, ...)"""
@@ -49,32 +47,45 @@ def _wrapped(press):
     return out
 
 
-def warn_if_chain_depends_on_kept_order(first, later, where: str) -> bool:
-    """One-time ``logger.warning`` when a press that looks at token ORDER (anything but the order-blind row scorers Knorm / KeyDiff /
-    QFilter / CUR-without-sinks is treated as order-dependent: "last W tokens", sinks, chunks, re-rotation, recency) runs on a cache that
-    an earlier ScorerPress pruned with ``kept_order = "position"``: the reference hands that press the survivors in descending SCORE
-    order (scorer_press.py:95-100), this package in ascending position order, so the chain keeps different tokens than the reference
-    unless ``kept_order = "score"`` is set on the earlier press (composed_press.py:56-62).  Returns whether the
-    situation was detected (tests)."""
-    global _ORDER_WARNED
+def _order_blind(p) -> bool:
+    """row scorers whose result does not depend on where a token sits in the (already pruned) cache"""
+    from kvpress_amd.presses.cur_press import CURPress
     from kvpress_amd.presses.keydiff_press import KeyDiffPress
     from kvpress_amd.presses.knorm_press import KnormPress
     from kvpress_amd.presses.qfilter_press import QFilterPress
 
-    order_blind = (KnormPress, KeyDiffPress, QFilterPress)
+    if isinstance(p, CURPress):     # sinks and the local normalisation windows are positional
+        return p.num_sinks == 0 and not (p.use_local_approximation and p.local_window_size)
+    return isinstance(p, (KnormPress, KeyDiffPress, QFilterPress))
+
+
+def resolve_chain_kept_order(first, later, where: str):
+    """A press that looks at token ORDER ("last W tokens", sinks, chunks, re-rotation, recency: anything but the order-blind row scorers
+    Knorm / KeyDiff / QFilter / CUR without sinks and windows) running on a cache that an earlier ScorerPress has pruned sees the
+    survivors in descending SCORE order in the reference (scorer_press.py:95-100; composed_press.py:56-62).  This package's default is
+    ascending position order, so such a chain would keep different tokens.  Round 6: the chain makes
+    itself reference-identical -- every earlier ScorerPress whose ``kept_order`` was not set on the INSTANCE is switched to "score" (the
+    fused score-order path, +14 % on that press only) and an info line says so; an instance the user explicitly set to "position" is
+    respected and gets a warning per chain object (not per process).  Returns "switched", "warned" or None (tests)."""
     pruners = [p for p in _wrapped(first) if isinstance(p, ScorerPress) and p.kept_order == "position" and p.compression_ratio != 0]
     dependents = [p for q in later for p in _wrapped(q)]
-    dependents = [p for p in dependents if not isinstance(p, order_blind) and type(p).__name__ not in ("ComposedPress", "PerLayerCompressionPress", "DecodingPress")]
+    dependents = [p for p in dependents if not _order_blind(p) and type(p).__name__ not in ("ComposedPress", "PerLayerCompressionPress", "DecodingPress")]
     if not pruners or not dependents:
-        return False
-    if not _ORDER_WARNED:
-        _ORDER_WARNED = True
+        return None
+    explicit = [p for p in pruners if "kept_order" in vars(p)]
+    for p in pruners:
+        if "kept_order" not in vars(p):
+            p.kept_order = "score"
+    if explicit:
         logger.warning(
-            "%s: %s runs on a cache that %s has already pruned with kept_order='position' (survivors in ascending position order). The "
-            "reference stores them in descending score order, so this order-dependent press sees different 'last' / 'first' tokens than "
-            "in NVIDIA/kvpress; set kept_order='score' on the earlier press for reference-identical chains. (Shown once.)",
-            where, type(dependents[0]).__name__, type(pruners[0]).__name__)
-    return True
+            "%s: %s runs on a cache that %s has already pruned with kept_order='position' (set on the instance: survivors in ascending "
+            "position order). The reference stores them in descending score order, so this order-dependent press sees different 'last' / "
+            "'first' tokens than in NVIDIA/kvpress; set kept_order='score' (or leave it unset) for reference-identical chains.",
+            where, type(dependents[0]).__name__, type(explicit[0]).__name__)
+        return "warned"
+    logger.info("%s: %s now keeps its survivors in the reference's order (kept_order='score'): %s behind it depends on token order.",
+                where, type(pruners[0]).__name__, type(dependents[0]).__name__)
+    return "switched"
 
 
 @dataclass

@@ -86,5 +86,58 @@ def main(argv):
               f"{[float(out[f'gap_{i}'].min()) for i in range(len(ratios))]}")
 
 
+# ---- chains (round 6): an order-dependent press behind a ScorerPress -----------------------------------------------------------------
+# composed_press.py:56-62 runs the presses' hooks one after the other on the SAME cache layer, so the second press sees the survivors of
+# the first in `scores.topk` order (descending score).  The fixtures hold the reference's final K' / V' after p1.compress -> p2.compress
+# (float32 mode) for one chain with an exactly defined result (Knorm -> StreamingLLM: sinks + most recent OF THE SCORE-ORDERED cache) and
+# one with a float score in the second stage (Knorm -> SnapKV: the window are the last W rows of the score-ordered cache), with the
+# relative gap of the second stage's scores at its threshold.  Row order inside the result: the second stage's topk order, which for
+# StreamingLLM's 0/1 scores is a pure tie (unspecified by torch) -- the tests compare the rows as SETS per (batch, head).
+CHAIN_CASES = {
+    "chain_kn_stream": ("kn_tiny_d6", 0.25, ("StreamingLLMPress", dict(compression_ratio=0.5, n_sink=3))),
+    "chain_kn_snap": ("sk_257_A", 0.25, ("SnapKVPress", dict(compression_ratio=0.5))),
+}
+
+
+def main_chains():
+    from gen_golden import _install_shims
+
+    _install_shims()
+    import numpy as np
+    import torch
+    import kvpress as K  # the reference
+
+    import _inputs
+
+    outdir = os.path.join(REPO, "tests", "golden")
+    for cname, (case, r1, (p2name, p2kw)) in CHAIN_CASES.items():
+        s = _inputs.make_case(case)
+        att, rot, hidden, pe = _inputs.build_llama_attention(s, torch.float32)
+        keys = torch.from_numpy(s["keys"]).float()
+        values = torch.from_numpy(s["values"]).float()
+        kwargs = {"position_embeddings": pe}
+        if p2name == "SnapKVPress":
+            p2kw = dict(p2kw, window_size=s["W"], kernel_size=s["ks"])
+        p1, p2 = K.KnormPress(compression_ratio=r1), getattr(K, p2name)(**p2kw)
+        with torch.no_grad():
+            k1, v1 = p1.compress(att, hidden, keys, values, None, kwargs)
+            k2, v2 = p2.compress(att, hidden, k1, v1, None, kwargs)
+            sc2 = p2.score(att, hidden, k1, v1, None, kwargs).double()
+        n2 = k2.shape[2]
+        top = sc2.topk(n2 + 1, dim=-1).values if n2 < sc2.shape[-1] else None
+        gap = ((top[..., -2] - top[..., -1]) / top[..., -2].abs().clamp_min(1e-300)).numpy() if top is not None else np.full(k2.shape[:2], np.inf)
+        dt = _inputs.torch_dtype(s["dtype"])
+        out = {"gap2": gap}
+        for nm, t_ in (("ko", k2), ("vo", v2)):
+            assert torch.equal(t_.to(dt).float(), t_)
+            out[nm] = t_.numpy().astype(np.float32) if dt == torch.float32 else t_.to(dt).view(torch.int16).numpy().view(np.uint16)
+        path = os.path.join(outdir, f"order_{cname}.npz")
+        np.savez_compressed(path, **out)
+        print(f"order_{cname}: {tuple(k2.shape)}; {os.path.getsize(path)} bytes; min gap at the second threshold {float(np.min(gap)):.3e}")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    if sys.argv[1:] == ["chains"]:
+        main_chains()
+    else:
+        main(sys.argv[1:])

@@ -142,7 +142,7 @@ def paths():
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     al = lambda x: (x + 255) // 256 * 256
-    bar_off = (2 * al(R * 4096 * 4) + al(R * 256 * 4)) // 4 + 8 * 32 + 32   # topk_ws_layout: hist1, hist2, hist3, bar (+ 8 lines + 1)
+    bar_off = (2 * al(R * 4096 * 4) + al(R * 256 * 4)) // 4 + 32 * 32 + 32   # topk_ws_layout: hist1, hist2, hist3, bar (+ TC_MAXC = 32 lines + 1)
 
     def run(x, k, flags=0):
         sc = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
@@ -153,7 +153,7 @@ def paths():
             rc = L.kvp_topk_select(P(sc), R, x.shape[1], x.shape[1], k, n.ORDER_POSITION | n.TOPK_WS_CLEAN | flags, P(idx), P(ws), nws, st)
             assert rc == 0, L.kvp_last_error()
             torch.cuda.synchronize()
-        m = ws.view(torch.int32).cpu().numpy()[bar_off:bar_off + 32 * 16].reshape(32, 16)[:, :R]
+        m = ws.view(torch.int32).cpu().numpy()[bar_off:bar_off + 32 * 32].reshape(32, 32)[:, :R]
         assert L.kvp_async_error_check() == 0
         return idx.cpu().numpy(), m
 

@@ -19,7 +19,7 @@ def lib():
     return _native.lib()
 
 
-def declared_symbols(headers=("kvpress_hip.h", "kvpress_hip_extra.h")):
+def declared_symbols(headers=("kvpress_hip.h",)):
     names = set()
     for h in headers:
         text = open(os.path.join(ROOT, "include", h)).read()
@@ -29,23 +29,60 @@ def declared_symbols(headers=("kvpress_hip.h", "kvpress_hip_extra.h")):
 
 
 def test_hot_path_boundary_has_no_out_of_scope_entry_points():
-    """include/kvpress_hip.h is SURVEY section 8's boundary; the round-1 extras (SURVEY section 2 out of scope) live in kvpress_hip_extra.h."""
+    """include/kvpress_hip.h is SURVEY section 8's boundary and nothing else: the round-1 extras (SURVEY section 2 out of scope) live in
+    kvpress_hip_extra.h and their own shared library, measurement / test aids in kvpress_hip_lab.h."""
     main = declared_symbols(("kvpress_hip.h",))
-    assert not [n for n in main if any(t in n for t in ("lagkv", "think", "observed", "rowl1", "zero_channels"))]
+    assert not [n for n in main if any(t in n for t in ("lagkv", "think", "observed", "rowl1", "zero_channels", "prof", "clock_probe", "occupy", "tuning"))]
     assert set(declared_symbols(("kvpress_hip_extra.h",))) >= {"kvp_lagkv_score", "kvp_think_channel_scores", "kvp_observed_attention_score"}
+    assert set(declared_symbols(("kvpress_hip_lab.h",))) == {"kvp_prof_enable", "kvp_prof_count", "kvp_prof_get", "kvp_clock_probe", "kvp_occupy_cus",
+                                                            "kvp_tuning_reload"}
+
+
+def test_boundary_entries_cite_the_reference():
+    """every entry of the boundary header sits under a comment that names the reference lines it replaces (file.py:line), apart from
+    the three pieces of plumbing (version, last error, asynchronous-error poll) and the *_workspace_bytes companions"""
+    text = open(os.path.join(ROOT, "include", "kvpress_hip.h")).read()
+    plumbing = {"kvp_version", "kvp_last_error", "kvp_async_error_check"}
+    last_comment, uncited = "", []
+    for m in re.finditer(r"/\*.*?\*/|\b(kvp_[a-z0-9_]+)\s*\(", text, flags=re.S):
+        if m.group(0).startswith("/*"):
+            if len(m.group(0)) > 120:     # a section comment, not an inline remark
+                last_comment = m.group(0)
+        elif m.group(1) not in plumbing and not m.group(1).endswith("_workspace_bytes"):
+            if not re.search(r"[a-z_]+\.py:\d+", last_comment):
+                uncited.append(m.group(1))
+    assert not uncited, f"boundary entries without a reference citation: {uncited}"
 
 
 def test_header_symbols_exported(lib):
+    from kvpress_amd import _native
+
     names = declared_symbols()
     assert len(names) >= 16
-    for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/kvpress_hip.h but not exported"
+    for n in names + declared_symbols(("kvpress_hip_lab.h",)):
+        assert hasattr(lib, n), f"{n} declared in include/ but not exported by libkvpress_hip.so"
+    clib = _native.contrib_lib()
+    for n in declared_symbols(("kvpress_hip_extra.h",)):
+        assert hasattr(clib, n), f"{n} declared in include/kvpress_hip_extra.h but not exported by libkvpress_hip_contrib.so"
+        assert n not in names
+
+
+def test_product_library_exports_no_contrib_kernels():
+    import subprocess
+
+    from kvpress_amd import _native
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True).stdout
+    assert "kvp_topk_select" in out
+    assert not [l for l in out.splitlines() if any(t in l for t in ("lagkv", "think", "observed_attention", "zero_channels"))]
 
 
 def test_binding_covers_header(lib):
     from kvpress_amd import _native
 
     assert sorted(_native.SIGNATURES) == declared_symbols()
+    assert sorted(_native.LAB_SIGNATURES) == declared_symbols(("kvpress_hip_lab.h",))
+    assert sorted(_native.CONTRIB_SIGNATURES) == declared_symbols(("kvpress_hip_extra.h",))
 
 
 def test_version_and_errors(lib):

@@ -1,5 +1,6 @@
 """world_size-2 test (gloo, CPU) of the multi-GPU plumbing in bench.py: batch sharding with no
 data-path collective, and the max-over-ranks step time."""
+import glob
 import os
 import socket
 import sys
@@ -234,3 +235,32 @@ def test_n_rank_line_has_the_same_shape_as_the_single_rank_line():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
                 "roofline", "cpu_baseline"):
         assert key in stub, key
+
+
+def test_roofline_block_prefers_the_profilers_durations():
+    """with a rocprofv3 kernel-trace table at hand every per-kernel number of the roofline block comes from
+    it (the HIP-event table is kept as path.kernels_us_events), `frac` follows from algorithmic bytes / that duration, the self-made
+    floor lives under path.model only, and the kernels' sum is checked against the step."""
+    import json
+
+    import bench
+
+    d = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_kernels_snapkv128k.json")))[-1]))
+    avg = {k: (v, d["launches_per_step"][k]) for k, v in d["kernels_avg_ms"].items()}
+    t_step = 0.2632e-3
+    traced = {"gather_vec_kernel": (85.29, 449), "snapkv_p1_asm": (71.75, 450), "snapkv_p2_asm": (71.27, 450), "qproj_rope_kernel": (15.47, 450),
+              "topk_cluster_kernel": (15.33, 449), "softmax_combine_kernel": (4.89, 450)}
+    rf = bench.roofline_block(avg, "snapkv128k", 1, t_step, 1, "off", traced, "live: test")
+    assert rf["kernel"] == "gather_vec_kernel" and rf["avg_launch_us"] == 85.29 and rf["timing_source"] == "live: test"
+    assert abs(rf["frac"] - 536870912 / 85.29e-6 / 8e12) < 2e-4 and abs(rf["p1_frac"] - 268435456 / 71.75e-6 / 8e12) < 2e-4
+    assert rf["path"]["kernels_us"]["gather_vec_kernel"] == 85.29 and rf["path"]["kernels_us_events"]["gather_vec_kernel"] > 85.29
+    assert abs(rf["path"]["kernels_sum_us"] - 264.0) < 0.1 and rf["path"]["kernels_sum_le_1p02_step"] is True
+    assert "path_model_us" not in rf and "path_frac_of_model" not in rf and 0 < rf["path"]["model"]["frac_of_step"] < 1
+    ev = bench.roofline_block(avg, "snapkv128k", 1, t_step, 1, "off")          # no profiler pass: the event table, and the line says so
+    assert "HIP events" in ev["timing_source"] and ev["avg_launch_us"] > 85.29 and set(ev) == set(rf)
+    # display names of the profiler against the library's launch names
+    assert bench.match_kernel("gather_vec_kernel", "void (anonymous namespace)::gather_vec_kernel<16, true>((anonymous namespace)::GatherArgs)")
+    assert bench.match_kernel("softmax_combine_kernel", "softmax_combine_kernel(float const*, float const*, unsigned int)")
+    assert not bench.match_kernel("snapkv_p1", "void snapkv_p1_asm<2>(SnapArgs)") and not bench.match_kernel("row_kernel", "void x::topk_row_kernel<1, -1>()")
+    # more than one batch element per GPU: the shard of a rank is BATCH[workload] consecutive elements
+    assert bench.BATCH["snapkv128k_b2"] == 2 and bench.shard_batch(2 * 2, 2, 1) == (2, 4) and bench.algorithmic_bytes("snapkv", 131072, 0.5, B=2)["total"] == 2 * 805306368

@@ -199,13 +199,15 @@ def test_topk_second_pass_variants(S, knobs):
         assert np.array_equal(got, O.topk_select(-flat, S // 2)), f"variant {variant} S={S} smallest"
 
 
-@pytest.mark.parametrize("R,S", [(1, 16385), (3, 20000), (8, 32769), (7, 40000), (9, 40000), (8, 131008), (2, 131073), (5, 262144), (2, 262145)])
+@pytest.mark.parametrize("R,S", [(1, 16385), (3, 20000), (8, 32769), (7, 40000), (9, 40000), (8, 131008), (2, 131073), (5, 262144), (2, 262145),
+                                 (16, 131008), (17, 40000), (32, 65537), (33, 20000)])
 def test_topk_cluster_select_rows_and_lengths(R, S, knobs):
     """The cluster select (topk_cluster.hip: 32 workgroups per row, keys in registers, cluster barriers between the digit steps)
     over its whole range of row lengths (every keys-per-thread instantiation, partially filled last slots, unaligned rows), with
-    fewer rows than clusters, twice through the same self-cleaning workspace, k smallest, score
-    order; 9 rows or 262145 scores are past its range and take the (chunk, row) passes.  Against the oracle AND bit-identical
-    to KVP_TK_CLUSTER=0."""
+    fewer rows than clusters and -- round 6: batches of more than one element -- with MORE rows than the 8 clusters the device holds
+    at once (9, 16, 17, 32 rows: one launch, the later clusters start as the first retire), twice through the same self-cleaning
+    workspace, k smallest, score order; 33 rows or 262145 scores are past its range and take the (chunk, row) passes.  Against the
+    oracle AND bit-identical to KVP_TK_CLUSTER=0."""
     rs = np.random.RandomState(R * 1000003 + S)
     N = native()
     flat = (2.0 ** -17 * (1 + 0.05 * rs.standard_normal((R, S)))).astype(np.float32)
@@ -218,7 +220,7 @@ def test_topk_cluster_select_rows_and_lengths(R, S, knobs):
             knobs(KVP_TK_CLUSTER=0)
             legacy = N.topk_select(t, k)
             assert torch.equal(got, legacy), f"R={R} S={S} k={k}: cluster != passes"
-            if R * S <= 8 * 131072:
+            if R * S <= 8 * 131072 or (k == S // 2 and sc_np is flat):
                 assert np.array_equal(got.cpu().numpy(), O.topk_select(sc_np, k)), f"R={R} S={S} k={k}"
     knobs(KVP_TK_CLUSTER=None)
     t = torch.from_numpy(flat).to(DEV)
@@ -977,6 +979,42 @@ def test_fused_compress_in_score_order_equals_modular(S):
         ko, vo = N.knorm_compress(k, v, n, N.ORDER_SCORE)
         wk, wv = N.gather_kv(k, v, N.topk_select(sn, n, N.ORDER_SCORE))
         assert torch.equal(ko, wk) and torch.equal(vo, wv), f"knorm S={S} n={n}"
+
+
+@pytest.mark.parametrize("S", [32833, 70003, 131072])
+@pytest.mark.parametrize("data", ["flat", "tied", "constant"])
+def test_fused_snapkv_hist1_cluster_select(S, data):
+    """the cluster select's HIST1 form (first digit accumulated by the kernel that wrote the scores, three rounds with counter
+    barriers) is what the fused SnapKV compress takes for kernel_size != 5 on rows beyond 16384 columns (the kernel_size-5 path pools
+    inside the select's own loader).  Driven here on flat keys, keys with many exact duplicates (tied column sums) and CONSTANT keys
+    (every score of a row equal: the whole selection is decided by the tie rule), twice through the same self-cleaning workspace and
+    for both orders: the bytes of the modular sequence score -> kvp_topk_select -> gather."""
+    N = native()
+    g = torch.Generator(device=DEV); g.manual_seed(S + len(data))
+    k = torch.randn((1, 8, S, 128), generator=g, device=DEV).to(torch.bfloat16)
+    v = torch.randn((1, 8, S, 128), generator=g, device=DEV).to(torch.bfloat16)
+    q = torch.randn((1, 32, 64, 128), generator=g, device=DEV).to(torch.bfloat16)
+    if data == "tied":
+        k[:, :, ::3] = k[:, :, 5:6]
+    elif data == "constant":
+        k[:] = k[:, :, 7:8]
+    else:
+        k.mul_(0.05)
+    ang = torch.rand((1, 64, 128), generator=g, device=DEV)
+    c, si = torch.cos(ang).to(torch.bfloat16), torch.sin(ang).to(torch.bfloat16)
+    for ks in (3, 7):
+        sc = N.snapkv_score_rope(q, c, si, k, ks)
+        if data == "constant":   # away from the pooling edges every column sum of a head is the same value
+            body = sc[0, :, 8:S - 64 - 8]
+            assert (body == body[:, :1]).all()
+        for n in sorted({65, S // 2, S - 1}) * 2:
+            ko, vo = N.snapkv_compress_rope(q, c, si, k, v, ks, n)
+            wk, wv = N.gather_kv(k, v, N.topk_select(sc, n))
+            assert torch.equal(ko, wk) and torch.equal(vo, wv), f"S={S} {data} ks={ks} n={n}"
+        ko, vo = N.snapkv_compress_rope(q, c, si, k, v, ks, S // 2, N.ORDER_SCORE)
+        wk, wv = N.gather_kv(k, v, N.topk_select(sc, S // 2, N.ORDER_SCORE))
+        assert torch.equal(ko, wk) and torch.equal(vo, wv), f"S={S} {data} ks={ks} score order"
+    N.async_error_check()
 
 
 def test_snapkv_single_row_rotary_table_broadcasts():

@@ -119,3 +119,70 @@ def test_kept_order_score_equals_reference_tensors_host(name, fake_native):
     (and this file's run logic) where no GPU exists."""
     stats = check_case(name, "cpu", fake_native, force_f32=True)
     assert any(a > 0 for _, a, _ in stats), stats
+
+
+# ---- chains (round 6): ComposedPress / PrefillDecodingPress switch the earlier press to the reference's order by themselves -----------
+CHAINS = {
+    "chain_kn_stream": ("kn_tiny_d6", 0.25, lambda P, s: P.StreamingLLMPress(compression_ratio=0.5, n_sink=3)),
+    "chain_kn_snap": ("sk_257_A", 0.25, lambda P, s: P.SnapKVPress(compression_ratio=0.5, window_size=s["W"], kernel_size=s["ks"])),
+}
+
+
+def _sorted_rows(t):
+    """rows of [n, D] in lexicographic order (the data is random: rows are distinct)"""
+    rows = [tuple(r) for r in t.double().tolist()]
+    return sorted(rows)
+
+
+def check_chain(cname, device, explicit_position=False):
+    """p1.compress -> p2.compress the way composed_press.py:56-62 chains the hooks, against the REAL reference's final K' / V'
+    (tests/golden/order_chain_*.npz, oracle/gen_golden_order.py chains).  Returns the number of (batch, head) rows whose kept SET equals
+    the reference's."""
+    import kvpress_amd as P
+
+    case, r1, mk2 = CHAINS[cname]
+    s = _inputs.make_case(case)
+    fx = np.load(os.path.join(GOLD, f"order_{cname}.npz"))
+    dt = torch.float32
+    att, rot, hidden, pe = _inputs.build_llama_attention(s, dt, device)
+    keys = torch.from_numpy(s["keys"]).to(device=device, dtype=dt)
+    values = torch.from_numpy(s["values"]).to(device=device, dtype=dt)
+    kwargs = {"position_embeddings": pe}
+    p1, p2 = P.KnormPress(compression_ratio=r1), mk2(P, s)
+    if explicit_position:
+        p1.kept_order = "position"
+    chain = P.ComposedPress([p1, p2])
+    chain._check_kept_order()                      # what the chain's first hook call does
+    assert p1.kept_order == ("position" if explicit_position else "score")
+    with torch.no_grad():
+        k1, v1 = p1.compress(att, hidden, keys, values, None, kwargs)
+        k2, v2 = p2.compress(att, hidden, k1, v1, None, kwargs)
+    case_dt = _inputs.torch_dtype(s["dtype"])
+    ko_ref, vo_ref = _load_rows(fx, "ko", case_dt).to(dt), _load_rows(fx, "vo", case_dt).to(dt)
+    assert tuple(k2.shape) == tuple(ko_ref.shape)
+    k2, v2 = k2.cpu(), v2.cpu()
+    same = 0
+    B, H = k2.shape[:2]
+    for b in range(B):
+        for h in range(H):
+            same += int(_sorted_rows(k2[b, h]) == _sorted_rows(ko_ref[b, h]) and _sorted_rows(v2[b, h]) == _sorted_rows(vo_ref[b, h]))
+    return same, B * H, float(fx["gap2"].min())
+
+
+@pytest.mark.parametrize("cname", list(CHAINS))
+def test_chain_equals_reference_host(cname, fake_native):
+    same, total, gap = check_chain(cname, "cpu")
+    assert same == total, (cname, same, total, gap)
+
+
+def test_chain_with_explicit_position_order_differs_from_reference_host(fake_native):
+    """the control: pinned to position order, the sinks / recent tokens of the second stage are other tokens than the reference's"""
+    same, total, _ = check_chain("chain_kn_stream", "cpu", explicit_position=True)
+    assert same < total
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cname", list(CHAINS))
+def test_chain_equals_reference_gpu(cname):
+    same, total, gap = check_chain(cname, "cuda:0")
+    assert same == total, (cname, same, total, gap)

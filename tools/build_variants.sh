@@ -9,7 +9,7 @@ for spec in "$@"; do
   name=${spec%%=*}; abl=${spec#*=}
   env $abl python tools/gen_stage_asm.py kernel > /dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -amdgpu-mfma-vgpr-form $(env $abl bash -c 'echo ${KVP_VARIANT_CFLAGS:-}') -c kvpress_amd/csrc/snapkv_mfma.hip -o /tmp/snapkv_mfma_$name.o 2>/tmp/snapkv_mfma_$name.err || { cat /tmp/snapkv_mfma_$name.err; exit 1; }
-  objs=$(ls kvpress_amd/build/*.o | grep -v snapkv_mfma.o)
+  objs=$(ls kvpress_amd/build/*.o | grep -v 'snapkv_mfma.o\|/contrib_')
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o kvpress_amd/lib/variants/$name.so $objs /tmp/snapkv_mfma_$name.o
   echo "built $name ($abl)"
 done
@@ -19,7 +19,7 @@ python tools/gen_stage_asm.py kernel > /dev/null   # restore the production loop
 if [[ " $* " == *" tc_timing "* ]]; then
   python tools/make_tc_timing.py /tmp/topk_cluster_timing.hip
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Ikvpress_amd/csrc -c /tmp/topk_cluster_timing.hip -o /tmp/topk_cluster_timing.o
-  objs=$(ls kvpress_amd/build/*.o | grep -v topk_cluster.o)
+  objs=$(ls kvpress_amd/build/*.o | grep -v 'topk_cluster.o\|/contrib_')
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o kvpress_amd/lib/variants/tc_timing.so $objs /tmp/topk_cluster_timing.o
   echo "built tc_timing"
 fi

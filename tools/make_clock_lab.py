@@ -122,7 +122,7 @@ def main():
             sys.exit(r.stderr)
         objs.append(obj)
     bdir = os.path.join(ROOT, "kvpress_amd", "build")
-    rest = [os.path.join(bdir, f) for f in sorted(os.listdir(bdir)) if f.endswith(".o") and f not in ("snapkv_mfma.o", "gather.o")]
+    rest = [os.path.join(bdir, f) for f in sorted(os.listdir(bdir)) if f.endswith(".o") and not f.startswith("contrib_") and f not in ("snapkv_mfma.o", "gather.o")]
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *rest, *objs], capture_output=True, text=True)
     if r.returncode:
         sys.exit(r.stderr)

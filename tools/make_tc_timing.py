@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MACRO = '''#define TC_STAMP(i) do { if (threadIdx.x == 0 && cluster == 0) TCW(bar)[TC_CLUSTERS * 32 + 32 + slot * 16 + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
+MACRO = '''#define TC_STAMP(i) do { if (threadIdx.x == 0 && cluster == 0) TCW(bar)[TC_MAXC * 32 + 32 + slot * 32 + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
     TC_STAMP(0);
 '''
 # (anchor line fragment, stamp index, "before" | "after"); the two-hop form (round 5).  Stamp 11 = 1 if the two-hop form finished the
@@ -48,7 +48,7 @@ def main(out):
     text = "\n".join(res)
     tail = "            if (rank0 + i < k) out[rank0 + i] = ob[i];\n"
     assert text.count(tail) == 1, "anchor for the final stamp moved"
-    text = text.replace(tail, tail + "        TC_STAMP(10);\n        if (threadIdx.x == 0 && cluster == 0) TCW(bar)[TC_CLUSTERS * 32 + 32 + slot * 16 + 11] = done ? 1u : 0u;\n")
+    text = text.replace(tail, tail + "        TC_STAMP(10);\n        if (threadIdx.x == 0 && cluster == 0) TCW(bar)[TC_MAXC * 32 + 32 + slot * 32 + 11] = done ? 1u : 0u;\n")
     used.add(10)
     missing = sorted(set(range(11)) - used)
     assert not missing, f"anchors moved: stamps {missing} not placed"

@@ -60,13 +60,13 @@ def stamps(R, S, flat=True):
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     al = lambda x: (x + 255) // 256 * 256
-    bar_off = (2 * al(R * 4096 * 4) + al(R * 256 * 4)) // 4 + 8 * 32 + 32
+    bar_off = (2 * al(R * 4096 * 4) + al(R * 256 * 4)) // 4 + 32 * 32 + 32
     names = ["start", "keys", "window", "hw flushed", "digit", "records", "barrier", "rec in LDS", "T", "offsets", "end"]
     for it in range(6):
         rc = L.kvp_topk_select(P(sc), R, S, S, S // 2, N.TOPK_WS_CLEAN, P(idx), P(ws), nws, st)
         assert rc == 0, L.kvp_last_error()
         torch.cuda.synchronize()
-    w = ws.view(torch.int32).cpu().numpy().astype(np.int64)[bar_off:bar_off + 32 * 16].reshape(32, 16)[:, :12]
+    w = ws.view(torch.int32).cpu().numpy().astype(np.int64)[bar_off:bar_off + 32 * 32].reshape(32, 32)[:, :12]
     t0 = w[:, 0].min()
     rel = (w - t0) * 0.01   # us
     print(f"cluster kernel phase stamps, R={R} S={S} {'flat' if flat else 'wide'} (us since the first workgroup of cluster 0 started; min / median / max over its 32 slots)")
