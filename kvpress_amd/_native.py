@@ -416,11 +416,12 @@ USE_LIBRARY_QPROJ = os.environ.get("KVP_LIBRARY_QPROJ", "1") != "0"
 
 
 def qproj_rope_supported(module, hidden_states: torch.Tensor, window: int) -> bool:
-    """Should the press project the window in the library?  USE_LIBRARY_QPROJ, qproj_rope_eligible, and ONE batch element: the
-    kernel streams the whole q_proj weight once per batch element (its grid is (columns, batch)), which is what a single window
-    costs anyway but not what a batch does -- ChunkPress hands the wrapped press its 128 chunks as a batch of 128 windows, and a
-    GEMM over all 8192 rows reads the weight once."""
-    return USE_LIBRARY_QPROJ and hidden_states.shape[0] == 1 and qproj_rope_eligible(module, hidden_states, window)
+    """Should the press project the window in the library?  USE_LIBRARY_QPROJ, qproj_rope_eligible, and at most TWO batch elements: the
+    kernel streams the q_proj weight once per batch element (its grid is (columns, batch); the second element's slices come from the
+    L2s / memory-side cache), a GEMM over all B x 64 rows reads it once.  Measured on the cold weight (profiles/r06_qproj_batch_lab.txt):
+    B = 1 22.2 us against GEMM 22.7 + RoPE launch ~5; B = 2 26.7 against 24.3 + 5; B = 4 45.2 against 23.6 + 5 -- so up to two.
+    (ChunkPress hands the wrapped press its 128 chunks as a batch of 128 windows: 1239 against 195 us.)"""
+    return USE_LIBRARY_QPROJ and hidden_states.shape[0] <= 2 and qproj_rope_eligible(module, hidden_states, window)
 
 
 _QP_ELIGIBLE: dict = {}   # (id(module), weight data_ptr, weight version, dtype, window) -> the module-side half of the answer

@@ -268,13 +268,13 @@ void qstats_plan(int64_t Sq, int64_t nbh, uint32_t& nchunk, uint32_t& rows) {
 // =================================================================================================
 // (2) logits
 // =================================================================================================
-constexpr int EL_CHUNK = 4096;  // keys per workgroup
+constexpr int EL_CHUNK = 4096;  // keys per workgroup, at least (ea_mfma_logits_chunk doubles it until the grid is one resident round)
 constexpr int EL_TILE = 128;    // keys per LDS tile: ONE workgroup barrier per 128 keys (64-key tiles: a third of the wave cycles parked at it)
 constexpr int EL_SUBS = EL_TILE / 32;
 constexpr int EL_TILEB = EL_TILE * EM_ROWB;
 
 template <int DT, bool HAS_COV>
-__global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk,
+__global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk, uint32_t chunk_keys,
                                                                         float* __restrict__ part_m, float* __restrict__ part_z) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * EL_TILEB];
     __shared__ float red[3][8][EL_TILE];   // [tile % 3][wave strip x lane half][key]: the eight partial row-dots of a key.  Three: a tile's
@@ -328,8 +328,8 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_kernel(EaArgs a,
 #pragma unroll
     for (int r = 0; r < 16; ++r) muv[r] = a.mu[(size_t)bhq * 128 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg] * a.inv_sqrt_d;
 
-    const uint32_t kbeg = chunk * EL_CHUNK;
-    const uint32_t kend = min(kbeg + EL_CHUNK, a.Sp);
+    const uint32_t kbeg = chunk * chunk_keys;
+    const uint32_t kend = min(kbeg + chunk_keys, a.Sp);
     const uint32_t ntiles = (kend - kbeg + EL_TILE - 1) / EL_TILE;
     float* lrow = logits + (size_t)bhq * a.Sp;
     float m_run = KVP_NEG_INF, z_run = 0.f;  // threads 0..127: running softmax partial of the keys they own
@@ -535,7 +535,7 @@ __device__ __forceinline__ void el_tri_build(const float* __restrict__ cov_head,
     }
 
 template <int DT>
-__global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_tri_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk,
+__global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_tri_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk, uint32_t chunk_keys,
                                                                        float* __restrict__ part_m, float* __restrict__ part_z) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * EL_TILEB];
     __shared__ float red[3][8][EL_TILE];
@@ -553,15 +553,34 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_tri_kernel(EaArg
     const int64_t row_bytes = a.k_ss * 2;
     if (threadIdx.x < 128) mus[threadIdx.x] = a.mu[(size_t)bhq * 128 + threadIdx.x] * a.inv_sqrt_d;
 
-    const uint32_t kbeg = chunk * EL_CHUNK;
-    const uint32_t kend = min(kbeg + EL_CHUNK, a.Sp);
+    const uint32_t kbeg = chunk * chunk_keys;
+    const uint32_t kend = min(kbeg + chunk_keys, a.Sp);
     const uint32_t ntiles = (kend - kbeg + EL_TILE - 1) / EL_TILE;
     float* lrow = logits + (size_t)bhq * a.Sp;
     float m_run = KVP_NEG_INF, z_run = 0.f;
 
     const uint32_t ldsbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const uint32_t dg = lane >> 4, di16 = lane & 15;
+    // Round 6: a tile that lies inside the sequence is requested with ONE per-lane offset (row 4 wv + dg of a 16-row group, swizzled chunk:
+    // the same for all eight groups, 16 j does not touch the row's low bits) on top of a SCALAR base that advances by 16 rows per request --
+    // no vector address arithmetic in the tile loop (it was ~48 of its ~200 VALU instructions per tile, on a SIMD where VALU and matrix
+    // instructions do not overlap).  The last tile of a sequence (rows clamped to Sp - 1) and rows further than 2 GiB apart keep the per-lane form.
+    const uint32_t grow = 4 * wv + dg;
+    const bool fast_rows = row_bytes > 0 && row_bytes * EL_TILE < ((int64_t)1 << 31);
+    const uint32_t goff = (uint32_t)(grow * (uint32_t)row_bytes) + ((di16 ^ (grow & 15)) << 4);
     auto request_tile = [&](uint32_t row0, uint32_t buf_off) {
+        if (fast_rows && row0 + EL_TILE <= a.Sp) {
+            const char* sb = kb + (int64_t)row0 * row_bytes;   // uniform: scalar registers
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t la = __builtin_amdgcn_readfirstlane(ldsbase + buf_off + (16 * j + 4 * wv) * EM_ROWB);
+                const uint64_t sj = (uint64_t)(uintptr_t)(sb + (int64_t)(16 * j) * row_bytes);
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)sj), hi = __builtin_amdgcn_readfirstlane((uint32_t)(sj >> 32));
+                const uint64_t sbase = ((uint64_t)hi << 32) | lo;
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la), "v"(goff), "s"(sbase) : "memory");
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const uint32_t trow = 16 * j + 4 * wv + dg;
@@ -627,15 +646,18 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_tri_kernel(EaArg
             for (int i = 0; i < NB; ++i) acc = mma32<DT>(fb.lo[i], kf[2 * SB + i], acc);
         };
         auto rowdot = [&](const uint2 (&kk)[4], uint32_t sub, int strip, const f32x16& acc, float (*redb)[EL_TILE]) {
-            float v0 = 0.f, v1 = 0.f;
+            // two interleaved fma chains (even / odd accumulator rows) as ONE packed chain (v_pk_fma_f32: 8 instead of 16 issue slots;
+            // component for component the arithmetic of the scalar form: the same bits)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 v = {0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                v0 = fmaf(lo16<DT>(kk[q].x), acc[4 * q + 0], v0);
-                v1 = fmaf(hi16<DT>(kk[q].x), acc[4 * q + 1], v1);
-                v0 = fmaf(lo16<DT>(kk[q].y), acc[4 * q + 2], v0);
-                v1 = fmaf(hi16<DT>(kk[q].y), acc[4 * q + 3], v1);
+                const f32x2 k0 = {lo16<DT>(kk[q].x), hi16<DT>(kk[q].x)}, a0 = {acc[4 * q + 0], acc[4 * q + 1]};
+                v = __builtin_elementwise_fma(k0, a0, v);
+                const f32x2 k1 = {lo16<DT>(kk[q].y), hi16<DT>(kk[q].y)}, a1 = {acc[4 * q + 2], acc[4 * q + 3]};
+                v = __builtin_elementwise_fma(k1, a1, v);
             }
-            redb[2 * strip + kg][sub * 32 + n] = v0 + v1;
+            redb[2 * strip + kg][sub * 32 + n] = v.x + v.y;
         };
         f32x16 acc0, acc1;
         uint4 kfa[8], kfb[8];
@@ -766,19 +788,31 @@ bool ea_mfma_logits_eligible(const EaArgs& a, int dtype) {
            aligned8(a.k_sh) && aligned8(a.k_ss) && a.G <= 65535;
 }
 size_t ea_mfma_logits_scratch_bytes(int64_t, int64_t, int64_t) { return 0; }
-uint32_t ea_mfma_logits_nblk(const EaArgs& a) { return (a.Sp + EL_CHUNK - 1) / EL_CHUNK; }
+// Keys per workgroup: 4096, doubled while the grid exceeds ONE resident round (two 4-wave workgroups per CU).  A workgroup's start-up
+// -- every wave packs its strips of the covariance into hi / lo MFMA fragments: ~3000 VALU instructions -- was a third of the
+// kernel's VALU work at 32 tiles per workgroup (10 432 instructions per wave against 204 per tile in the loop: round 6), and on this
+// SIMD VALU and matrix instructions do not overlap: 128k tokens x 32 heads now run as 512 workgroups of 64 tiles.
+static uint32_t ea_mfma_logits_chunk(const EaArgs& a) {
+    uint32_t chunk = EL_CHUNK;
+    const uint64_t heads = (uint64_t)a.B * a.Hkv * a.G;
+    while (chunk < 65536 && (uint64_t)((a.Sp + chunk - 1) / chunk) * heads > 512) chunk *= 2;
+    return chunk;
+}
+uint32_t ea_mfma_logits_nblk(const EaArgs& a) { const uint32_t c = ea_mfma_logits_chunk(a); return (a.Sp + c - 1) / c; }
 
 int ea_mfma_logits(const EaArgs& a, int dtype, float* logits, uint32_t nblk, float* part_m, float* part_z, void*, hipStream_t stream) {
+    const uint32_t ck = ea_mfma_logits_chunk(a);
+    KVP_CHECK_ARG(nblk == (a.Sp + ck - 1) / ck, "ea_logits_mfma: nblk %u does not match the chunk plan", nblk);
     const uint64_t units = (uint64_t)nblk * a.B * a.Hkv;
     KVP_CHECK_ARG((units + 7) / 8 * 8 * a.G < ((uint64_t)1 << 31), "ea_logits_mfma: grid too large");
     const dim3 grid((uint32_t)((units + 7) / 8 * 8 * a.G));   // (unit, head-in-group) -> linear id: see the kernel
     if (a.cov) {   // the quadratic form on the doubled upper triangle of the covariance (2b): exact for any matrix, 40 instead of 64 MFMAs per tile and wave
-        if (dtype == KVP_BF16) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)));
-        else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_F16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)));
+        if (dtype == KVP_BF16) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z)));
+        else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_F16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z)));
     } else if (dtype == KVP_BF16) {   // use_covariance = False: the mean term only
-        KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_kernel<KVP_BF16, false><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)));
+        KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_kernel<KVP_BF16, false><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z)));
     } else {
-        KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_kernel<KVP_F16, false><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, part_m, part_z)));
+        KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_kernel<KVP_F16, false><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z)));
     }
     KVP_CHECK_LAUNCH("ea_logits_mfma");
     return KVP_OK;

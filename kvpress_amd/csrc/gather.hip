@@ -153,7 +153,11 @@ extern "C" int kvp_gather_kv(const void* k, int64_t k_sb, int64_t k_sh, int64_t 
     const uint32_t gpb = GA_THREADS / lpr;
     const uint64_t groups_needed = ((uint64_t)n + GA_UNROLL - 1) / GA_UNROLL;
     const uint64_t bx_full = (groups_needed + gpb - 1) / gpb;
-    const uint64_t bx_cap = std::max<uint64_t>(1, ((uint64_t)256 * 8 + BH - 1) / BH);   // 8 workgroups of 256 threads per CU (4 / 16 measured slower)
+    // 8 workgroups of 256 threads per CU (4 / 16 measured slower) -- but never fewer than 256 per (b, h) plane: the grid is dispatched
+    // plane after plane, so with 256 workgroups per plane at most 8 planes (32 K / V / K' / V' streams) are in flight whatever the
+    // batch; 2048 / BH per plane put all 32 planes of a batch of four in flight at once and the copy fell from 6.0 to 4.2 TB/s
+    // (round 6, knorm128k_b4: 513 us for 4 x 90)
+    const uint64_t bx_cap = std::max<uint64_t>(256, ((uint64_t)256 * 8 + BH - 1) / BH);
     const uint32_t bx = (uint32_t)std::max<uint64_t>(1, std::min(bx_full, bx_cap));
     // Streaming (non-temporal) loads / stores when K + V do not fit the memory-side cache anyway (the cache is 256 MiB; the cutoff
     // chosen by measurement is 192 MiB of K + V): the copy must not

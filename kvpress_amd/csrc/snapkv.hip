@@ -340,6 +340,8 @@ struct SnapWs {
     float* colsum2;  // G > 4 (two group-blocks per kv-head in the MFMA pass 2): the second block's column sums, added in a fixed order
     float* bmax;  // per-workgroup maxima of the pool kernel (<= 4096)
     void* qrot;   // [B,Hq,W,D] RoPE'd window queries (kvp_snapkv_score_rope)
+    uint32_t* p1_ticks;   // [planes][nchunk] pass-1 workgroup times, [planes][nchunk][2] pass-2 tile ranges (snapkv_internal.h: snapkv_p2_shares_plan)
+    uint32_t* p2_ranges;
     size_t total_bytes;
 };
 
@@ -362,6 +364,10 @@ SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, in
     w.colsum = (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4);
     w.colsum2 = Hq / std::max<int64_t>(1, Hkv) > 4 ? (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4) : nullptr;
     w.qrot = take((size_t)B * Hq * W * D * 4);
+    // (planes * nchunk <= max(planes, 256): one resident round of workgroups; planes = B * Hkv * (1 or 2 group-blocks))
+    const size_t nwg = (size_t)std::max<int64_t>(B * Hkv * 2, 256);
+    w.p1_ticks = (uint32_t*)take(nwg * 4);
+    w.p2_ranges = (uint32_t*)take(nwg * 8);
     w.total_bytes = off;
     return w;
 }
@@ -448,9 +454,17 @@ int snapkv_score_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, c
 
     if (snapkv_mfma_eligible(a, dtype)) {
         const uint32_t nchunk = snapkv_mfma_nchunk(a);
-        if (int rc = snapkv_mfma_p1(a, dtype, nchunk, w.part_m, w.part_z, stream)) return rc;
-        KVP_SOFTMAX_COMBINE(stream, w.part_m, w.part_z, nrows, nchunk, w.rowstat, (uint32_t)W, norm_base);
-        if (int rc = snapkv_mfma_p2(a, dtype, w.rowstat, w.colsum, w.colsum2, stream)) return rc;
+        const bool shares = snapkv_p2_shares_plan(a, nchunk);   // pass 2's tile ranges from pass 1's workgroup times (snapkv_internal.h)
+        if (int rc = snapkv_mfma_p1(a, dtype, nchunk, w.part_m, w.part_z, shares ? w.p1_ticks : nullptr, stream)) return rc;
+        if (shares) {
+            const uint32_t nplanes = (uint32_t)(B * Hkv) * ((a.G + 3) / 4);
+            if (int rc = snapkv_combine_shares(w.part_m, w.part_z, nrows, nchunk, w.rowstat, (uint32_t)W, norm_base, w.p1_ticks, w.p2_ranges, nplanes,
+                                               (uint32_t)((S - W + 127) / 128), stream))
+                return rc;
+        } else {
+            KVP_SOFTMAX_COMBINE(stream, w.part_m, w.part_z, nrows, nchunk, w.rowstat, (uint32_t)W, norm_base);
+        }
+        if (int rc = snapkv_mfma_p2(a, dtype, w.rowstat, w.colsum, w.colsum2, shares ? w.p2_ranges : nullptr, stream)) return rc;
     } else {
         const uint32_t nchunk = (uint32_t)((S + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC);
         const size_t lds1 = ((size_t)SK_SUB * (D + 1) + 2 * (size_t)W) * 4;

@@ -122,6 +122,13 @@ struct TileWalk {
         kbeg = chunk * MF_TILE;
         klast = kbeg + (ntiles ? ntiles - 1 : 0) * tstride;  // requests past the end re-fetch the last tile (L2 hits, never read)
     }
+    // a contiguous range of tiles [first, first + n) (pass 2 with shares from pass 1's clock: snapkv_internal.h)
+    __device__ TileWalk(uint32_t first, uint32_t n, int) {
+        ntiles = n;
+        tstride = MF_TILE;
+        kbeg = first * MF_TILE;
+        klast = kbeg + (ntiles ? ntiles - 1 : 0) * tstride;
+    }
     __device__ __forceinline__ uint32_t key0(uint32_t t) const { return min(kbeg + t * tstride, klast); }
 };
 __device__ __forceinline__ int ring_next(int b) { return b + 1 == MF_NBUF ? 0 : b + 1; }
@@ -302,7 +309,8 @@ template <typename T> __device__ __forceinline__ T* uni(T* p) {
 // Requires all eight waves active (G % 4 == 0).
 template <int DT>
 __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_asm(SnapArgs a, uint32_t ngb, uint32_t nchunk,
-                                                               float* __restrict__ part_m, float* __restrict__ part_z) {
+                                                               float* __restrict__ part_m, float* __restrict__ part_z, uint32_t* __restrict__ ticks) {
+    const uint64_t t_start = ticks ? __builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz wall clock: this workgroup's time -> pass 2's tile shares
     constexpr int NB = KVP_P1_NBUF;   // ring depth of this kernel: NB - 1 tiles of 32 KiB in flight per workgroup (cold K from HBM
                                       // needs more than the two of the three-buffer ring: measured 3.5 TB/s with two)
     __shared__ __attribute__((aligned(16))) unsigned char lds[NB * MF_TILEB];
@@ -420,6 +428,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_asm(SnapArgs a, uint3
         part_m[o] = mm;
         part_z[o] = zz;
     }
+    if (ticks && threadIdx.x == 0)
+        ticks[((size_t)b * gridDim.y + blockIdx.y) * nchunk + chunk] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_start);
 }
 
 // =================================================================================================
@@ -565,12 +575,22 @@ static uint32_t mfma_nchunk_for(const SnapArgs& a, uint32_t nkeys) {
 }
 uint32_t snapkv_mfma_nchunk(const SnapArgs& a) { return mfma_nchunk_for(a, a.S); }
 
-int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m, float* part_z, hipStream_t stream) {
+// pass 2 can take its tile ranges from pass 1's workgroup times when both passes run the hand-scheduled kernels on the same grid and
+// every walk is long (>= 8 tiles: a range never shrinks below the three tiles a ragged tail hands to the plain path).
+// KVP_SK_BALANCE=0 keeps the static interleaved walk (A/B runs).
+bool snapkv_p2_shares_plan(const SnapArgs& a, uint32_t nchunk_p1) {
+    if (a.G % 4 != 0 || a.S <= a.W) return false;
+    const uint32_t Sm = a.S - a.W;
+    const uint32_t ntiles = (Sm + MF_TILE - 1) / MF_TILE;
+    return mfma_nchunk_for(a, Sm) == nchunk_p1 && nchunk_p1 >= 2 && nchunk_p1 <= 256 && ntiles >= 8 * nchunk_p1 && kvp_env_int("KVP_SK_BALANCE", 1) != 0;
+}
+
+int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m, float* part_z, uint32_t* p1_ticks, hipStream_t stream) {
     const uint32_t ngb = (a.G + 3) / 4;
     const dim3 grid(nchunk, a.Hkv * ngb, a.B);
     if (a.G % 4 == 0) {   // hand-scheduled tile loop: all eight waves of a workgroup own a q-head half
-        if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_asm", stream, snapkv_p1_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
-        else KVP_LAUNCH("snapkv_p1_asm", stream, snapkv_p1_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
+        if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_asm", stream, snapkv_p1_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, p1_ticks));
+        else KVP_LAUNCH("snapkv_p1_asm", stream, snapkv_p1_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, p1_ticks));
         KVP_CHECK_LAUNCH("snapkv_p1_asm");
         return KVP_OK;
     }
@@ -590,7 +610,7 @@ int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m,
 // take the C++ path below.  Requires all eight waves active (G % 4 == 0).
 template <int DT>
 __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_asm(SnapArgs a, uint32_t ngb, const float* __restrict__ rowstat,
-                                                               float* __restrict__ colsum, float* __restrict__ colsum2) {
+                                                               float* __restrict__ colsum, float* __restrict__ colsum2, const uint32_t* __restrict__ ranges) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[MF_NBUF * MF_TILEB];
     __shared__ __attribute__((aligned(16))) unsigned char red3[KVP_P2_RED_BYTES];
     __shared__ float red[2][MF_WAVES][MF_TILE];
@@ -604,7 +624,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_asm(SnapArgs a, uint3
 
     const char* kbase = static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2;
     const KStream ks_(kbase, a.k_ss * 2, a.S);
-    const TileWalk tw(chunk, gridDim.x, Sm);
+    // this workgroup's tiles: a contiguous range sized by pass 1's clock (ranges[plane][chunk] = first tile, tiles), or the static
+    // interleaved walk.  Either way a tile's column sums are computed by one workgroup in a fixed order: the same bits.
+    const uint32_t* rg = ranges ? ranges + (((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + chunk) * 2 : nullptr;
+    const TileWalk tw = rg ? TileWalk(uni(rg[0]), uni(rg[1]), 0) : TileWalk(chunk, gridDim.x, Sm);
     if (tw.ntiles == 0) return;
     ks_.request_tile(lds, tw.key0(0));
     ks_.request_tile(lds + MF_TILEB, tw.key0(1));
@@ -706,20 +729,87 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_asm(SnapArgs a, uint3
     wait_all_landed();
 }
 
+// ---- the combine launch with pass 2's tile shares (snapkv_internal.h: snapkv_p2_shares_plan) ---------------------------------------
+// Blocks 0 .. nrb - 1: softmax_combine_kernel's rows, instruction for instruction (same merge order: the same normalisers whether or not
+// the shares are computed).  Blocks nrb .. nrb + nplanes - 1: one plane each -- thread c holds workgroup c's pass-1 time, clamped to
+// [tmin, 2 tmin] (a workgroup that was held up for a reason of its own must not starve), speed = 1 / time, inclusive scan over the
+// plane's workgroups, end_c = round(ntiles * prefix_c / total): contiguous ranges, monotone, the last one ends at ntiles.
+namespace {
+__global__ __launch_bounds__(256) void softmax_combine_shares_kernel(const float* __restrict__ part_m, const float* __restrict__ part_z, uint32_t nrows,
+                                                                     uint32_t nchunk, float* __restrict__ a, uint32_t W, uint32_t norm_base, uint32_t nrb,
+                                                                     const uint32_t* __restrict__ ticks, uint32_t* __restrict__ ranges, uint32_t ntiles) {
+    if (blockIdx.x < nrb) {
+        const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+        const uint32_t lane = threadIdx.x & 63;
+        if (row >= nrows) return;
+        float m = KVP_NEG_INF, z = 0.f;
+        for (uint32_t j = lane; j < nchunk; j += 64) softmax_merge(m, z, part_m[(size_t)row * nchunk + j], part_z[(size_t)row * nchunk + j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(m, o), z2 = __shfl_xor(z, o);
+            softmax_merge(m, z, m2, z2);
+        }
+        if (lane == 0) a[row] = m + log2f(z) - (norm_base ? log2f((float)(norm_base + row % W)) : 0.f);
+        return;
+    }
+    __shared__ uint32_t s_min[4];
+    __shared__ double s_sum[4];
+    const uint32_t plane = blockIdx.x - nrb, c = threadIdx.x;
+    const uint32_t tk = c < nchunk ? max(ticks[(size_t)plane * nchunk + c], 1u) : 0xFFFFFFFFu;
+    uint32_t mn = tk;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+    if ((c & 63) == 0) s_min[c >> 6] = mn;
+    __syncthreads();
+    const uint32_t tmin = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+    const double speed = c < nchunk ? 1.0 / (double)min(tk, 2u * tmin) : 0.0;
+    double incl = speed;   // inclusive scan over the 256 threads: inside the wave, then over the four waves, always in index order
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(incl, o);
+        if ((int)(c & 63) >= o) incl += up;
+    }
+    if ((c & 63) == 63) s_sum[c >> 6] = incl;
+    __syncthreads();
+    double base = 0.0, total = 0.0;
+    for (uint32_t w = 0; w < 4; ++w) {
+        if (w < (c >> 6)) base += s_sum[w];
+        total += s_sum[w];
+    }
+    incl += base;
+    if (c < nchunk) {
+        const double excl = incl - speed;
+        const uint32_t end = c + 1 == nchunk ? ntiles : min((uint32_t)__double2uint_rn((double)ntiles * incl / total), ntiles);
+        const uint32_t beg = c == 0 ? 0u : min((uint32_t)__double2uint_rn((double)ntiles * excl / total), ntiles);
+        ranges[((size_t)plane * nchunk + c) * 2] = beg;
+        ranges[((size_t)plane * nchunk + c) * 2 + 1] = end > beg ? end - beg : 0u;
+    }
+}
+}  // namespace
+
+int snapkv_combine_shares(const float* part_m, const float* part_z, uint32_t nrows, uint32_t nchunk, float* rowstat, uint32_t W, uint32_t norm_base,
+                          const uint32_t* p1_ticks, uint32_t* p2_ranges, uint32_t nplanes, uint32_t ntiles_p2, hipStream_t stream) {
+    const uint32_t nrb = (nrows + 3) / 4;
+    KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_shares_kernel<<<nrb + nplanes, 256, 0, stream>>>(part_m, part_z, nrows, nchunk, rowstat, W,
+                                                                                                                  norm_base, nrb, p1_ticks, p2_ranges, ntiles_p2));
+    KVP_CHECK_LAUNCH("snapkv(combine + shares)");
+    return KVP_OK;
+}
+
 namespace {
 __global__ __launch_bounds__(256) void add_slab_kernel(float* __restrict__ x, const float* __restrict__ y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] += y[i];
 }
 }  // namespace
 
-int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, float* colsum2, hipStream_t stream) {
+int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, float* colsum2, const uint32_t* p2_ranges, hipStream_t stream) {
     const uint32_t ngb = (a.G + 3) / 4;
     const uint32_t Sm = a.S - a.W;
     KVP_CHECK_ARG(ngb <= 2 && (ngb == 1 || colsum2), "snapkv_p2_mfma: G = %u needs the second column-sum slab", a.G);
     const dim3 grid(mfma_nchunk_for(a, Sm), a.Hkv * ngb, a.B);
     if (a.G % 4 == 0) {   // hand-scheduled tile loop
-        if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
-        else KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
+        if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2, p2_ranges));
+        else KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2, p2_ranges));
     } else if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
     else KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
     KVP_CHECK_LAUNCH("snapkv_p2_mfma");

@@ -98,10 +98,14 @@ def main():
           f"score(heads 4-7) {timeit(score_B):6.1f}  gather(heads 0-3) {timeit(gather_A):6.1f}  "
           f"back to back score(4-7); gather(0-3) {timeit(lambda: (score_B(), gather_A())):6.1f} us", flush=True)
 
-    for ng in (32, 64, 96, 128):
+    # which CUs a mask bit enables is probed by tools/cumask_map.hip; both plausible layouts are run: "rr" = bit i is CU i / 8 of XCD i % 8
+    # (KFD's round-robin order), "blk" = bit i is CU i % 32 of XCD i / 32.  Either way the gather gets ng / 8 CUs of EVERY XCD.
+    for layout, ng in [(l, n) for l in ("rr", "blk") for n in (64, 96, 128)]:
         nb = 256 - ng
-        # of every 8 consecutive bits (= one CU index on each of the 8 XCDs) the gather takes whole groups: ng / 8 CU indices per XCD
-        bits_g = [(i // 8) < (ng // 8) for i in range(256)]
+        if layout == "rr":
+            bits_g = [(i // 8) < (ng // 8) for i in range(256)]
+        else:
+            bits_g = [(i % 32) < (ng // 8) for i in range(256)]
         bits_s = [not b for b in bits_g]
         sg, ss = masked_stream(bits_g), masked_stream(bits_s)
         os.environ["KVP_SK_SLOTS"] = str(nb)
@@ -130,7 +134,7 @@ def main():
             main_s.wait_stream(sg)
 
         t_s, t_g, t_c = timeit(on(ss, score_B)), timeit(on(sg, gather_A)), timeit(conc)
-        print(f"gather on {ng:3d} CUs | score on {nb:3d} CUs (KVP_SK_SLOTS={nb}): score(4-7) alone {t_s:6.1f}  gather(0-3) alone {t_g:6.1f}  "
+        print(f"[{layout}] gather on {ng:3d} CUs | score on {nb:3d} CUs (KVP_SK_SLOTS={nb}): score(4-7) alone {t_s:6.1f}  gather(0-3) alone {t_g:6.1f}  "
               f"concurrent {t_c:6.1f} us", flush=True)
     os.environ["KVP_SK_SLOTS"] = "256"
     _native.tuning_reload()
