@@ -17,9 +17,10 @@
 // (triu(-inf, diagonal=S-W+1), snapkv_press.py:63-65) only touches the last W columns, which
 // are dropped from the result (:67): it matters for the normaliser (pass 1) only.
 //
-// Two implementations of p1/p2: the generic VALU kernels in this file (any W, D, dtype,
-// stride; used for small/odd shapes) and the MFMA kernels in snapkv_mfma.hip (bf16/f16,
-// D=128, W=64, G<=8: the Llama-3.1-8B hot path).
+// Two implementations of p1/p2: the MFMA kernels in snapkv_mfma.hip (bf16 / f16, head size 128 or 64, G <= 8, ANY window size
+// since round 6: blocks of 64 padded window rows, snapkv_internal.h -- hand-scheduled loops for D = 128 with G % 4 == 0, the
+// Llama-3.1-8B hot path, compiler-scheduled kernels otherwise) and the generic VALU kernels in this file (any D, float32, any
+// stride: correctness fallbacks, ~40x slower -- profiles/r06_shape_sweep*.txt).
 #include "kvp_common.h"
 #include "softmax_stats.h"
 #include "snapkv_internal.h"
@@ -338,6 +339,7 @@ struct SnapWs {
     float* rowstat;
     float* colsum;
     float* colsum2;  // G > 4 (two group-blocks per kv-head in the MFMA pass 2): the second block's column sums, added in a fixed order
+    float* colsumx;  // W > 64 (several 64-row blocks of the window in the MFMA passes): the later blocks' column sums, added in block order
     float* bmax;  // per-workgroup maxima of the pool kernel (<= 4096)
     void* qrot;   // [B,Hq,W,D] RoPE'd window queries (kvp_snapkv_score_rope)
     uint32_t* p1_ticks;   // [planes][nchunk] pass-1 workgroup times, [planes][nchunk][2] pass-2 tile ranges (snapkv_internal.h: snapkv_p2_shares_plan)
@@ -356,13 +358,14 @@ SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, in
     };
     // generic kernels: one workgroup per 512 keys; MFMA kernels: up to one per 128-key tile, never more than 256 (snapkv_mfma_nchunk)
     const int64_t nchunk_max = std::max<int64_t>((S + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC, std::min<int64_t>((S + 127) / 128, 256));
-    const size_t rows = (size_t)B * Hq * W;
+    const size_t rows = (size_t)B * Hq * snapkv_wp((uint32_t)W);   // the MFMA path keeps its statistics per PADDED window row (snapkv_internal.h)
     w.bmax = (float*)take((size_t)std::max<int64_t>(4096, B * Hkv) * 4);
     w.part_m = (float*)take(rows * nchunk_max * 4);
     w.part_z = (float*)take(rows * nchunk_max * 4);
     w.rowstat = (float*)take(rows * 4);
     w.colsum = (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4);
     w.colsum2 = Hq / std::max<int64_t>(1, Hkv) > 4 ? (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4) : nullptr;
+    w.colsumx = W > 64 ? (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4) : nullptr;
     w.qrot = take((size_t)B * Hq * W * D * 4);
     // (planes * nchunk <= max(planes, 256): one resident round of workgroups; planes = B * Hkv * (1 or 2 group-blocks))
     const size_t nwg = (size_t)std::max<int64_t>(B * Hkv * 2, 256);
@@ -449,6 +452,7 @@ int snapkv_score_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, c
     a.k_sb = k_sb; a.k_sh = k_sh; a.k_ss = k_ss;
     a.B = (uint32_t)B; a.Hq = (uint32_t)Hq; a.Hkv = (uint32_t)Hkv; a.G = (uint32_t)(Hq / Hkv);
     a.S = (uint32_t)S; a.W = (uint32_t)W; a.D = (uint32_t)D;
+    a.Wp = snapkv_wp(a.W); a.rblk = 0;
     a.c = (float)(1.4426950408889634 / sqrt((double)D));
     const uint32_t nrows = (uint32_t)(B * Hq * W);
 
@@ -456,15 +460,17 @@ int snapkv_score_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, c
         const uint32_t nchunk = snapkv_mfma_nchunk(a);
         const bool shares = snapkv_p2_shares_plan(a, nchunk);   // pass 2's tile ranges from pass 1's workgroup times (snapkv_internal.h)
         if (int rc = snapkv_mfma_p1(a, dtype, nchunk, w.part_m, w.part_z, shares ? w.p1_ticks : nullptr, stream)) return rc;
+        // (this path's statistics are per PADDED window row: Wp rows per head, the first Wp - W of them padding with normaliser +inf)
+        const uint32_t nrows_p = (uint32_t)(B * Hq) * a.Wp, pad = a.Wp - a.W;
         if (shares) {
             const uint32_t nplanes = (uint32_t)(B * Hkv) * ((a.G + 3) / 4);
-            if (int rc = snapkv_combine_shares(w.part_m, w.part_z, nrows, nchunk, w.rowstat, (uint32_t)W, norm_base, w.p1_ticks, w.p2_ranges, nplanes,
+            if (int rc = snapkv_combine_shares(w.part_m, w.part_z, nrows_p, nchunk, w.rowstat, a.Wp, norm_base, pad, w.p1_ticks, w.p2_ranges, nplanes,
                                                (uint32_t)((S - W + 127) / 128), stream))
                 return rc;
         } else {
-            KVP_SOFTMAX_COMBINE(stream, w.part_m, w.part_z, nrows, nchunk, w.rowstat, (uint32_t)W, norm_base);
+            KVP_SOFTMAX_COMBINE(stream, w.part_m, w.part_z, nrows_p, nchunk, w.rowstat, a.Wp, norm_base, pad);
         }
-        if (int rc = snapkv_mfma_p2(a, dtype, w.rowstat, w.colsum, w.colsum2, shares ? w.p2_ranges : nullptr, stream)) return rc;
+        if (int rc = snapkv_mfma_p2(a, dtype, w.rowstat, w.colsum, w.colsum2, w.colsumx, shares ? w.p2_ranges : nullptr, stream)) return rc;
     } else {
         const uint32_t nchunk = (uint32_t)((S + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC);
         const size_t lds1 = ((size_t)SK_SUB * (D + 1) + 2 * (size_t)W) * 4;

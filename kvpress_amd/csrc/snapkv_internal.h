@@ -9,9 +9,16 @@ struct SnapArgs {
     int64_t k_sb, k_sh, k_ss;
     uint32_t B, Hq, Hkv, G, S, W, D;
     float c;  // log2(e) / sqrt(D): logits in log2 units
+    // MFMA kernels (round 6: any window size).  They work on blocks of 64 window rows; a window of W rows is padded AT THE FRONT to
+    // Wp = 64 * ceil(W / 64) rows (padded row p = real row p - (Wp - W); rows p < Wp - W are padding: they read real row 0, their
+    // statistics are never used and their normaliser is +inf, so they add 0 to every column sum).  Padded row p may attend keys
+    // <= S - Wp + p: the reference's causal rule (snapkv_press.py:63-65) in padded coordinates.  The partial statistics and the
+    // normalisers of this path are indexed [B, Hq, Wp]; `rblk` is the 64-row block a launch works on.
+    uint32_t Wp, rblk;
 };
+__host__ __device__ inline uint32_t snapkv_wp(uint32_t W) { return (W + 63u) / 64u * 64u; }
 
-// MFMA fast path (bf16/f16, D = 128, W = 64, G <= 8, 16-byte aligned rows)
+// MFMA fast path (bf16/f16, D = 128, G <= 8, 16-byte aligned rows; any window size since round 6)
 bool snapkv_mfma_eligible(const SnapArgs& a, int dtype);
 uint32_t snapkv_mfma_nchunk(const SnapArgs& a);
 // p1_ticks (may be null): [planes][nchunk] wall time of every pass-1 workgroup in 10 ns ticks (plane = (b, kv-head, group-block)) --
@@ -19,7 +26,9 @@ uint32_t snapkv_mfma_nchunk(const SnapArgs& a);
 int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m, float* part_z, uint32_t* p1_ticks, hipStream_t stream);
 // colsum2: scratch of the size of colsum, needed when G > 4 (the second group-block's sums; merged in a fixed order: deterministic)
 // p2_ranges (may be null): [planes][nchunk][2] = (first tile, tiles) of every pass-2 workgroup; null = the interleaved static walk
-int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, float* colsum2, const uint32_t* p2_ranges, hipStream_t stream);
+// colsumx: a third scratch slab of the size of colsum, needed when W > 64 (the column sums of the row blocks after the first, added in order)
+int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, float* colsum2, float* colsumx, const uint32_t* p2_ranges,
+                   hipStream_t stream);
 // Pass 2 balanced by pass 1's clock (round 6).  Under the package power limit the XCDs run the window-attention passes at clocks 5-6 %
 // apart (profiles/r05_clock_power.txt), so with equal tile counts the slowest XCD sets the launch span.  Pass 1 and pass 2 have the same
 // shape and run microseconds apart: the wall time of a pass-1 workgroup predicts the speed of the pass-2 workgroup with the same block
@@ -30,7 +39,7 @@ int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* co
 // (Pass 1 cannot be treated the same way: its (max, sum) partials are per WALK, i.e. their rounding depends on the tile assignment.)
 bool snapkv_p2_shares_plan(const SnapArgs& a, uint32_t nchunk_p1);
 int snapkv_combine_shares(const float* part_m, const float* part_z, uint32_t nrows, uint32_t nchunk, float* rowstat, uint32_t W, uint32_t norm_base,
-                          const uint32_t* p1_ticks, uint32_t* p2_ranges, uint32_t nplanes, uint32_t ntiles_p2, hipStream_t stream);
+                          uint32_t pad, const uint32_t* p1_ticks, uint32_t* p2_ranges, uint32_t nplanes, uint32_t ntiles_p2, hipStream_t stream);
 
 enum { SNAP_FINISH_FULL = 0,    // pool + scale into `scores`, pad columns = max + 1
        SNAP_FINISH_NO_PAD = 1,  // pool + scale, pad columns left unwritten (fused compress: they are kept by construction)

@@ -1,4 +1,6 @@
-// SnapKV window-attention passes on the gfx950 matrix cores (bf16 / f16, D = 128, W = 64).
+// SnapKV window-attention passes on the gfx950 matrix cores (bf16 / f16; D = 128 or 64; any window size: blocks of 64 padded rows).
+// (The text below describes the D = 128 geometry the kernels were designed on; KGeo<DK> holds the numbers of the other head size, and
+// "windows of any size" further down how a window that is not 64 rows maps onto the 64-row blocks.)
 //
 // Work decomposition (per launch): workgroup = (tile set, kv-head [x group-block], batch), 8 waves, ONE workgroup
 // per CU; wave w owns half a q-head of the GQA group (q-head w/2, window rows 32*(w&1) .. +32), whose Q fragments
@@ -49,6 +51,19 @@ constexpr int MF_CHUNK = 128;        // minimum keys per workgroup: one tile (me
 constexpr int MF_ROWB = 256;         // bytes per key row (D = 128, 2-byte elements)
 constexpr int MF_TILEB = MF_TILE * MF_ROWB;
 static_assert(MF_TILEB / 16 / MF_THREADS == MF_SUBS, "one DMA request per thread per sub-tile step");
+// Geometry of a K tile for a head of DK k-steps of 16 elements (round 6: D = 128 -> DK = 8, D = 64 -> DK = 4; 2-byte elements).
+template <int DK> struct KGeo {
+    static constexpr int ROWB = DK * 32;            // bytes per key row
+    static constexpr int CPR = ROWB / 16;           // 16-byte chunks per row
+    static constexpr int RPW = 1024 / ROWB;         // rows one wave's request moves (64 lanes x 16 bytes)
+    static constexpr int RPR = (MF_THREADS / 64) * RPW;   // rows one request of the workgroup moves
+    static constexpr int NREQ = MF_TILE / RPR;      // requests per thread and tile
+    static constexpr int TILEB = MF_TILE * ROWB;
+    static_assert(RPR % CPR == 0 && MF_TILE % RPR == 0, "the swizzle of a row depends on its index inside a request only");
+    // XOR swizzle of a tile row's 16-byte slots: 16 consecutive rows of a fragment read must hit 16 distinct slots of the 256-byte
+    // bank line -- rows of 256 bytes: the row's low four bits; rows of 128 bytes (two per bank line): bits 1 .. 3
+    static __device__ __forceinline__ uint32_t sw(uint32_t row) { return DK == 8 ? (row & 15u) : ((row >> 1) & 7u); }
+};
 
 template <int DT> __device__ __forceinline__ f32x16 mma32(const uint4& a, const uint4& b, f32x16 c);
 template <> __device__ __forceinline__ f32x16 mma32<KVP_BF16>(const uint4& a, const uint4& b, f32x16 c) {
@@ -65,49 +80,57 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // fetches chunk p ^ (row & 15) of row 32 i + 4 w + lr, which the DMA drops into LDS slot p of that row.
 // Row indices are clamped to S-1 (unconditional requests): rows past S are copies of the last row; they are masked
 // (pass 1) or never stored (pass 2).
-struct KStream {
+// (written out for D = 128: DK = 8, 4 rows per wave and request, 4 requests per tile; KGeo<DK> holds the numbers of the other head sizes)
+template <int DK>
+struct KStreamT {
+    using Geo = KGeo<DK>;
     const char* kb;     // K[b, h, 0, 0]
     int64_t k_ssb;      // bytes between keys
     uint32_t S;
-    uint32_t lrow;      // 4 w + lr
-    uint32_t choff;     // byte offset of this lane's chunk inside a row: (p ^ (lrow & 15)) << 4  (32 i is a multiple of 16)
-    uint32_t ldsrow;    // 4 w: first row of this wave's 1 KiB block inside a sub-tile
-    __device__ KStream(const char* kb_, int64_t k_ssb_, uint32_t S_) : kb(kb_), k_ssb(k_ssb_), S(S_) {
+    uint32_t lrow;      // RPW w + lr
+    uint32_t choff;     // byte offset of this lane's chunk inside a row: (p ^ sw(lrow)) << 4  (a request's first row is a multiple of the swizzle period)
+    uint32_t ldsrow;    // RPW w: first row of this wave's 1 KiB block inside a request
+    __device__ KStreamT(const char* kb_, int64_t k_ssb_, uint32_t S_) : kb(kb_), k_ssb(k_ssb_), S(S_) {
         const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        lrow = wv * 4 + (lane >> 4);
-        choff = ((lane & 15) ^ (lrow & 15)) << 4;
-        ldsrow = wv * 4;
+        lrow = wv * Geo::RPW + lane / Geo::CPR;
+        choff = ((lane % Geo::CPR) ^ Geo::sw(lrow)) << 4;
+        ldsrow = wv * Geo::RPW;
     }
     __device__ __forceinline__ void request(unsigned char* buf, uint32_t key0, int i) const {
-        const uint32_t kk = min(key0 + i * 32 + lrow, S - 1);
+        const uint32_t kk = min(key0 + i * Geo::RPR + lrow, S - 1);
         const char* g = kb + (int64_t)kk * k_ssb + choff;
         const uint32_t la = __builtin_amdgcn_readfirstlane(
-            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(buf + (i * 32 + ldsrow) * MF_ROWB));
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(buf + (i * Geo::RPR + ldsrow) * Geo::ROWB));
         // M0 is a reserved register that hipcc never keeps values in (nothing else in these kernels uses it)
         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(g) : "memory");
     }
     __device__ __forceinline__ void request_tile(unsigned char* buf, uint32_t key0) const {
 #pragma unroll
-        for (int i = 0; i < MF_SUBS; ++i) request(buf, key0, i);
+        for (int i = 0; i < Geo::NREQ; ++i) request(buf, key0, i);
     }
 };
+typedef KStreamT<8> KStream;
 // s_waitcnt through the builtin (simm16: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8): unlike an asm string, hipcc's own
 // wait-count bookkeeping sees it, so it stops re-waiting for the Q-fragment loads inside the tile loop.
 // only the newest tile's MF_SUBS requests of this wave may still be in flight
 __device__ __forceinline__ void wait_tile_landed() { __builtin_amdgcn_s_waitcnt(0x0F70 | MF_SUBS); }
+template <int DK> __device__ __forceinline__ void wait_tile_landed_t() { __builtin_amdgcn_s_waitcnt(0x0F70 | KGeo<DK>::NREQ); }
 __device__ __forceinline__ void wait_all_landed() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 // fragment of the 32-key sub-tile `sub` for k-step ks: lane (n = lane & 31, kg = lane >> 5)
-__device__ __forceinline__ uint4 kfrag(const unsigned char* buf, uint32_t sub, uint32_t ks, uint32_t n, uint32_t kg) {
+template <int DK>
+__device__ __forceinline__ uint4 kfrag_t(const unsigned char* buf, uint32_t sub, uint32_t ks, uint32_t n, uint32_t kg) {
     const uint32_t row = sub * 32 + n;
-    return *reinterpret_cast<const uint4*>(buf + row * MF_ROWB + (((ks * 2 + kg) ^ (row & 15)) << 4));
+    return *reinterpret_cast<const uint4*>(buf + row * KGeo<DK>::ROWB + (((ks * 2 + kg) ^ KGeo<DK>::sw(row)) << 4));
 }
+__device__ __forceinline__ uint4 kfrag(const unsigned char* buf, uint32_t sub, uint32_t ks, uint32_t n, uint32_t kg) { return kfrag_t<8>(buf, sub, ks, n, kg); }
 
 // Q fragments of 32 window rows of one q-head: lane (n, kg) holds row row0+n, dims ks*16+kg*8..+8
-__device__ __forceinline__ void load_qfrags(uint4 (&qf)[8], const char* __restrict__ qrow0, int64_t q_swb, uint32_t n, uint32_t kg) {
+// (qrow: this lane's query row, see mf_qrow)
+template <int DK>
+__device__ __forceinline__ void load_qfrags(uint4 (&qf)[DK], const char* __restrict__ qrow, uint32_t kg) {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-        qf[ks] = *reinterpret_cast<const uint4*>(qrow0 + (int64_t)n * q_swb + (ks * 16 + kg * 8) * 2);
+    for (int ks = 0; ks < DK; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(qrow + (ks * 16 + kg * 8) * 2);
 }
 
 // Tile -> workgroup mapping is INTERLEAVED: workgroup `chunk` of the nchunk workgroups of a kv-head takes
@@ -134,13 +157,25 @@ struct TileWalk {
 __device__ __forceinline__ int ring_next(int b) { return b + 1 == MF_NBUF ? 0 : b + 1; }
 __device__ __forceinline__ int ring_prev(int b) { return b == 0 ? MF_NBUF - 1 : b - 1; }
 
+// ---- windows of any size (SnapArgs: Wp, rblk) ------------------------------------------------------------------------------------
+// The kernels work on ONE block of 64 padded window rows per launch.  Row r (0 .. 63) of block a.rblk is padded row p = 64 rblk + r:
+__device__ __forceinline__ uint32_t mf_weff(const SnapArgs& a) { return a.Wp - 64u * a.rblk; }         // row r may attend keys <= S - weff + r
+__device__ __forceinline__ uint32_t mf_prow(const SnapArgs& a, uint32_t r) { return 64u * a.rblk + r; }  // index into [.., Wp] statistics
+// the query row it reads: real row p - (Wp - W); a padding row reads real row 0 (valid memory; its results are never used)
+__device__ __forceinline__ uint32_t mf_qrow(const SnapArgs& a, uint32_t r) {
+    const uint32_t p = mf_prow(a, r), pad = a.Wp - a.W;
+    return p >= pad ? p - pad : 0u;
+}
+
 // =================================================================================================
 // pass 1: per (row, chunk) partial max / sum-exp (log2 units)
 // =================================================================================================
-template <int DT>
+template <int DT, int DK>
 __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint32_t ngb, uint32_t nchunk,
                                                                 float* __restrict__ part_m, float* __restrict__ part_z) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[MF_NBUF * MF_TILEB];
+    using Geo = KGeo<DK>;
+    constexpr int TILEB = Geo::TILEB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[MF_NBUF * TILEB];
     const uint32_t chunk = blockIdx.x, b = blockIdx.z;
     const uint32_t h = blockIdx.y / ngb, gb = blockIdx.y - h * ngb;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -150,21 +185,21 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
     const bool active = rg < a.G;
     const uint32_t hq = h * a.G + (active ? rg : 0);
 
-    const KStream ks_(static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2, a.k_ss * 2, a.S);
+    const KStreamT<DK> ks_(static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2, a.k_ss * 2, a.S);
     const TileWalk tw(chunk, nchunk, a.S);
     // the first two K tiles are requested BEFORE the Q fragments: one memory round trip for both
     if (tw.ntiles > 0) {
         ks_.request_tile(lds, tw.key0(0));
-        ks_.request_tile(lds + MF_TILEB, tw.key0(1));
+        ks_.request_tile(lds + TILEB, tw.key0(1));
     }
-    uint4 qf[8];
-    load_qfrags(qf, static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)row0 * a.q_sw) * 2,
-                a.q_sw * 2, n, kg);
+    uint4 qf[DK];
+    load_qfrags<DK>(qf, static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)mf_qrow(a, row0 + n) * a.q_sw) * 2, kg);
     wait_all_landed();  // K tiles 0 and 1 and the Q fragments are in; from here on vmcnt only counts the K stream
 
     float m = KVP_NEG_INF, z = 0.f;  // raw-logit running max / sum-exp of window row row0 + n over this lane's keys
     const float c = a.c;
-    const uint32_t w = row0 + n;     // window row: token S-W+w sees keys <= S-W+w
+    const uint32_t w = row0 + n;     // row of this launch's 64-row block: it sees keys <= S - weff + w
+    const uint32_t weff = mf_weff(a);
 
     // softmax-update of the 16 finished logits of one sub-tile (lane's q row: running max m, sum-exp z);
     // MASKED: causal mask / sequence tail handled per element (only the last tiles of a head)
@@ -173,7 +208,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t kk = key0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                if (kk >= a.S || kk > a.S - a.W + w) acc[r] = KVP_NEG_INF;
+                if (kk >= a.S || kk > a.S - weff + w) acc[r] = KVP_NEG_INF;
             }
         }
         float tm = acc[0];
@@ -197,23 +232,24 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
     // fragment reads of the next sub-tile, and the MFMA chain of this sub-tile interleaved (1 MFMA : 6 VALU) with
     // the softmax of the previous one.  Straight-line code (no masks: every tile but the last ones of a head).
     auto compute_fast = [&](const unsigned char* buf, unsigned char* bufr, uint32_t keyr) {
-        uint4 kf[2][8];
+        constexpr int EPS = 16 / DK;   // logits of the previous sub-tile exponentiated beside one MFMA of this one
+        uint4 kf[2][DK];
         f32x16 acc[2];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) kf[0][ks] = kfrag(buf, 0, ks, n, kg);
+        for (int ks = 0; ks < DK; ++ks) kf[0][ks] = kfrag_t<DK>(buf, 0, ks, n, kg);
 #pragma unroll
         for (int sub = 0; sub < MF_SUBS; ++sub) {
             if (sub + 1 < MF_SUBS) {
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) kf[(sub + 1) & 1][ks] = kfrag(buf, sub + 1, ks, n, kg);
+                for (int ks = 0; ks < DK; ++ks) kf[(sub + 1) & 1][ks] = kfrag_t<DK>(buf, sub + 1, ks, n, kg);
             }
-            ks_.request(bufr, keyr, sub);
+            if (sub < Geo::NREQ) ks_.request(bufr, keyr, sub);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[sub & 1][i] = 0.f;
             if (sub == 0) {
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc[0] = mma32<DT>(kf[0][ks], qf[ks], acc[0]);  // C[key][q row]
+                for (int ks = 0; ks < DK; ++ks) acc[0] = mma32<DT>(kf[0][ks], qf[ks], acc[0]);  // C[key][q row]
             } else {
                 // MFMA chain of this sub-tile || softmax of the previous one
                 const f32x16& ap = acc[(sub - 1) & 1];
@@ -224,18 +260,21 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
                 const float off = -mn * c;
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
+                for (int ks = 0; ks < DK; ++ks) {
                     acc[sub & 1] = mma32<DT>(kf[sub & 1][ks], qf[ks], acc[sub & 1]);
-                    s0 += fast_exp2(fmaf(ap[2 * ks], c, off));
-                    s1 += fast_exp2(fmaf(ap[2 * ks + 1], c, off));
+#pragma unroll
+                    for (int e = 0; e < EPS; e += 2) {   // (the same two interleaved sums for every head size: element i goes to sum i & 1)
+                        s0 += fast_exp2(fmaf(ap[EPS * ks + e], c, off));
+                        s1 += fast_exp2(fmaf(ap[EPS * ks + e + 1], c, off));
+                    }
                 }
                 z = z * fast_exp2(fmaf(m, c, off)) + (s0 + s1);
                 m = mn;
                 __builtin_amdgcn_sched_group_barrier(0x2, 12, 0);   // max chain + offsets while the fragments land
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);  // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);  // 6 VALU: 2 x (fma, exp, add)
+                for (int ks = 0; ks < DK; ++ks) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);        // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x2, 3 * EPS, 0);  // EPS x (fma, exp, add)
                 }
             }
         }
@@ -245,20 +284,20 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
     // the last tiles of a head (causal mask over the window, keys past S): chain, then the masked update, per sub-tile
     auto compute_masked = [&](uint32_t key0, const unsigned char* buf, unsigned char* bufr, uint32_t keyr) {
         for (int sub = 0; sub < MF_SUBS; ++sub) {
-            uint4 kf[8];
+            uint4 kf[DK];
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) kf[ks] = kfrag(buf, sub, ks, n, kg);
-            ks_.request(bufr, keyr, sub);
+            for (int ks = 0; ks < DK; ++ks) kf[ks] = kfrag_t<DK>(buf, sub, ks, n, kg);
+            if (sub < Geo::NREQ) ks_.request(bufr, keyr, sub);
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) acc = mma32<DT>(kf[ks], qf[ks], acc);
+            for (int ks = 0; ks < DK; ++ks) acc = mma32<DT>(kf[ks], qf[ks], acc);
             softmax16(acc, key0, sub, true);
         }
     };
     auto compute = [&](uint32_t key0, const unsigned char* buf, unsigned char* bufr, uint32_t keyr) {
-        if (key0 + (MF_TILE - 1) > a.S - a.W) compute_masked(key0, buf, bufr, keyr);  // some (row, key) is masked / past S
+        if (key0 + (MF_TILE - 1) > a.S - weff) compute_masked(key0, buf, bufr, keyr);  // some (row, key) is masked / past S
         else compute_fast(buf, bufr, keyr);
     };
 
@@ -266,11 +305,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
         __syncthreads();
         int bc = 0;
         for (uint32_t t = 0; t < tw.ntiles; ++t) {
-            unsigned char* bufr = lds + ring_prev(bc) * MF_TILEB;  // tile t-1's buffer: everybody left it at the last barrier
-            if (active) compute(tw.key0(t), lds + bc * MF_TILEB, bufr, tw.key0(t + 2));
+            unsigned char* bufr = lds + ring_prev(bc) * TILEB;  // tile t-1's buffer: everybody left it at the last barrier
+            if (active) compute(tw.key0(t), lds + bc * TILEB, bufr, tw.key0(t + 2));
             else ks_.request_tile(bufr, tw.key0(t + 2));
             __builtin_amdgcn_sched_barrier(0);
-            wait_tile_landed();  // this wave's part of tile t+1 is in LDS ...
+            wait_tile_landed_t<DK>();  // this wave's part of tile t+1 is in LDS ...
             __syncthreads();     // ... and so is everybody else's; all fragment reads of tile t are done
             bc = ring_next(bc);
         }
@@ -282,7 +321,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
         const float m2 = __shfl_xor(mm, 32), z2 = __shfl_xor(zz, 32);
         softmax_merge(mm, zz, m2, z2);
         if (kg == 0) {
-            const size_t o = ((size_t)(b * a.Hq + hq) * a.W + w) * nchunk + chunk;
+            const size_t o = ((size_t)(b * a.Hq + hq) * a.Wp + mf_prow(a, w)) * nchunk + chunk;
             part_m[o] = mm;
             part_z[o] = zz;
         }
@@ -328,12 +367,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_asm(SnapArgs a, uint3
 #pragma unroll
         for (int i = 0; i < NB - 1; ++i) ks_.request_tile(lds + i * MF_TILEB, tw.key0(i));
     }
-    const char* qrow = static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)(row0 + n) * a.q_sw) * 2 + kg * 16;
-    // tiles for the asm loop: the leading unmasked ones (every key <= S - W).  Its requests run NB - 1 tiles ahead with the tile
+    const char* qrow = static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)mf_qrow(a, row0 + n) * a.q_sw) * 2 + kg * 16;
+    const uint32_t weff = mf_weff(a);
+    // tiles for the asm loop: the leading unmasked ones (every key <= S - weff).  Its requests run NB - 1 tiles ahead with the tile
     // index clamped to the walk's last tile and no per-row clamp: if that last tile is ragged (rows past S), the C++ loop below
     // must be the one that requests it.
     uint32_t nfast = 0;
-    while (nfast < tw.ntiles && tw.kbeg + nfast * tw.tstride + (MF_TILE - 1) <= a.S - a.W) ++nfast;
+    while (nfast < tw.ntiles && tw.kbeg + nfast * tw.tstride + (MF_TILE - 1) <= a.S - weff) ++nfast;
     const bool last_full = tw.klast + (MF_TILE - 1) <= a.S - 1;
     const uint32_t nasm = last_full ? nfast : min(nfast, tw.ntiles >= (uint32_t)NB ? tw.ntiles - NB : 0u);
 
@@ -378,7 +418,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_asm(SnapArgs a, uint3
             const unsigned char* buf = lds + bc * MF_TILEB;
             unsigned char* bufr = lds + ((bc + NB - 1) % NB) * MF_TILEB;   // the previous tile's buffer: everybody left it at the last barrier
             const uint32_t key0 = tw.key0(t), keyr = tw.key0(t + NB - 1);
-            const bool masked = key0 + (MF_TILE - 1) > a.S - a.W;
+            const bool masked = key0 + (MF_TILE - 1) > a.S - weff;
             for (int sub = 0; sub < MF_SUBS; ++sub) {
                 uint4 kf[8];
 #pragma unroll
@@ -393,7 +433,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_asm(SnapArgs a, uint3
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t kk = key0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                        if (kk >= a.S || kk > a.S - a.W + w) acc[r] = KVP_NEG_INF;
+                        if (kk >= a.S || kk > a.S - weff + w) acc[r] = KVP_NEG_INF;
                     }
                 }
                 float tm = acc[0];
@@ -424,7 +464,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_asm(SnapArgs a, uint3
     const float m2 = __shfl_xor(mm, 32), z2 = __shfl_xor(zz, 32);
     softmax_merge(mm, zz, m2, z2);
     if (kg == 0) {
-        const size_t o = ((size_t)(b * a.Hq + hq) * a.W + row0 + n) * nchunk + chunk;
+        const size_t o = ((size_t)(b * a.Hq + hq) * a.Wp + mf_prow(a, row0 + n)) * nchunk + chunk;
         part_m[o] = mm;
         part_z[o] = zz;
     }
@@ -435,10 +475,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_asm(SnapArgs a, uint3
 // =================================================================================================
 // pass 2: colsum[b,h,key] = sum over the group's G*64 rows of 2^(L2 - a_row), keys < S - W
 // =================================================================================================
-template <int DT>
+template <int DT, int DK>
 __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint32_t ngb, const float* __restrict__ rowstat,
                                                                 float* __restrict__ colsum, float* __restrict__ colsum2) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[MF_NBUF * MF_TILEB];
+    using Geo = KGeo<DK>;
+    constexpr int TILEB = Geo::TILEB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[MF_NBUF * TILEB];
     __shared__ float red[2][MF_WAVES][MF_TILE];
     const uint32_t chunk = blockIdx.x, b = blockIdx.z;
     const uint32_t h = blockIdx.y / ngb, gb = blockIdx.y - h * ngb;
@@ -450,18 +492,17 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
     const uint32_t hq = h * a.G + (active ? rg : 0);
     const uint32_t Sm = a.S - a.W;
 
-    const KStream ks_(static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2, a.k_ss * 2, a.S);
+    const KStreamT<DK> ks_(static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2, a.k_ss * 2, a.S);
     const TileWalk tw(chunk, gridDim.x, Sm);
     if (tw.ntiles == 0) return;
     // the first two K tiles are requested BEFORE the Q fragments and normalisers: one memory round trip for all
     ks_.request_tile(lds, tw.key0(0));
-    ks_.request_tile(lds + MF_TILEB, tw.key0(1));
-    uint4 qf[8];
-    load_qfrags(qf, static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)row0 * a.q_sw) * 2,
-                a.q_sw * 2, n, kg);
+    ks_.request_tile(lds + TILEB, tw.key0(1));
+    uint4 qf[DK];
+    load_qfrags<DK>(qf, static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)mf_qrow(a, row0 + n) * a.q_sw) * 2, kg);
     // normalisers of the 16 q rows this lane sees in the C layout: row = row0 + (r&3) + 8*(r>>2) + 4*kg
     float ar[16];
-    const float* ars = rowstat + (size_t)(b * a.Hq + hq) * a.W + row0;
+    const float* ars = rowstat + (size_t)(b * a.Hq + hq) * a.Wp + mf_prow(a, row0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) ar[r] = -ars[(r & 3) + 8 * (r >> 2) + 4 * kg];
     wait_all_landed();  // K tiles 0 and 1, Q fragments and normalisers are in; from here on vmcnt only counts the K stream (+ the flush stores)
@@ -485,39 +526,43 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
     };
     // one tile, software-pipelined like pass 1: MFMA chain of sub-tile s || exp/add stream of sub-tile s-1
     auto compute = [&](const unsigned char* buf, int par, unsigned char* bufr, uint32_t keyr) {
-        uint4 kf[2][8];
+        constexpr int EPS = 16 / DK;
+        uint4 kf[2][DK];
         f32x16 acc[2];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) kf[0][ks] = kfrag(buf, 0, ks, n, kg);
+        for (int ks = 0; ks < DK; ++ks) kf[0][ks] = kfrag_t<DK>(buf, 0, ks, n, kg);
 #pragma unroll
         for (int sub = 0; sub < MF_SUBS; ++sub) {
             if (sub + 1 < MF_SUBS) {
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) kf[(sub + 1) & 1][ks] = kfrag(buf, sub + 1, ks, n, kg);
+                for (int ks = 0; ks < DK; ++ks) kf[(sub + 1) & 1][ks] = kfrag_t<DK>(buf, sub + 1, ks, n, kg);
             }
-            ks_.request(bufr, keyr, sub);
+            if (sub < Geo::NREQ) ks_.request(bufr, keyr, sub);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[sub & 1][i] = 0.f;
             if (sub == 0) {
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc[0] = mma32<DT>(qf[ks], kf[0][ks], acc[0]);  // C[q row][key]
+                for (int ks = 0; ks < DK; ++ks) acc[0] = mma32<DT>(qf[ks], kf[0][ks], acc[0]);  // C[q row][key]
             } else {
                 const f32x16& ap = acc[(sub - 1) & 1];
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
+                for (int ks = 0; ks < DK; ++ks) {
                     acc[sub & 1] = mma32<DT>(qf[ks], kf[sub & 1][ks], acc[sub & 1]);
-                    s0 += fast_exp2(fmaf(ap[2 * ks], c, ar[2 * ks]));
-                    s1 += fast_exp2(fmaf(ap[2 * ks + 1], c, ar[2 * ks + 1]));
+#pragma unroll
+                    for (int e = 0; e < EPS; e += 2) {
+                        s0 += fast_exp2(fmaf(ap[EPS * ks + e], c, ar[EPS * ks + e]));
+                        s1 += fast_exp2(fmaf(ap[EPS * ks + e + 1], c, ar[EPS * ks + e + 1]));
+                    }
                 }
                 float s = s0 + s1;
                 s += __shfl_xor(s, 32);
                 if (kg == 0) red[par][wv][(sub - 1) * 32 + n] = s;
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
+                for (int ks = 0; ks < DK; ++ks) {
                     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x2, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 3 * EPS, 0);
                 }
             }
         }
@@ -538,11 +583,11 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
     __syncthreads();
     int bc = 0;
     for (uint32_t t = 0; t < tw.ntiles; ++t) {
-        unsigned char* bufr = lds + ring_prev(bc) * MF_TILEB;
-        if (active) compute(lds + bc * MF_TILEB, t & 1, bufr, tw.key0(t + 2));
+        unsigned char* bufr = lds + ring_prev(bc) * TILEB;
+        if (active) compute(lds + bc * TILEB, t & 1, bufr, tw.key0(t + 2));
         else ks_.request_tile(bufr, tw.key0(t + 2));
         __builtin_amdgcn_sched_barrier(0);
-        wait_tile_landed();
+        wait_tile_landed_t<DK>();
         __syncthreads();
         flush(tw.key0(t), t & 1);
         bc = ring_next(bc);
@@ -554,7 +599,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
 
 bool snapkv_mfma_eligible(const SnapArgs& a, int dtype) {
     if (dtype != KVP_BF16 && dtype != KVP_F16) return false;
-    if (a.D != 128 || a.W != 64 || a.G > 8) return false;
+    if ((a.D != 128 && a.D != 64) || a.W < 1 || a.W > 4096 || a.G > 8) return false;   // (any window: blocks of 64 rows, snapkv_internal.h)
     auto al8 = [](int64_t x) { return x % 8 == 0; };
     if (((uintptr_t)a.q % 16) || ((uintptr_t)a.k % 16)) return false;
     return al8(a.q_sb) && al8(a.q_sh) && al8(a.q_sw) && al8(a.k_sb) && al8(a.k_sh) && al8(a.k_ss);
@@ -579,25 +624,30 @@ uint32_t snapkv_mfma_nchunk(const SnapArgs& a) { return mfma_nchunk_for(a, a.S);
 // every walk is long (>= 8 tiles: a range never shrinks below the three tiles a ragged tail hands to the plain path).
 // KVP_SK_BALANCE=0 keeps the static interleaved walk (A/B runs).
 bool snapkv_p2_shares_plan(const SnapArgs& a, uint32_t nchunk_p1) {
-    if (a.G % 4 != 0 || a.S <= a.W) return false;
+    if (a.G % 4 != 0 || a.D != 128 || a.S <= a.W) return false;
     const uint32_t Sm = a.S - a.W;
     const uint32_t ntiles = (Sm + MF_TILE - 1) / MF_TILE;
     return mfma_nchunk_for(a, Sm) == nchunk_p1 && nchunk_p1 >= 2 && nchunk_p1 <= 256 && ntiles >= 8 * nchunk_p1 && kvp_env_int("KVP_SK_BALANCE", 1) != 0;
 }
 
-int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m, float* part_z, uint32_t* p1_ticks, hipStream_t stream) {
-    const uint32_t ngb = (a.G + 3) / 4;
-    const dim3 grid(nchunk, a.Hkv * ngb, a.B);
-    if (a.G % 4 == 0) {   // hand-scheduled tile loop: all eight waves of a workgroup own a q-head half
-        if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_asm", stream, snapkv_p1_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, p1_ticks));
-        else KVP_LAUNCH("snapkv_p1_asm", stream, snapkv_p1_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, p1_ticks));
-        KVP_CHECK_LAUNCH("snapkv_p1_asm");
-        return KVP_OK;
+int snapkv_mfma_p1(const SnapArgs& a0, int dtype, uint32_t nchunk, float* part_m, float* part_z, uint32_t* p1_ticks, hipStream_t stream) {
+    const uint32_t ngb = (a0.G + 3) / 4;
+    const dim3 grid(nchunk, a0.Hkv * ngb, a0.B);
+    SnapArgs a = a0;
+    for (a.rblk = 0; a.rblk < a.Wp / 64; ++a.rblk) {   // one launch per block of 64 (padded) window rows
+        if (a.G % 4 == 0 && a.D == 128) {   // hand-scheduled tile loop: all eight waves of a workgroup own a q-head half
+            if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_asm", stream, snapkv_p1_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, p1_ticks));
+            else KVP_LAUNCH("snapkv_p1_asm", stream, snapkv_p1_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z, p1_ticks));
+            KVP_CHECK_LAUNCH("snapkv_p1_asm");
+            continue;
+        }
+        // G = 1, 2, 3, 5, 6, 7 (partially filled workgroups) and head size 64: the compiler-scheduled kernels
+#define KVP_P1_MFMA(DTV, DKV) KVP_LAUNCH("snapkv_p1_mfma", stream, (snapkv_p1_mfma<DTV, DKV><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z)))
+        if (a.D == 128) { if (dtype == KVP_BF16) KVP_P1_MFMA(KVP_BF16, 8); else KVP_P1_MFMA(KVP_F16, 8); }
+        else { if (dtype == KVP_BF16) KVP_P1_MFMA(KVP_BF16, 4); else KVP_P1_MFMA(KVP_F16, 4); }
+#undef KVP_P1_MFMA
+        KVP_CHECK_LAUNCH("snapkv_p1_mfma");
     }
-    // G = 1, 2, 3, 5, 6, 7 (partially filled workgroups): the compiler-scheduled kernel
-    if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
-    else KVP_LAUNCH("snapkv_p1_mfma", stream, snapkv_p1_mfma<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z));
-    KVP_CHECK_LAUNCH("snapkv_p1_mfma");
     return KVP_OK;
 }
 
@@ -631,8 +681,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_asm(SnapArgs a, uint3
     if (tw.ntiles == 0) return;
     ks_.request_tile(lds, tw.key0(0));
     ks_.request_tile(lds + MF_TILEB, tw.key0(1));
-    const char* qrow = static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)(row0 + n) * a.q_sw) * 2 + kg * 16;
-    const float* ars = rowstat + (size_t)(b * a.Hq + hq) * a.W + row0;
+    const char* qrow = static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)mf_qrow(a, row0 + n) * a.q_sw) * 2 + kg * 16;
+    const float* ars = rowstat + (size_t)(b * a.Hq + hq) * a.Wp + mf_prow(a, row0);
     float* cs = (gb == 0 ? colsum : colsum2) + (size_t)(b * a.Hkv + h) * Sm;
     const float c = a.c;
 
@@ -736,7 +786,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_asm(SnapArgs a, uint3
 // plane's workgroups, end_c = round(ntiles * prefix_c / total): contiguous ranges, monotone, the last one ends at ntiles.
 namespace {
 __global__ __launch_bounds__(256) void softmax_combine_shares_kernel(const float* __restrict__ part_m, const float* __restrict__ part_z, uint32_t nrows,
-                                                                     uint32_t nchunk, float* __restrict__ a, uint32_t W, uint32_t norm_base, uint32_t nrb,
+                                                                     uint32_t nchunk, float* __restrict__ a, uint32_t W, uint32_t norm_base, uint32_t pad, uint32_t nrb,
                                                                      const uint32_t* __restrict__ ticks, uint32_t* __restrict__ ranges, uint32_t ntiles) {
     if (blockIdx.x < nrb) {
         const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -749,7 +799,7 @@ __global__ __launch_bounds__(256) void softmax_combine_shares_kernel(const float
             const float m2 = __shfl_xor(m, o), z2 = __shfl_xor(z, o);
             softmax_merge(m, z, m2, z2);
         }
-        if (lane == 0) a[row] = m + log2f(z) - (norm_base ? log2f((float)(norm_base + row % W)) : 0.f);
+        if (lane == 0) a[row] = softmax_row_normaliser(m, z, row, W, norm_base, pad);
         return;
     }
     __shared__ uint32_t s_min[4];
@@ -788,10 +838,10 @@ __global__ __launch_bounds__(256) void softmax_combine_shares_kernel(const float
 }  // namespace
 
 int snapkv_combine_shares(const float* part_m, const float* part_z, uint32_t nrows, uint32_t nchunk, float* rowstat, uint32_t W, uint32_t norm_base,
-                          const uint32_t* p1_ticks, uint32_t* p2_ranges, uint32_t nplanes, uint32_t ntiles_p2, hipStream_t stream) {
+                          uint32_t pad, const uint32_t* p1_ticks, uint32_t* p2_ranges, uint32_t nplanes, uint32_t ntiles_p2, hipStream_t stream) {
     const uint32_t nrb = (nrows + 3) / 4;
     KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_shares_kernel<<<nrb + nplanes, 256, 0, stream>>>(part_m, part_z, nrows, nchunk, rowstat, W,
-                                                                                                                  norm_base, nrb, p1_ticks, p2_ranges, ntiles_p2));
+                                                                                                                  norm_base, pad, nrb, p1_ticks, p2_ranges, ntiles_p2));
     KVP_CHECK_LAUNCH("snapkv(combine + shares)");
     return KVP_OK;
 }
@@ -802,21 +852,37 @@ __global__ __launch_bounds__(256) void add_slab_kernel(float* __restrict__ x, co
 }
 }  // namespace
 
-int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, float* colsum2, const uint32_t* p2_ranges, hipStream_t stream) {
-    const uint32_t ngb = (a.G + 3) / 4;
-    const uint32_t Sm = a.S - a.W;
-    KVP_CHECK_ARG(ngb <= 2 && (ngb == 1 || colsum2), "snapkv_p2_mfma: G = %u needs the second column-sum slab", a.G);
-    const dim3 grid(mfma_nchunk_for(a, Sm), a.Hkv * ngb, a.B);
-    if (a.G % 4 == 0) {   // hand-scheduled tile loop
-        if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2, p2_ranges));
-        else KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2, p2_ranges));
-    } else if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
-    else KVP_LAUNCH("snapkv_p2_mfma", stream, snapkv_p2_mfma<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, colsum, colsum2));
-    KVP_CHECK_LAUNCH("snapkv_p2_mfma");
-    if (ngb == 2) {  // colsum += colsum2, always in this order: run-to-run identical scores (float atomics were not)
-        const size_t n = (size_t)a.B * a.Hkv * Sm;
-        KVP_LAUNCH("add_slab_kernel", stream, add_slab_kernel<<<(unsigned)std::min<size_t>((n + 255) / 256, 4096), 256, 0, stream>>>(colsum, colsum2, n));
-        KVP_CHECK_LAUNCH("snapkv_p2_mfma(add)");
+int snapkv_mfma_p2(const SnapArgs& a0, int dtype, const float* rowstat, float* colsum, float* colsum2, float* colsumx, const uint32_t* p2_ranges,
+                   hipStream_t stream) {
+    const uint32_t ngb = (a0.G + 3) / 4;
+    const uint32_t Sm = a0.S - a0.W;
+    const uint32_t nrblk = a0.Wp / 64;
+    KVP_CHECK_ARG(ngb <= 2 && (ngb == 1 || colsum2), "snapkv_p2_mfma: G = %u needs the second column-sum slab", a0.G);
+    KVP_CHECK_ARG(nrblk == 1 || colsumx, "snapkv_p2_mfma: W = %u needs the row-block slab", a0.W);
+    const dim3 grid(mfma_nchunk_for(a0, Sm), a0.Hkv * ngb, a0.B);
+    const size_t nsum = (size_t)a0.B * a0.Hkv * Sm;
+    const unsigned ablocks = (unsigned)std::min<size_t>((nsum + 255) / 256, 4096);
+    SnapArgs a = a0;
+    for (a.rblk = 0; a.rblk < nrblk; ++a.rblk) {
+        // the first 64-row block writes the column sums, every later one its own slab that is then added: always in block order
+        // (run-to-run identical scores; float atomics were not)
+        float* cs = a.rblk == 0 ? colsum : colsumx;
+#define KVP_P2_MFMA(DTV, DKV) KVP_LAUNCH("snapkv_p2_mfma", stream, (snapkv_p2_mfma<DTV, DKV><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, cs, colsum2)))
+        if (a.G % 4 == 0 && a.D == 128) {   // hand-scheduled tile loop
+            if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, cs, colsum2, p2_ranges));
+            else KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, cs, colsum2, p2_ranges));
+        } else if (a.D == 128) { if (dtype == KVP_BF16) KVP_P2_MFMA(KVP_BF16, 8); else KVP_P2_MFMA(KVP_F16, 8); }
+        else { if (dtype == KVP_BF16) KVP_P2_MFMA(KVP_BF16, 4); else KVP_P2_MFMA(KVP_F16, 4); }
+#undef KVP_P2_MFMA
+        KVP_CHECK_LAUNCH("snapkv_p2_mfma");
+        if (ngb == 2) {  // cs += colsum2 (the second group-block's sums)
+            KVP_LAUNCH("add_slab_kernel", stream, add_slab_kernel<<<ablocks, 256, 0, stream>>>(cs, colsum2, nsum));
+            KVP_CHECK_LAUNCH("snapkv_p2_mfma(add)");
+        }
+        if (a.rblk > 0) {
+            KVP_LAUNCH("add_slab_kernel", stream, add_slab_kernel<<<ablocks, 256, 0, stream>>>(colsum, colsumx, nsum));
+            KVP_CHECK_LAUNCH("snapkv_p2_mfma(add rows)");
+        }
     }
     return KVP_OK;
 }

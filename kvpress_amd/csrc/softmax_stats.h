@@ -26,10 +26,19 @@ __device__ __forceinline__ void softmax_merge(float& m, float& z, float m2, floa
 }
 
 // a[row] = M + log2(Z) from part_m/part_z [nrows][nchunk]; one wave per row (rows = [.., W] window rows when norm_base is used).
+// pad > 0 (SnapKV's MFMA path, snapkv_internal.h): rows are [.., W] PADDED window rows whose first `pad` are padding: their
+// normaliser becomes +inf (2^(L2 - inf) = 0: they add nothing to a column sum), the real window row of row p is p - pad.
+__device__ __forceinline__ float softmax_row_normaliser(float m, float z, uint32_t row, uint32_t W, uint32_t norm_base, uint32_t pad) {
+    const uint32_t wp = W ? row % W : 0u;
+    if (wp < pad) return __builtin_huge_valf();
+    // norm_base != 0 (FINCH, finch_press.py:71-74): window row w is weighted by its number of visible keys
+    // norm_base + w, i.e. its log2-normaliser is lowered by log2 of that count
+    return m + log2f(z) - (norm_base ? log2f((float)(norm_base + wp - pad)) : 0.f);
+}
 static __global__ __launch_bounds__(256) void softmax_combine_kernel(const float* __restrict__ part_m,
                                                               const float* __restrict__ part_z, uint32_t nrows,
                                                               uint32_t nchunk, float* __restrict__ a, uint32_t W = 0,
-                                                              uint32_t norm_base = 0) {
+                                                              uint32_t norm_base = 0, uint32_t pad = 0) {
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     if (row >= nrows) return;
@@ -40,9 +49,7 @@ static __global__ __launch_bounds__(256) void softmax_combine_kernel(const float
         const float m2 = __shfl_xor(m, o), z2 = __shfl_xor(z, o);
         softmax_merge(m, z, m2, z2);
     }
-    // norm_base != 0 (FINCH, finch_press.py:71-74): window row w = row % W is weighted by its number of visible keys
-    // norm_base + w, i.e. its log2-normaliser is lowered by log2 of that count
-    if (lane == 0) a[row] = m + log2f(z) - (norm_base ? log2f((float)(norm_base + row % W)) : 0.f);
+    if (lane == 0) a[row] = softmax_row_normaliser(m, z, row, W, norm_base, pad);
 }
 
 // The same with one THREAD per row, for many rows with few partials each (ChunkPress scores every 1024-token chunk as a batch
@@ -50,12 +57,12 @@ static __global__ __launch_bounds__(256) void softmax_combine_kernel(const float
 // nchunk <= 2 (a wave's lanes 0 and 1), hence the same bits there; used for nchunk <= 2 only.
 static __global__ __launch_bounds__(256) void softmax_combine_rows_kernel(const float* __restrict__ part_m, const float* __restrict__ part_z,
                                                                            uint32_t nrows, uint32_t nchunk, float* __restrict__ a, uint32_t W = 0,
-                                                                           uint32_t norm_base = 0) {
+                                                                           uint32_t norm_base = 0, uint32_t pad = 0) {
     const uint32_t row = blockIdx.x * 256 + threadIdx.x;
     if (row >= nrows) return;
     float m = KVP_NEG_INF, z = 0.f;
     for (uint32_t j = 0; j < nchunk; ++j) softmax_merge(m, z, part_m[(size_t)row * nchunk + j], part_z[(size_t)row * nchunk + j]);
-    a[row] = m + log2f(z) - (norm_base ? log2f((float)(norm_base + row % W)) : 0.f);
+    a[row] = softmax_row_normaliser(m, z, row, W, norm_base, pad);
 }
 // launch helper: picks the row-per-thread form for many rows with <= 2 partials
 #define KVP_SOFTMAX_COMBINE(stream, part_m, part_z, nrows, nchunk, a, ...)                                                                  \

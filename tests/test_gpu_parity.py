@@ -303,6 +303,30 @@ def test_snapkv_kernel_vs_oracle(name):
         assert ok, f"{name} r={r}: {msg}"
 
 
+@pytest.mark.parametrize("D", [128, 64])
+@pytest.mark.parametrize("W,S,G,ks", [(1, 700, 4, 1), (1, 5000, 2, 1), (7, 300, 4, 5), (32, 1000, 4, 5), (33, 2100, 1, 3), (63, 64, 4, 5), (64, 65, 3, 5),
+                                      (65, 700, 4, 5), (100, 4200, 4, 5), (128, 129, 2, 5), (130, 9000, 8, 7), (200, 2500, 4, 5), (257, 40000, 4, 5)])
+def test_snapkv_any_window_on_the_mfma_path(W, S, G, ks, D):
+    """Round 6: the MFMA passes take ANY window size (TOVA's W = 1, FINCH's question length, user-chosen windows) as blocks of 64
+    padded rows -- padding in front, normaliser +inf, the reference's causal rule in padded coordinates (snapkv_internal.h) -- for
+    head sizes 128 and 64, G = 1 .. 8 (hand-scheduled loops for D = 128 and G % 4 == 0, the compiler-scheduled kernels otherwise), down to
+    S = W + 1 (every tile masked).  Scores against the float64 oracle; pad columns; a batch of two through the same call."""
+    rs = np.random.RandomState(W * 131 + S + G + D)
+    N = native()
+    B, H = 2, 2
+    q = _inputs.round_to((rs.standard_normal((B, H * G, W, D)) * 1.5).astype(np.float32), "bf16")
+    k = rs.standard_normal((B, H, S, D)).astype(np.float32)
+    k[1, :, : S // 3] *= 3.0   # uneven logits: the lazy offset's raises, rows whose maximum sits in the masked tail
+    k = _inputs.round_to(k, "bf16")
+    want = O.snapkv_score(q, k, ks)
+    got = N.snapkv_score(to_dev(q, "bf16"), to_dev(k, "bf16"), ks).cpu().numpy()
+    assert_scores_close(got[..., :-W], want[..., :-W], RTOL, f"W={W} S={S} G={G} D={D}")
+    fill = np.float32(got[..., :-W].max()) + np.float32(1.0)
+    assert np.all(got[..., -W:] == fill)
+    one = N.snapkv_score(to_dev(q[:1], "bf16"), to_dev(k[:1], "bf16"), ks).cpu().numpy()
+    assert_scores_close(one[..., :-W], want[:1, :, :-W], RTOL, f"W={W} S={S} G={G} D={D} (B = 1)")
+
+
 @pytest.mark.parametrize("S,Hq", [(192, 4), (4160, 4), (33000, 2), (40000, 8)])
 def test_snapkv_kernel_many_chunks(S, Hq):
     """One kv-head: the MFMA passes split S into as many single-tile workgroups as fit (up to 256) - the partial

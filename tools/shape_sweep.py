@@ -53,7 +53,7 @@ def case(kind, B, Hq, Hkv, S, D, dt, W=64, ks=5, ratio=0.5, note=""):
             return N.gather_kv(k, v, N.topk_select(sc, n))
     t = timeit(fn)
     print(f"{kind:7s} B={B} Hq={Hq:2d} Hkv={Hkv:2d} S={S:6d} D={D:3d} {str(dt).split('.')[-1]:8s} W={W:2d} ks={ks} r={ratio}: {t:8.1f} us  "
-          f"{bytes_ / t / 1e6 / 8000:.3f} of 8 TB/s   {note}", flush=True)
+          f"{bytes_ / (t * 1e-6) / 8e12:.3f} of 8 TB/s   {note}", flush=True)
     del k, v
     torch.cuda.empty_cache()
 
@@ -69,9 +69,9 @@ def main():
     case("snapkv", 1, 16, 8, S, 128, bf, note="G = 2: compiler-scheduled MFMA passes")
     case("snapkv", 1, 24, 8, S, 128, bf, note="G = 3: compiler-scheduled MFMA passes")
     case("snapkv", 1, 64, 8, S, 128, bf, note="G = 8: two group-blocks, second column-sum slab")
-    case("snapkv", 1, 32, 8, S, 64, bf, note="D = 64: generic (non-MFMA) kernels")
+    case("snapkv", 1, 32, 8, S, 64, bf, note="D = 64: compiler-scheduled MFMA passes (round 6; before: generic kernels, 3206 us)")
     case("snapkv", 1, 32, 8, S, 128, f32, note="float32 model: generic kernels")
-    case("snapkv", 1, 32, 8, S, 128, bf, W=32, note="window 32: generic kernels")
+    case("snapkv", 1, 32, 8, S, 128, bf, W=32, note="window 32: hand-scheduled passes on a padded 64-row block (round 6; before: generic kernels, 3812 us)")
     case("snapkv", 1, 32, 8, S, 128, bf, ks=7, note="kernel_size 7: pooling launch + HIST1 cluster select")
     case("snapkv", 4, 32, 8, S, 128, bf, note="batch 4 (32 rows: one cluster launch, four resident rounds)")
     case("snapkv", 8, 32, 8, S, 128, bf, note="batch 8 (64 rows: the (chunk, row) passes)")
