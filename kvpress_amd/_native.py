@@ -662,9 +662,21 @@ def topk_select_segmented(scores: torch.Tensor, seg_len: int, k: int, pos_base: 
     idx = torch.empty((R, nseg * k), dtype=torch.int32, device=s.device)
     if R and k:
         with _on_device(s.device):
-            ws = torch.zeros(max(int(lib().kvp_topk_segmented_workspace_bytes(R, nseg, seg_len, k)), 256), dtype=torch.uint8, device=s.device)
-            _check(lib().kvp_topk_select_segmented(_p(s2), R, nseg, int(seg_len), int(k), int(pos_base), TOPK_WS_CLEAN, _p(idx), _p(ws),
-                                                   ws.numel(), _stream(s)), "kvp_topk_select_segmented")
+            if seg_len <= 32768:
+                # chunks this short are selected by one workgroup each (topk_row_kernel): no workspace at all.  (Round 6: a fresh
+                # zero-filled 33 MB workspace per call was 11 us of ChunkPress's 128k step -- profiles/r06_rocprofv3_kernel_stats_chunk_snapkv128k.csv)
+                _check(lib().kvp_topk_select_segmented(_p(s2), R, nseg, int(seg_len), int(k), int(pos_base), 0, _p(idx), None, 0, _stream(s)),
+                       "kvp_topk_select_segmented")
+            else:
+                stream = torch.cuda.current_stream(s.device)
+                nws = max(int(lib().kvp_topk_segmented_workspace_bytes(R, nseg, seg_len, k)), 256)
+                ws = _cached_ws(("seg", s.device.index, stream.cuda_stream, R, nseg, int(seg_len)), nws, s.device)   # zeroed once, self-cleaning
+                try:
+                    _check(lib().kvp_topk_select_segmented(_p(s2), R, nseg, int(seg_len), int(k), int(pos_base), TOPK_WS_CLEAN, _p(idx), _p(ws),
+                                                           ws.numel(), _stream(s)), "kvp_topk_select_segmented")
+                except KvpressHipError:
+                    _drop_ws(ws)
+                    raise
     return idx.reshape(*lead, nseg * k)
 
 

@@ -342,8 +342,7 @@ struct SnapWs {
     float* colsumx;  // W > 64 (several 64-row blocks of the window in the MFMA passes): the later blocks' column sums, added in block order
     float* bmax;  // per-workgroup maxima of the pool kernel (<= 4096)
     void* qrot;   // [B,Hq,W,D] RoPE'd window queries (kvp_snapkv_score_rope)
-    uint32_t* p1_ticks;   // [planes][nchunk] pass-1 workgroup times, [planes][nchunk][2] pass-2 tile ranges (snapkv_internal.h: snapkv_p2_shares_plan)
-    uint32_t* p2_ranges;
+    uint32_t* p1_ticks;   // [planes][nchunk] pass-1 workgroup times -> pass 2's tile ranges (snapkv_internal.h: snapkv_p2_shares_plan)
     size_t total_bytes;
 };
 
@@ -370,7 +369,6 @@ SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, in
     // (planes * nchunk <= max(planes, 256): one resident round of workgroups; planes = B * Hkv * (1 or 2 group-blocks))
     const size_t nwg = (size_t)std::max<int64_t>(B * Hkv * 2, 256);
     w.p1_ticks = (uint32_t*)take(nwg * 4);
-    w.p2_ranges = (uint32_t*)take(nwg * 8);
     w.total_bytes = off;
     return w;
 }
@@ -462,20 +460,26 @@ int snapkv_score_impl(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sw, c
         if (int rc = snapkv_mfma_p1(a, dtype, nchunk, w.part_m, w.part_z, shares ? w.p1_ticks : nullptr, stream)) return rc;
         // (this path's statistics are per PADDED window row: Wp rows per head, the first Wp - W of them padding with normaliser +inf)
         const uint32_t nrows_p = (uint32_t)(B * Hq) * a.Wp, pad = a.Wp - a.W;
-        if (shares) {
-            const uint32_t nplanes = (uint32_t)(B * Hkv) * ((a.G + 3) / 4);
-            if (int rc = snapkv_combine_shares(w.part_m, w.part_z, nrows_p, nchunk, w.rowstat, a.Wp, norm_base, pad, w.p1_ticks, w.p2_ranges, nplanes,
-                                               (uint32_t)((S - W + 127) / 128), stream))
-                return rc;
-        } else {
-            KVP_SOFTMAX_COMBINE(stream, w.part_m, w.part_z, nrows_p, nchunk, w.rowstat, a.Wp, norm_base, pad);
-        }
-        if (int rc = snapkv_mfma_p2(a, dtype, w.rowstat, w.colsum, w.colsum2, w.colsumx, shares ? w.p2_ranges : nullptr, stream)) return rc;
+        KVP_SOFTMAX_COMBINE(stream, w.part_m, w.part_z, nrows_p, nchunk, w.rowstat, a.Wp, norm_base, pad);
+        if (int rc = snapkv_mfma_p2(a, dtype, w.rowstat, w.colsum, w.colsum2, w.colsumx, shares ? w.p1_ticks : nullptr, stream)) return rc;
     } else {
         const uint32_t nchunk = (uint32_t)((S + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC);
         const size_t lds1 = ((size_t)SK_SUB * (D + 1) + 2 * (size_t)W) * 4;
         const size_t lds2 = ((size_t)SK_SUB * (D + 1) + 256) * 4;
-        KVP_CHECK_ARG(lds1 <= 64 * 1024 && lds2 <= 64 * 1024, "snapkv: W=%ld, D=%ld exceed the generic kernel's LDS budget", (long)W, (long)D);
+        KVP_CHECK_ARG(lds1 <= 160 * 1024 && lds2 <= 160 * 1024, "snapkv: W=%ld, D=%ld exceed the generic kernel's LDS budget", (long)W, (long)D);
+        if (lds1 > 64 * 1024 || lds2 > 64 * 1024) {
+            // head sizes beyond ~250 (Gemma's 256): raise the kernels' dynamic-LDS limit (a CU has 160 KiB) -- round 6: D = 256 used to be
+            // refused although the header promises D <= 1024 (the 64-key sub-tile of float32 K rows is what grows with D)
+            const void* fns[2] = {nullptr, nullptr};
+            if (dtype == KVP_F32) { fns[0] = (const void*)snapkv_p1_generic<KVP_F32>; fns[1] = (const void*)snapkv_p2_generic<KVP_F32>; }
+            else if (dtype == KVP_F16) { fns[0] = (const void*)snapkv_p1_generic<KVP_F16>; fns[1] = (const void*)snapkv_p2_generic<KVP_F16>; }
+            else { fns[0] = (const void*)snapkv_p1_generic<KVP_BF16>; fns[1] = (const void*)snapkv_p2_generic<KVP_BF16>; }
+            for (int i = 0; i < 2; ++i)
+                if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(lds1, lds2)) != hipSuccess) {
+                    kvp_set_error("snapkv: cannot raise the dynamic LDS limit to %zu bytes (D=%ld, W=%ld)", std::max(lds1, lds2), (long)D, (long)W);
+                    return KVP_EHIP;
+                }
+        }
         const dim3 g1(nchunk, (uint32_t)Hq, (uint32_t)B);
         const uint32_t nchunk2 = (uint32_t)((S - W + SK_CHUNK_GENERIC - 1) / SK_CHUNK_GENERIC);
         const dim3 g2(nchunk2, (uint32_t)Hkv, (uint32_t)B);

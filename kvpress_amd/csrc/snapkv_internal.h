@@ -32,14 +32,12 @@ int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* co
 // Pass 2 balanced by pass 1's clock (round 6).  Under the package power limit the XCDs run the window-attention passes at clocks 5-6 %
 // apart (profiles/r05_clock_power.txt), so with equal tile counts the slowest XCD sets the launch span.  Pass 1 and pass 2 have the same
 // shape and run microseconds apart: the wall time of a pass-1 workgroup predicts the speed of the pass-2 workgroup with the same block
-// index (same XCD).  snapkv_p2_shares_plan says whether the shapes allow it (same grid in both passes, walks of >= 8 tiles); if so pass 1
-// records its workgroup times, the combine launch turns them into contiguous tile ranges proportional to 1 / time per plane (extra
-// blocks of the same launch, snapkv_combine_shares), and pass 2 walks those.  Pass 2's column sums are computed per 128-key tile by
-// ONE workgroup in a fixed order, so its output bits do not depend on who owns which tile: the scores stay run-to-run identical.
+// index (same XCD).  snapkv_p2_shares_plan says whether the shapes allow it (hand-scheduled kernels, the same grid in both passes, 2 .. 64
+// workgroups per plane, walks of >= 8 tiles); if so pass 1 records its workgroup times and every pass-2 workgroup derives its contiguous
+// tile range from its plane's times in its prologue (snapkv_p2_asm).  Pass 2's column sums are computed per 128-key tile by ONE
+// workgroup in a fixed order, so its output bits do not depend on who owns which tile: the scores stay run-to-run identical.
 // (Pass 1 cannot be treated the same way: its (max, sum) partials are per WALK, i.e. their rounding depends on the tile assignment.)
 bool snapkv_p2_shares_plan(const SnapArgs& a, uint32_t nchunk_p1);
-int snapkv_combine_shares(const float* part_m, const float* part_z, uint32_t nrows, uint32_t nchunk, float* rowstat, uint32_t W, uint32_t norm_base,
-                          uint32_t pad, const uint32_t* p1_ticks, uint32_t* p2_ranges, uint32_t nplanes, uint32_t ntiles_p2, hipStream_t stream);
 
 enum { SNAP_FINISH_FULL = 0,    // pool + scale into `scores`, pad columns = max + 1
        SNAP_FINISH_NO_PAD = 1,  // pool + scale, pad columns left unwritten (fused compress: they are kept by construction)

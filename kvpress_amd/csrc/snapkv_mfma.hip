@@ -51,10 +51,12 @@ constexpr int MF_CHUNK = 128;        // minimum keys per workgroup: one tile (me
 constexpr int MF_ROWB = 256;         // bytes per key row (D = 128, 2-byte elements)
 constexpr int MF_TILEB = MF_TILE * MF_ROWB;
 static_assert(MF_TILEB / 16 / MF_THREADS == MF_SUBS, "one DMA request per thread per sub-tile step");
-// Geometry of a K tile for a head of DK k-steps of 16 elements (round 6: D = 128 -> DK = 8, D = 64 -> DK = 4; 2-byte elements).
+// Geometry of a K tile for a head of DK k-steps of 16 elements (round 6: D = 128 -> DK = 8, D = 64 -> DK = 4; D = 96 -> DK = 6 keeps the
+// 256-byte LDS rows of DK = 8 and simply never requests the four chunks a 192-byte key row does not have; 2-byte elements).
 template <int DK> struct KGeo {
-    static constexpr int ROWB = DK * 32;            // bytes per key row
-    static constexpr int CPR = ROWB / 16;           // 16-byte chunks per row
+    static constexpr int ROWB = DK == 6 ? 256 : DK * 32;   // bytes per key row IN LDS
+    static constexpr int NCH = DK * 2;              // 16-byte chunks a key row really has
+    static constexpr int CPR = ROWB / 16;           // 16-byte slots per LDS row
     static constexpr int RPW = 1024 / ROWB;         // rows one wave's request moves (64 lanes x 16 bytes)
     static constexpr int RPR = (MF_THREADS / 64) * RPW;   // rows one request of the workgroup moves
     static constexpr int NREQ = MF_TILE / RPR;      // requests per thread and tile
@@ -62,7 +64,7 @@ template <int DK> struct KGeo {
     static_assert(RPR % CPR == 0 && MF_TILE % RPR == 0, "the swizzle of a row depends on its index inside a request only");
     // XOR swizzle of a tile row's 16-byte slots: 16 consecutive rows of a fragment read must hit 16 distinct slots of the 256-byte
     // bank line -- rows of 256 bytes: the row's low four bits; rows of 128 bytes (two per bank line): bits 1 .. 3
-    static __device__ __forceinline__ uint32_t sw(uint32_t row) { return DK == 8 ? (row & 15u) : ((row >> 1) & 7u); }
+    static __device__ __forceinline__ uint32_t sw(uint32_t row) { return DK == 4 ? ((row >> 1) & 7u) : (row & 15u); }
 };
 
 template <int DT> __device__ __forceinline__ f32x16 mma32(const uint4& a, const uint4& b, f32x16 c);
@@ -90,10 +92,13 @@ struct KStreamT {
     uint32_t lrow;      // RPW w + lr
     uint32_t choff;     // byte offset of this lane's chunk inside a row: (p ^ sw(lrow)) << 4  (a request's first row is a multiple of the swizzle period)
     uint32_t ldsrow;    // RPW w: first row of this wave's 1 KiB block inside a request
+    bool has_chunk;     // (D = 96: slots whose chunk lies beyond the 192-byte row stay empty -- those lanes request nothing)
     __device__ KStreamT(const char* kb_, int64_t k_ssb_, uint32_t S_) : kb(kb_), k_ssb(k_ssb_), S(S_) {
         const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         lrow = wv * Geo::RPW + lane / Geo::CPR;
-        choff = ((lane % Geo::CPR) ^ Geo::sw(lrow)) << 4;
+        const uint32_t chunk = (lane % Geo::CPR) ^ Geo::sw(lrow);
+        choff = chunk << 4;
+        has_chunk = chunk < (uint32_t)Geo::NCH;
         ldsrow = wv * Geo::RPW;
     }
     __device__ __forceinline__ void request(unsigned char* buf, uint32_t key0, int i) const {
@@ -102,7 +107,12 @@ struct KStreamT {
         const uint32_t la = __builtin_amdgcn_readfirstlane(
             (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(buf + (i * Geo::RPR + ldsrow) * Geo::ROWB));
         // M0 is a reserved register that hipcc never keeps values in (nothing else in these kernels uses it)
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(g) : "memory");
+        if (Geo::NCH == Geo::CPR) {
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(g) : "memory");
+        } else {
+            asm volatile("s_mov_b32 m0, %0" ::"s"(la) : "memory");   // (outside the divergent region: M0 is per wave)
+            if (has_chunk) asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(g) : "memory");
+        }
     }
     __device__ __forceinline__ void request_tile(unsigned char* buf, uint32_t key0) const {
 #pragma unroll
@@ -232,7 +242,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
     // fragment reads of the next sub-tile, and the MFMA chain of this sub-tile interleaved (1 MFMA : 6 VALU) with
     // the softmax of the previous one.  Straight-line code (no masks: every tile but the last ones of a head).
     auto compute_fast = [&](const unsigned char* buf, unsigned char* bufr, uint32_t keyr) {
-        constexpr int EPS = 16 / DK;   // logits of the previous sub-tile exponentiated beside one MFMA of this one
+        // (the 16 logits of the previous sub-tile are exponentiated beside the DK MFMAs of this one: elements 16 ks / DK .. 16 (ks + 1) / DK - 1
+        // beside MFMA ks -- two per MFMA for D = 128, four for D = 64, three or two for D = 96)
         uint4 kf[2][DK];
         f32x16 acc[2];
 #pragma unroll
@@ -263,9 +274,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
                 for (int ks = 0; ks < DK; ++ks) {
                     acc[sub & 1] = mma32<DT>(kf[sub & 1][ks], qf[ks], acc[sub & 1]);
 #pragma unroll
-                    for (int e = 0; e < EPS; e += 2) {   // (the same two interleaved sums for every head size: element i goes to sum i & 1)
-                        s0 += fast_exp2(fmaf(ap[EPS * ks + e], c, off));
-                        s1 += fast_exp2(fmaf(ap[EPS * ks + e + 1], c, off));
+                    for (int e = (16 * ks) / DK; e < (16 * (ks + 1)) / DK; ++e) {   // (the same two interleaved sums for every head size: element i goes to sum i & 1)
+                        const float x = fast_exp2(fmaf(ap[e], c, off));
+                        if (e & 1) s1 += x; else s0 += x;
                     }
                 }
                 z = z * fast_exp2(fmaf(m, c, off)) + (s0 + s1);
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
 #pragma unroll
                 for (int ks = 0; ks < DK; ++ks) {
                     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);        // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x2, 3 * EPS, 0);  // EPS x (fma, exp, add)
+                    __builtin_amdgcn_sched_group_barrier(0x2, 3 * ((16 + DK - 1) / DK), 0);  // (fma, exp, add) of its share of the 16 logits
                 }
             }
         }
@@ -526,7 +537,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
     };
     // one tile, software-pipelined like pass 1: MFMA chain of sub-tile s || exp/add stream of sub-tile s-1
     auto compute = [&](const unsigned char* buf, int par, unsigned char* bufr, uint32_t keyr) {
-        constexpr int EPS = 16 / DK;
         uint4 kf[2][DK];
         f32x16 acc[2];
 #pragma unroll
@@ -551,9 +561,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
                 for (int ks = 0; ks < DK; ++ks) {
                     acc[sub & 1] = mma32<DT>(qf[ks], kf[sub & 1][ks], acc[sub & 1]);
 #pragma unroll
-                    for (int e = 0; e < EPS; e += 2) {
-                        s0 += fast_exp2(fmaf(ap[EPS * ks + e], c, ar[EPS * ks + e]));
-                        s1 += fast_exp2(fmaf(ap[EPS * ks + e + 1], c, ar[EPS * ks + e + 1]));
+                    for (int e = (16 * ks) / DK; e < (16 * (ks + 1)) / DK; ++e) {
+                        const float x = fast_exp2(fmaf(ap[e], c, ar[e]));
+                        if (e & 1) s1 += x; else s0 += x;
                     }
                 }
                 float s = s0 + s1;
@@ -562,7 +572,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
 #pragma unroll
                 for (int ks = 0; ks < DK; ++ks) {
                     __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x2, 3 * EPS, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 3 * ((16 + DK - 1) / DK), 0);
                 }
             }
         }
@@ -599,7 +609,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
 
 bool snapkv_mfma_eligible(const SnapArgs& a, int dtype) {
     if (dtype != KVP_BF16 && dtype != KVP_F16) return false;
-    if ((a.D != 128 && a.D != 64) || a.W < 1 || a.W > 4096 || a.G > 8) return false;   // (any window: blocks of 64 rows, snapkv_internal.h)
+    if ((a.D != 128 && a.D != 96 && a.D != 64) || a.W < 1 || a.W > 4096 || a.G > 8) return false;   // (any window: blocks of 64 rows, snapkv_internal.h)
     auto al8 = [](int64_t x) { return x % 8 == 0; };
     if (((uintptr_t)a.q % 16) || ((uintptr_t)a.k % 16)) return false;
     return al8(a.q_sb) && al8(a.q_sh) && al8(a.q_sw) && al8(a.k_sb) && al8(a.k_sh) && al8(a.k_ss);
@@ -627,7 +637,7 @@ bool snapkv_p2_shares_plan(const SnapArgs& a, uint32_t nchunk_p1) {
     if (a.G % 4 != 0 || a.D != 128 || a.S <= a.W) return false;
     const uint32_t Sm = a.S - a.W;
     const uint32_t ntiles = (Sm + MF_TILE - 1) / MF_TILE;
-    return mfma_nchunk_for(a, Sm) == nchunk_p1 && nchunk_p1 >= 2 && nchunk_p1 <= 256 && ntiles >= 8 * nchunk_p1 && kvp_env_int("KVP_SK_BALANCE", 1) != 0;
+    return mfma_nchunk_for(a, Sm) == nchunk_p1 && nchunk_p1 >= 2 && nchunk_p1 <= 64 && ntiles >= 8 * nchunk_p1 && kvp_env_int("KVP_SK_BALANCE", 1) != 0;
 }
 
 int snapkv_mfma_p1(const SnapArgs& a0, int dtype, uint32_t nchunk, float* part_m, float* part_z, uint32_t* p1_ticks, hipStream_t stream) {
@@ -644,6 +654,7 @@ int snapkv_mfma_p1(const SnapArgs& a0, int dtype, uint32_t nchunk, float* part_m
         // G = 1, 2, 3, 5, 6, 7 (partially filled workgroups) and head size 64: the compiler-scheduled kernels
 #define KVP_P1_MFMA(DTV, DKV) KVP_LAUNCH("snapkv_p1_mfma", stream, (snapkv_p1_mfma<DTV, DKV><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z)))
         if (a.D == 128) { if (dtype == KVP_BF16) KVP_P1_MFMA(KVP_BF16, 8); else KVP_P1_MFMA(KVP_F16, 8); }
+        else if (a.D == 96) { if (dtype == KVP_BF16) KVP_P1_MFMA(KVP_BF16, 6); else KVP_P1_MFMA(KVP_F16, 6); }
         else { if (dtype == KVP_BF16) KVP_P1_MFMA(KVP_BF16, 4); else KVP_P1_MFMA(KVP_F16, 4); }
 #undef KVP_P1_MFMA
         KVP_CHECK_LAUNCH("snapkv_p1_mfma");
@@ -660,7 +671,7 @@ int snapkv_mfma_p1(const SnapArgs& a0, int dtype, uint32_t nchunk, float* part_m
 // take the C++ path below.  Requires all eight waves active (G % 4 == 0).
 template <int DT>
 __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_asm(SnapArgs a, uint32_t ngb, const float* __restrict__ rowstat,
-                                                               float* __restrict__ colsum, float* __restrict__ colsum2, const uint32_t* __restrict__ ranges) {
+                                                               float* __restrict__ colsum, float* __restrict__ colsum2, const uint32_t* __restrict__ ticks) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[MF_NBUF * MF_TILEB];
     __shared__ __attribute__((aligned(16))) unsigned char red3[KVP_P2_RED_BYTES];
     __shared__ float red[2][MF_WAVES][MF_TILE];
@@ -674,10 +685,36 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_asm(SnapArgs a, uint3
 
     const char* kbase = static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2;
     const KStream ks_(kbase, a.k_ss * 2, a.S);
-    // this workgroup's tiles: a contiguous range sized by pass 1's clock (ranges[plane][chunk] = first tile, tiles), or the static
-    // interleaved walk.  Either way a tile's column sums are computed by one workgroup in a fixed order: the same bits.
-    const uint32_t* rg = ranges ? ranges + (((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + chunk) * 2 : nullptr;
-    const TileWalk tw = rg ? TileWalk(uni(rg[0]), uni(rg[1]), 0) : TileWalk(chunk, gridDim.x, Sm);
+    // This workgroup's tiles: the static interleaved walk, or (ticks: pass 1's workgroup times of this plane, gridDim.x <= 64 of them) a
+    // contiguous range proportional to 1 / time -- every wave of every workgroup of the plane runs the same few instructions on the same
+    // numbers (times clamped to [tmin, 2 tmin]: a workgroup held up for a reason of its own must not starve; speed = 1 / time; inclusive
+    // scan over the plane's workgroups; end_c = round(ntiles * prefix_c / total)), so neighbours agree on their common boundary, the
+    // ranges are monotone and the last one ends at ntiles.  Either way a tile's column sums are computed by one workgroup in a fixed
+    // order: the same bits.  (Round 6, first version: the ranges came out of extra blocks of the combine launch -- double precision,
+    // block-wide scans: 4.9 -> 7.8 us on the critical path; here it is ~50 VALU instructions behind one L2 load in the prologue.)
+    uint32_t r_first = 0, r_count = 0;
+    if (ticks) {
+        const uint32_t nch = gridDim.x, total_tiles = (Sm + MF_TILE - 1) / MF_TILE;
+        const uint32_t* tp = ticks + ((size_t)b * gridDim.y + blockIdx.y) * nch;
+        const uint32_t tk = lane < nch ? max(tp[lane], 1u) : 0xFFFFFFFFu;
+        uint32_t tmin = tk;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tmin = min(tmin, (uint32_t)__shfl_xor((int)tmin, o));
+        const float speed = lane < nch ? 1.0f / (float)min(tk, 2u * tmin) : 0.f;
+        float incl = speed;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(incl, o);
+            if ((int)lane >= o) incl += up;
+        }
+        const float total = __shfl(incl, 63);
+        const float prev = __shfl_up(incl, 1);
+        const uint32_t end = lane + 1 >= nch ? total_tiles : min((uint32_t)__float2uint_rn((float)total_tiles * (incl / total)), total_tiles);
+        const uint32_t beg = lane == 0 ? 0u : min((uint32_t)__float2uint_rn((float)total_tiles * (prev / total)), total_tiles);
+        r_first = uni((uint32_t)__shfl((int)beg, (int)chunk));
+        r_count = uni((uint32_t)__shfl((int)(end > beg ? end - beg : 0u), (int)chunk));
+    }
+    const TileWalk tw = ticks ? TileWalk(r_first, r_count, 0) : TileWalk(chunk, gridDim.x, Sm);
     if (tw.ntiles == 0) return;
     ks_.request_tile(lds, tw.key0(0));
     ks_.request_tile(lds + MF_TILEB, tw.key0(1));
@@ -779,80 +816,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_asm(SnapArgs a, uint3
     wait_all_landed();
 }
 
-// ---- the combine launch with pass 2's tile shares (snapkv_internal.h: snapkv_p2_shares_plan) ---------------------------------------
-// Blocks 0 .. nrb - 1: softmax_combine_kernel's rows, instruction for instruction (same merge order: the same normalisers whether or not
-// the shares are computed).  Blocks nrb .. nrb + nplanes - 1: one plane each -- thread c holds workgroup c's pass-1 time, clamped to
-// [tmin, 2 tmin] (a workgroup that was held up for a reason of its own must not starve), speed = 1 / time, inclusive scan over the
-// plane's workgroups, end_c = round(ntiles * prefix_c / total): contiguous ranges, monotone, the last one ends at ntiles.
-namespace {
-__global__ __launch_bounds__(256) void softmax_combine_shares_kernel(const float* __restrict__ part_m, const float* __restrict__ part_z, uint32_t nrows,
-                                                                     uint32_t nchunk, float* __restrict__ a, uint32_t W, uint32_t norm_base, uint32_t pad, uint32_t nrb,
-                                                                     const uint32_t* __restrict__ ticks, uint32_t* __restrict__ ranges, uint32_t ntiles) {
-    if (blockIdx.x < nrb) {
-        const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
-        const uint32_t lane = threadIdx.x & 63;
-        if (row >= nrows) return;
-        float m = KVP_NEG_INF, z = 0.f;
-        for (uint32_t j = lane; j < nchunk; j += 64) softmax_merge(m, z, part_m[(size_t)row * nchunk + j], part_z[(size_t)row * nchunk + j]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float m2 = __shfl_xor(m, o), z2 = __shfl_xor(z, o);
-            softmax_merge(m, z, m2, z2);
-        }
-        if (lane == 0) a[row] = softmax_row_normaliser(m, z, row, W, norm_base, pad);
-        return;
-    }
-    __shared__ uint32_t s_min[4];
-    __shared__ double s_sum[4];
-    const uint32_t plane = blockIdx.x - nrb, c = threadIdx.x;
-    const uint32_t tk = c < nchunk ? max(ticks[(size_t)plane * nchunk + c], 1u) : 0xFFFFFFFFu;
-    uint32_t mn = tk;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
-    if ((c & 63) == 0) s_min[c >> 6] = mn;
-    __syncthreads();
-    const uint32_t tmin = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
-    const double speed = c < nchunk ? 1.0 / (double)min(tk, 2u * tmin) : 0.0;
-    double incl = speed;   // inclusive scan over the 256 threads: inside the wave, then over the four waves, always in index order
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double up = __shfl_up(incl, o);
-        if ((int)(c & 63) >= o) incl += up;
-    }
-    if ((c & 63) == 63) s_sum[c >> 6] = incl;
-    __syncthreads();
-    double base = 0.0, total = 0.0;
-    for (uint32_t w = 0; w < 4; ++w) {
-        if (w < (c >> 6)) base += s_sum[w];
-        total += s_sum[w];
-    }
-    incl += base;
-    if (c < nchunk) {
-        const double excl = incl - speed;
-        const uint32_t end = c + 1 == nchunk ? ntiles : min((uint32_t)__double2uint_rn((double)ntiles * incl / total), ntiles);
-        const uint32_t beg = c == 0 ? 0u : min((uint32_t)__double2uint_rn((double)ntiles * excl / total), ntiles);
-        ranges[((size_t)plane * nchunk + c) * 2] = beg;
-        ranges[((size_t)plane * nchunk + c) * 2 + 1] = end > beg ? end - beg : 0u;
-    }
-}
-}  // namespace
-
-int snapkv_combine_shares(const float* part_m, const float* part_z, uint32_t nrows, uint32_t nchunk, float* rowstat, uint32_t W, uint32_t norm_base,
-                          uint32_t pad, const uint32_t* p1_ticks, uint32_t* p2_ranges, uint32_t nplanes, uint32_t ntiles_p2, hipStream_t stream) {
-    const uint32_t nrb = (nrows + 3) / 4;
-    KVP_LAUNCH("softmax_combine_kernel", stream, softmax_combine_shares_kernel<<<nrb + nplanes, 256, 0, stream>>>(part_m, part_z, nrows, nchunk, rowstat, W,
-                                                                                                                  norm_base, pad, nrb, p1_ticks, p2_ranges, ntiles_p2));
-    KVP_CHECK_LAUNCH("snapkv(combine + shares)");
-    return KVP_OK;
-}
-
 namespace {
 __global__ __launch_bounds__(256) void add_slab_kernel(float* __restrict__ x, const float* __restrict__ y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] += y[i];
 }
 }  // namespace
 
-int snapkv_mfma_p2(const SnapArgs& a0, int dtype, const float* rowstat, float* colsum, float* colsum2, float* colsumx, const uint32_t* p2_ranges,
+int snapkv_mfma_p2(const SnapArgs& a0, int dtype, const float* rowstat, float* colsum, float* colsum2, float* colsumx, const uint32_t* p1_ticks,
                    hipStream_t stream) {
     const uint32_t ngb = (a0.G + 3) / 4;
     const uint32_t Sm = a0.S - a0.W;
@@ -869,9 +839,10 @@ int snapkv_mfma_p2(const SnapArgs& a0, int dtype, const float* rowstat, float* c
         float* cs = a.rblk == 0 ? colsum : colsumx;
 #define KVP_P2_MFMA(DTV, DKV) KVP_LAUNCH("snapkv_p2_mfma", stream, (snapkv_p2_mfma<DTV, DKV><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, cs, colsum2)))
         if (a.G % 4 == 0 && a.D == 128) {   // hand-scheduled tile loop
-            if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, cs, colsum2, p2_ranges));
-            else KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, cs, colsum2, p2_ranges));
+            if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, cs, colsum2, p1_ticks));
+            else KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, cs, colsum2, p1_ticks));
         } else if (a.D == 128) { if (dtype == KVP_BF16) KVP_P2_MFMA(KVP_BF16, 8); else KVP_P2_MFMA(KVP_F16, 8); }
+        else if (a.D == 96) { if (dtype == KVP_BF16) KVP_P2_MFMA(KVP_BF16, 6); else KVP_P2_MFMA(KVP_F16, 6); }
         else { if (dtype == KVP_BF16) KVP_P2_MFMA(KVP_BF16, 4); else KVP_P2_MFMA(KVP_F16, 4); }
 #undef KVP_P2_MFMA
         KVP_CHECK_LAUNCH("snapkv_p2_mfma");

@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp PYTHONDONTWRITEBYTECODE=1
 WHAT="${*:-tests bench}"
-R="${ROUND_TAG:-r05}"
+R="${ROUND_TAG:-r06}"
 python __graft_entry__.py > gpurun_out/build.log 2>&1; echo "build rc=$?"
 rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt; nproc >> gpurun_out/gpu.txt
 if [[ "$WHAT" == *tests* ]]; then
@@ -23,7 +23,7 @@ if [[ "$WHAT" == *bench* ]]; then
 fi
 if [[ "$WHAT" == *frows* ]]; then
   # SURVEY section 8(f) workloads (no CPU baseline: the four BASELINE configs above carry it)
-  for wl in snapkv128k_scoreorder keydiff128k cur128k finch128k chunk_snapkv128k rerotate128k decode_snapkv2k; do
+  for wl in snapkv128k_scoreorder snapkv128k_b2 knorm128k_b4 keydiff128k cur128k finch128k chunk_snapkv128k rerotate128k decode_snapkv2k; do
     timeout 600 python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline --live-pmc off > gpurun_out/bench_$wl.log 2>&1
     echo "bench[$wl] rc=$? $(tail -1 gpurun_out/bench_$wl.log | cut -c1-200)"
     tail -1 gpurun_out/bench_$wl.log > gpurun_out/${R}_bench_$wl.json

@@ -254,7 +254,7 @@ def test_roofline_block_prefers_the_profilers_durations():
     assert rf["kernel"] == "gather_vec_kernel" and rf["avg_launch_us"] == 85.29 and rf["timing_source"] == "live: test"
     assert abs(rf["frac"] - 536870912 / 85.29e-6 / 8e12) < 2e-4 and abs(rf["p1_frac"] - 268435456 / 71.75e-6 / 8e12) < 2e-4
     assert rf["path"]["kernels_us"]["gather_vec_kernel"] == 85.29 and rf["path"]["kernels_us_events"]["gather_vec_kernel"] > 85.29
-    assert abs(rf["path"]["kernels_sum_us"] - 264.0) < 0.1 and rf["path"]["kernels_sum_le_1p02_step"] is True
+    assert abs(rf["path"]["kernels_sum_us"] - 264.0) < 0.1 and rf["path"]["kernels_sum_le_1p04_step"] is True and rf["path"]["kernels_sum_over_step"] < 1.01
     assert "path_model_us" not in rf and "path_frac_of_model" not in rf and 0 < rf["path"]["model"]["frac_of_step"] < 1
     ev = bench.roofline_block(avg, "snapkv128k", 1, t_step, 1, "off")          # no profiler pass: the event table, and the line says so
     assert "HIP events" in ev["timing_source"] and ev["avg_launch_us"] > 85.29 and set(ev) == set(rf)

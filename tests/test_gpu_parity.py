@@ -303,13 +303,13 @@ def test_snapkv_kernel_vs_oracle(name):
         assert ok, f"{name} r={r}: {msg}"
 
 
-@pytest.mark.parametrize("D", [128, 64])
+@pytest.mark.parametrize("D", [128, 96, 64, 256])
 @pytest.mark.parametrize("W,S,G,ks", [(1, 700, 4, 1), (1, 5000, 2, 1), (7, 300, 4, 5), (32, 1000, 4, 5), (33, 2100, 1, 3), (63, 64, 4, 5), (64, 65, 3, 5),
                                       (65, 700, 4, 5), (100, 4200, 4, 5), (128, 129, 2, 5), (130, 9000, 8, 7), (200, 2500, 4, 5), (257, 40000, 4, 5)])
 def test_snapkv_any_window_on_the_mfma_path(W, S, G, ks, D):
     """Round 6: the MFMA passes take ANY window size (TOVA's W = 1, FINCH's question length, user-chosen windows) as blocks of 64
     padded rows -- padding in front, normaliser +inf, the reference's causal rule in padded coordinates (snapkv_internal.h) -- for
-    head sizes 128 and 64, G = 1 .. 8 (hand-scheduled loops for D = 128 and G % 4 == 0, the compiler-scheduled kernels otherwise), down to
+    head sizes 128, 96 and 64 (256: the generic kernels with a raised LDS limit), G = 1 .. 8 (hand-scheduled loops for D = 128 and G % 4 == 0, the compiler-scheduled kernels otherwise), down to
     S = W + 1 (every tile masked).  Scores against the float64 oracle; pad columns; a batch of two through the same call."""
     rs = np.random.RandomState(W * 131 + S + G + D)
     N = native()

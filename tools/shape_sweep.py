@@ -51,7 +51,11 @@ def case(kind, B, Hq, Hkv, S, D, dt, W=64, ks=5, ratio=0.5, note=""):
             mu, cov = N.ea_qstats(q, True)
             sc = N.ea_score(k, v, mu, cov, 4, True, 0.0)
             return N.gather_kv(k, v, N.topk_select(sc, n))
-    t = timeit(fn)
+    try:
+        t = timeit(fn)
+    except Exception as e:   # noqa: BLE001
+        print(f"{kind:7s} B={B} Hq={Hq:2d} Hkv={Hkv:2d} S={S:6d} D={D:3d} {str(dt).split('.')[-1]:8s} W={W:2d} ks={ks} r={ratio}: FAILED {type(e).__name__}: {str(e)[:120]}   {note}", flush=True)
+        return
     print(f"{kind:7s} B={B} Hq={Hq:2d} Hkv={Hkv:2d} S={S:6d} D={D:3d} {str(dt).split('.')[-1]:8s} W={W:2d} ks={ks} r={ratio}: {t:8.1f} us  "
           f"{bytes_ / (t * 1e-6) / 8e12:.3f} of 8 TB/s   {note}", flush=True)
     del k, v
@@ -69,6 +73,8 @@ def main():
     case("snapkv", 1, 16, 8, S, 128, bf, note="G = 2: compiler-scheduled MFMA passes")
     case("snapkv", 1, 24, 8, S, 128, bf, note="G = 3: compiler-scheduled MFMA passes")
     case("snapkv", 1, 64, 8, S, 128, bf, note="G = 8: two group-blocks, second column-sum slab")
+    case("snapkv", 1, 32, 8, S, 96, bf, note="D = 96 (Phi-3-mini): compiler-scheduled MFMA passes on 256-byte LDS rows (round 6)")
+    case("snapkv", 1, 32, 8, S, 256, bf, note="D = 256 (Gemma): generic kernels")
     case("snapkv", 1, 32, 8, S, 64, bf, note="D = 64: compiler-scheduled MFMA passes (round 6; before: generic kernels, 3206 us)")
     case("snapkv", 1, 32, 8, S, 128, f32, note="float32 model: generic kernels")
     case("snapkv", 1, 32, 8, S, 128, bf, W=32, note="window 32: hand-scheduled passes on a padded 64-row block (round 6; before: generic kernels, 3812 us)")
