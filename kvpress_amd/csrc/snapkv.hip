@@ -17,7 +17,7 @@
 // (triu(-inf, diagonal=S-W+1), snapkv_press.py:63-65) only touches the last W columns, which
 // are dropped from the result (:67): it matters for the normaliser (pass 1) only.
 //
-// Two implementations of p1/p2: the MFMA kernels in snapkv_mfma.hip (bf16 / f16, head size 128 or 64, G <= 8, ANY window size
+// Two implementations of p1/p2: the MFMA kernels in snapkv_mfma.hip (bf16 / f16, head size 64 / 96 / 128 / 256, G <= 8, ANY window size
 // since round 6: blocks of 64 padded window rows, snapkv_internal.h -- hand-scheduled loops for D = 128 with G % 4 == 0, the
 // Llama-3.1-8B hot path, compiler-scheduled kernels otherwise) and the generic VALU kernels in this file (any D, float32, any
 // stride: correctness fallbacks, ~40x slower -- profiles/r06_shape_sweep*.txt).

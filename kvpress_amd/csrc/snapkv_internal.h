@@ -18,7 +18,7 @@ struct SnapArgs {
 };
 __host__ __device__ inline uint32_t snapkv_wp(uint32_t W) { return (W + 63u) / 64u * 64u; }
 
-// MFMA fast path (bf16/f16, D = 128, G <= 8, 16-byte aligned rows; any window size since round 6)
+// MFMA fast path (bf16/f16, D = 64 / 96 / 128 / 256, G <= 8, 16-byte aligned rows; any window size since round 6)
 bool snapkv_mfma_eligible(const SnapArgs& a, int dtype);
 uint32_t snapkv_mfma_nchunk(const SnapArgs& a);
 // p1_ticks (may be null): [planes][nchunk] wall time of every pass-1 workgroup in 10 ns ticks (plane = (b, kv-head, group-block)) --

@@ -1,6 +1,7 @@
-// SnapKV window-attention passes on the gfx950 matrix cores (bf16 / f16; D = 128 or 64; any window size: blocks of 64 padded rows).
+// SnapKV window-attention passes on the gfx950 matrix cores (bf16 / f16; D = 64 / 96 / 128 / 256; any window size: blocks of 64 padded rows).
 // (The text below describes the D = 128 geometry the kernels were designed on; KGeo<DK> holds the numbers of the other head size, and
-// "windows of any size" further down how a window that is not 64 rows maps onto the 64-row blocks.)
+// "windows of any size" further down how a window that is not 64 rows maps onto the 64-row blocks.  The hand-scheduled loops are D = 128 with
+// G % 4 == 0; everything else runs snapkv_p1_mfma / snapkv_p2_mfma, templated on the head size.)
 //
 // Work decomposition (per launch): workgroup = (tile set, kv-head [x group-block], batch), 8 waves, ONE workgroup
 // per CU; wave w owns half a q-head of the GQA group (q-head w/2, window rows 32*(w&1) .. +32), whose Q fragments
@@ -52,7 +53,8 @@ constexpr int MF_ROWB = 256;         // bytes per key row (D = 128, 2-byte eleme
 constexpr int MF_TILEB = MF_TILE * MF_ROWB;
 static_assert(MF_TILEB / 16 / MF_THREADS == MF_SUBS, "one DMA request per thread per sub-tile step");
 // Geometry of a K tile for a head of DK k-steps of 16 elements (round 6: D = 128 -> DK = 8, D = 64 -> DK = 4; D = 96 -> DK = 6 keeps the
-// 256-byte LDS rows of DK = 8 and simply never requests the four chunks a 192-byte key row does not have; 2-byte elements).
+// 256-byte LDS rows of DK = 8 and simply never requests the four chunks a 192-byte key row does not have; D = 256 -> DK = 16: 64 KiB
+// tiles, so a ring of TWO buffers (one tile of prefetch) and single-buffered fragment registers; 2-byte elements).
 template <int DK> struct KGeo {
     static constexpr int ROWB = DK == 6 ? 256 : DK * 32;   // bytes per key row IN LDS
     static constexpr int NCH = DK * 2;              // 16-byte chunks a key row really has
@@ -61,10 +63,14 @@ template <int DK> struct KGeo {
     static constexpr int RPR = (MF_THREADS / 64) * RPW;   // rows one request of the workgroup moves
     static constexpr int NREQ = MF_TILE / RPR;      // requests per thread and tile
     static constexpr int TILEB = MF_TILE * ROWB;
-    static_assert(RPR % CPR == 0 && MF_TILE % RPR == 0, "the swizzle of a row depends on its index inside a request only");
+    static constexpr int NBUF = DK <= 8 ? 3 : 2;    // LDS ring: NBUF - 1 tiles of prefetch (three 64 KiB tiles would not fit the CU's 160 KiB)
+    static constexpr int NKF = DK <= 8 ? 2 : 1;     // fragment register sets: the next sub-tile's reads overlap this one's chain where they fit
+    static_assert(RPR % 16 == 0 && MF_TILE % RPR == 0, "the swizzle of a row (period: 16 rows) depends on its index inside a request only");
     // XOR swizzle of a tile row's 16-byte slots: 16 consecutive rows of a fragment read must hit 16 distinct slots of the 256-byte
     // bank line -- rows of 256 bytes: the row's low four bits; rows of 128 bytes (two per bank line): bits 1 .. 3
     static __device__ __forceinline__ uint32_t sw(uint32_t row) { return DK == 4 ? ((row >> 1) & 7u) : (row & 15u); }
+    static __device__ __forceinline__ int ring_next(int b) { return b + 1 == NBUF ? 0 : b + 1; }
+    static __device__ __forceinline__ int ring_prev(int b) { return b == 0 ? NBUF - 1 : b - 1; }
 };
 
 template <int DT> __device__ __forceinline__ f32x16 mma32(const uint4& a, const uint4& b, f32x16 c);
@@ -118,13 +124,19 @@ struct KStreamT {
 #pragma unroll
         for (int i = 0; i < Geo::NREQ; ++i) request(buf, key0, i);
     }
+    // the requests of a tile that are issued beside sub-tile `sub` of the tile being computed (they trickle instead of arriving as a burst)
+    __device__ __forceinline__ void request_part(unsigned char* buf, uint32_t key0, int sub) const {
+#pragma unroll
+        for (int i = (sub * Geo::NREQ) / MF_SUBS; i < ((sub + 1) * Geo::NREQ) / MF_SUBS; ++i) request(buf, key0, i);
+    }
 };
 typedef KStreamT<8> KStream;
 // s_waitcnt through the builtin (simm16: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8): unlike an asm string, hipcc's own
 // wait-count bookkeeping sees it, so it stops re-waiting for the Q-fragment loads inside the tile loop.
 // only the newest tile's MF_SUBS requests of this wave may still be in flight
 __device__ __forceinline__ void wait_tile_landed() { __builtin_amdgcn_s_waitcnt(0x0F70 | MF_SUBS); }
-template <int DK> __device__ __forceinline__ void wait_tile_landed_t() { __builtin_amdgcn_s_waitcnt(0x0F70 | KGeo<DK>::NREQ); }
+// (only the requests of tiles newer than t + 1 may still be in flight: (NBUF - 2) tiles' worth)
+template <int DK> __device__ __forceinline__ void wait_tile_landed_t() { __builtin_amdgcn_s_waitcnt(0x0F70 | ((KGeo<DK>::NBUF - 2) * KGeo<DK>::NREQ)); }
 __device__ __forceinline__ void wait_all_landed() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 // fragment of the 32-key sub-tile `sub` for k-step ks: lane (n = lane & 31, kg = lane >> 5)
@@ -185,7 +197,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
                                                                 float* __restrict__ part_m, float* __restrict__ part_z) {
     using Geo = KGeo<DK>;
     constexpr int TILEB = Geo::TILEB;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[MF_NBUF * TILEB];
+    constexpr int NBUF = Geo::NBUF, NKF = Geo::NKF;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * TILEB];
     const uint32_t chunk = blockIdx.x, b = blockIdx.z;
     const uint32_t h = blockIdx.y / ngb, gb = blockIdx.y - h * ngb;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -197,10 +210,10 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
 
     const KStreamT<DK> ks_(static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2, a.k_ss * 2, a.S);
     const TileWalk tw(chunk, nchunk, a.S);
-    // the first two K tiles are requested BEFORE the Q fragments: one memory round trip for both
+    // the first K tiles are requested BEFORE the Q fragments: one memory round trip for all
     if (tw.ntiles > 0) {
-        ks_.request_tile(lds, tw.key0(0));
-        ks_.request_tile(lds + TILEB, tw.key0(1));
+#pragma unroll
+        for (int i = 0; i < NBUF - 1; ++i) ks_.request_tile(lds + i * TILEB, tw.key0(i));
     }
     uint4 qf[DK];
     load_qfrags<DK>(qf, static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)mf_qrow(a, row0 + n) * a.q_sw) * 2, kg);
@@ -244,17 +257,21 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
     auto compute_fast = [&](const unsigned char* buf, unsigned char* bufr, uint32_t keyr) {
         // (the 16 logits of the previous sub-tile are exponentiated beside the DK MFMAs of this one: elements 16 ks / DK .. 16 (ks + 1) / DK - 1
         // beside MFMA ks -- two per MFMA for D = 128, four for D = 64, three or two for D = 96)
-        uint4 kf[2][DK];
+        uint4 kf[NKF][DK];
         f32x16 acc[2];
 #pragma unroll
         for (int ks = 0; ks < DK; ++ks) kf[0][ks] = kfrag_t<DK>(buf, 0, ks, n, kg);
 #pragma unroll
         for (int sub = 0; sub < MF_SUBS; ++sub) {
-            if (sub + 1 < MF_SUBS) {
+            if (NKF == 2 && sub + 1 < MF_SUBS) {
 #pragma unroll
-                for (int ks = 0; ks < DK; ++ks) kf[(sub + 1) & 1][ks] = kfrag_t<DK>(buf, sub + 1, ks, n, kg);
+                for (int ks = 0; ks < DK; ++ks) kf[(sub + 1) & (NKF - 1)][ks] = kfrag_t<DK>(buf, sub + 1, ks, n, kg);
             }
-            if (sub < Geo::NREQ) ks_.request(bufr, keyr, sub);
+            if (NKF == 1 && sub > 0) {   // (one register set: this sub-tile's fragments are read now, after the previous chain)
+#pragma unroll
+                for (int ks = 0; ks < DK; ++ks) kf[0][ks] = kfrag_t<DK>(buf, sub, ks, n, kg);
+            }
+            ks_.request_part(bufr, keyr, sub);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[sub & 1][i] = 0.f;
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < DK; ++ks) {
-                    acc[sub & 1] = mma32<DT>(kf[sub & 1][ks], qf[ks], acc[sub & 1]);
+                    acc[sub & 1] = mma32<DT>(kf[sub & (NKF - 1)][ks], qf[ks], acc[sub & 1]);
 #pragma unroll
                     for (int e = (16 * ks) / DK; e < (16 * (ks + 1)) / DK; ++e) {   // (the same two interleaved sums for every head size: element i goes to sum i & 1)
                         const float x = fast_exp2(fmaf(ap[e], c, off));
@@ -298,7 +315,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
             uint4 kf[DK];
 #pragma unroll
             for (int ks = 0; ks < DK; ++ks) kf[ks] = kfrag_t<DK>(buf, sub, ks, n, kg);
-            if (sub < Geo::NREQ) ks_.request(bufr, keyr, sub);
+            ks_.request_part(bufr, keyr, sub);
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -316,13 +333,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
         __syncthreads();
         int bc = 0;
         for (uint32_t t = 0; t < tw.ntiles; ++t) {
-            unsigned char* bufr = lds + ring_prev(bc) * TILEB;  // tile t-1's buffer: everybody left it at the last barrier
-            if (active) compute(tw.key0(t), lds + bc * TILEB, bufr, tw.key0(t + 2));
-            else ks_.request_tile(bufr, tw.key0(t + 2));
+            unsigned char* bufr = lds + Geo::ring_prev(bc) * TILEB;  // tile t-1's buffer: everybody left it at the last barrier
+            if (active) compute(tw.key0(t), lds + bc * TILEB, bufr, tw.key0(t + NBUF - 1));
+            else ks_.request_tile(bufr, tw.key0(t + NBUF - 1));
             __builtin_amdgcn_sched_barrier(0);
             wait_tile_landed_t<DK>();  // this wave's part of tile t+1 is in LDS ...
             __syncthreads();     // ... and so is everybody else's; all fragment reads of tile t are done
-            bc = ring_next(bc);
+            bc = Geo::ring_next(bc);
         }
         wait_all_landed();
     }
@@ -491,7 +508,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
                                                                 float* __restrict__ colsum, float* __restrict__ colsum2) {
     using Geo = KGeo<DK>;
     constexpr int TILEB = Geo::TILEB;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[MF_NBUF * TILEB];
+    constexpr int NBUF = Geo::NBUF, NKF = Geo::NKF;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * TILEB];
     __shared__ float red[2][MF_WAVES][MF_TILE];
     const uint32_t chunk = blockIdx.x, b = blockIdx.z;
     const uint32_t h = blockIdx.y / ngb, gb = blockIdx.y - h * ngb;
@@ -506,9 +524,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
     const KStreamT<DK> ks_(static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh) * 2, a.k_ss * 2, a.S);
     const TileWalk tw(chunk, gridDim.x, Sm);
     if (tw.ntiles == 0) return;
-    // the first two K tiles are requested BEFORE the Q fragments and normalisers: one memory round trip for all
-    ks_.request_tile(lds, tw.key0(0));
-    ks_.request_tile(lds + TILEB, tw.key0(1));
+    // the first K tiles are requested BEFORE the Q fragments and normalisers: one memory round trip for all
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) ks_.request_tile(lds + i * TILEB, tw.key0(i));
     uint4 qf[DK];
     load_qfrags<DK>(qf, static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)mf_qrow(a, row0 + n) * a.q_sw) * 2, kg);
     // normalisers of the 16 q rows this lane sees in the C layout: row = row0 + (r&3) + 8*(r>>2) + 4*kg
@@ -537,17 +555,21 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
     };
     // one tile, software-pipelined like pass 1: MFMA chain of sub-tile s || exp/add stream of sub-tile s-1
     auto compute = [&](const unsigned char* buf, int par, unsigned char* bufr, uint32_t keyr) {
-        uint4 kf[2][DK];
+        uint4 kf[NKF][DK];
         f32x16 acc[2];
 #pragma unroll
         for (int ks = 0; ks < DK; ++ks) kf[0][ks] = kfrag_t<DK>(buf, 0, ks, n, kg);
 #pragma unroll
         for (int sub = 0; sub < MF_SUBS; ++sub) {
-            if (sub + 1 < MF_SUBS) {
+            if (NKF == 2 && sub + 1 < MF_SUBS) {
 #pragma unroll
-                for (int ks = 0; ks < DK; ++ks) kf[(sub + 1) & 1][ks] = kfrag_t<DK>(buf, sub + 1, ks, n, kg);
+                for (int ks = 0; ks < DK; ++ks) kf[(sub + 1) & (NKF - 1)][ks] = kfrag_t<DK>(buf, sub + 1, ks, n, kg);
             }
-            if (sub < Geo::NREQ) ks_.request(bufr, keyr, sub);
+            if (NKF == 1 && sub > 0) {
+#pragma unroll
+                for (int ks = 0; ks < DK; ++ks) kf[0][ks] = kfrag_t<DK>(buf, sub, ks, n, kg);
+            }
+            ks_.request_part(bufr, keyr, sub);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[sub & 1][i] = 0.f;
@@ -559,7 +581,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < DK; ++ks) {
-                    acc[sub & 1] = mma32<DT>(qf[ks], kf[sub & 1][ks], acc[sub & 1]);
+                    acc[sub & 1] = mma32<DT>(qf[ks], kf[sub & (NKF - 1)][ks], acc[sub & 1]);
 #pragma unroll
                     for (int e = (16 * ks) / DK; e < (16 * (ks + 1)) / DK; ++e) {
                         const float x = fast_exp2(fmaf(ap[e], c, ar[e]));
@@ -593,14 +615,14 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
     __syncthreads();
     int bc = 0;
     for (uint32_t t = 0; t < tw.ntiles; ++t) {
-        unsigned char* bufr = lds + ring_prev(bc) * TILEB;
-        if (active) compute(lds + bc * TILEB, t & 1, bufr, tw.key0(t + 2));
-        else ks_.request_tile(bufr, tw.key0(t + 2));
+        unsigned char* bufr = lds + Geo::ring_prev(bc) * TILEB;
+        if (active) compute(lds + bc * TILEB, t & 1, bufr, tw.key0(t + NBUF - 1));
+        else ks_.request_tile(bufr, tw.key0(t + NBUF - 1));
         __builtin_amdgcn_sched_barrier(0);
         wait_tile_landed_t<DK>();
         __syncthreads();
         flush(tw.key0(t), t & 1);
-        bc = ring_next(bc);
+        bc = Geo::ring_next(bc);
     }
     wait_all_landed();
 }
@@ -609,7 +631,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
 
 bool snapkv_mfma_eligible(const SnapArgs& a, int dtype) {
     if (dtype != KVP_BF16 && dtype != KVP_F16) return false;
-    if ((a.D != 128 && a.D != 96 && a.D != 64) || a.W < 1 || a.W > 4096 || a.G > 8) return false;   // (any window: blocks of 64 rows, snapkv_internal.h)
+    if ((a.D != 256 && a.D != 128 && a.D != 96 && a.D != 64) || a.W < 1 || a.W > 4096 || a.G > 8) return false;   // (any window: blocks of 64 rows, snapkv_internal.h)
     auto al8 = [](int64_t x) { return x % 8 == 0; };
     if (((uintptr_t)a.q % 16) || ((uintptr_t)a.k % 16)) return false;
     return al8(a.q_sb) && al8(a.q_sh) && al8(a.q_sw) && al8(a.k_sb) && al8(a.k_sh) && al8(a.k_ss);
@@ -653,7 +675,8 @@ int snapkv_mfma_p1(const SnapArgs& a0, int dtype, uint32_t nchunk, float* part_m
         }
         // G = 1, 2, 3, 5, 6, 7 (partially filled workgroups) and head size 64: the compiler-scheduled kernels
 #define KVP_P1_MFMA(DTV, DKV) KVP_LAUNCH("snapkv_p1_mfma", stream, (snapkv_p1_mfma<DTV, DKV><<<grid, MF_THREADS, 0, stream>>>(a, ngb, nchunk, part_m, part_z)))
-        if (a.D == 128) { if (dtype == KVP_BF16) KVP_P1_MFMA(KVP_BF16, 8); else KVP_P1_MFMA(KVP_F16, 8); }
+        if (a.D == 256) { if (dtype == KVP_BF16) KVP_P1_MFMA(KVP_BF16, 16); else KVP_P1_MFMA(KVP_F16, 16); }
+        else if (a.D == 128) { if (dtype == KVP_BF16) KVP_P1_MFMA(KVP_BF16, 8); else KVP_P1_MFMA(KVP_F16, 8); }
         else if (a.D == 96) { if (dtype == KVP_BF16) KVP_P1_MFMA(KVP_BF16, 6); else KVP_P1_MFMA(KVP_F16, 6); }
         else { if (dtype == KVP_BF16) KVP_P1_MFMA(KVP_BF16, 4); else KVP_P1_MFMA(KVP_F16, 4); }
 #undef KVP_P1_MFMA
@@ -841,7 +864,8 @@ int snapkv_mfma_p2(const SnapArgs& a0, int dtype, const float* rowstat, float* c
         if (a.G % 4 == 0 && a.D == 128) {   // hand-scheduled tile loop
             if (dtype == KVP_BF16) KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_BF16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, cs, colsum2, p1_ticks));
             else KVP_LAUNCH("snapkv_p2_asm", stream, snapkv_p2_asm<KVP_F16><<<grid, MF_THREADS, 0, stream>>>(a, ngb, rowstat, cs, colsum2, p1_ticks));
-        } else if (a.D == 128) { if (dtype == KVP_BF16) KVP_P2_MFMA(KVP_BF16, 8); else KVP_P2_MFMA(KVP_F16, 8); }
+        } else if (a.D == 256) { if (dtype == KVP_BF16) KVP_P2_MFMA(KVP_BF16, 16); else KVP_P2_MFMA(KVP_F16, 16); }
+        else if (a.D == 128) { if (dtype == KVP_BF16) KVP_P2_MFMA(KVP_BF16, 8); else KVP_P2_MFMA(KVP_F16, 8); }
         else if (a.D == 96) { if (dtype == KVP_BF16) KVP_P2_MFMA(KVP_BF16, 6); else KVP_P2_MFMA(KVP_F16, 6); }
         else { if (dtype == KVP_BF16) KVP_P2_MFMA(KVP_BF16, 4); else KVP_P2_MFMA(KVP_F16, 4); }
 #undef KVP_P2_MFMA

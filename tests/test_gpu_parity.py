@@ -309,7 +309,7 @@ def test_snapkv_kernel_vs_oracle(name):
 def test_snapkv_any_window_on_the_mfma_path(W, S, G, ks, D):
     """Round 6: the MFMA passes take ANY window size (TOVA's W = 1, FINCH's question length, user-chosen windows) as blocks of 64
     padded rows -- padding in front, normaliser +inf, the reference's causal rule in padded coordinates (snapkv_internal.h) -- for
-    head sizes 128, 96 and 64 (256: the generic kernels with a raised LDS limit), G = 1 .. 8 (hand-scheduled loops for D = 128 and G % 4 == 0, the compiler-scheduled kernels otherwise), down to
+    head sizes 256, 128, 96 and 64, G = 1 .. 8 (hand-scheduled loops for D = 128 and G % 4 == 0, the compiler-scheduled kernels otherwise), down to
     S = W + 1 (every tile masked).  Scores against the float64 oracle; pad columns; a batch of two through the same call."""
     rs = np.random.RandomState(W * 131 + S + G + D)
     N = native()

@@ -74,7 +74,7 @@ def main():
     case("snapkv", 1, 24, 8, S, 128, bf, note="G = 3: compiler-scheduled MFMA passes")
     case("snapkv", 1, 64, 8, S, 128, bf, note="G = 8: two group-blocks, second column-sum slab")
     case("snapkv", 1, 32, 8, S, 96, bf, note="D = 96 (Phi-3-mini): compiler-scheduled MFMA passes on 256-byte LDS rows (round 6)")
-    case("snapkv", 1, 32, 8, S, 256, bf, note="D = 256 (Gemma): generic kernels")
+    case("snapkv", 1, 32, 8, S, 256, bf, note="D = 256 (Gemma): compiler-scheduled MFMA passes, two-buffer ring of 64 KiB tiles (round 6)")
     case("snapkv", 1, 32, 8, S, 64, bf, note="D = 64: compiler-scheduled MFMA passes (round 6; before: generic kernels, 3206 us)")
     case("snapkv", 1, 32, 8, S, 128, f32, note="float32 model: generic kernels")
     case("snapkv", 1, 32, 8, S, 128, bf, W=32, note="window 32: hand-scheduled passes on a padded 64-row block (round 6; before: generic kernels, 3812 us)")
