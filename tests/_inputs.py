@@ -56,6 +56,11 @@ CASES = {
     # wider hidden states: the library's own window q_proj + RoPE kernel applies (hidden % 256 == 0)
     "sk_h512_bf16": dict(kind="snapkv", B=2, H=2, G=4, S=300, D=128, dtype="bf16", data="B", seed=30, W=64, ks=5, hsz=512),
     "sk_h1024_f16": dict(kind="snapkv", B=1, H=1, G=8, S=1000, D=128, dtype="f16", data="A", seed=40, W=64, ks=5, hsz=1024),
+    # round 6: windows that are not 64 rows and the other head sizes of the reference's supported models on the MFMA passes
+    "sk_w100_d96": dict(kind="snapkv", B=1, H=2, G=4, S=700, D=96, dtype="bf16", data="B", seed=141, W=100, ks=5),
+    "sk_w200_d256": dict(kind="snapkv", B=1, H=1, G=2, S=1100, D=256, dtype="bf16", data="A", seed=142, W=200, ks=3),
+    "sk_w7_d64_bf16": dict(kind="snapkv", B=2, H=2, G=4, S=900, D=64, dtype="bf16", data="B", seed=143, W=7, ks=5),
+    "sk_w130_d128": dict(kind="snapkv", B=1, H=2, G=4, S=2000, D=128, dtype="bf16", data="B", seed=144, W=130, ks=7),
     # ---- ExpectedAttentionPress --------------------------------------------------------
     "ea_tiny": dict(kind="ea", B=2, H=2, G=2, S=100, D=16, dtype="f32", data="A", seed=31),
     "ea_23": dict(kind="ea", B=1, H=2, G=1, S=23, D=16, dtype="f32", data="A", seed=32,
