@@ -308,7 +308,23 @@ def rocpd_kernel_durations(db_path: str) -> dict:
     return per
 
 
-def live_kernel_trace(names, workload: str, timeout_s: float = 240.0):
+def write_kernel_stats_csv(per: dict, path: str) -> None:
+    """rocprofv3 --stats' kernel table (same columns) from the dispatch durations of a trace database: so that the committed
+    profiles/<round>_rocprofv3_kernel_stats_<workload>.csv is the very data the line's per-kernel numbers were averaged from."""
+    rows = []
+    for name, durs in per.items():
+        ns = [d * 1e3 for d in durs]
+        mean = sum(ns) / len(ns)
+        sd = (sum((x - mean) ** 2 for x in ns) / max(1, len(ns) - 1)) ** 0.5
+        rows.append((sum(ns), name, len(ns), mean, min(ns), max(ns), sd))
+    tot = sum(r[0] for r in rows) or 1.0
+    with open(path, "w") as f:
+        f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n')
+        for total, name, n, mean, mn, mx, sd in sorted(rows, reverse=True):
+            f.write(f'"{name}",{n},{total:.0f},{mean:.6f},{100 * total / tot:.2f},{mn:.0f},{mx:.0f},{sd:.6f}\n')
+
+
+def live_kernel_trace(names, workload: str, timeout_s: float = 240.0, csv_path=None):
     """({library kernel name: (average us per launch, dispatches)}, provenance): kernel durations as rocprofv3 measures them -- the
     numbers profiles/<round>_rocprofv3_kernel_stats_<workload>.csv holds -- taken NOW by one `rocprofv3 --kernel-trace` pass (no
     counters) around a child run of this same script and workload; averages over ALL the child's dispatches of a kernel, as `--stats`
@@ -347,6 +363,11 @@ def live_kernel_trace(names, workload: str, timeout_s: float = 240.0):
                             per.setdefault(name, []).extend(durs)
                     except Exception as e:   # noqa: BLE001
                         return None, f"live kernel-trace pass: cannot read {f} ({type(e).__name__})"
+    if csv_path:
+        try:
+            write_kernel_stats_csv(per, csv_path)
+        except OSError as e:
+            print(f"[bench] cannot write {csv_path}: {e}", file=sys.stderr)
     out = {}
     for short in names:
         durs = [x for name, ds in per.items() if match_kernel(short, name) for x in ds]
@@ -693,6 +714,9 @@ def main():
                     help="roofline.traffic: auto = measure it now with two rocprofv3 --pmc passes around a 3-step child run (N = 1, ~40 s); "
                          "off = quote the committed summary of this build (profiles/<round>_pmc_summary_<workload>.txt)")
     ap.add_argument("--profile-json", default=None, help="also dump the per-kernel HIP-event table here")
+    ap.add_argument("--trace-stats-csv", default=None,
+                    help="write the kernel statistics of the live rocprofv3 --kernel-trace pass (the data behind the line's per-kernel numbers) "
+                         "here, in rocprofv3 --stats' CSV format: profiles/<round>_rocprofv3_kernel_stats_<workload>.csv")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL); gloo + --stub-step exercises the launcher on CPU (tests)")
     ap.add_argument("--stub-step", type=float, default=None, metavar="MS",
@@ -763,7 +787,8 @@ def run(args, world: int, rank: int, device, stub: bool):
     bpg = BATCH.get(args.workload, 1)
     lo, hi = shard_batch(world * bpg, world, rank)  # global batch = BATCH[workload] (default one) elements per GPU (weak scaling)
     head = measure(args.workload, args.steps, args.warmup, args.prewarm_ms, world, rank, lo, hi, device, args.live_pmc, args.profile_json,
-                   cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline), parity=(rank == 0 and world == 1))   # (N > 1: timing only)
+                   cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline), parity=(rank == 0 and world == 1),   # (N > 1: timing only)
+                   trace_csv=args.trace_stats_csv)
     # ---- BASELINE.json's other single-GPU configurations, measured in the SAME run so that the driver's record carries them
     # (VERDICT r3 #7): config 2 (Knorm 32k) and config 4 (ExpectedAttention 128k).  After the headline's timed region; N = 1 only.
     extra = None
@@ -843,7 +868,7 @@ def fixture_parity(workload, press, att, hidden, keys, values, kwargs, n_kept):
         return {"fixture": f"tests/golden/{name}.npz", "ok": False, "error": str(e)[:300]}
 
 
-def measure(workload, steps, warmup, prewarm_ms, world, rank, lo, hi, device, live_pmc, profile_json, cpu: bool, parity: bool) -> dict:
+def measure(workload, steps, warmup, prewarm_ms, world, rank, lo, hi, device, live_pmc, profile_json, cpu: bool, parity: bool, trace_csv=None) -> dict:
     """One workload on this rank's shard: inputs, pre-warm, W warm-up + K timed steps (barrier + sync bracketed, MAX over ranks),
     then -- outside the timed region -- per-kernel HIP-event timing, the roofline block, the fixture parity check and the CPU baseline."""
     import torch
@@ -898,7 +923,7 @@ def measure(workload, steps, warmup, prewarm_ms, world, rank, lo, hi, device, li
         traced, traced_source = None, ("not requested" if live_pmc == "off" else f"no live pass with {world} ranks")
         if world == 1 and live_pmc != "off":
             try:
-                traced, traced_source = live_kernel_trace(list(avg), workload)
+                traced, traced_source = live_kernel_trace(list(avg), workload, csv_path=trace_csv)
             except Exception as e:   # noqa: BLE001 -- the bench line must never die in its optional profiler pass
                 traced, traced_source = None, f"live kernel-trace pass raised {type(e).__name__}: {e}"
         roofline = roofline_block(avg, workload, B, t_step, world, live_pmc, traced, traced_source)

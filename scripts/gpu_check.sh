@@ -16,7 +16,8 @@ if [[ "$WHAT" == *tests* ]]; then
 fi
 if [[ "$WHAT" == *bench* ]]; then
   for wl in ${BENCH_WL:-knorm32k knorm128k snapkv128k ea128k}; do
-    timeout 900 python bench.py --workload $wl --profile-json gpurun_out/${R}_kernels_$wl.json > gpurun_out/bench_$wl.log 2>&1
+    # (the kernel-statistics CSV is written by the bench run itself from the trace pass its per-kernel numbers come from)
+    timeout 900 python bench.py --workload $wl --profile-json gpurun_out/${R}_kernels_$wl.json --trace-stats-csv gpurun_out/${R}_rocprofv3_kernel_stats_$wl.csv > gpurun_out/bench_$wl.log 2>&1
     echo "bench[$wl] rc=$? $(tail -1 gpurun_out/bench_$wl.log | cut -c1-300)"
     tail -1 gpurun_out/bench_$wl.log > gpurun_out/${R}_bench_$wl.json
   done

@@ -3,5 +3,5 @@
 # statistics, PMC summaries, clock / power record (incl. the ExpectedAttention kernels), end-to-end prefill
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-export ROUND_TAG=r06 PROF_WL="snapkv128k knorm32k knorm128k ea128k snapkv128k_b2 chunk_snapkv128k" PMC_WL="snapkv128k knorm32k ea128k"
+export ROUND_TAG=r06 PROF_WL="snapkv128k_b2 chunk_snapkv128k" PMC_WL="snapkv128k knorm32k ea128k"
 bash scripts/gpu_check.sh tests bench frows prof pmc e2e power
