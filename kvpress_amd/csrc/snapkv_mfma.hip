@@ -222,7 +222,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
     float m = KVP_NEG_INF, z = 0.f;  // raw-logit running max / sum-exp of window row row0 + n over this lane's keys
     const float c = a.c;
     const uint32_t w = row0 + n;     // row of this launch's 64-row block: it sees keys <= S - weff + w
-    const uint32_t weff = mf_weff(a);
+    // row r of this block may attend keys <= mlim + r.  SIGNED: with a padded window S - Wp can be negative (S = 253, W = 200: Wp = 256);
+    // the unsigned form classified such tiles as unmasked (found by tools/snapkv_shape_fuzz.py)
+    const int32_t mlim = (int32_t)a.S - (int32_t)mf_weff(a);
 
     // softmax-update of the 16 finished logits of one sub-tile (lane's q row: running max m, sum-exp z);
     // MASKED: causal mask / sequence tail handled per element (only the last tiles of a head)
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t kk = key0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                if (kk >= a.S || kk > a.S - weff + w) acc[r] = KVP_NEG_INF;
+                if (kk >= a.S || (int32_t)kk > mlim + (int32_t)w) acc[r] = KVP_NEG_INF;
             }
         }
         float tm = acc[0];
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_mfma(SnapArgs a, uint
         }
     };
     auto compute = [&](uint32_t key0, const unsigned char* buf, unsigned char* bufr, uint32_t keyr) {
-        if (key0 + (MF_TILE - 1) > a.S - weff) compute_masked(key0, buf, bufr, keyr);  // some (row, key) is masked / past S
+        if ((int32_t)(key0 + (MF_TILE - 1)) > mlim) compute_masked(key0, buf, bufr, keyr);  // some (row, key) is masked / past S
         else compute_fast(buf, bufr, keyr);
     };
 
@@ -396,12 +398,14 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_asm(SnapArgs a, uint3
         for (int i = 0; i < NB - 1; ++i) ks_.request_tile(lds + i * MF_TILEB, tw.key0(i));
     }
     const char* qrow = static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)mf_qrow(a, row0 + n) * a.q_sw) * 2 + kg * 16;
-    const uint32_t weff = mf_weff(a);
+    // row r of this block may attend keys <= mlim + r.  SIGNED: with a padded window S - Wp can be negative (S = 253, W = 200: Wp = 256);
+    // the unsigned form classified such tiles as unmasked (found by tools/snapkv_shape_fuzz.py)
+    const int32_t mlim = (int32_t)a.S - (int32_t)mf_weff(a);
     // tiles for the asm loop: the leading unmasked ones (every key <= S - weff).  Its requests run NB - 1 tiles ahead with the tile
     // index clamped to the walk's last tile and no per-row clamp: if that last tile is ragged (rows past S), the C++ loop below
     // must be the one that requests it.
     uint32_t nfast = 0;
-    while (nfast < tw.ntiles && tw.kbeg + nfast * tw.tstride + (MF_TILE - 1) <= a.S - weff) ++nfast;
+    while (nfast < tw.ntiles && (int32_t)(tw.kbeg + nfast * tw.tstride + (MF_TILE - 1)) <= mlim) ++nfast;
     const bool last_full = tw.klast + (MF_TILE - 1) <= a.S - 1;
     const uint32_t nasm = last_full ? nfast : min(nfast, tw.ntiles >= (uint32_t)NB ? tw.ntiles - NB : 0u);
 
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_asm(SnapArgs a, uint3
             const unsigned char* buf = lds + bc * MF_TILEB;
             unsigned char* bufr = lds + ((bc + NB - 1) % NB) * MF_TILEB;   // the previous tile's buffer: everybody left it at the last barrier
             const uint32_t key0 = tw.key0(t), keyr = tw.key0(t + NB - 1);
-            const bool masked = key0 + (MF_TILE - 1) > a.S - weff;
+            const bool masked = (int32_t)(key0 + (MF_TILE - 1)) > mlim;
             for (int sub = 0; sub < MF_SUBS; ++sub) {
                 uint4 kf[8];
 #pragma unroll
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p1_asm(SnapArgs a, uint3
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t kk = key0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                        if (kk >= a.S || kk > a.S - weff + w) acc[r] = KVP_NEG_INF;
+                        if (kk >= a.S || (int32_t)kk > mlim + (int32_t)w) acc[r] = KVP_NEG_INF;
                     }
                 }
                 float tm = acc[0];

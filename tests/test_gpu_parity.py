@@ -306,7 +306,9 @@ def test_snapkv_kernel_vs_oracle(name):
 @pytest.mark.parametrize("D", [128, 96, 64, 256])
 @pytest.mark.parametrize("W,S,G,ks", [(1, 700, 4, 1), (1, 5000, 2, 1), (7, 300, 4, 5), (32, 1000, 4, 5), (33, 2100, 1, 3), (63, 64, 4, 5), (64, 65, 3, 5),
                                       (65, 700, 4, 5), (100, 4200, 4, 5), (128, 129, 2, 5), (130, 9000, 8, 7), (200, 2500, 4, 5), (257, 40000, 4, 5),
-                                      (64, 3000, 5, 5), (64, 3000, 6, 5), (40, 1500, 7, 5), (64, 20000, 1, 5), (64, 20000, 2, 5)])
+                                      (64, 3000, 5, 5), (64, 3000, 6, 5), (40, 1500, 7, 5), (64, 20000, 1, 5), (64, 20000, 2, 5),
+                                      # S < Wp (the padded window is longer than the sequence): the fuzz's round-6 find
+                                      (200, 253, 7, 5), (65, 66, 4, 1), (130, 150, 2, 3), (1, 2, 4, 1), (10, 40, 8, 5)])
 def test_snapkv_any_window_on_the_mfma_path(W, S, G, ks, D):
     """Round 6: the MFMA passes take ANY window size (TOVA's W = 1, FINCH's question length, user-chosen windows) as blocks of 64
     padded rows -- padding in front, normaliser +inf, the reference's causal rule in padded coordinates (snapkv_internal.h) -- for
