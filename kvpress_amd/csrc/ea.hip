@@ -399,7 +399,7 @@ extern "C" int kvp_ea_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t 
         kvp_set_error("ea_qstats: workspace too small (%zu < %zu)", ws_bytes, need);
         return KVP_EWORKSPACE;
     }
-    if (ea_mfma_qstats_eligible(q, q_sb, q_sh, q_ss, dtype, Sq, D))
+    if (ea_mfma_qstats_eligible(q, q_sb, q_sh, q_ss, dtype, Hq, Sq, D))
         return ea_mfma_qstats(q, q_sb, q_sh, q_ss, dtype, B, Hq, Sq, D, mu, cov, ws, stream);
 
     EaStatWs w = carve_stat_ws(ws, B, Hq, Sq, D);

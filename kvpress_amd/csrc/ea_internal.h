@@ -12,8 +12,8 @@ struct EaArgs {
     uint32_t* clear_word;  // nullable: a word the logits kernel sets to 0 (the arrival counter of the finalize pass that follows it in the stream)
 };
 
-// MFMA fast paths (bf16/f16, D = 128)
-bool ea_mfma_qstats_eligible(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int dtype, int64_t Sq, int64_t D);
+// MFMA fast paths (bf16/f16; D = 128, the statistics also D = 64 with neighbouring heads, the logits also D = 64 / 96)
+bool ea_mfma_qstats_eligible(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int dtype, int64_t Hq, int64_t Sq, int64_t D);
 size_t ea_mfma_qstats_ws_bytes(int64_t B, int64_t Hq, int64_t Sq, int64_t D);
 int ea_mfma_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int dtype, int64_t B, int64_t Hq, int64_t Sq,
                    int64_t D, float* mu, float* cov, void* ws, hipStream_t stream);

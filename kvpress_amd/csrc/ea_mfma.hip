@@ -1,4 +1,4 @@
-// ExpectedAttention on the matrix cores (bf16 / f16, D = 128): query statistics and quadratic-form logits.
+// ExpectedAttention on the matrix cores (bf16 / f16; D = 128, round 6: also 64 and -- the logits -- 96): query statistics and quadratic-form logits.
 //
 // (1) ea_qstats_mfma  -- mu, cov of the pre-RoPE queries (expected_attention_press.py:74-80), one pass over Q.
 //     cov = X^T X needs, for both MFMA operands, "column fragments" (a lane holds several ROWS s of one dimension d), while X is
@@ -72,6 +72,8 @@ struct QstatArgs {
     float* dsum;  // [B*Hq][nchunk][128]   sum over the chunk's rows of (x - m0)
     float* m0;    // [B*Hq][nchunk][128]
     uint32_t nt;  // non-temporal Q stream (read once)
+    uint32_t nch; // 16-byte chunks a row of one head really has: 16 (D = 128); 12 / 8 (round 6: D = 96 / 64 as heads of 128 dimensions whose upper
+                  // dimensions are zero: the LDS tiles are zeroed once and the lanes of the missing chunks never request anything)
 };
 
 // ---- (1b) query statistics with transposed LDS reads (gfx950 ds_read_b64_tr_b16) -------------------------------------------------
@@ -106,6 +108,11 @@ __global__ __launch_bounds__(EM_THREADS, ET_OCC) void ea_qstats_tr_kernel(QstatA
     // ---- LDS-DMA: request j (0..3) of a tile moves rows 16 j + 4 wv + g; lane slot i16 fetches chunk i16 ^ (g << 2) (row & 3 == g)
     const uint32_t ldsbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const uint32_t gch = (i16 ^ (g << 2)) << 4;
+    const bool has_chunk = (gch >> 4) < a.nch;
+    if (a.nch < 16) {   // zero dimensions of a narrow head: written once, never overwritten (only the lanes with a chunk request)
+        for (uint32_t e = threadIdx.x; e < (uint32_t)(ET_NBUF * EM_TILEB / 16); e += EM_THREADS) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
     auto request_tile = [&](uint32_t t, uint32_t buf) {
         const uint32_t row0 = rbeg + min(t, ntiles - 1) * EM_TILE;   // past the end: re-fetch the last tile (never read)
 #pragma unroll
@@ -113,8 +120,16 @@ __global__ __launch_bounds__(EM_THREADS, ET_OCC) void ea_qstats_tr_kernel(QstatA
             const uint32_t row = min(row0 + 16 * j + 4 * wv + g, a.Sq - 1);   // rows past the end are zeroed in LDS below
             const char* gp = base + (int64_t)row * row_bytes + gch;
             const uint32_t la = __builtin_amdgcn_readfirstlane(ldsbase + buf * EM_TILEB + (16 * j + 4 * wv) * EM_ROWB);
-            if (a.nt) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(la), "v"(gp) : "memory");
-            else asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(gp) : "memory");
+            if (a.nch == 16) {
+                if (a.nt) asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(la), "v"(gp) : "memory");
+                else asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(gp) : "memory");
+            } else {   // (every wave has lanes with a chunk: all waves issue all requests, the vmcnt bookkeeping below holds)
+                asm volatile("s_mov_b32 m0, %0" ::"s"(la) : "memory");
+                if (has_chunk) {
+                    if (a.nt) asm volatile("global_load_lds_dwordx4 %0, off nt" ::"v"(gp) : "memory");
+                    else asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(gp) : "memory");
+                }
+            }
         }
     };
 #pragma unroll
@@ -194,7 +209,10 @@ __global__ __launch_bounds__(EM_THREADS, ET_OCC) void ea_qstats_tr_kernel(QstatA
 // grid = (16, B*Hq): workgroup x handles cov elements [x*1024, (x+1)*1024) of one head (and x == 0 also writes mu).
 __global__ __launch_bounds__(256) void ea_qstats_combine(const float* __restrict__ s2, const float* __restrict__ dsum,
                                                          const float* __restrict__ m0, uint32_t Sq, uint32_t nchunk,
-                                                         uint32_t rows_per_chunk, float* __restrict__ mu, float* __restrict__ cov) {
+                                                         uint32_t rows_per_chunk, float* __restrict__ mu, float* __restrict__ cov, uint32_t pair, uint32_t dout) {
+    // pair != 0 (D = 64, ea_mfma_qstats): a "head" of this kernel is a PAIR of 64-dimensional heads that sit next to each other in a token row;
+    // mu [.., 2 p + {0, 1}, 64] is the pair's 128 means as they are, cov gets the two diagonal 64 x 64 blocks (the cross-head blocks are dropped)
+    // dout < 128 (D = 96, D = 64 in other layouts): the head's statistics are the leading dout x dout block of a 128-wide head padded with zeros
     extern __shared__ float sm[];  // muc[nchunk][128], del[nchunk][128], mug[128]
     float* muc = sm;
     float* del = sm + nchunk * 128;
@@ -216,7 +234,7 @@ __global__ __launch_bounds__(256) void ea_qstats_combine(const float* __restrict
             s += nc * muc[c * 128 + threadIdx.x];
         }
         mug[threadIdx.x] = s * invN;
-        if (blockIdx.x == 0) mu[(size_t)bh * 128 + threadIdx.x] = s * invN;
+        if (blockIdx.x == 0 && threadIdx.x < dout) mu[(size_t)bh * dout + threadIdx.x] = s * invN;
     }
     __syncthreads();
     if (!cov) return;
@@ -248,7 +266,11 @@ __global__ __launch_bounds__(256) void ea_qstats_combine(const float* __restrict
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cov[(size_t)bh * 16384 + e0 + q * 256] = s[q] * invN;
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t e = e0 + q * 256, i = e >> 7, j = e & 127;
+        if (!pair) { if (i < dout && j < dout) cov[((size_t)bh * dout + i) * dout + j] = s[q] * invN; }
+        else if (((i ^ j) & 64) == 0) cov[(((size_t)bh * 2 + (i >> 6)) * 64 + (i & 63)) * 64 + (j & 63)] = s[q] * invN;
+    }
 }
 
 // Partials per head: about two workgroups per CU over all heads (32 heads: 16 chunks of 8192 rows), at least 4096 rows each.  Fewer
@@ -742,32 +764,223 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_tri_kernel(EaArg
     }
 }
 
+// ---- (2c) head sizes 64 and 96 (round 6) -----------------------------------------------------------------------------------------------
+// The same quadratic form on the doubled upper triangle, hi + lo split, for heads of DK = 4 / 6 k-steps of 16 dimensions (Llama-3.2-1B,
+// Qwen2-0.5B: D = 64; Phi-3-mini: 96) -- they took the scalar generic kernel (32k tokens x 32 heads: 1.06 ms against 0.17 for D = 128).
+// With D / 32 = 2 or 3 strips of U there is nothing to balance across waves: wave w takes the 32-key sub-tile w of every 128-key tile with ALL
+// strips (6 / 12 (strip, k-step) products: 12 / 24 MFMAs per wave and tile), adds the strips' row-dots in registers, folds its two lane halves
+// with one cross-lane read and owns its 32 logits (store + running softmax partial): no partial-sum buffers, one barrier per tile (the K ring).
+// K rows of 128 bytes sit two per LDS bank line, so their 16-byte slots rotate with bits 1 .. 3 of the row; rows of 192 bytes keep 256-byte LDS
+// rows and the lanes whose chunk does not exist request nothing (as snapkv_mfma.hip's KGeo).  Compiler-scheduled: these shapes are not the benchmark's.
+template <int DK> struct ElGeo {
+    static constexpr int D = DK * 16;
+    static constexpr int NS = DK / 2;                     // 32-row strips of U
+    static constexpr int ROWB = DK == 4 ? 128 : 256;      // bytes per key row IN LDS
+    static constexpr int NCH = DK * 2;                    // 16-byte chunks a key row has
+    static constexpr int CPR = ROWB / 16;
+    static constexpr int RPW = 1024 / ROWB;               // rows one wave's request moves
+    static constexpr int RPR = (EM_THREADS / 64) * RPW;   // rows one request of the workgroup moves
+    static constexpr int NREQ = EL_TILE / RPR;
+    static constexpr int TILEB = EL_TILE * ROWB;
+    static constexpr int OCC = DK == 4 ? 3 : 2;           // workgroups per CU (registers: 6 / 12 hi + lo fragment pairs -- four per CU spilled five; LDS: 2 x 16 / 32 KiB)
+    static_assert(RPR % 16 == 0 && EL_TILE % RPR == 0, "the swizzle of a row depends on its index inside a request only");
+    static __device__ __forceinline__ uint32_t sw(uint32_t row) { return DK == 4 ? ((row >> 1) & 7u) : (row & 15u); }
+};
+template <int DT, int DK, int S_> struct ElSmallFrag { uint4 hi[DK - 2 * S_], lo[DK - 2 * S_]; };
+
+template <int DT, int DK, int S_>
+__device__ __forceinline__ void el_small_build(const float* __restrict__ cov_head, uint32_t n, uint32_t kg, float inv_2d, ElSmallFrag<DT, DK, S_>& f) {
+    constexpr int D = DK * 16;
+    const uint32_t j = 32 * S_ + n;   // this lane's row of U
+#pragma unroll
+    for (int i = 0; i < DK - 2 * S_; ++i) {
+        const int ks = 2 * S_ + i;
+        const float* crow = cov_head + (size_t)j * D + ks * 16 + kg * 8;
+        const float4 u = *reinterpret_cast<const float4*>(crow), w = *reinterpret_cast<const float4*>(crow + 4);
+        float x[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t c = ks * 16 + kg * 8 + e;
+            const float t = cov_head[(size_t)c * D + j];
+            x[e] = (c > j ? x[e] + t : (c == j ? x[e] : 0.f)) * inv_2d;   // (1 / 2d is a power of two for D = 64 only; the hi + lo split carries whatever the product rounds to)
+        }
+        uint32_t hw[4], lw[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            hw[p] = pack2<DT>(x[2 * p], x[2 * p + 1]);
+            lw[p] = pack2<DT>(x[2 * p] - lo16<DT>(hw[p]), x[2 * p + 1] - hi16<DT>(hw[p]));
+        }
+        f.hi[i] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        f.lo[i] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+    }
+}
+
+template <int DT, int DK, bool HAS_COV>
+__global__ __launch_bounds__(EM_THREADS, ElGeo<DK>::OCC) void ea_logits_mfma_small_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk, uint32_t chunk_keys,
+                                                                                          float* __restrict__ part_m, float* __restrict__ part_z) {
+    using Geo = ElGeo<DK>;
+    constexpr int D = Geo::D;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * Geo::TILEB];
+    __shared__ __attribute__((aligned(16))) float mus[D];
+    __shared__ float wred[8];
+    if (a.clear_word && blockIdx.x == 0 && threadIdx.x == 0) *a.clear_word = 0;
+    const uint32_t slot = blockIdx.x >> 3, g = slot % a.G;   // XCD-aware order: see ea_logits_mfma_kernel
+    const uint32_t unit = (slot / a.G) * 8 + (blockIdx.x & 7);
+    if (unit >= nblk * a.B * a.Hkv) return;
+    const uint32_t chunk = unit % nblk, bh = unit / nblk;
+    const uint32_t b = bh / a.Hkv, h = bh - b * a.Hkv;
+    const uint32_t hq = h * a.G + g, bhq = b * a.Hq + hq;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t n = lane & 31, kg = lane >> 5;
+    const char* kb = static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh + (int64_t)a.n_sink * a.k_ss) * 2;
+    const int64_t row_bytes = a.k_ss * 2;
+    if (threadIdx.x < D) mus[threadIdx.x] = a.mu[(size_t)bhq * D + threadIdx.x] * a.inv_sqrt_d;
+
+    const uint32_t kbeg = chunk * chunk_keys;
+    const uint32_t kend = min(kbeg + chunk_keys, a.Sp);
+    const uint32_t ntiles = (kend - kbeg + EL_TILE - 1) / EL_TILE;
+    float* lrow = logits + (size_t)bhq * a.Sp;
+    float m_run = KVP_NEG_INF, z_run = 0.f;   // lanes 0 .. 31 of every wave: the keys they own
+
+    const uint32_t ldsbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const uint32_t rrow = Geo::RPW * wv + lane / Geo::CPR;                 // this lane's row inside a request
+    const uint32_t rchunk = (lane % Geo::CPR) ^ Geo::sw(rrow);             // (a request's first row is a multiple of the swizzle period)
+    auto request_tile = [&](uint32_t row0, uint32_t buf_off) {
+#pragma unroll
+        for (int j = 0; j < Geo::NREQ; ++j) {
+            const uint32_t r = min(row0 + Geo::RPR * j + rrow, a.Sp - 1);   // rows past the end: any valid row (never stored)
+            const char* gp = kb + (int64_t)r * row_bytes + (rchunk << 4);
+            const uint32_t la = __builtin_amdgcn_readfirstlane(ldsbase + buf_off + (Geo::RPR * j + Geo::RPW * wv) * Geo::ROWB);
+            if (Geo::NCH == Geo::CPR) {
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(gp) : "memory");
+            } else {
+                asm volatile("s_mov_b32 m0, %0" ::"s"(la) : "memory");
+                if (rchunk < (uint32_t)Geo::NCH) asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(gp) : "memory");
+            }
+        }
+    };
+    request_tile(kbeg, 0);
+
+    ElSmallFrag<DT, DK, 0> f0;
+    ElSmallFrag<DT, DK, 1> f1;
+    ElSmallFrag<DT, DK, (DK > 4 ? 2 : 1)> f2;   // (D = 64: unused)
+    if (HAS_COV) {
+        const float* cov_head = a.cov + (size_t)bhq * D * D;
+        el_small_build<DT, DK, 0>(cov_head, n, kg, a.inv_2d, f0);
+        el_small_build<DT, DK, 1>(cov_head, n, kg, a.inv_2d, f1);
+        if (DK > 4) el_small_build<DT, DK, (DK > 4 ? 2 : 1)>(cov_head, n, kg, a.inv_2d, f2);
+    }
+    const uint32_t row = wv * 32 + n;                       // this lane's key row of every tile
+    const uint32_t rsw = Geo::sw(row);
+    // one strip: C[row of U][key] = mu_r / sqrt(d) + (U k)_r / 2d on an accumulator that starts at mu / sqrt(d), then its dot with k (read back in
+    // the C layout: dims 32 s + 8 q + 4 kg + {0 .. 3} of key n)
+    auto strip = [&](auto s_tag, const auto& f, const unsigned char* buf, const uint4 (&kf)[DK]) -> float {
+        constexpr int S = decltype(s_tag)::value;
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 m4 = *reinterpret_cast<const float4*>(&mus[32 * S + 8 * q + 4 * kg]);
+            acc[4 * q] = m4.x; acc[4 * q + 1] = m4.y; acc[4 * q + 2] = m4.z; acc[4 * q + 3] = m4.w;
+        }
+        uint2 kk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kk[q] = *reinterpret_cast<const uint2*>(buf + row * Geo::ROWB + (((S * 4 + q) ^ rsw) << 4) + kg * 8);
+        if (HAS_COV) {
+#pragma unroll
+            for (int i = 0; i < DK - 2 * S; ++i) acc = mma32<DT>(f.hi[i], kf[2 * S + i], acc);
+#pragma unroll
+            for (int i = 0; i < DK - 2 * S; ++i) acc = mma32<DT>(f.lo[i], kf[2 * S + i], acc);
+        }
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v0 = fmaf(lo16<DT>(kk[q].x), acc[4 * q + 0], v0);
+            v1 = fmaf(hi16<DT>(kk[q].x), acc[4 * q + 1], v1);
+            v0 = fmaf(lo16<DT>(kk[q].y), acc[4 * q + 2], v0);
+            v1 = fmaf(hi16<DT>(kk[q].y), acc[4 * q + 3], v1);
+        }
+        return v0 + v1;
+    };
+    unsigned char* bufc = lds;
+    unsigned char* bufn = lds + Geo::TILEB;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's part of tile 0 has landed
+    __syncthreads();                      // (also publishes mus)
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const uint32_t key0 = kbeg + t * EL_TILE;
+        if (t + 1 < ntiles) request_tile(key0 + EL_TILE, (uint32_t)(bufn - lds));   // into the buffer tile t - 1 left at the last barrier
+        uint4 kf[DK];
+        if (HAS_COV) {
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(bufc + row * Geo::ROWB + (((ks * 2 + kg) ^ rsw) << 4));
+        }
+        float v = strip(std::integral_constant<int, 0>{}, f0, bufc, kf);
+        v += strip(std::integral_constant<int, 1>{}, f1, bufc, kf);
+        if (DK > 4) v += strip(std::integral_constant<int, (DK > 4 ? 2 : 1)>{}, f2, bufc, kf);
+        v += __shfl_xor(v, 32);   // the two lane halves hold the two halves of every strip's dims
+        const uint32_t kk = key0 + row;
+        if (kg == 0 && kk < kend) {
+            const float l2 = v * KVP_LOG2E;
+            lrow[kk] = l2;
+            softmax_merge(m_run, z_run, l2, 1.0f);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): tile t + 1 has landed (this wave's part; the barrier covers the others)
+        __syncthreads();
+        unsigned char* tmp = bufc; bufc = bufn; bufn = tmp;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m_run, o), z2 = __shfl_xor(z_run, o);
+        softmax_merge(m_run, z_run, m2, z2);
+    }
+    if (lane == 0) { wred[2 * wv] = m_run; wred[2 * wv + 1] = z_run; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) softmax_merge(m_run, z_run, wred[2 * w], wred[2 * w + 1]);
+        part_m[(size_t)bhq * nblk + chunk] = m_run;
+        part_z[(size_t)bhq * nblk + chunk] = z_run;
+    }
+}
+
 bool aligned8(int64_t x) { return x % 8 == 0; }
 
 }  // namespace
 
 // ---- host ---------------------------------------------------------------------------------------
-bool ea_mfma_qstats_eligible(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int dtype, int64_t Sq, int64_t D) {
+bool ea_mfma_qstats_eligible(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int dtype, int64_t Hq, int64_t Sq, int64_t D) {
     // 16-bit rounding of the shifted products: relative covariance error ~ 4.6e-3 / sqrt(Sq) (1 sigma); shorter
     // sequences take the exact fp32 generic kernels
-    return (dtype == KVP_BF16 || dtype == KVP_F16) && D == 128 && Sq >= 4096 && (uintptr_t)q % 16 == 0 && aligned8(q_sb) &&
-           aligned8(q_sh) && aligned8(q_ss);
+    const bool ok = (dtype == KVP_BF16 || dtype == KVP_F16) && Sq >= 4096 && (uintptr_t)q % 16 == 0 && aligned8(q_sb) && aligned8(q_sh) && aligned8(q_ss);
+    (void)q_sh; (void)Hq;
+    // Round 6, D = 64: the queries as the projection leaves them -- [B, S, Hq, 64] seen as [B, Hq, S, 64], heads 64 elements apart -- are rows
+    // of Hq / 2 "heads" of 128 dimensions; the syrk of such a pair holds the two heads' second moments in its diagonal blocks (twice the matrix
+    // work a 64-wide syrk needs, on a kernel that waits for HBM).  D = 96 and the other layouts of D = 64: a head of 128 dimensions whose upper
+    // ones are zero (QstatArgs::nch).
+    return ok && (D == 128 || D == 64 || D == 96);
 }
+static bool qstats_pairs(int64_t q_sh, int64_t Hq, int64_t D) { return D == 64 && q_sh == 64 && Hq % 2 == 0; }
 
 size_t ea_mfma_qstats_ws_bytes(int64_t B, int64_t Hq, int64_t Sq, int64_t D) {
-    if (D != 128) return 0;
+    if (D != 128 && D != 64 && D != 96) return 0;
     uint32_t nchunk, rows;
-    qstats_plan(Sq, B * Hq, nchunk, rows);
-    return (size_t)B * Hq * nchunk * (128 * 128 + 256) * 4 + 1024;
+    qstats_plan(Sq, B * Hq, nchunk, rows);   // (pairs of heads: half the heads, at most twice the chunks: never more than this)
+    size_t need = (size_t)B * Hq * nchunk * (128 * 128 + 256) * 4 + 1024;
+    if (D == 64 && Hq % 2 == 0) {
+        qstats_plan(Sq, B * (Hq / 2), nchunk, rows);
+        need = std::max(need, (size_t)B * (Hq / 2) * nchunk * (128 * 128 + 256) * 4 + 1024);
+    }
+    return need;
 }
 
 int ea_mfma_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int dtype, int64_t B, int64_t Hq, int64_t Sq, int64_t D,
                    float* mu, float* cov, void* ws, hipStream_t stream) {
-    (void)D;
+    const uint32_t pair = qstats_pairs(q_sh, Hq, D);
+    if (pair) { Hq /= 2; q_sh = 128; }   // pairs of neighbouring 64-dimensional heads as heads of 128 (ea_mfma_qstats_eligible)
     QstatArgs a;
     a.q = q; a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss;
     a.B = (uint32_t)B; a.Hq = (uint32_t)Hq; a.Sq = (uint32_t)Sq;
     qstats_plan(Sq, B * Hq, a.nchunk, a.rows_per_chunk);
+    a.nch = pair ? 16u : (uint32_t)(D / 8);
     a.nt = (uint64_t)B * Hq * Sq * 256 > (192ull << 20);   // streaming Q loads when Q cannot stay in the memory-side cache anyway (as kvp_gather_kv)
     const size_t nbh = (size_t)B * Hq;
     a.s2 = static_cast<float*>(ws);
@@ -778,13 +991,13 @@ int ea_mfma_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int 
     if (dtype == KVP_BF16) KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_BF16, 3, 3><<<grid, EM_THREADS, 0, stream>>>(a)));
     else KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_F16, 3, 3><<<grid, EM_THREADS, 0, stream>>>(a)));
     const size_t sm = ((size_t)a.nchunk * 256 + 128) * 4;
-    KVP_LAUNCH("ea_qstats_combine", stream, ea_qstats_combine<<<dim3(16, (uint32_t)nbh), 256, sm, stream>>>(a.s2, a.dsum, a.m0, a.Sq, a.nchunk, a.rows_per_chunk, mu, cov));
+    KVP_LAUNCH("ea_qstats_combine", stream, ea_qstats_combine<<<dim3(16, (uint32_t)nbh), 256, sm, stream>>>(a.s2, a.dsum, a.m0, a.Sq, a.nchunk, a.rows_per_chunk, mu, cov, pair, pair ? 128u : (uint32_t)D));
     KVP_CHECK_LAUNCH("ea_qstats_mfma");
     return KVP_OK;
 }
 
 bool ea_mfma_logits_eligible(const EaArgs& a, int dtype) {
-    return (dtype == KVP_BF16 || dtype == KVP_F16) && a.D == 128 && a.Sp >= 64 && (uintptr_t)a.k % 16 == 0 && aligned8(a.k_sb) &&
+    return (dtype == KVP_BF16 || dtype == KVP_F16) && (a.D == 128 || a.D == 64 || a.D == 96) && a.Sp >= 64 && (uintptr_t)a.k % 16 == 0 && aligned8(a.k_sb) &&
            aligned8(a.k_sh) && aligned8(a.k_ss) && a.G <= 65535;
 }
 size_t ea_mfma_logits_scratch_bytes(int64_t, int64_t, int64_t) { return 0; }
@@ -795,7 +1008,8 @@ size_t ea_mfma_logits_scratch_bytes(int64_t, int64_t, int64_t) { return 0; }
 static uint32_t ea_mfma_logits_chunk(const EaArgs& a) {
     uint32_t chunk = EL_CHUNK;
     const uint64_t heads = (uint64_t)a.B * a.Hkv * a.G;
-    while (chunk < 65536 && (uint64_t)((a.Sp + chunk - 1) / chunk) * heads > 512) chunk *= 2;
+    const uint64_t resident = a.D == 64 ? 768 : 512;   // (D = 64: three of its small workgroups per CU)
+    while (chunk < 65536 && (uint64_t)((a.Sp + chunk - 1) / chunk) * heads > resident) chunk *= 2;
     return chunk;
 }
 uint32_t ea_mfma_logits_nblk(const EaArgs& a) { const uint32_t c = ea_mfma_logits_chunk(a); return (a.Sp + c - 1) / c; }
@@ -806,6 +1020,18 @@ int ea_mfma_logits(const EaArgs& a, int dtype, float* logits, uint32_t nblk, flo
     const uint64_t units = (uint64_t)nblk * a.B * a.Hkv;
     KVP_CHECK_ARG((units + 7) / 8 * 8 * a.G < ((uint64_t)1 << 31), "ea_logits_mfma: grid too large");
     const dim3 grid((uint32_t)((units + 7) / 8 * 8 * a.G));   // (unit, head-in-group) -> linear id: see the kernel
+    if (a.D != 128) {   // head sizes 64 and 96: (2c)
+#define KVP_EL_SMALL(DTV, DKV)                                                                                                                         \
+    do {                                                                                                                                               \
+        if (a.cov) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_small_kernel<DTV, DKV, true><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z))); \
+        else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_small_kernel<DTV, DKV, false><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z)));    \
+    } while (0)
+        if (dtype == KVP_BF16) { if (a.D == 64) KVP_EL_SMALL(KVP_BF16, 4); else KVP_EL_SMALL(KVP_BF16, 6); }
+        else { if (a.D == 64) KVP_EL_SMALL(KVP_F16, 4); else KVP_EL_SMALL(KVP_F16, 6); }
+#undef KVP_EL_SMALL
+        KVP_CHECK_LAUNCH("ea_logits_mfma");
+        return KVP_OK;
+    }
     if (a.cov) {   // the quadratic form on the doubled upper triangle of the covariance (2b): exact for any matrix, 40 instead of 64 MFMAs per tile and wave
         if (dtype == KVP_BF16) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z)));
         else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_F16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z)));

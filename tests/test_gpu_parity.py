@@ -816,6 +816,63 @@ def test_ea_logits_triangular_form_vs_oracle():
             assert rel0.max() <= 1e-3, (dtype, S, "mean only", rel0.max())
 
 
+@pytest.mark.parametrize("D", [64, 96])
+def test_ea_logits_small_heads_vs_oracle(D):
+    """Round 6: head sizes 64 (Llama-3.2-1B, Qwen2-0.5B) and 96 (Phi-3-mini) on the matrix cores (ea_logits_mfma_small_kernel: every wave
+    takes one 32-key sub-tile with all two / three strips of the doubled upper triangle) instead of the scalar generic kernel: symmetric
+    and ASYMMETRIC covariances, GQA groups 1 .. 7, ragged lengths from one partial tile to several chunks, sinks, both 16-bit dtypes, a
+    [B, S, H, D] K buffer seen as [B, H, S, D], the mean-only form, a batch of two."""
+    N = native()
+    rs = np.random.RandomState(600 + D)
+    for dtype in ("bf16", "f16"):
+        for B, Hq, Hkv, S, n_sink, sym, bshd in ((1, 8, 2, 4500, 4, True, False), (2, 4, 4, 70, 0, True, True), (1, 7, 1, 9000, 3, False, False),
+                                                 (1, 32, 8, 12345, 4, True, True), (2, 6, 2, 333, 1, False, False), (1, 3, 3, 197, 7, True, False)):
+            kn = _inputs.round_to((rs.standard_normal((B, Hkv, S, D)) * 0.8).astype(np.float32), dtype)
+            vn = _inputs.round_to(rs.standard_normal((B, Hkv, S, D)).astype(np.float32), dtype)
+            mu = (rs.standard_normal((B, Hq, D)) * 0.4).astype(np.float32)
+            a = (rs.standard_normal((B, Hq, D, D)) * 0.06).astype(np.float32)
+            cov = a @ a.transpose(0, 1, 3, 2)
+            if not sym:
+                cov = cov + 0.01 * rs.standard_normal((B, Hq, D, D)).astype(np.float32)
+            k = to_dev(np.ascontiguousarray(kn.transpose(0, 2, 1, 3)), dtype).transpose(1, 2) if bshd else to_dev(kn, dtype)
+            v = to_dev(vn, dtype)
+            want = O.ea_score(kn, vn, mu, cov, n_sink, True, 0.0)
+            got = N.ea_score(k, v, torch.from_numpy(mu).to(DEV), torch.from_numpy(cov).to(DEV), n_sink, True, 0.0).cpu().numpy()
+            rel = np.abs(got[..., n_sink:] - want[..., n_sink:]) / np.abs(want[..., n_sink:])
+            assert rel.max() <= 1e-4, (dtype, D, S, sym, rel.max())   # (measured ~1e-6: the contract is 1e-3)
+            if n_sink:
+                assert np.all(got[..., :n_sink] == np.float32(got[..., n_sink:].max()) + np.float32(1.0))
+            want0 = O.ea_score(kn, vn, mu, None, n_sink, False, 0.01)
+            got0 = N.ea_score(k, v, torch.from_numpy(mu).to(DEV), None, n_sink, False, 0.01).cpu().numpy()
+            rel0 = np.abs(got0[..., n_sink:] - want0[..., n_sink:]) / np.abs(want0[..., n_sink:])
+            assert rel0.max() <= 1e-4, (dtype, D, S, "mean only", rel0.max())
+
+
+@pytest.mark.parametrize("D", [64, 96])
+def test_ea_qstats_narrow_heads_on_the_matrix_cores(D):
+    """Round 6: the statistics of 64- and 96-dimensional heads on the 128-wide syrk.  D = 64 with the queries as q_proj leaves them ([B, S, Hq * 64]:
+    heads 64 elements apart, an even number of them) runs as PAIRS of heads (the diagonal blocks of a pair's second moments are the two heads'
+    own); D = 96, an odd head count and a contiguous [B, Hq, S, D] tensor run as heads of 128 dimensions whose upper ones are zero in LDS
+    (the lanes of the missing chunks request nothing).  Large means, dominant channels, a ragged tail, both dtypes."""
+    rs = np.random.RandomState(D)
+    N = native()
+    for dtype, (B, Hq, Sq) in (("bf16", (1, 6, 10000)), ("f16", (2, 2, 4500)), ("bf16", (1, 3, 5000))):
+        q = rs.standard_normal((B, Hq, Sq, D)).astype(np.float32) * np.exp(0.5 * rs.standard_normal((1, Hq, 1, D))).astype(np.float32)
+        q += rs.standard_normal((1, Hq, 1, D)).astype(np.float32) * 2.0
+        q[:, :, :, ::13] *= 5.0
+        q = _inputs.round_to(q, dtype)
+        mu_w, cov_w = O.ea_query_stats(q, True)
+        d = np.sqrt(np.einsum("bhii->bhi", cov_w))
+        layouts = {"q_proj": to_dev(np.ascontiguousarray(q.transpose(0, 2, 1, 3)), dtype).transpose(1, 2), "contiguous": to_dev(q, dtype)}
+        for lname, qt in layouts.items():
+            mu, cov = N.ea_qstats(qt, True)
+            assert np.abs(mu.cpu().numpy() - mu_w).max() <= 1e-5 * np.abs(mu_w).max() + 1e-6, (dtype, lname)
+            err = np.abs(cov.cpu().numpy() - cov_w) / (d[..., :, None] * d[..., None, :])
+            assert err.max() <= 1e-3 and err.mean() <= 1e-4, (dtype, lname, Hq, err.max(), err.mean())
+            mu2, cov2 = N.ea_qstats(qt, False)
+            assert cov2 is None and np.abs(mu2.cpu().numpy() - mu_w).max() <= 1e-5 * np.abs(mu_w).max() + 1e-6
+
+
 def test_ea_fused_finalize_equals_three_kernels(knobs):
     """kvp_ea_score's one-pass ||v|| + row normalisers + finalize (ea_vnorm_finalize_kernel: 256-byte rows, >= 4096 scored keys) against
     the three kernels it replaces (KVP_EA_FUSED_FINALIZE=0: the generic path other shapes take): the same bits, with and without sinks, GQA

@@ -57,7 +57,7 @@ def main():
     args = ap.parse_args()
     rs = np.random.RandomState(args.seed)
     for it in range(args.rounds):
-        R = int(rs.randint(1, 9))
+        R = int(rs.randint(1, 9)) if rs.randint(3) else int(rs.randint(9, 41))   # round 6: up to 32 rows per cluster launch, more in several
         S = int(rs.choice([rs.randint(16385, 20000), rs.randint(20000, 40000), rs.randint(40000, 70000), rs.randint(70000, 140000), rs.randint(140000, 262145), 131072]))
         x, kind = rows(rs, R, S)
         k = int(rs.choice([1, S - 1, S // 2, max(1, int(S * rs.uniform(0.02, 0.98))), max(1, int(S * rs.uniform(0.0, 1.0)))]))
@@ -79,14 +79,15 @@ def main():
             dt = torch.bfloat16 if it % 8 == 0 else torch.float16
             Sk = int(rs.choice([rs.randint(16385, 40000), 32768, rs.randint(40000, 140000)]))
             nk = max(1, int(Sk * rs.uniform(0.1, 0.9)))
-            kk = (torch.randn((1, 8, Sk, 128), device=DEV) * float(rs.choice([0.3, 1.0, 3.0]))).to(dt)
-            vv = torch.randn((1, 8, Sk, 128), device=DEV).to(dt)
+            Bk, Hk = int(rs.choice([1, 1, 2, 3, 4])), int(rs.choice([8, 8, 2, 5]))   # round 6: batches (B * H rows in one cluster launch up to 32)
+            kk = (torch.randn((Bk, Hk, Sk, 128), device=DEV) * float(rs.choice([0.3, 1.0, 3.0]))).to(dt)
+            vv = torch.randn((Bk, Hk, Sk, 128), device=DEV).to(dt)
             ko, vo = N.knorm_compress(kk, vv, nk)
             sc = N.rownorm_score(kk, -1.0)                    # the same norms through the stand-alone kernel (tested against the oracle elsewhere)
-            idx = torch.from_numpy(O.topk_select(sc.cpu().numpy().reshape(8, Sk), nk)).to(DEV).long()
-            assert torch.equal(ko[0], torch.gather(kk[0], 1, idx[..., None].expand(-1, -1, 128))), f"round {it}: knorm_compress keys S={Sk} n={nk}"
-            assert torch.equal(vo[0], torch.gather(vv[0], 1, idx[..., None].expand(-1, -1, 128))), f"round {it}: knorm_compress values S={Sk} n={nk}"
-            msg += f"  knorm_compress[{str(dt)[6:]} S={Sk} n={nk}] ok"
+            idx = torch.from_numpy(O.topk_select(sc.cpu().numpy().reshape(Bk * Hk, Sk), nk).reshape(Bk, Hk, nk)).to(DEV).long()
+            assert torch.equal(ko, torch.gather(kk, 2, idx[..., None].expand(-1, -1, -1, 128))), f"round {it}: knorm_compress keys B={Bk} H={Hk} S={Sk} n={nk}"
+            assert torch.equal(vo, torch.gather(vv, 2, idx[..., None].expand(-1, -1, -1, 128))), f"round {it}: knorm_compress values B={Bk} H={Hk} S={Sk} n={nk}"
+            msg += f"  knorm_compress[{str(dt)[6:]} B={Bk} H={Hk} S={Sk} n={nk}] ok"
         torch.cuda.synchronize()
         N.async_error_check()
         print(msg, flush=True)

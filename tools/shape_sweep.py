@@ -87,7 +87,9 @@ def main():
     case("knorm", 8, 32, 8, S, 128, bf, note="batch 8 (64 rows)")
     case("knorm", 1, 12, 12, 2048, 64, f32, note="config 1's shape (OPT-125m geometry)")
     case("ea", 1, 32, 8, S, 128, bf, ratio=0.7, note="kernel-only, MFMA statistics + triangular quadratic form")
-    case("ea", 1, 32, 8, S, 64, bf, ratio=0.7, note="D = 64: generic kernels")
+    case("ea", 1, 32, 8, S, 64, bf, ratio=0.7, note="D = 64 (round 6: statistics over pairs of neighbouring heads + small-head quadratic form on the matrix cores; before: 1060 us)")
+    case("ea", 1, 32, 32, S, 96, bf, ratio=0.7, note="D = 96 (Phi-3-mini, MHA; round 6: statistics as zero-padded heads of 128 + small-head quadratic form; before: 1081 us with generic statistics)")
+    case("ea", 1, 32, 8, 131072, 64, bf, ratio=0.7, note="D = 64 at 128k")
     case("ea", 1, 32, 8, 8192, 128, f32, ratio=0.7, note="float32: generic kernels")
 
 
