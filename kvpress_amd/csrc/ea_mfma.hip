@@ -1006,10 +1006,21 @@ size_t ea_mfma_logits_scratch_bytes(int64_t, int64_t, int64_t) { return 0; }
 // kernel's VALU work at 32 tiles per workgroup (10 432 instructions per wave against 204 per tile in the loop: round 6), and on this
 // SIMD VALU and matrix instructions do not overlap: 128k tokens x 32 heads now run as 512 workgroups of 64 tiles.
 static uint32_t ea_mfma_logits_chunk(const EaArgs& a) {
-    uint32_t chunk = EL_CHUNK;
     const uint64_t heads = (uint64_t)a.B * a.Hkv * a.G;
-    const uint64_t resident = a.D == 64 ? 768 : 512;   // (D = 64: three of its small workgroups per CU)
-    while (chunk < 65536 && (uint64_t)((a.Sp + chunk - 1) / chunk) * heads > resident) chunk *= 2;
+    if (a.D != 128) {   // the small-head kernel (2c).  tools/ea_small_lab.py (ea_score, 32 heads; chunk x workgroup limit): 32k tokens D = 64 43.8 us at
+                        // (2048, 768) against 49.8 at (4096, .) and 51-85 with more, shorter workgroups; 128k 120 against 129; D = 96 112 against 115-197
+#ifdef KVP_EA_SMALL_LAB   // (lab build of tools/ea_small_lab.py only)
+        uint32_t chunk = (uint32_t)std::max(128, kvp_env_int("KVP_EA_SMALL_CHUNK", 2048)) / 128 * 128;
+        const uint64_t limit = (uint64_t)std::max(1, kvp_env_int("KVP_EA_SMALL_WGS", 768));
+#else
+        uint32_t chunk = 2048;
+        const uint64_t limit = 768;
+#endif
+        while (chunk < 65536 && (uint64_t)((a.Sp + chunk - 1) / chunk) * heads > limit) chunk *= 2;
+        return chunk;
+    }
+    uint32_t chunk = EL_CHUNK;
+    while (chunk < 65536 && (uint64_t)((a.Sp + chunk - 1) / chunk) * heads > 512) chunk *= 2;
     return chunk;
 }
 uint32_t ea_mfma_logits_nblk(const EaArgs& a) { const uint32_t c = ea_mfma_logits_chunk(a); return (a.Sp + c - 1) / c; }

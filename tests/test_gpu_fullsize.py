@@ -414,6 +414,109 @@ def test_ea_qstats_128k_large_mean_adversarial():
     print(f"ea qstats 128k adversarial: cov err {err.max().item():.2e} sigma_i sigma_j, final score err {rel.max().item():.2e}")
 
 
+@pytest.mark.parametrize("Dn,layout", [(64, "q_proj"), (64, "contiguous"), (96, "q_proj")])
+def test_ea_narrow_heads_at_size(Dn, layout):
+    """Round 6: ExpectedAttention for head sizes 64 / 96 at a size where the statistics stream Q with non-temporal loads (> 192 MiB of rows) and
+    the logits run several chunks per head: statistics against float64 (pairs of neighbouring heads for D = 64 in the projection's layout,
+    zero-padded heads of 128 otherwise) and the final scores through kvp_ea_score within 1e-3 of the float64 chain."""
+    S, Sk, Hq, Hkv = 40960, 20000, 32, 8
+    g = torch.Generator(device=DEV)
+    g.manual_seed(600 + Dn)
+    sig = torch.exp(0.4 * torch.randn((1, 1, Hq * Dn), generator=g, device=DEV))
+    mean = torch.randn((1, 1, Hq * Dn), generator=g, device=DEV) * sig * 2.0
+    q = (torch.randn((1, S, Hq * Dn), generator=g, device=DEV) * sig + mean).to(torch.bfloat16)
+    qt = q.view(1, S, Hq, Dn).transpose(1, 2)
+    if layout == "contiguous":
+        qt = qt.contiguous()
+    mu, cov = _native().ea_qstats(qt, True)
+    mu_r = torch.empty((1, Hq, Dn), dtype=torch.float64, device=DEV)
+    cov_r = torch.empty((1, Hq, Dn, Dn), dtype=torch.float64, device=DEV)
+    for h in range(Hq):
+        x = qt[0, h].double()
+        mu_r[0, h] = x.mean(0)
+        xc = x - mu_r[0, h]
+        cov_r[0, h] = xc.T @ xc / S
+    assert ((mu.double() - mu_r).abs() <= 1e-5 * mu_r.abs().amax() + 1e-6).all()
+    d = cov_r.diagonal(dim1=-2, dim2=-1).sqrt()
+    err = (cov.double() - cov_r).abs() / (d.unsqueeze(-1) * d.unsqueeze(-2))
+    assert err.max() <= 1e-3, f"covariance error {err.max().item():.2e} sigma_i sigma_j"
+    keys = (torch.randn((1, Hkv, Sk, Dn), generator=g, device=DEV) * 0.3).to(torch.bfloat16)
+    values = torch.randn((1, Hkv, Sk, Dn), generator=g, device=DEV).to(torch.bfloat16)
+    sc = _native().ea_score(keys, values, mu, cov, 4, True, 0.0)
+    G = Hq // Hkv
+    ref = torch.empty((1, Hkv, Sk - 4), dtype=torch.float64, device=DEV)
+    for h in range(Hkv):
+        kh = keys[0, h, 4:].double()
+        acc = 0
+        for gq in range(G):
+            hq = h * G + gq
+            lg = kh @ mu_r[0, hq] / Dn ** 0.5 + ((kh @ cov_r[0, hq]) * kh).sum(-1) / Dn / 2
+            acc = acc + torch.softmax(lg, dim=-1)
+        ref[0, h] = acc / G * values[0, h, 4:].double().norm(dim=-1)
+    rel = (sc[..., 4:].double() - ref).abs() / ref.abs().clamp_min(1e-300)
+    assert rel.max() <= 1e-3, f"final scores differ by {rel.max().item():.2e}"
+    print(f"ea D={Dn} {layout}: cov err {err.max().item():.2e} sigma_i sigma_j, final score err {rel.max().item():.2e}")
+
+
+@pytest.mark.parametrize("Dn", [64, 96])
+def test_expected_attention_press_on_narrow_head_models(Dn):
+    """ExpectedAttentionPress.score on an attention module with 64- / 96-dimensional heads (Llama-3.2-1B / Phi-3-mini class; round 6: their statistics
+    and quadratic form run on the matrix cores) against a float64 restatement of expected_attention_press.py:62-165 fed with the module's own bf16
+    queries: the projection's layout, the averaged RoPE on a D x D covariance, the GQA mean, the sink pad."""
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaAttention, LlamaRotaryEmbedding
+
+    import kvpress_amd as P
+
+    Hq, Hkv, S, n_sink, nfut = 8, 2, 9000, 4, 512
+    cfg = LlamaConfig(hidden_size=512, num_attention_heads=Hq, num_key_value_heads=Hkv, head_dim=Dn, num_hidden_layers=1, intermediate_size=256,
+                      vocab_size=128, max_position_embeddings=16384, rope_theta=10000.0)
+    torch.manual_seed(Dn)
+    att = LlamaAttention(cfg, layer_idx=0).eval()
+    with torch.no_grad():
+        att.q_proj.weight.mul_(3.0)   # queries of order 1 (the default initializer_range gives logits ~0: nothing to tell apart)
+    att = att.to(DEV, torch.bfloat16)
+    rot = LlamaRotaryEmbedding(cfg).to(DEV)
+    att.rotary_emb = rot
+    g = torch.Generator(device=DEV)
+    g.manual_seed(Dn + 1)
+    hidden = (torch.randn((1, S, 512), generator=g, device=DEV) + 0.3).to(torch.bfloat16)
+    keys = (torch.randn((1, Hkv, S, Dn), generator=g, device=DEV) * 0.8).to(torch.bfloat16)
+    values = torch.randn((1, Hkv, S, Dn), generator=g, device=DEV).to(torch.bfloat16)
+    press = P.ExpectedAttentionPress(0.5)
+    with torch.no_grad():
+        sc = press.score(att, hidden, keys, values, None, {})
+        q = att.q_proj(hidden[:, n_sink:]).view(1, S - n_sink, Hq, Dn).transpose(1, 2).double()
+        mu = q.mean(dim=2)
+        c = q - mu.unsqueeze(2)
+        cov = torch.matmul(c.transpose(2, 3), c) / (S - n_sink)
+        pos = torch.arange(S, S + nfut, device=DEV)[None]
+        cos, sin = rot(torch.zeros(1, device=DEV, dtype=torch.float32), pos)
+        cos, sin = cos[0].double(), sin[0].double()
+        Pm = torch.zeros((Dn, Dn), device=DEV, dtype=torch.float64)
+        Pm[Dn // 2:, : Dn // 2] = torch.eye(Dn // 2, device=DEV, dtype=torch.float64)
+        Pm[: Dn // 2, Dn // 2:] = -torch.eye(Dn // 2, device=DEV, dtype=torch.float64)
+        R = (cos.unsqueeze(1) * torch.eye(Dn, device=DEV, dtype=torch.float64) + sin.unsqueeze(1) * Pm).mean(0)
+        mu = mu @ R.T
+        cov = R @ cov @ R.T
+        ref = torch.empty((1, Hkv, S - n_sink), device=DEV, dtype=torch.float64)
+        for h in range(Hkv):
+            kh = keys[0, h, n_sink:].double()
+            acc = 0
+            for gq in range(Hq // Hkv):
+                hq = h * (Hq // Hkv) + gq
+                lg = kh @ mu[0, hq] / Dn ** 0.5 + ((kh @ cov[0, hq]) * kh).sum(-1) / Dn / 2
+                acc = acc + torch.softmax(lg, dim=-1)
+            ref[0, h] = acc / (Hq // Hkv) * values[0, h, n_sink:].double().norm(dim=-1)
+    got = sc[..., n_sink:].double()
+    rel = (got - ref).abs() / ref.abs().clamp_min(1e-300)
+    assert rel.max() <= 1e-3, f"D={Dn}: scores differ by {rel.max().item():.2e}"
+    assert (sc[..., :n_sink] > sc[..., n_sink:].max()).all()
+    spread = (ref.max() / ref.min()).item()
+    assert spread > 3.0, f"the case does not tell keys apart (max / min score {spread:.2f})"
+    print(f"EA press D={Dn}: max rel err {rel.max().item():.2e}, score spread {spread:.1f}")
+
+
 def test_f_rows_at_128k_properties():
     """The §8(f) kernels at the BASELINE size (8 x 131072 x 128 bf16: the slot walks, the streaming loads and the one-pass gather +
     re-rotation are what runs there), through size-independent properties: the row norms against torch in float64, the default walk ==
