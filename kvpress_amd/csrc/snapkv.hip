@@ -17,7 +17,7 @@
 // (triu(-inf, diagonal=S-W+1), snapkv_press.py:63-65) only touches the last W columns, which
 // are dropped from the result (:67): it matters for the normaliser (pass 1) only.
 //
-// Two implementations of p1/p2: the MFMA kernels in snapkv_mfma.hip (bf16 / f16, head size 64 / 96 / 128 / 256, G <= 8, ANY window size
+// Two implementations of p1/p2: the MFMA kernels in snapkv_mfma.hip (bf16 / f16, head size 64 / 96 / 128 / 256, G <= 16, ANY window size
 // since round 6: blocks of 64 padded window rows, snapkv_internal.h -- hand-scheduled loops for D = 128 with G % 4 == 0, the
 // Llama-3.1-8B hot path, compiler-scheduled kernels otherwise) and the generic VALU kernels in this file (any D, float32, any
 // stride: correctness fallbacks, ~40x slower -- profiles/r06_shape_sweep*.txt).
@@ -338,7 +338,7 @@ struct SnapWs {
     float* part_z;
     float* rowstat;
     float* colsum;
-    float* colsum2;  // G > 4 (two group-blocks per kv-head in the MFMA pass 2): the second block's column sums, added in a fixed order
+    float* colsum2;  // G > 4 (several group-blocks of four q-heads per kv-head in the MFMA pass 2): [group-blocks - 1] slabs of column sums, added in block order
     float* colsumx;  // W > 64 (several 64-row blocks of the window in the MFMA passes): the later blocks' column sums, added in block order
     float* bmax;  // per-workgroup maxima of the pool kernel (<= 4096)
     void* qrot;   // [B,Hq,W,D] RoPE'd window queries (kvp_snapkv_score_rope)
@@ -363,11 +363,12 @@ SnapWs carve_snap_ws(void* ws, int64_t B, int64_t Hq, int64_t Hkv, int64_t S, in
     w.part_z = (float*)take(rows * nchunk_max * 4);
     w.rowstat = (float*)take(rows * 4);
     w.colsum = (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4);
-    w.colsum2 = Hq / std::max<int64_t>(1, Hkv) > 4 ? (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4) : nullptr;
+    const int64_t ngb = (Hq / std::max<int64_t>(1, Hkv) + 3) / 4;   // group-blocks of four q-heads per kv-head (MFMA pass 2: one column-sum slab each)
+    w.colsum2 = ngb > 1 ? (float*)take((size_t)(ngb - 1) * B * Hkv * (S > W ? S - W : 0) * 4) : nullptr;
     w.colsumx = W > 64 ? (float*)take((size_t)B * Hkv * (S > W ? S - W : 0) * 4) : nullptr;
     w.qrot = take((size_t)B * Hq * W * D * 4);
-    // (planes * nchunk <= max(planes, 256): one resident round of workgroups; planes = B * Hkv * (1 or 2 group-blocks))
-    const size_t nwg = (size_t)std::max<int64_t>(B * Hkv * 2, 256);
+    // (planes * nchunk <= max(planes, 256): one resident round of workgroups; planes = B * Hkv * group-blocks)
+    const size_t nwg = (size_t)std::max<int64_t>(B * Hkv * ngb, 256);
     w.p1_ticks = (uint32_t*)take(nwg * 4);
     w.total_bytes = off;
     return w;

@@ -18,13 +18,13 @@ struct SnapArgs {
 };
 __host__ __device__ inline uint32_t snapkv_wp(uint32_t W) { return (W + 63u) / 64u * 64u; }
 
-// MFMA fast path (bf16/f16, D = 64 / 96 / 128 / 256, G <= 8, 16-byte aligned rows; any window size since round 6)
+// MFMA fast path (bf16/f16, D = 64 / 96 / 128 / 256, G <= 16, 16-byte aligned rows; any window size since round 6)
 bool snapkv_mfma_eligible(const SnapArgs& a, int dtype);
 uint32_t snapkv_mfma_nchunk(const SnapArgs& a);
 // p1_ticks (may be null): [planes][nchunk] wall time of every pass-1 workgroup in 10 ns ticks (plane = (b, kv-head, group-block)) --
 // the input of pass 2's tile shares, see snapkv_p2_shares
 int snapkv_mfma_p1(const SnapArgs& a, int dtype, uint32_t nchunk, float* part_m, float* part_z, uint32_t* p1_ticks, hipStream_t stream);
-// colsum2: scratch of the size of colsum, needed when G > 4 (the second group-block's sums; merged in a fixed order: deterministic)
+// colsum2: (group-blocks - 1) scratch slabs of the size of colsum, needed when G > 4 (the further group-blocks' sums; merged in block order: deterministic)
 // p2_ranges (may be null): [planes][nchunk][2] = (first tile, tiles) of every pass-2 workgroup; null = the interleaved static walk
 // colsumx: a third scratch slab of the size of colsum, needed when W > 64 (the column sums of the row blocks after the first, added in order)
 int snapkv_mfma_p2(const SnapArgs& a, int dtype, const float* rowstat, float* colsum, float* colsum2, float* colsumx, const uint32_t* p2_ranges,

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
 
     const float c = a.c;
     // group-block 0 owns colsum, group-block 1 (G > 4) its own slab: no float atomics, the two are added afterwards in a fixed order
-    float* cs = (gb == 0 ? colsum : colsum2) + (size_t)(b * a.Hkv + h) * Sm;
+    float* cs = (gb == 0 ? colsum : colsum2 + (size_t)(gb - 1) * a.B * a.Hkv * Sm) + (size_t)(b * a.Hkv + h) * Sm;   // (a slab per further group-block)
     const uint32_t nact = 2 * min(4u, a.G - gb * 4);  // active waves in this workgroup
 
     // column sums of P = 2^(L2 - a_row) over this wave's 32 q rows for the 32 keys of one finished sub-tile
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_mfma(SnapArgs a, uint
 
 bool snapkv_mfma_eligible(const SnapArgs& a, int dtype) {
     if (dtype != KVP_BF16 && dtype != KVP_F16) return false;
-    if ((a.D != 256 && a.D != 128 && a.D != 96 && a.D != 64) || a.W < 1 || a.W > 4096 || a.G > 8) return false;   // (any window: blocks of 64 rows, snapkv_internal.h)
+    if ((a.D != 256 && a.D != 128 && a.D != 96 && a.D != 64) || a.W < 1 || a.W > 4096 || a.G > 16) return false;   // (any window: blocks of 64 rows, snapkv_internal.h)
     auto al8 = [](int64_t x) { return x % 8 == 0; };
     if (((uintptr_t)a.q % 16) || ((uintptr_t)a.k % 16)) return false;
     return al8(a.q_sb) && al8(a.q_sh) && al8(a.q_sw) && al8(a.k_sb) && al8(a.k_sh) && al8(a.k_ss);
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_asm(SnapArgs a, uint3
     ks_.request_tile(lds + MF_TILEB, tw.key0(1));
     const char* qrow = static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh + (int64_t)mf_qrow(a, row0 + n) * a.q_sw) * 2 + kg * 16;
     const float* ars = rowstat + (size_t)(b * a.Hq + hq) * a.Wp + mf_prow(a, row0);
-    float* cs = (gb == 0 ? colsum : colsum2) + (size_t)(b * a.Hkv + h) * Sm;
+    float* cs = (gb == 0 ? colsum : colsum2 + (size_t)(gb - 1) * a.B * a.Hkv * Sm) + (size_t)(b * a.Hkv + h) * Sm;   // (a slab per further group-block)
     const float c = a.c;
 
     uint32_t nfast = 0;   // tiles stored completely (all 128 keys < S - W)
@@ -844,8 +844,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_asm(SnapArgs a, uint3
 }
 
 namespace {
-__global__ __launch_bounds__(256) void add_slab_kernel(float* __restrict__ x, const float* __restrict__ y, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] += y[i];
+// x += y[0] + y[1] + ... (nslab slabs of n floats, added one after the other in slab order: run-to-run identical)
+__global__ __launch_bounds__(256) void add_slab_kernel(float* __restrict__ x, const float* __restrict__ y, size_t n, uint32_t nslab = 1) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = x[i];
+        for (uint32_t j = 0; j < nslab; ++j) s += y[(size_t)j * n + i];
+        x[i] = s;
+    }
 }
 }  // namespace
 
@@ -854,7 +859,7 @@ int snapkv_mfma_p2(const SnapArgs& a0, int dtype, const float* rowstat, float* c
     const uint32_t ngb = (a0.G + 3) / 4;
     const uint32_t Sm = a0.S - a0.W;
     const uint32_t nrblk = a0.Wp / 64;
-    KVP_CHECK_ARG(ngb <= 2 && (ngb == 1 || colsum2), "snapkv_p2_mfma: G = %u needs the second column-sum slab", a0.G);
+    KVP_CHECK_ARG(ngb == 1 || colsum2, "snapkv_p2_mfma: G = %u needs the column-sum slabs of its further group-blocks", a0.G);
     KVP_CHECK_ARG(nrblk == 1 || colsumx, "snapkv_p2_mfma: W = %u needs the row-block slab", a0.W);
     const dim3 grid(mfma_nchunk_for(a0, Sm), a0.Hkv * ngb, a0.B);
     const size_t nsum = (size_t)a0.B * a0.Hkv * Sm;
@@ -874,8 +879,8 @@ int snapkv_mfma_p2(const SnapArgs& a0, int dtype, const float* rowstat, float* c
         else { if (dtype == KVP_BF16) KVP_P2_MFMA(KVP_BF16, 4); else KVP_P2_MFMA(KVP_F16, 4); }
 #undef KVP_P2_MFMA
         KVP_CHECK_LAUNCH("snapkv_p2_mfma");
-        if (ngb == 2) {  // cs += colsum2 (the second group-block's sums)
-            KVP_LAUNCH("add_slab_kernel", stream, add_slab_kernel<<<ablocks, 256, 0, stream>>>(cs, colsum2, nsum));
+        if (ngb > 1) {  // cs += colsum2[0] + colsum2[1] + ... (the further group-blocks' sums, in block order)
+            KVP_LAUNCH("add_slab_kernel", stream, add_slab_kernel<<<ablocks, 256, 0, stream>>>(cs, colsum2, nsum, ngb - 1));
             KVP_CHECK_LAUNCH("snapkv_p2_mfma(add)");
         }
         if (a.rblk > 0) {

@@ -308,11 +308,13 @@ def test_snapkv_kernel_vs_oracle(name):
                                       (65, 700, 4, 5), (100, 4200, 4, 5), (128, 129, 2, 5), (130, 9000, 8, 7), (200, 2500, 4, 5), (257, 40000, 4, 5),
                                       (64, 3000, 5, 5), (64, 3000, 6, 5), (40, 1500, 7, 5), (64, 20000, 1, 5), (64, 20000, 2, 5),
                                       # S < Wp (the padded window is longer than the sequence): the fuzz's round-6 find
-                                      (200, 253, 7, 5), (65, 66, 4, 1), (130, 150, 2, 3), (1, 2, 4, 1), (10, 40, 8, 5)])
+                                      (200, 253, 7, 5), (65, 66, 4, 1), (130, 150, 2, 3), (1, 2, 4, 1), (10, 40, 8, 5),
+                                      # more than two group-blocks of four q-heads per kv-head (Llama-3.1-405B, Qwen3-235B: G = 16; Mistral-Large: 12)
+                                      (64, 3000, 12, 5), (64, 3000, 16, 5), (40, 1500, 9, 5), (130, 5000, 13, 3)])
 def test_snapkv_any_window_on_the_mfma_path(W, S, G, ks, D):
     """Round 6: the MFMA passes take ANY window size (TOVA's W = 1, FINCH's question length, user-chosen windows) as blocks of 64
     padded rows -- padding in front, normaliser +inf, the reference's causal rule in padded coordinates (snapkv_internal.h) -- for
-    head sizes 256, 128, 96 and 64, G = 1 .. 8 (hand-scheduled loops for D = 128 and G % 4 == 0, the compiler-scheduled kernels otherwise), down to
+    head sizes 256, 128, 96 and 64, G = 1 .. 16 (hand-scheduled loops for D = 128 and G % 4 == 0, the compiler-scheduled kernels otherwise), down to
     S = W + 1 (every tile masked).  Scores against the float64 oracle; pad columns; a batch of two through the same call."""
     rs = np.random.RandomState(W * 131 + S + G + D)
     N = native()
@@ -1108,8 +1110,8 @@ def test_snapkv_scores_are_run_to_run_identical_with_balanced_pass2(knobs):
     same holds for a ragged length (where the walk's last tiles take the plain path) and for a batch of two."""
     N = native()
     g = torch.Generator(device=DEV); g.manual_seed(606)
-    for B, S in ((1, 131072), (1, 131072 - 1000 + 37), (2, 70003)):
-        k = torch.randn((B, 8, S, 128), generator=g, device=DEV).to(torch.bfloat16)
+    for B, S, Hkv in ((1, 131072, 8), (1, 131072 - 1000 + 37, 8), (2, 70003, 8), (1, 60000, 2)):   # (the last: G = 16, four group-blocks per kv-head)
+        k = torch.randn((B, Hkv, S, 128), generator=g, device=DEV).to(torch.bfloat16)
         q = (torch.randn((B, 32, 64, 128), generator=g, device=DEV) * 1.2).to(torch.bfloat16)
         knobs(KVP_SK_BALANCE=None)
         ref = N.snapkv_score(q, k, 5)

@@ -73,6 +73,8 @@ def main():
     case("snapkv", 1, 16, 8, S, 128, bf, note="G = 2: compiler-scheduled MFMA passes")
     case("snapkv", 1, 24, 8, S, 128, bf, note="G = 3: compiler-scheduled MFMA passes")
     case("snapkv", 1, 64, 8, S, 128, bf, note="G = 8: two group-blocks, second column-sum slab")
+    case("snapkv", 1, 128, 8, S, 128, bf, note="G = 16 (Llama-3.1-405B geometry): four group-blocks (generic kernels until round 6)")
+    case("snapkv", 1, 96, 8, S, 128, bf, note="G = 12 (Mistral-Large geometry)")
     case("snapkv", 1, 32, 8, S, 96, bf, note="D = 96 (Phi-3-mini): compiler-scheduled MFMA passes on 256-byte LDS rows (round 6)")
     case("snapkv", 1, 32, 8, S, 256, bf, note="D = 256 (Gemma): compiler-scheduled MFMA passes, two-buffer ring of 64 KiB tiles (round 6)")
     case("snapkv", 1, 32, 8, S, 64, bf, note="D = 64: compiler-scheduled MFMA passes (round 6; before: generic kernels, 3206 us)")

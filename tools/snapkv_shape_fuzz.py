@@ -33,7 +33,7 @@ def main():
     bad = 0
     for it in range(args.rounds):
         D = int(rs.choice([64, 96, 128, 256]))
-        G = int(rs.choice([1, 2, 3, 4, 4, 5, 6, 7, 8]))
+        G = int(rs.choice([1, 2, 3, 4, 4, 5, 6, 7, 8, 9, 12, 16]))
         H = int(rs.choice([1, 2, 3]))
         B = int(rs.choice([1, 1, 2]))
         W = int(rs.choice([1, 2, 7, 31, 32, 33, 63, 64, 64, 65, 100, 127, 128, 129, 200, 300]))
