@@ -211,7 +211,7 @@ __global__ __launch_bounds__(EA_THREADS) void ea_finalize_kernel(const float* __
 // The 16 lanes of a row group share the score arithmetic of the group's four keys in flight: lane (u, g) = (lir / G, lir % G) loads the
 // logit of key u and query head g TOGETHER with the V rows (the first version left the whole finalize to lane 0 after the reduction: its
 // G dependent loads per key sat exposed behind every step, 85 us instead of the three kernels' 65), exponentiates it, and a G - 1 step
-// DPP scan (row_shr:1) adds the G terms in ea_finalize_kernel's order; the lane of the last head writes the score.  G = 1, 2 or 4.
+// DPP scan (row_shr:1) adds the G terms in ea_finalize_kernel's order; the lane of the last head writes the score.  G = 1, 2, 4; round 6: 8 and 16 (in rounds).
 constexpr int EVF_THREADS = 1024;
 template <int DT, bool NT, int G>
 __global__ __launch_bounds__(EVF_THREADS) void ea_vnorm_finalize_kernel(const typename Elem<DT>::T* __restrict__ v, int64_t v_sb, int64_t v_sh, int64_t v_ss,
@@ -242,8 +242,12 @@ __global__ __launch_bounds__(EVF_THREADS) void ea_vnorm_finalize_kernel(const ty
     float* __restrict__ out = scores + (size_t)bh * S + n_sink;
     const float invG = 1.0f / (float)G;
     const uint32_t lir = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const uint32_t my_u = lir / G, my_g = lir % G;   // lanes 0 .. 4 G - 1 of the group: key in flight, query head
-    const bool scorer = lir < 4 * G;
+    // G <= 4: lanes 0 .. 4 G - 1 of the group score the four keys in flight at once (key lir / G, query head lir % G).  G = 8 / 16 (round 6: the
+    // 70B- / 405B-class groups): the 16 lanes cover 2 / 1 keys x G heads per ROUND, NR = 2 / 4 rounds per step -- the same scan, the same order.
+    constexpr int KPR = G <= 4 ? 4 : 16 / G;   // keys scored per round
+    constexpr int NR = 4 / KPR;                // rounds per step of four keys
+    const uint32_t my_u = lir / G, my_g = lir % G;
+    const bool scorer = lir < KPR * G;
     const float my_a = scorer ? ag[my_g] : 0.f;
     const float* __restrict__ lrow = logits + (size_t)(row0 + my_g) * Sp;
     const uint32_t r0 = blockIdx.x * rows_per_wg, r1 = min(Sp, r0 + rows_per_wg);
@@ -256,8 +260,12 @@ __global__ __launch_bounds__(EVF_THREADS) void ea_vnorm_finalize_kernel(const ty
             vv[u] = make_uint4(0, 0, 0, 0);
             if (s < r1) vv[u] = ld16<NT>(base + (int64_t)s * v_ss + (size_t)lir * 8);
         }
-        const uint32_t my_s = it + my_u * 64 + grp;
-        const float lg = (scorer && my_s < r1) ? lrow[my_s] : 0.f;
+        float lg[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const uint32_t s_r = it + (r * KPR + my_u) * 64 + grp;
+            lg[r] = (scorer && s_r < r1) ? lrow[s_r] : 0.f;
+        }
         float acc[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -269,19 +277,23 @@ __global__ __launch_bounds__(EVF_THREADS) void ea_vnorm_finalize_kernel(const ty
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o);   // every lane of the group ends with the row's sum
         }
-        const float e = exp2f(lg - my_a);
-        float p = e;   // ea_finalize_kernel: p = 0; p += e_0; p += e_1; ...  (0 + e_0 = e_0)
 #pragma unroll
-        for (int k = 1; k < G; ++k) {
-            const float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
-            if (my_g == (uint32_t)k) p = prev + e;
-        }
-        if (scorer && my_g == G - 1 && my_s < r1) {
-            const float ss = my_u == 0 ? acc[0] : my_u == 1 ? acc[1] : my_u == 2 ? acc[2] : acc[3];
-            p *= invG;
-            p = (p + epsilon) * (1.0f * sqrtf(ss));
-            out[my_s] = p;
-            vmax = fmaxf(vmax, p);
+        for (int r = 0; r < NR; ++r) {
+            const float e = exp2f(lg[r] - my_a);
+            float p = e;   // ea_finalize_kernel: p = 0; p += e_0; p += e_1; ...  (0 + e_0 = e_0)
+#pragma unroll
+            for (int k = 1; k < G; ++k) {
+                const float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+                if (my_g == (uint32_t)k) p = prev + e;
+            }
+            const uint32_t u_r = r * KPR + my_u, s_r = it + u_r * 64 + grp;
+            if (scorer && my_g == G - 1 && s_r < r1) {
+                const float ss = u_r == 0 ? acc[0] : u_r == 1 ? acc[1] : u_r == 2 ? acc[2] : acc[3];
+                p *= invG;
+                p = (p + epsilon) * (1.0f * sqrtf(ss));
+                out[s_r] = p;
+                vmax = fmaxf(vmax, p);
+            }
         }
     }
     // Global maximum and the sink pad (max + 1, expected_attention_press.py:163) without a second launch: every workgroup publishes its
@@ -473,7 +485,7 @@ extern "C" int kvp_ea_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
     const uint32_t nrows = (uint32_t)(B * Hq);
     const int64_t es = kvp_elem_size(dtype);
     auto al16 = [&](int64_t elems) { return (elems * es) % 16 == 0; };
-    if (use_vnorm && dtype != KVP_F32 && D * es == 256 && (Hq / Hkv == 1 || Hq / Hkv == 2 || Hq / Hkv == 4) && Sp >= 4096 && B * Hkv <= 1024 && ((uintptr_t)v % 16) == 0 && al16(v_sb) &&
+    if (use_vnorm && dtype != KVP_F32 && D * es == 256 && (Hq / Hkv == 1 || Hq / Hkv == 2 || Hq / Hkv == 4 || Hq / Hkv == 8 || Hq / Hkv == 16) && Sp >= 4096 && B * Hkv <= 1024 && ((uintptr_t)v % 16) == 0 && al16(v_sb) &&
         al16(v_sh) && al16(v_ss) && kvp_env_int("KVP_EA_FUSED_FINALIZE", 1) != 0) {
         const uint32_t BH = (uint32_t)(B * Hkv);
         const uint64_t want = std::max<uint64_t>(1, (256 + BH - 1) / BH);   // about one 1024-thread workgroup per CU
@@ -484,7 +496,7 @@ extern "C" int kvp_ea_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
         const bool nt = (uint64_t)BH * Sp * 256 > (192ull << 20);   // read-once V (rownorm.hip: rn_streaming)
         const char* vp = static_cast<const char*>(v) + n_sink * v_ss * es;
 #define KVP_EVF(DTV, TT, NTV, GV) KVP_LAUNCH("ea_vnorm_finalize_kernel", stream, (ea_vnorm_finalize_kernel<DTV, NTV, GV><<<grid, EVF_THREADS, 0, stream>>>(reinterpret_cast<const TT*>(vp), v_sb, v_sh, v_ss, w.logits, w.part_m, w.part_z, nblk, (uint32_t)Hq, (uint32_t)Hkv, (uint32_t)S, (uint32_t)n_sink, epsilon, scores, w.bmax, (uint32_t)rows, a.clear_word)))
-#define KVP_EVF_G(DTV, TT, NTV) do { switch (Hq / Hkv) { case 1: KVP_EVF(DTV, TT, NTV, 1); break; case 2: KVP_EVF(DTV, TT, NTV, 2); break; default: KVP_EVF(DTV, TT, NTV, 4); break; } } while (0)
+#define KVP_EVF_G(DTV, TT, NTV) do { switch (Hq / Hkv) { case 1: KVP_EVF(DTV, TT, NTV, 1); break; case 2: KVP_EVF(DTV, TT, NTV, 2); break; case 4: KVP_EVF(DTV, TT, NTV, 4); break; case 8: KVP_EVF(DTV, TT, NTV, 8); break; default: KVP_EVF(DTV, TT, NTV, 16); break; } } while (0)
         if (dtype == KVP_BF16) { if (nt) KVP_EVF_G(KVP_BF16, uint16_t, true); else KVP_EVF_G(KVP_BF16, uint16_t, false); }
         else { if (nt) KVP_EVF_G(KVP_F16, _Float16, true); else KVP_EVF_G(KVP_F16, _Float16, false); }
 #undef KVP_EVF_G

@@ -843,8 +843,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void snapkv_p2_asm(SnapArgs a, uint3
     wait_all_landed();
 }
 
-namespace {
 // x += y[0] + y[1] + ... (nslab slabs of n floats, added one after the other in slab order: run-to-run identical)
+namespace {
 __global__ __launch_bounds__(256) void add_slab_kernel(float* __restrict__ x, const float* __restrict__ y, size_t n, uint32_t nslab = 1) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float s = x[i];

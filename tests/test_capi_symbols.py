@@ -155,3 +155,19 @@ def test_generated_asm_loops_are_up_to_date():
     finally:
         os.environ.update(env)
     assert open(os.path.join(root, "kvpress_amd", "csrc", "snapkv_asm.inc")).read() == gen.gen_kernel_inc()
+
+
+def test_clock_lab_patch_points_exist():
+    """tools/make_clock_lab.py (the in-kernel clock stamps behind profiles/rNN_clock_power.txt) patches snapkv_mfma.hip and gather.hip at
+    textual markers; an edit that moves one of them must fail HERE, not in the middle of a GPU run (round 6: a comment did)."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_clock_lab", os.path.join(root, "tools", "make_clock_lab.py"))
+    lab = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lab)
+    for name, fn in (("snapkv_mfma", lab.patch_snapkv), ("gather", lab.patch_gather)):
+        src = open(os.path.join(root, "kvpress_amd", "csrc", name + ".hip")).read()
+        out = fn(src)
+        assert "kvp_lab_begin(0);" in out and "kvp_lab_end(" in out and len(out) > len(src)

@@ -878,12 +878,13 @@ def test_ea_qstats_narrow_heads_on_the_matrix_cores(D):
 def test_ea_fused_finalize_equals_three_kernels(knobs):
     """kvp_ea_score's one-pass ||v|| + row normalisers + finalize (ea_vnorm_finalize_kernel: 256-byte rows, >= 4096 scored keys) against
     the three kernels it replaces (KVP_EA_FUSED_FINALIZE=0: the generic path other shapes take): the same bits, with and without sinks, GQA
-    groups of 1 / 2 / 4 (one pass) and 8 (the three kernels), ragged lengths, a strided V view."""
+    groups of 1 / 2 / 4 / 8 / 16 (one pass; 8 and 16 since round 6, in rounds of 2 / 1 keys per 16 lanes) and 3 (the three kernels), ragged lengths, a strided V view."""
     N = native()
     g = torch.Generator(device=DEV)
     g.manual_seed(5)
     for dt in (torch.bfloat16, torch.float16):
-        for B, Hq, Hkv, S, n_sink in ((1, 8, 2, 6000, 4), (2, 4, 4, 4100, 0), (1, 16, 2, 9001, 7), (1, 32, 8, 20000, 4), (1, 4, 2, 5003, 1)):
+        for B, Hq, Hkv, S, n_sink in ((1, 8, 2, 6000, 4), (2, 4, 4, 4100, 0), (1, 16, 2, 9001, 7), (1, 32, 8, 20000, 4), (1, 4, 2, 5003, 1), (1, 32, 2, 5000, 4), (2, 16, 1, 4200, 0),
+                                      (1, 6, 2, 4500, 4)):
             k = (torch.randn((B, Hkv, S, 128), generator=g, device=DEV) * 0.5).to(dt)
             vfull = torch.randn((B, S, Hkv, 128), generator=g, device=DEV).to(dt)
             v = vfull.transpose(1, 2)                                   # [B, Hkv, S, 128] view of a [B, S, Hkv, 128] buffer
