@@ -476,7 +476,14 @@ extern "C" int kvp_ea_score(const void* k, int64_t k_sb, int64_t k_sh, int64_t k
     } else {
         nblk = (uint32_t)((Sp + EA_SUB - 1) / EA_SUB);
         const size_t lds = ((size_t)EA_SUB * (D + 1) + 512) * 4;
-        KVP_CHECK_ARG(lds <= 64 * 1024, "ea_score: D=%ld exceeds the generic kernel's LDS budget", (long)D);
+        KVP_CHECK_ARG(lds <= 160 * 1024, "ea_score: D=%ld exceeds the generic kernel's LDS budget", (long)D);
+        if (lds > 64 * 1024) {   // head sizes of 256 and more (Gemma: 66 KiB for the 64-key tile of float32 rows): above the default limit of a launch, inside the CU's 160 KiB -- was refused until round 6
+            const void* fn = dtype == KVP_F32 ? (const void*)ea_logits_generic<KVP_F32> : dtype == KVP_F16 ? (const void*)ea_logits_generic<KVP_F16> : (const void*)ea_logits_generic<KVP_BF16>;
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                kvp_set_error("ea_score: cannot raise the dynamic LDS limit to %zu bytes (D=%ld)", lds, (long)D);
+                return KVP_EHIP;
+            }
+        }
         const dim3 grid(nblk, (uint32_t)Hq, (uint32_t)B);
         if (dtype == KVP_F32) KVP_LAUNCH("ea_logits_generic", stream, ea_logits_generic<KVP_F32><<<grid, EA_THREADS, lds, stream>>>(a, w.logits, nblk, w.part_m, w.part_z));
         else if (dtype == KVP_F16) KVP_LAUNCH("ea_logits_generic", stream, ea_logits_generic<KVP_F16><<<grid, EA_THREADS, lds, stream>>>(a, w.logits, nblk, w.part_m, w.part_z));

@@ -74,7 +74,12 @@ struct QstatArgs {
     uint32_t nt;  // non-temporal Q stream (read once)
     uint32_t nch; // 16-byte chunks a row of one head really has: 16 (D = 128); 12 / 8 (round 6: D = 96 / 64 as heads of 128 dimensions whose upper
                   // dimensions are zero: the LDS tiles are zeroed once and the lanes of the missing chunks never request anything)
+    uint32_t quarters;  // D = 256 (round 6): a "head" of this kernel is one of the SIX pairs of 64-dimension quarters of a real head (EQ_QA / EQ_QB):
+                        // every pair of dimensions meets in one of them, the combine scatters the 128 x 128 results into the 256 x 256 covariance
 };
+// the six pairs of quarters: pairs 0 and 1 also own the diagonal blocks (quarters 0, 1 and 2, 3) and the means
+__device__ __constant__ const uint32_t EQ_QA[6] = {0, 2, 0, 1, 0, 1};
+__device__ __constant__ const uint32_t EQ_QB[6] = {1, 3, 2, 3, 3, 2};
 
 // ---- (1b) query statistics with transposed LDS reads (gfx950 ds_read_b64_tr_b16) -------------------------------------------------
 // Per (head, chunk of rows) partials: raw second moments sum x x^T (m0 = 0) and column sums; the row -> column transpose a syrk needs
@@ -98,7 +103,8 @@ __global__ __launch_bounds__(EM_THREADS, ET_OCC) void ea_qstats_tr_kernel(QstatA
     const uint32_t n = lane & 31, kg = lane >> 5;
     const uint32_t g = lane >> 4, i16 = lane & 15, t2 = i16 >> 2;
     const uint32_t bh = b * a.Hq + hq;
-    const char* base = static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hq * a.q_sh) * 2;
+    const uint32_t hreal = a.quarters ? hq / 6 : hq, qpair = a.quarters ? hq % 6 : 0;
+    const char* base = static_cast<const char*>(a.q) + ((int64_t)b * a.q_sb + (int64_t)hreal * a.q_sh) * 2;
     const int64_t row_bytes = a.q_ss * 2;
     const uint32_t rbeg = chunk * a.rows_per_chunk;
     const uint32_t rend = min(rbeg + a.rows_per_chunk, a.Sq);
@@ -107,8 +113,10 @@ __global__ __launch_bounds__(EM_THREADS, ET_OCC) void ea_qstats_tr_kernel(QstatA
 
     // ---- LDS-DMA: request j (0..3) of a tile moves rows 16 j + 4 wv + g; lane slot i16 fetches chunk i16 ^ (g << 2) (row & 3 == g)
     const uint32_t ldsbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const uint32_t gch = (i16 ^ (g << 2)) << 4;
-    const bool has_chunk = (gch >> 4) < a.nch;
+    const uint32_t gchunk = i16 ^ (g << 2);
+    // byte offset of this lane's 16-byte chunk inside the head's row (quarters: chunks 0 .. 7 lie in quarter QA, 8 .. 15 in quarter QB of a 512-byte row)
+    const uint32_t gch = a.quarters ? (gchunk < 8 ? EQ_QA[qpair] * 128 + gchunk * 16 : EQ_QB[qpair] * 128 + (gchunk - 8) * 16) : gchunk << 4;
+    const bool has_chunk = gchunk < a.nch;
     if (a.nch < 16) {   // zero dimensions of a narrow head: written once, never overwritten (only the lanes with a chunk request)
         for (uint32_t e = threadIdx.x; e < (uint32_t)(ET_NBUF * EM_TILEB / 16); e += EM_THREADS) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0, 0, 0, 0);
         __syncthreads();
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(EM_THREADS, ET_OCC) void ea_qstats_tr_kernel(QstatA
 // grid = (16, B*Hq): workgroup x handles cov elements [x*1024, (x+1)*1024) of one head (and x == 0 also writes mu).
 __global__ __launch_bounds__(256) void ea_qstats_combine(const float* __restrict__ s2, const float* __restrict__ dsum,
                                                          const float* __restrict__ m0, uint32_t Sq, uint32_t nchunk,
-                                                         uint32_t rows_per_chunk, float* __restrict__ mu, float* __restrict__ cov, uint32_t pair, uint32_t dout) {
+                                                         uint32_t rows_per_chunk, float* __restrict__ mu, float* __restrict__ cov, uint32_t pair, uint32_t dout, uint32_t quarters) {
     // pair != 0 (D = 64, ea_mfma_qstats): a "head" of this kernel is a PAIR of 64-dimensional heads that sit next to each other in a token row;
     // mu [.., 2 p + {0, 1}, 64] is the pair's 128 means as they are, cov gets the two diagonal 64 x 64 blocks (the cross-head blocks are dropped)
     // dout < 128 (D = 96, D = 64 in other layouts): the head's statistics are the leading dout x dout block of a 128-wide head padded with zeros
@@ -234,7 +242,9 @@ __global__ __launch_bounds__(256) void ea_qstats_combine(const float* __restrict
             s += nc * muc[c * 128 + threadIdx.x];
         }
         mug[threadIdx.x] = s * invN;
-        if (blockIdx.x == 0 && threadIdx.x < dout) mu[(size_t)bh * dout + threadIdx.x] = s * invN;
+        if (quarters) {   // (bh = real head * 6 + pair of quarters: pairs 0 and 1 hold dimensions 0 .. 127 and 128 .. 255 in order)
+            if (blockIdx.x == 0 && bh % 6 < 2) mu[(size_t)(bh / 6) * 256 + (bh % 6) * 128 + threadIdx.x] = s * invN;
+        } else if (blockIdx.x == 0 && threadIdx.x < dout) mu[(size_t)bh * dout + threadIdx.x] = s * invN;
     }
     __syncthreads();
     if (!cov) return;
@@ -268,7 +278,10 @@ __global__ __launch_bounds__(256) void ea_qstats_combine(const float* __restrict
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t e = e0 + q * 256, i = e >> 7, j = e & 127;
-        if (!pair) { if (i < dout && j < dout) cov[((size_t)bh * dout + i) * dout + j] = s[q] * invN; }
+        if (quarters) {
+            const uint32_t p = bh % 6, Qi = (i >> 6) ? EQ_QB[p] : EQ_QA[p], Qj = (j >> 6) ? EQ_QB[p] : EQ_QA[p];
+            if (Qi != Qj || p < 2) cov[((size_t)(bh / 6) * 256 + Qi * 64 + (i & 63)) * 256 + Qj * 64 + (j & 63)] = s[q] * invN;
+        } else if (!pair) { if (i < dout && j < dout) cov[((size_t)bh * dout + i) * dout + j] = s[q] * invN; }
         else if (((i ^ j) & 64) == 0) cov[(((size_t)bh * 2 + (i >> 6)) * 64 + (i & 63)) * 64 + (j & 63)] = s[q] * invN;
     }
 }
@@ -942,6 +955,151 @@ __global__ __launch_bounds__(EM_THREADS, ElGeo<DK>::OCC) void ea_logits_mfma_sma
     }
 }
 
+// ---- (2d) head size 256 (Gemma; round 6) -------------------------------------------------------------------------------------------
+// Eight strips of U, 16 k-steps: strip s has k-steps 2 s .. 15, i.e. 16 + 14 + ... + 2 = 72 (strip, k-step) products per 32-key sub-tile.
+// Wave w holds strips w and 7 - w (18 products: the same for every wave; 144 hi / lo fragment registers -- with the K fragments and two
+// accumulators more than 256, so ONE workgroup per CU with the whole register file: launch_bounds(256, 1)) and walks all four sub-tiles of a
+// 128-key tile; its two strips' row-dots of a key are added in registers, the lane halves folded by one cross-lane read, the four waves'
+// partials meet in LDS (double-buffered: the fold of tile t runs after the barrier that also publishes tile t + 1).  K rows are 512 bytes:
+// a wave's LDS-DMA request moves two rows, the slots of a row rotate with its low four bits inside each 256-byte half.  Compiler-scheduled
+// (the generic kernel this replaces took 13.6 ms for 32k tokens x 32 heads and was refused outright before round 6).
+constexpr int EB_ROWB = 512;
+constexpr int EB_TILEB = EL_TILE * EB_ROWB;   // 64 KiB
+template <int DT, bool HAS_COV>
+__global__ __launch_bounds__(EM_THREADS, 1) void ea_logits_mfma_big_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk, uint32_t chunk_keys,
+                                                                           float* __restrict__ part_m, float* __restrict__ part_z) {
+    constexpr int D = 256, DK = 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_lds[];   // 2 x 64 KiB of K tiles | red[2][4][128] | mus[256] | wred[8]
+    unsigned char* lds = big_lds;
+    float (*red)[4][EL_TILE] = reinterpret_cast<float (*)[4][EL_TILE]>(big_lds + 2 * EB_TILEB);
+    float* mus = reinterpret_cast<float*>(big_lds + 2 * EB_TILEB + 2 * 4 * EL_TILE * 4);
+    float* wred = mus + D;
+    if (a.clear_word && blockIdx.x == 0 && threadIdx.x == 0) *a.clear_word = 0;
+    const uint32_t slot = blockIdx.x >> 3, g = slot % a.G;   // XCD-aware order: see ea_logits_mfma_kernel
+    const uint32_t unit = (slot / a.G) * 8 + (blockIdx.x & 7);
+    if (unit >= nblk * a.B * a.Hkv) return;
+    const uint32_t chunk = unit % nblk, bh = unit / nblk;
+    const uint32_t b = bh / a.Hkv, h = bh - b * a.Hkv;
+    const uint32_t hq = h * a.G + g, bhq = b * a.Hq + hq;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t n = lane & 31, kg = lane >> 5;
+    const char* kb = static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh + (int64_t)a.n_sink * a.k_ss) * 2;
+    const int64_t row_bytes = a.k_ss * 2;
+    mus[threadIdx.x] = a.mu[(size_t)bhq * D + threadIdx.x] * a.inv_sqrt_d;   // (256 threads, 256 dimensions)
+
+    const uint32_t kbeg = chunk * chunk_keys;
+    const uint32_t kend = min(kbeg + chunk_keys, a.Sp);
+    const uint32_t ntiles = (kend - kbeg + EL_TILE - 1) / EL_TILE;
+    float* lrow = logits + (size_t)bhq * a.Sp;
+    float m_run = KVP_NEG_INF, z_run = 0.f;   // threads 0 .. 127: the keys they fold
+
+    // LDS-DMA: request j (0 .. 15) of a tile moves rows 8 j + 2 wv + lane / 32; lane slot p = lane % 32 fetches chunk p ^ (row & 15) (bit 4 of the
+    // chunk -- the 256-byte half -- stays): the rows of a request alternate between two swizzle phases (8 j is 0 or 8 mod 16)
+    const uint32_t ldsbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const uint32_t rrow = 2 * wv + (lane >> 5), rp = lane & 31;
+    const uint32_t rch0 = (rp ^ (rrow & 15)) << 4, rch1 = (rp ^ ((rrow + 8) & 15)) << 4;
+    auto request_tile = [&](uint32_t row0, uint32_t buf_off) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t r = min(row0 + 8 * j + rrow, a.Sp - 1);   // rows past the end: any valid row (never stored)
+            const char* gp = kb + (int64_t)r * row_bytes + ((j & 1) ? rch1 : rch0);
+            const uint32_t la = __builtin_amdgcn_readfirstlane(ldsbase + buf_off + (8 * j + 2 * wv) * EB_ROWB);
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(gp) : "memory");
+        }
+    };
+    request_tile(kbeg, 0);
+
+    auto fold = [&](uint32_t tile) {   // logit of key tile * 128 + tid from the four waves' partials, running softmax partial
+        if (threadIdx.x < EL_TILE) {
+            const uint32_t kk = kbeg + tile * EL_TILE + threadIdx.x;
+            if (kk < kend) {
+                const float (*rr)[EL_TILE] = red[tile & 1];
+                const float l2 = ((rr[0][threadIdx.x] + rr[1][threadIdx.x]) + (rr[2][threadIdx.x] + rr[3][threadIdx.x])) * KVP_LOG2E;
+                lrow[kk] = l2;
+                softmax_merge(m_run, z_run, l2, 1.0f);
+            }
+        }
+    };
+    auto walk = [&](auto sa_tag) {
+        constexpr int SA = decltype(sa_tag)::value, SB = 7 - SA;   // SA < SB: strip SA has the longer chains and the lower first k-step
+        ElSmallFrag<DT, DK, SA> fa;
+        ElSmallFrag<DT, DK, SB> fb;
+        if (HAS_COV) {
+            const float* cov_head = a.cov + (size_t)bhq * D * D;
+            el_small_build<DT, DK, SA>(cov_head, n, kg, a.inv_2d, fa);
+            el_small_build<DT, DK, SB>(cov_head, n, kg, a.inv_2d, fb);
+        }
+        auto strip = [&](auto s_tag, const auto& f, const unsigned char* buf, uint32_t row, const uint4 (&kf)[DK]) -> float {
+            constexpr int S = decltype(s_tag)::value;
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 m4 = *reinterpret_cast<const float4*>(&mus[32 * S + 8 * q + 4 * kg]);
+                acc[4 * q] = m4.x; acc[4 * q + 1] = m4.y; acc[4 * q + 2] = m4.z; acc[4 * q + 3] = m4.w;
+            }
+            uint2 kk[4];   // K in the C layout: dims 32 S + 8 q + 4 kg + {0 .. 3} of key `row`: 8 bytes of 16-byte chunk 4 S + q
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kk[q] = *reinterpret_cast<const uint2*>(buf + row * EB_ROWB + (((S * 4 + q) ^ (row & 15)) << 4) + kg * 8);
+            if (HAS_COV) {
+#pragma unroll
+                for (int i = 0; i < DK - 2 * S; ++i) acc = mma32<DT>(f.hi[i], kf[2 * S + i], acc);
+#pragma unroll
+                for (int i = 0; i < DK - 2 * S; ++i) acc = mma32<DT>(f.lo[i], kf[2 * S + i], acc);
+            }
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v0 = fmaf(lo16<DT>(kk[q].x), acc[4 * q + 0], v0);
+                v1 = fmaf(hi16<DT>(kk[q].x), acc[4 * q + 1], v1);
+                v0 = fmaf(lo16<DT>(kk[q].y), acc[4 * q + 2], v0);
+                v1 = fmaf(hi16<DT>(kk[q].y), acc[4 * q + 3], v1);
+            }
+            return v0 + v1;
+        };
+        unsigned char* bufc = lds;
+        unsigned char* bufn = lds + EB_TILEB;
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's part of tile 0 has landed
+        __syncthreads();                      // (also publishes mus)
+        for (uint32_t t = 0; t < ntiles; ++t) {
+            if (t + 1 < ntiles) request_tile(kbeg + (t + 1) * EL_TILE, (uint32_t)(bufn - lds));   // into the buffer tile t - 1 left at the last barrier
+#pragma unroll 1
+            for (uint32_t sub = 0; sub < (uint32_t)EL_SUBS; ++sub) {
+                const uint32_t row = sub * 32 + n;
+                uint4 kf[DK];
+                if (HAS_COV) {
+#pragma unroll
+                    for (int ks = 2 * SA; ks < DK; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(bufc + row * EB_ROWB + (((ks * 2 + kg) ^ (row & 15)) << 4));
+                }
+                float v = strip(std::integral_constant<int, SA>{}, fa, bufc, row, kf) + strip(std::integral_constant<int, SB>{}, fb, bufc, row, kf);
+                v += __shfl_xor(v, 32);   // the two lane halves hold the two halves of a strip's dims
+                if (kg == 0) red[t & 1][wv][row] = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): tile t + 1 has landed (this wave's part; the barrier covers the others)
+            __syncthreads();
+            unsigned char* tmp = bufc; bufc = bufn; bufn = tmp;
+            fold(t);
+        }
+    };
+    if (wv == 0) walk(std::integral_constant<int, 0>{});
+    else if (wv == 1) walk(std::integral_constant<int, 1>{});
+    else if (wv == 2) walk(std::integral_constant<int, 2>{});
+    else walk(std::integral_constant<int, 3>{});
+
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m_run, o), z2 = __shfl_xor(z_run, o);
+        softmax_merge(m_run, z_run, m2, z2);
+    }
+    if (lane == 0) { wred[2 * wv] = m_run; wred[2 * wv + 1] = z_run; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        softmax_merge(m_run, z_run, wred[2], wred[3]);   // (waves 0 and 1 own the keys)
+        part_m[(size_t)bhq * nblk + chunk] = m_run;
+        part_z[(size_t)bhq * nblk + chunk] = z_run;
+    }
+}
+constexpr size_t EB_LDS_BYTES = 2 * EB_TILEB + 2 * 4 * EL_TILE * 4 + 256 * 4 + 8 * 4;
+
 bool aligned8(int64_t x) { return x % 8 == 0; }
 
 }  // namespace
@@ -956,12 +1114,13 @@ bool ea_mfma_qstats_eligible(const void* q, int64_t q_sb, int64_t q_sh, int64_t 
     // of Hq / 2 "heads" of 128 dimensions; the syrk of such a pair holds the two heads' second moments in its diagonal blocks (twice the matrix
     // work a 64-wide syrk needs, on a kernel that waits for HBM).  D = 96 and the other layouts of D = 64: a head of 128 dimensions whose upper
     // ones are zero (QstatArgs::nch).
-    return ok && (D == 128 || D == 64 || D == 96);
+    return ok && (D == 128 || D == 64 || D == 96 || (D == 256 && Hq * 6 <= 65535));
 }
 static bool qstats_pairs(int64_t q_sh, int64_t Hq, int64_t D) { return D == 64 && q_sh == 64 && Hq % 2 == 0; }
 
 size_t ea_mfma_qstats_ws_bytes(int64_t B, int64_t Hq, int64_t Sq, int64_t D) {
-    if (D != 128 && D != 64 && D != 96) return 0;
+    if (D != 128 && D != 64 && D != 96 && D != 256) return 0;
+    if (D == 256) Hq *= 6;   // six pairs of quarters per head
     uint32_t nchunk, rows;
     qstats_plan(Sq, B * Hq, nchunk, rows);   // (pairs of heads: half the heads, at most twice the chunks: never more than this)
     size_t need = (size_t)B * Hq * nchunk * (128 * 128 + 256) * 4 + 1024;
@@ -974,14 +1133,16 @@ size_t ea_mfma_qstats_ws_bytes(int64_t B, int64_t Hq, int64_t Sq, int64_t D) {
 
 int ea_mfma_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int dtype, int64_t B, int64_t Hq, int64_t Sq, int64_t D,
                    float* mu, float* cov, void* ws, hipStream_t stream) {
-    const uint32_t pair = qstats_pairs(q_sh, Hq, D);
+    const uint32_t pair = qstats_pairs(q_sh, Hq, D), quarters = D == 256;
     if (pair) { Hq /= 2; q_sh = 128; }   // pairs of neighbouring 64-dimensional heads as heads of 128 (ea_mfma_qstats_eligible)
+    if (quarters) Hq *= 6;               // D = 256: six pairs of quarters per head (QstatArgs::quarters)
     QstatArgs a;
     a.q = q; a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss;
     a.B = (uint32_t)B; a.Hq = (uint32_t)Hq; a.Sq = (uint32_t)Sq;
     qstats_plan(Sq, B * Hq, a.nchunk, a.rows_per_chunk);
-    a.nch = pair ? 16u : (uint32_t)(D / 8);
-    a.nt = (uint64_t)B * Hq * Sq * 256 > (192ull << 20);   // streaming Q loads when Q cannot stay in the memory-side cache anyway (as kvp_gather_kv)
+    a.nch = (pair || quarters) ? 16u : (uint32_t)(D / 8);
+    a.quarters = quarters;
+    a.nt = !quarters && (uint64_t)B * Hq * Sq * 256 > (192ull << 20);   // streaming Q loads when Q cannot stay in the memory-side cache anyway (as kvp_gather_kv); quarters: every row is read by three pairs -- let that cache keep it
     const size_t nbh = (size_t)B * Hq;
     a.s2 = static_cast<float*>(ws);
     a.dsum = a.s2 + nbh * a.nchunk * 16384;
@@ -991,13 +1152,13 @@ int ea_mfma_qstats(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_ss, int 
     if (dtype == KVP_BF16) KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_BF16, 3, 3><<<grid, EM_THREADS, 0, stream>>>(a)));
     else KVP_LAUNCH("ea_qstats_mfma", stream, (ea_qstats_tr_kernel<KVP_F16, 3, 3><<<grid, EM_THREADS, 0, stream>>>(a)));
     const size_t sm = ((size_t)a.nchunk * 256 + 128) * 4;
-    KVP_LAUNCH("ea_qstats_combine", stream, ea_qstats_combine<<<dim3(16, (uint32_t)nbh), 256, sm, stream>>>(a.s2, a.dsum, a.m0, a.Sq, a.nchunk, a.rows_per_chunk, mu, cov, pair, pair ? 128u : (uint32_t)D));
+    KVP_LAUNCH("ea_qstats_combine", stream, ea_qstats_combine<<<dim3(16, (uint32_t)nbh), 256, sm, stream>>>(a.s2, a.dsum, a.m0, a.Sq, a.nchunk, a.rows_per_chunk, mu, cov, pair, (pair || quarters) ? 128u : (uint32_t)D, quarters));
     KVP_CHECK_LAUNCH("ea_qstats_mfma");
     return KVP_OK;
 }
 
 bool ea_mfma_logits_eligible(const EaArgs& a, int dtype) {
-    return (dtype == KVP_BF16 || dtype == KVP_F16) && (a.D == 128 || a.D == 64 || a.D == 96) && a.Sp >= 64 && (uintptr_t)a.k % 16 == 0 && aligned8(a.k_sb) &&
+    return (dtype == KVP_BF16 || dtype == KVP_F16) && (a.D == 128 || a.D == 64 || a.D == 96 || a.D == 256) && a.Sp >= 64 && (uintptr_t)a.k % 16 == 0 && aligned8(a.k_sb) &&
            aligned8(a.k_sh) && aligned8(a.k_ss) && a.G <= 65535;
 }
 size_t ea_mfma_logits_scratch_bytes(int64_t, int64_t, int64_t) { return 0; }
@@ -1007,6 +1168,11 @@ size_t ea_mfma_logits_scratch_bytes(int64_t, int64_t, int64_t) { return 0; }
 // SIMD VALU and matrix instructions do not overlap: 128k tokens x 32 heads now run as 512 workgroups of 64 tiles.
 static uint32_t ea_mfma_logits_chunk(const EaArgs& a) {
     const uint64_t heads = (uint64_t)a.B * a.Hkv * a.G;
+    if (a.D == 256) {   // (2d): one workgroup per CU; 2048 keys each, doubled while the grid exceeds two rounds
+        uint32_t chunk = 2048;
+        while (chunk < 65536 && (uint64_t)((a.Sp + chunk - 1) / chunk) * heads > 512) chunk *= 2;
+        return chunk;
+    }
     if (a.D != 128) {   // the small-head kernel (2c).  tools/ea_small_lab.py (ea_score, 32 heads; chunk x workgroup limit): 32k tokens D = 64 43.8 us at
                         // (2048, 768) against 49.8 at (4096, .) and 51-85 with more, shorter workgroups; 128k 120 against 129; D = 96 112 against 115-197
 #ifdef KVP_EA_SMALL_LAB   // (lab build of tools/ea_small_lab.py only)
@@ -1031,6 +1197,24 @@ int ea_mfma_logits(const EaArgs& a, int dtype, float* logits, uint32_t nblk, flo
     const uint64_t units = (uint64_t)nblk * a.B * a.Hkv;
     KVP_CHECK_ARG((units + 7) / 8 * 8 * a.G < ((uint64_t)1 << 31), "ea_logits_mfma: grid too large");
     const dim3 grid((uint32_t)((units + 7) / 8 * 8 * a.G));   // (unit, head-in-group) -> linear id: see the kernel
+    if (a.D == 256) {   // (2d)
+        const void* fns[4] = {(const void*)ea_logits_mfma_big_kernel<KVP_BF16, true>, (const void*)ea_logits_mfma_big_kernel<KVP_BF16, false>,
+                              (const void*)ea_logits_mfma_big_kernel<KVP_F16, true>, (const void*)ea_logits_mfma_big_kernel<KVP_F16, false>};
+        const void* fn = fns[(dtype == KVP_BF16 ? 0 : 2) + (a.cov ? 0 : 1)];
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EB_LDS_BYTES) != hipSuccess) {
+            kvp_set_error("ea_logits_mfma: cannot raise the dynamic LDS limit to %zu bytes", EB_LDS_BYTES);
+            return KVP_EHIP;
+        }
+        if (dtype == KVP_BF16) {
+            if (a.cov) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_big_kernel<KVP_BF16, true><<<grid, EM_THREADS, EB_LDS_BYTES, stream>>>(a, logits, nblk, ck, part_m, part_z)));
+            else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_big_kernel<KVP_BF16, false><<<grid, EM_THREADS, EB_LDS_BYTES, stream>>>(a, logits, nblk, ck, part_m, part_z)));
+        } else {
+            if (a.cov) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_big_kernel<KVP_F16, true><<<grid, EM_THREADS, EB_LDS_BYTES, stream>>>(a, logits, nblk, ck, part_m, part_z)));
+            else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_big_kernel<KVP_F16, false><<<grid, EM_THREADS, EB_LDS_BYTES, stream>>>(a, logits, nblk, ck, part_m, part_z)));
+        }
+        KVP_CHECK_LAUNCH("ea_logits_mfma");
+        return KVP_OK;
+    }
     if (a.D != 128) {   // head sizes 64 and 96: (2c)
 #define KVP_EL_SMALL(DTV, DKV)                                                                                                                         \
     do {                                                                                                                                               \

@@ -414,7 +414,7 @@ def test_ea_qstats_128k_large_mean_adversarial():
     print(f"ea qstats 128k adversarial: cov err {err.max().item():.2e} sigma_i sigma_j, final score err {rel.max().item():.2e}")
 
 
-@pytest.mark.parametrize("Dn,layout", [(64, "q_proj"), (64, "contiguous"), (96, "q_proj")])
+@pytest.mark.parametrize("Dn,layout", [(64, "q_proj"), (64, "contiguous"), (96, "q_proj"), (256, "q_proj")])
 def test_ea_narrow_heads_at_size(Dn, layout):
     """Round 6: ExpectedAttention for head sizes 64 / 96 at a size where the statistics stream Q with non-temporal loads (> 192 MiB of rows) and
     the logits run several chunks per head: statistics against float64 (pairs of neighbouring heads for D = 64 in the projection's layout,
@@ -458,7 +458,7 @@ def test_ea_narrow_heads_at_size(Dn, layout):
     print(f"ea D={Dn} {layout}: cov err {err.max().item():.2e} sigma_i sigma_j, final score err {rel.max().item():.2e}")
 
 
-@pytest.mark.parametrize("Dn", [64, 96])
+@pytest.mark.parametrize("Dn", [64, 96, 256])
 def test_expected_attention_press_on_narrow_head_models(Dn):
     """ExpectedAttentionPress.score on an attention module with 64- / 96-dimensional heads (Llama-3.2-1B / Phi-3-mini class; round 6: their statistics
     and quadratic form run on the matrix cores) against a float64 restatement of expected_attention_press.py:62-165 fed with the module's own bf16

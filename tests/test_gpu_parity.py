@@ -818,10 +818,11 @@ def test_ea_logits_triangular_form_vs_oracle():
             assert rel0.max() <= 1e-3, (dtype, S, "mean only", rel0.max())
 
 
-@pytest.mark.parametrize("D", [64, 96])
+@pytest.mark.parametrize("D", [64, 96, 256])
 def test_ea_logits_small_heads_vs_oracle(D):
     """Round 6: head sizes 64 (Llama-3.2-1B, Qwen2-0.5B) and 96 (Phi-3-mini) on the matrix cores (ea_logits_mfma_small_kernel: every wave
-    takes one 32-key sub-tile with all two / three strips of the doubled upper triangle) instead of the scalar generic kernel: symmetric
+    takes one 32-key sub-tile with all two / three strips of the doubled upper triangle) instead of the scalar generic kernel -- and 256
+    (Gemma), which the generic kernel REFUSED until round 6 (its 66 KiB tile is above a launch's default LDS limit): symmetric
     and ASYMMETRIC covariances, GQA groups 1 .. 7, ragged lengths from one partial tile to several chunks, sinks, both 16-bit dtypes, a
     [B, S, H, D] K buffer seen as [B, H, S, D], the mean-only form, a batch of two."""
     N = native()
@@ -850,12 +851,13 @@ def test_ea_logits_small_heads_vs_oracle(D):
             assert rel0.max() <= 1e-4, (dtype, D, S, "mean only", rel0.max())
 
 
-@pytest.mark.parametrize("D", [64, 96])
+@pytest.mark.parametrize("D", [64, 96, 256])
 def test_ea_qstats_narrow_heads_on_the_matrix_cores(D):
     """Round 6: the statistics of 64- and 96-dimensional heads on the 128-wide syrk.  D = 64 with the queries as q_proj leaves them ([B, S, Hq * 64]:
     heads 64 elements apart, an even number of them) runs as PAIRS of heads (the diagonal blocks of a pair's second moments are the two heads'
     own); D = 96, an odd head count and a contiguous [B, Hq, S, D] tensor run as heads of 128 dimensions whose upper ones are zero in LDS
-    (the lanes of the missing chunks request nothing).  Large means, dominant channels, a ragged tail, both dtypes."""
+    (the lanes of the missing chunks request nothing); D = 256 (Gemma) as the SIX pairs of 64-dimension quarters of every head, scattered into
+    the 256 x 256 covariance by the combine.  Large means, dominant channels, a ragged tail, both dtypes."""
     rs = np.random.RandomState(D)
     N = native()
     for dtype, (B, Hq, Sq) in (("bf16", (1, 6, 10000)), ("f16", (2, 2, 4500)), ("bf16", (1, 3, 5000))):

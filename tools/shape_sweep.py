@@ -92,6 +92,7 @@ def main():
     case("ea", 1, 32, 8, S, 64, bf, ratio=0.7, note="D = 64 (round 6: statistics over pairs of neighbouring heads + small-head quadratic form on the matrix cores; before: 1060 us)")
     case("ea", 1, 32, 32, S, 96, bf, ratio=0.7, note="D = 96 (Phi-3-mini, MHA; round 6: statistics as zero-padded heads of 128 + small-head quadratic form; before: 1081 us with generic statistics)")
     case("ea", 1, 32, 8, 131072, 64, bf, ratio=0.7, note="D = 64 at 128k")
+    case("ea", 1, 32, 8, S, 256, bf, ratio=0.7, note="D = 256 (Gemma; refused until round 6, generic kernels 13.6 ms; now statistics over pairs of quarters + its own quadratic-form kernel)")
     case("ea", 1, 32, 8, 8192, 128, f32, ratio=0.7, note="float32: generic kernels")
 
 
