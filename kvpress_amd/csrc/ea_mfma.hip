@@ -957,19 +957,24 @@ __global__ __launch_bounds__(EM_THREADS, ElGeo<DK>::OCC) void ea_logits_mfma_sma
 
 // ---- (2d) head size 256 (Gemma; round 6) -------------------------------------------------------------------------------------------
 // Eight strips of U, 16 k-steps: strip s has k-steps 2 s .. 15, i.e. 16 + 14 + ... + 2 = 72 (strip, k-step) products per 32-key sub-tile.
-// Wave w holds strips w and 7 - w (18 products: the same for every wave; 144 hi / lo fragment registers -- with the K fragments and two
-// accumulators more than 256, so ONE workgroup per CU with the whole register file: launch_bounds(256, 1)) and walks all four sub-tiles of a
-// 128-key tile; its two strips' row-dots of a key are added in registers, the lane halves folded by one cross-lane read, the four waves'
-// partials meet in LDS (double-buffered: the fold of tile t runs after the barrier that also publishes tile t + 1).  K rows are 512 bytes:
-// a wave's LDS-DMA request moves two rows, the slots of a row rotate with its low four bits inside each 256-byte half.  Compiler-scheduled
-// (the generic kernel this replaces took 13.6 ms for 32k tokens x 32 heads and was refused outright before round 6).
+// Eight waves: wave w holds strips p = w % 4 and 7 - p (18 products: the same for every wave; 144 hi / lo fragment registers) and takes
+// sub-tiles 2 (w / 4) and 2 (w / 4) + 1 of every 128-key tile -- two waves per SIMD with 256 registers each, so one wave's row-dots and LDS
+// waits sit under the other's matrix instructions.  A sub-tile's K fragments are read eight k-steps at a time into ONE register set (k-steps
+// 0 .. 7: only the longer strip has them; 8 .. 15: both strips, one after the other on one accumulator): 144 + 32 + 16 registers + addresses.
+// Every LDS address is a per-lane base computed once + an immediate (sub-tile: 16 KiB, upper half of a row: 256 bytes) -- the first version
+// recomputed them per sub-tile and kept accumulators in AGPRs: 234 VALU instructions per (wave, sub-tile) beside 36 matrix instructions,
+// 226 us for 32k tokens x 32 heads with the matrix pipe 34 % busy (PMC).  The strips' row-dots of a key are added in registers, the lane halves
+// folded by one cross-lane read, the four strip pairs' partials meet in LDS (double-buffered: the fold of tile t runs after the barrier that
+// also publishes tile t + 1).  K rows are 512 bytes: a wave's LDS-DMA request moves two rows, the slots of a row rotate with its low four
+// bits inside each 256-byte half.  (The generic kernel this replaces took 13.6 ms and was refused outright before round 6.)
+constexpr int EB_THREADS = 512;
 constexpr int EB_ROWB = 512;
 constexpr int EB_TILEB = EL_TILE * EB_ROWB;   // 64 KiB
 template <int DT, bool HAS_COV>
-__global__ __launch_bounds__(EM_THREADS, 1) void ea_logits_mfma_big_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk, uint32_t chunk_keys,
+__global__ __launch_bounds__(EB_THREADS, 1) void ea_logits_mfma_big_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk, uint32_t chunk_keys,
                                                                            float* __restrict__ part_m, float* __restrict__ part_z) {
     constexpr int D = 256, DK = 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char big_lds[];   // 2 x 64 KiB of K tiles | red[2][4][128] | mus[256] | wred[8]
+    extern __shared__ __attribute__((aligned(16))) unsigned char big_lds[];   // 2 x 64 KiB of K tiles | red[2][4][128] | mus[256] | wred[4]
     unsigned char* lds = big_lds;
     float (*red)[4][EL_TILE] = reinterpret_cast<float (*)[4][EL_TILE]>(big_lds + 2 * EB_TILEB);
     float* mus = reinterpret_cast<float*>(big_lds + 2 * EB_TILEB + 2 * 4 * EL_TILE * 4);
@@ -985,7 +990,7 @@ __global__ __launch_bounds__(EM_THREADS, 1) void ea_logits_mfma_big_kernel(EaArg
     const uint32_t n = lane & 31, kg = lane >> 5;
     const char* kb = static_cast<const char*>(a.k) + ((int64_t)b * a.k_sb + (int64_t)h * a.k_sh + (int64_t)a.n_sink * a.k_ss) * 2;
     const int64_t row_bytes = a.k_ss * 2;
-    mus[threadIdx.x] = a.mu[(size_t)bhq * D + threadIdx.x] * a.inv_sqrt_d;   // (256 threads, 256 dimensions)
+    if (threadIdx.x < D) mus[threadIdx.x] = a.mu[(size_t)bhq * D + threadIdx.x] * a.inv_sqrt_d;
 
     const uint32_t kbeg = chunk * chunk_keys;
     const uint32_t kend = min(kbeg + chunk_keys, a.Sp);
@@ -993,23 +998,23 @@ __global__ __launch_bounds__(EM_THREADS, 1) void ea_logits_mfma_big_kernel(EaArg
     float* lrow = logits + (size_t)bhq * a.Sp;
     float m_run = KVP_NEG_INF, z_run = 0.f;   // threads 0 .. 127: the keys they fold
 
-    // LDS-DMA: request j (0 .. 15) of a tile moves rows 8 j + 2 wv + lane / 32; lane slot p = lane % 32 fetches chunk p ^ (row & 15) (bit 4 of the
-    // chunk -- the 256-byte half -- stays): the rows of a request alternate between two swizzle phases (8 j is 0 or 8 mod 16)
+    // LDS-DMA: request j (0 .. 7) of a tile moves rows 16 j + 2 wv + lane / 32; lane slot p = lane % 32 fetches chunk p ^ (row & 15) (bit 4 of the
+    // chunk -- the 256-byte half -- stays)
     const uint32_t ldsbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const uint32_t rrow = 2 * wv + (lane >> 5), rp = lane & 31;
-    const uint32_t rch0 = (rp ^ (rrow & 15)) << 4, rch1 = (rp ^ ((rrow + 8) & 15)) << 4;
+    const uint32_t rrow = 2 * wv + (lane >> 5);
+    const uint32_t rch = ((lane & 31) ^ (rrow & 15)) << 4;
     auto request_tile = [&](uint32_t row0, uint32_t buf_off) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint32_t r = min(row0 + 8 * j + rrow, a.Sp - 1);   // rows past the end: any valid row (never stored)
-            const char* gp = kb + (int64_t)r * row_bytes + ((j & 1) ? rch1 : rch0);
-            const uint32_t la = __builtin_amdgcn_readfirstlane(ldsbase + buf_off + (8 * j + 2 * wv) * EB_ROWB);
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t r = min(row0 + 16 * j + rrow, a.Sp - 1);   // rows past the end: any valid row (never stored)
+            const char* gp = kb + (int64_t)r * row_bytes + rch;
+            const uint32_t la = __builtin_amdgcn_readfirstlane(ldsbase + buf_off + (16 * j + 2 * wv) * EB_ROWB);
             asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(gp) : "memory");
         }
     };
     request_tile(kbeg, 0);
 
-    auto fold = [&](uint32_t tile) {   // logit of key tile * 128 + tid from the four waves' partials, running softmax partial
+    auto fold = [&](uint32_t tile) {   // logit of key tile * 128 + tid from the four strip pairs' partials, running softmax partial
         if (threadIdx.x < EL_TILE) {
             const uint32_t kk = kbeg + tile * EL_TILE + threadIdx.x;
             if (kk < kend) {
@@ -1021,7 +1026,7 @@ __global__ __launch_bounds__(EM_THREADS, 1) void ea_logits_mfma_big_kernel(EaArg
         }
     };
     auto walk = [&](auto sa_tag) {
-        constexpr int SA = decltype(sa_tag)::value, SB = 7 - SA;   // SA < SB: strip SA has the longer chains and the lower first k-step
+        constexpr int SA = decltype(sa_tag)::value, SB = 7 - SA;   // SA < 4 <= SB: strip SB only has k-steps 8 .. 15
         ElSmallFrag<DT, DK, SA> fa;
         ElSmallFrag<DT, DK, SB> fb;
         if (HAS_COV) {
@@ -1029,23 +1034,26 @@ __global__ __launch_bounds__(EM_THREADS, 1) void ea_logits_mfma_big_kernel(EaArg
             el_small_build<DT, DK, SA>(cov_head, n, kg, a.inv_2d, fa);
             el_small_build<DT, DK, SB>(cov_head, n, kg, a.inv_2d, fb);
         }
-        auto strip = [&](auto s_tag, const auto& f, const unsigned char* buf, uint32_t row, const uint4 (&kf)[DK]) -> float {
-            constexpr int S = decltype(s_tag)::value;
-            f32x16 acc;
+        const uint32_t sub0 = 2 * (wv >> 2);            // this wave's first sub-tile
+        const uint32_t row = sub0 * 32 + n;             // (row & 15 == n & 15 for every sub-tile)
+        // per-lane byte offsets inside a tile buffer, sub-tile sub0: K fragment of k-step ks = fo[ks & 7] + (ks >> 3) * 256; K in the C layout for
+        // strip S, quarter q (dims 32 S + 8 q + 4 kg + {0 .. 3}: 8 bytes of chunk 4 S + q); the second sub-tile is + 16 KiB
+        uint32_t fo[8], koa[4], kob[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fo[i] = row * EB_ROWB + (((i * 2 + kg) ^ (n & 15)) << 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            koa[q] = row * EB_ROWB + ((SA * 4 + q) >> 4) * 256 + ((((SA * 4 + q) & 15) ^ (n & 15)) << 4) + kg * 8;
+            kob[q] = row * EB_ROWB + ((SB * 4 + q) >> 4) * 256 + ((((SB * 4 + q) & 15) ^ (n & 15)) << 4) + kg * 8;
+        }
+        auto acc_init = [&](int strip, f32x16& acc) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 m4 = *reinterpret_cast<const float4*>(&mus[32 * S + 8 * q + 4 * kg]);
+                const float4 m4 = *reinterpret_cast<const float4*>(&mus[32 * strip + 8 * q + 4 * kg]);
                 acc[4 * q] = m4.x; acc[4 * q + 1] = m4.y; acc[4 * q + 2] = m4.z; acc[4 * q + 3] = m4.w;
             }
-            uint2 kk[4];   // K in the C layout: dims 32 S + 8 q + 4 kg + {0 .. 3} of key `row`: 8 bytes of 16-byte chunk 4 S + q
-#pragma unroll
-            for (int q = 0; q < 4; ++q) kk[q] = *reinterpret_cast<const uint2*>(buf + row * EB_ROWB + (((S * 4 + q) ^ (row & 15)) << 4) + kg * 8);
-            if (HAS_COV) {
-#pragma unroll
-                for (int i = 0; i < DK - 2 * S; ++i) acc = mma32<DT>(f.hi[i], kf[2 * S + i], acc);
-#pragma unroll
-                for (int i = 0; i < DK - 2 * S; ++i) acc = mma32<DT>(f.lo[i], kf[2 * S + i], acc);
-            }
+        };
+        auto rowdot = [&](const uint2 (&kk)[4], const f32x16& acc) -> float {
             float v0 = 0.f, v1 = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1063,16 +1071,41 @@ __global__ __launch_bounds__(EM_THREADS, 1) void ea_logits_mfma_big_kernel(EaArg
         for (uint32_t t = 0; t < ntiles; ++t) {
             if (t + 1 < ntiles) request_tile(kbeg + (t + 1) * EL_TILE, (uint32_t)(bufn - lds));   // into the buffer tile t - 1 left at the last barrier
 #pragma unroll 1
-            for (uint32_t sub = 0; sub < (uint32_t)EL_SUBS; ++sub) {
-                const uint32_t row = sub * 32 + n;
-                uint4 kf[DK];
+            for (int u = 0; u < 2; ++u) {   // the wave's two sub-tiles (not unrolled: interleaving them doubles the live fragments -> spills)
+                const unsigned char* tb = bufc + u * 16384;
+                uint4 kf[8];
+                uint2 kka[4], kkb[4];
+                f32x16 acc;
+                acc_init(SA, acc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) kka[q] = *reinterpret_cast<const uint2*>(tb + koa[q]);
                 if (HAS_COV) {
 #pragma unroll
-                    for (int ks = 2 * SA; ks < DK; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(bufc + row * EB_ROWB + (((ks * 2 + kg) ^ (row & 15)) << 4));
+                    for (int ks = 2 * SA; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(tb + fo[ks]);
+#pragma unroll
+                    for (int ks = 2 * SA; ks < 8; ++ks) acc = mma32<DT>(fa.hi[ks - 2 * SA], kf[ks], acc);
+#pragma unroll
+                    for (int ks = 2 * SA; ks < 8; ++ks) acc = mma32<DT>(fa.lo[ks - 2 * SA], kf[ks], acc);
+#pragma unroll
+                    for (int ks = 8; ks < 16; ++ks) kf[ks - 8] = *reinterpret_cast<const uint4*>(tb + fo[ks - 8] + 256);
+#pragma unroll
+                    for (int ks = 8; ks < 16; ++ks) acc = mma32<DT>(fa.hi[ks - 2 * SA], kf[ks - 8], acc);
+#pragma unroll
+                    for (int ks = 8; ks < 16; ++ks) acc = mma32<DT>(fa.lo[ks - 2 * SA], kf[ks - 8], acc);
                 }
-                float v = strip(std::integral_constant<int, SA>{}, fa, bufc, row, kf) + strip(std::integral_constant<int, SB>{}, fb, bufc, row, kf);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) kkb[q] = *reinterpret_cast<const uint2*>(tb + kob[q]);
+                float v = rowdot(kka, acc);
+                acc_init(SB, acc);
+                if (HAS_COV) {
+#pragma unroll
+                    for (int ks = 2 * SB; ks < 16; ++ks) acc = mma32<DT>(fb.hi[ks - 2 * SB], kf[ks - 8], acc);
+#pragma unroll
+                    for (int ks = 2 * SB; ks < 16; ++ks) acc = mma32<DT>(fb.lo[ks - 2 * SB], kf[ks - 8], acc);
+                }
+                v += rowdot(kkb, acc);
                 v += __shfl_xor(v, 32);   // the two lane halves hold the two halves of a strip's dims
-                if (kg == 0) red[t & 1][wv][row] = v;
+                if (kg == 0) red[t & 1][wv & 3][row + u * 32] = v;
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): tile t + 1 has landed (this wave's part; the barrier covers the others)
             __syncthreads();
@@ -1080,17 +1113,19 @@ __global__ __launch_bounds__(EM_THREADS, 1) void ea_logits_mfma_big_kernel(EaArg
             fold(t);
         }
     };
-    if (wv == 0) walk(std::integral_constant<int, 0>{});
-    else if (wv == 1) walk(std::integral_constant<int, 1>{});
-    else if (wv == 2) walk(std::integral_constant<int, 2>{});
-    else walk(std::integral_constant<int, 3>{});
+    switch (wv & 3) {
+        case 0: walk(std::integral_constant<int, 0>{}); break;
+        case 1: walk(std::integral_constant<int, 1>{}); break;
+        case 2: walk(std::integral_constant<int, 2>{}); break;
+        default: walk(std::integral_constant<int, 3>{}); break;
+    }
 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float m2 = __shfl_xor(m_run, o), z2 = __shfl_xor(z_run, o);
         softmax_merge(m_run, z_run, m2, z2);
     }
-    if (lane == 0) { wred[2 * wv] = m_run; wred[2 * wv + 1] = z_run; }
+    if (lane == 0 && wv < 2) { wred[2 * wv] = m_run; wred[2 * wv + 1] = z_run; }
     __syncthreads();
     if (threadIdx.x == 0) {
         softmax_merge(m_run, z_run, wred[2], wred[3]);   // (waves 0 and 1 own the keys)
@@ -1098,7 +1133,7 @@ __global__ __launch_bounds__(EM_THREADS, 1) void ea_logits_mfma_big_kernel(EaArg
         part_z[(size_t)bhq * nblk + chunk] = z_run;
     }
 }
-constexpr size_t EB_LDS_BYTES = 2 * EB_TILEB + 2 * 4 * EL_TILE * 4 + 256 * 4 + 8 * 4;
+constexpr size_t EB_LDS_BYTES = 2 * EB_TILEB + 2 * 4 * EL_TILE * 4 + 256 * 4 + 4 * 4;
 
 bool aligned8(int64_t x) { return x % 8 == 0; }
 
@@ -1206,11 +1241,11 @@ int ea_mfma_logits(const EaArgs& a, int dtype, float* logits, uint32_t nblk, flo
             return KVP_EHIP;
         }
         if (dtype == KVP_BF16) {
-            if (a.cov) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_big_kernel<KVP_BF16, true><<<grid, EM_THREADS, EB_LDS_BYTES, stream>>>(a, logits, nblk, ck, part_m, part_z)));
-            else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_big_kernel<KVP_BF16, false><<<grid, EM_THREADS, EB_LDS_BYTES, stream>>>(a, logits, nblk, ck, part_m, part_z)));
+            if (a.cov) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_big_kernel<KVP_BF16, true><<<grid, EB_THREADS, EB_LDS_BYTES, stream>>>(a, logits, nblk, ck, part_m, part_z)));
+            else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_big_kernel<KVP_BF16, false><<<grid, EB_THREADS, EB_LDS_BYTES, stream>>>(a, logits, nblk, ck, part_m, part_z)));
         } else {
-            if (a.cov) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_big_kernel<KVP_F16, true><<<grid, EM_THREADS, EB_LDS_BYTES, stream>>>(a, logits, nblk, ck, part_m, part_z)));
-            else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_big_kernel<KVP_F16, false><<<grid, EM_THREADS, EB_LDS_BYTES, stream>>>(a, logits, nblk, ck, part_m, part_z)));
+            if (a.cov) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_big_kernel<KVP_F16, true><<<grid, EB_THREADS, EB_LDS_BYTES, stream>>>(a, logits, nblk, ck, part_m, part_z)));
+            else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_big_kernel<KVP_F16, false><<<grid, EB_THREADS, EB_LDS_BYTES, stream>>>(a, logits, nblk, ck, part_m, part_z)));
         }
         KVP_CHECK_LAUNCH("ea_logits_mfma");
         return KVP_OK;
