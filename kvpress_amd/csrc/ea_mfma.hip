@@ -801,7 +801,9 @@ template <int DK> struct ElGeo {
 };
 template <int DT, int DK, int S_> struct ElSmallFrag { uint4 hi[DK - 2 * S_], lo[DK - 2 * S_]; };
 
-template <int DT, int DK, int S_>
+// BATCH > 0: a scheduling barrier after every BATCH fragments -- the compiler otherwise hoists ALL their loads to the top (16 values per fragment:
+// with the 18 fragments of the D = 256 kernel that is more than the register file, and the f16 build spilled 312 registers at start-up)
+template <int DT, int DK, int S_, int BATCH = 0>
 __device__ __forceinline__ void el_small_build(const float* __restrict__ cov_head, uint32_t n, uint32_t kg, float inv_2d, ElSmallFrag<DT, DK, S_>& f) {
     constexpr int D = DK * 16;
     const uint32_t j = 32 * S_ + n;   // this lane's row of U
@@ -825,6 +827,7 @@ __device__ __forceinline__ void el_small_build(const float* __restrict__ cov_hea
         }
         f.hi[i] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
         f.lo[i] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        if (BATCH > 0 && i % (BATCH > 0 ? BATCH : 1) == (BATCH > 0 ? BATCH : 1) - 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -957,9 +960,10 @@ __global__ __launch_bounds__(EM_THREADS, ElGeo<DK>::OCC) void ea_logits_mfma_sma
 
 // ---- (2d) head size 256 (Gemma; round 6) -------------------------------------------------------------------------------------------
 // Eight strips of U, 16 k-steps: strip s has k-steps 2 s .. 15, i.e. 16 + 14 + ... + 2 = 72 (strip, k-step) products per 32-key sub-tile.
-// Eight waves: wave w holds strips p = w % 4 and 7 - p (18 products: the same for every wave; 144 hi / lo fragment registers) and takes
-// sub-tiles 2 (w / 4) and 2 (w / 4) + 1 of every 128-key tile -- two waves per SIMD with 256 registers each, so one wave's row-dots and LDS
-// waits sit under the other's matrix instructions.  A sub-tile's K fragments are read eight k-steps at a time into ONE register set (k-steps
+// Four waves: wave w holds strips w and 7 - w (18 products: the same for every wave; 144 hi / lo fragment registers) and walks all four
+// sub-tiles of every 128-key tile -- ONE workgroup per CU with the whole register file (launch_bounds(256, 1)): with eight waves of 256
+// registers (two per SIMD, measured the same: 215 against 226 us) the f16 build sat ON the register cliff and spilled 308 of them at any
+// change of its start-up code.  A sub-tile's K fragments are read eight k-steps at a time into ONE register set (k-steps
 // 0 .. 7: only the longer strip has them; 8 .. 15: both strips, one after the other on one accumulator): 144 + 32 + 16 registers + addresses.
 // Every LDS address is a per-lane base computed once + an immediate (sub-tile: 16 KiB, upper half of a row: 256 bytes) -- the first version
 // recomputed them per sub-tile and kept accumulators in AGPRs: 234 VALU instructions per (wave, sub-tile) beside 36 matrix instructions,
@@ -967,7 +971,7 @@ __global__ __launch_bounds__(EM_THREADS, ElGeo<DK>::OCC) void ea_logits_mfma_sma
 // folded by one cross-lane read, the four strip pairs' partials meet in LDS (double-buffered: the fold of tile t runs after the barrier that
 // also publishes tile t + 1).  K rows are 512 bytes: a wave's LDS-DMA request moves two rows, the slots of a row rotate with its low four
 // bits inside each 256-byte half.  (The generic kernel this replaces took 13.6 ms and was refused outright before round 6.)
-constexpr int EB_THREADS = 512;
+constexpr int EB_THREADS = 256;
 constexpr int EB_ROWB = 512;
 constexpr int EB_TILEB = EL_TILE * EB_ROWB;   // 64 KiB
 template <int DT, bool HAS_COV>
@@ -998,17 +1002,17 @@ __global__ __launch_bounds__(EB_THREADS, 1) void ea_logits_mfma_big_kernel(EaArg
     float* lrow = logits + (size_t)bhq * a.Sp;
     float m_run = KVP_NEG_INF, z_run = 0.f;   // threads 0 .. 127: the keys they fold
 
-    // LDS-DMA: request j (0 .. 7) of a tile moves rows 16 j + 2 wv + lane / 32; lane slot p = lane % 32 fetches chunk p ^ (row & 15) (bit 4 of the
-    // chunk -- the 256-byte half -- stays)
+    // LDS-DMA: request j (0 .. 15) of a tile moves rows 8 j + 2 wv + lane / 32; lane slot p = lane % 32 fetches chunk p ^ (row & 15) (bit 4 of the
+    // chunk -- the 256-byte half -- stays): the rows of a request alternate between two swizzle phases (8 j is 0 or 8 mod 16)
     const uint32_t ldsbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const uint32_t rrow = 2 * wv + (lane >> 5);
-    const uint32_t rch = ((lane & 31) ^ (rrow & 15)) << 4;
+    const uint32_t rch0 = ((lane & 31) ^ (rrow & 15)) << 4, rch1 = ((lane & 31) ^ ((rrow + 8) & 15)) << 4;
     auto request_tile = [&](uint32_t row0, uint32_t buf_off) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t r = min(row0 + 16 * j + rrow, a.Sp - 1);   // rows past the end: any valid row (never stored)
-            const char* gp = kb + (int64_t)r * row_bytes + rch;
-            const uint32_t la = __builtin_amdgcn_readfirstlane(ldsbase + buf_off + (16 * j + 2 * wv) * EB_ROWB);
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t r = min(row0 + 8 * j + rrow, a.Sp - 1);   // rows past the end: any valid row (never stored)
+            const char* gp = kb + (int64_t)r * row_bytes + ((j & 1) ? rch1 : rch0);
+            const uint32_t la = __builtin_amdgcn_readfirstlane(ldsbase + buf_off + (8 * j + 2 * wv) * EB_ROWB);
             asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(la), "v"(gp) : "memory");
         }
     };
@@ -1031,21 +1035,19 @@ __global__ __launch_bounds__(EB_THREADS, 1) void ea_logits_mfma_big_kernel(EaArg
         ElSmallFrag<DT, DK, SB> fb;
         if (HAS_COV) {
             const float* cov_head = a.cov + (size_t)bhq * D * D;
-            el_small_build<DT, DK, SA>(cov_head, n, kg, a.inv_2d, fa);
-            el_small_build<DT, DK, SB>(cov_head, n, kg, a.inv_2d, fb);
+            el_small_build<DT, DK, SA, 3>(cov_head, n, kg, a.inv_2d, fa);
+            __builtin_amdgcn_sched_barrier(0);
+            el_small_build<DT, DK, SB, 3>(cov_head, n, kg, a.inv_2d, fb);
         }
-        const uint32_t sub0 = 2 * (wv >> 2);            // this wave's first sub-tile
-        const uint32_t row = sub0 * 32 + n;             // (row & 15 == n & 15 for every sub-tile)
-        // per-lane byte offsets inside a tile buffer, sub-tile sub0: K fragment of k-step ks = fo[ks & 7] + (ks >> 3) * 256; K in the C layout for
-        // strip S, quarter q (dims 32 S + 8 q + 4 kg + {0 .. 3}: 8 bytes of chunk 4 S + q); the second sub-tile is + 16 KiB
-        uint32_t fo[8], koa[4], kob[4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) fo[i] = row * EB_ROWB + (((i * 2 + kg) ^ (n & 15)) << 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            koa[q] = row * EB_ROWB + ((SA * 4 + q) >> 4) * 256 + ((((SA * 4 + q) & 15) ^ (n & 15)) << 4) + kg * 8;
-            kob[q] = row * EB_ROWB + ((SB * 4 + q) >> 4) * 256 + ((((SB * 4 + q) & 15) ^ (n & 15)) << 4) + kg * 8;
-        }
+        const uint32_t row = n;                         // sub-tile 0 (row & 15 == n & 15 for every sub-tile)
+        // per-lane byte offsets inside a tile buffer, sub-tile 0 (sub-tile u is + u * 16 KiB): K fragments; K in the C layout for strip S,
+        // quarter q (dims 32 S + 8 q + 4 kg + {0 .. 3}: 8 bytes of chunk 4 S + q)
+        // (the swizzle is an XOR on bits 4 .. 7 of the offset, which the row, the lane half and the 256-byte half do not touch: chunk c of this lane's
+        //  row is at base ^ (c << 4) -- ONE register per address family instead of a table, the kernel is at the edge of its 256 registers)
+        const uint32_t fbase = row * EB_ROWB + ((kg ^ (n & 15)) << 4);      // fragment of k-step ks: (fbase ^ ((ks & 7) << 5)) + (ks >> 3) * 256
+        const uint32_t kbase = row * EB_ROWB + ((n & 15) << 4) + kg * 8;    // C-layout piece of chunk c: (kbase ^ ((c & 15) << 4)) + (c >> 4) * 256
+        auto fo = [&](int i) { return fbase ^ (uint32_t)(i << 5); };
+        auto ko = [&](int c) { return (kbase ^ (uint32_t)((c & 15) << 4)) + (uint32_t)((c >> 4) * 256); };
         auto acc_init = [&](int strip, f32x16& acc) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1071,30 +1073,30 @@ __global__ __launch_bounds__(EB_THREADS, 1) void ea_logits_mfma_big_kernel(EaArg
         for (uint32_t t = 0; t < ntiles; ++t) {
             if (t + 1 < ntiles) request_tile(kbeg + (t + 1) * EL_TILE, (uint32_t)(bufn - lds));   // into the buffer tile t - 1 left at the last barrier
 #pragma unroll 1
-            for (int u = 0; u < 2; ++u) {   // the wave's two sub-tiles (not unrolled: interleaving them doubles the live fragments -> spills)
+            for (int u = 0; u < EL_SUBS; ++u) {   // the tile's four sub-tiles (not unrolled)
                 const unsigned char* tb = bufc + u * 16384;
                 uint4 kf[8];
                 uint2 kka[4], kkb[4];
                 f32x16 acc;
                 acc_init(SA, acc);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) kka[q] = *reinterpret_cast<const uint2*>(tb + koa[q]);
+                for (int q = 0; q < 4; ++q) kka[q] = *reinterpret_cast<const uint2*>(tb + ko(SA * 4 + q));
                 if (HAS_COV) {
 #pragma unroll
-                    for (int ks = 2 * SA; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(tb + fo[ks]);
+                    for (int ks = 2 * SA; ks < 8; ++ks) kf[ks] = *reinterpret_cast<const uint4*>(tb + fo(ks));
 #pragma unroll
                     for (int ks = 2 * SA; ks < 8; ++ks) acc = mma32<DT>(fa.hi[ks - 2 * SA], kf[ks], acc);
 #pragma unroll
                     for (int ks = 2 * SA; ks < 8; ++ks) acc = mma32<DT>(fa.lo[ks - 2 * SA], kf[ks], acc);
 #pragma unroll
-                    for (int ks = 8; ks < 16; ++ks) kf[ks - 8] = *reinterpret_cast<const uint4*>(tb + fo[ks - 8] + 256);
+                    for (int ks = 8; ks < 16; ++ks) kf[ks - 8] = *reinterpret_cast<const uint4*>(tb + fo(ks - 8) + 256);
 #pragma unroll
                     for (int ks = 8; ks < 16; ++ks) acc = mma32<DT>(fa.hi[ks - 2 * SA], kf[ks - 8], acc);
 #pragma unroll
                     for (int ks = 8; ks < 16; ++ks) acc = mma32<DT>(fa.lo[ks - 2 * SA], kf[ks - 8], acc);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) kkb[q] = *reinterpret_cast<const uint2*>(tb + kob[q]);
+                for (int q = 0; q < 4; ++q) kkb[q] = *reinterpret_cast<const uint2*>(tb + ko(SB * 4 + q));
                 float v = rowdot(kka, acc);
                 acc_init(SB, acc);
                 if (HAS_COV) {
@@ -1105,7 +1107,7 @@ __global__ __launch_bounds__(EB_THREADS, 1) void ea_logits_mfma_big_kernel(EaArg
                 }
                 v += rowdot(kkb, acc);
                 v += __shfl_xor(v, 32);   // the two lane halves hold the two halves of a strip's dims
-                if (kg == 0) red[t & 1][wv & 3][row + u * 32] = v;
+                if (kg == 0) red[t & 1][wv][row + u * 32] = v;
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): tile t + 1 has landed (this wave's part; the barrier covers the others)
             __syncthreads();
@@ -1113,7 +1115,7 @@ __global__ __launch_bounds__(EB_THREADS, 1) void ea_logits_mfma_big_kernel(EaArg
             fold(t);
         }
     };
-    switch (wv & 3) {
+    switch (wv) {
         case 0: walk(std::integral_constant<int, 0>{}); break;
         case 1: walk(std::integral_constant<int, 1>{}); break;
         case 2: walk(std::integral_constant<int, 2>{}); break;
