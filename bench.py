@@ -746,6 +746,12 @@ def main():
         # sharding, barrier-bracketed timing, MAX over ranks -- can run on a one-GPU box.  Never set it for a measurement.
         share = os.environ.get("KVP_BENCH_SHARE_GPU") == "1"
         assert not (share and args.backend == "nccl"), "KVP_BENCH_SHARE_GPU needs --backend gloo (RCCL refuses two ranks on one GPU)"
+        if share:
+            # Two PROCESSES on one GPU break the one-launch select's contract (Concurrency: one cluster select in flight per device):
+            # launched at the same moment, each can hold CUs the other's rows wait for -- a circular wait that ends in the bounded time-out
+            # and a loud KVP_EASYNC (seen once in round 6: profiles/r06_gpu_tests_shared_gpu_timeout.txt).  The shared-GPU test mode therefore
+            # runs the multi-launch select, as a deployment that shares a GPU between processes should.
+            os.environ["KVP_TK_CLUSTER"] = "0"
         dev_index = 0 if share else local_rank
         assert torch.cuda.device_count() > dev_index, f"rank {rank}: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible on this node"
         device = torch.device("cuda", dev_index)

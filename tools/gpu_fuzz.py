@@ -42,7 +42,7 @@ def main():
         S = int(rs.choice([rs.randint(70, 600), rs.randint(4096, 4400), rs.randint(4500, 12000), rs.randint(12000, 16500)]))
         if it % 8 == 7:   # round 6: long rows x many heads -- ExpectedAttention's logits take chunks of 8192 keys (more than 512 workgroups of 4096)
             B, Hkv, G, S = 1, 8, 4, int(rs.randint(66000, 80000))
-        D = 128
+        D = 128 if it % 8 == 7 else int(rs.choice([128, 128, 64, 96, 256]))   # round 6: ExpectedAttention's matrix-core paths for the other head sizes
         n_sink = int(rs.choice([0, 1, 4, 7]))
         kn = _inputs.round_to((rs.standard_normal((B, Hkv, S, D)) * rs.choice([0.3, 1.0, 2.0])).astype(np.float32), dtype)
         vn = _inputs.round_to(rs.standard_normal((B, Hkv, S, D)).astype(np.float32), dtype)
@@ -52,7 +52,7 @@ def main():
             v = torch.from_numpy(vn).to(DEV).to(dt).transpose(1, 2).contiguous().transpose(1, 2)
         else:
             k, v = torch.from_numpy(kn).to(DEV).to(dt), torch.from_numpy(vn).to(DEV).to(dt)
-        msg = [f"round {it}: {dtype} B={B} Hkv={Hkv} G={G} S={S} sinks={n_sink} strided={strided}"]
+        msg = [f"round {it}: {dtype} B={B} Hkv={Hkv} G={G} S={S} D={D} sinks={n_sink} strided={strided}"]
         # row norms, KeyDiff, CUR
         e = rel(N.rownorm_score(k, -1.0).cpu().numpy(), O.knorm_score(kn))
         assert e <= 1e-5, ("rownorm", e)
@@ -80,6 +80,17 @@ def main():
             if n_sink:
                 assert np.array_equal(got[..., :n_sink], np.broadcast_to(got[..., n_sink:].max() + np.float32(1.0), got[..., :n_sink].shape))
             msg.append(f"ea[cov={use_cov},vnorm={use_vn}] {e:.1e}")
+        # query statistics (the matrix-core paths start at 4096 rows: pairs of heads / zero-padded heads / quarters for the head sizes off 128)
+        Hq_s = Hkv * G
+        if 4096 <= S and B * Hq_s * S * D * D <= 1.2e10:
+            qn = _inputs.round_to((rs.standard_normal((B, Hq_s, S, D)) * np.exp(0.4 * rs.standard_normal((1, Hq_s, 1, D))) + rs.standard_normal((1, Hq_s, 1, D))).astype(np.float32), dtype)
+            mu_w, cov_w = O.ea_query_stats(qn, True)
+            qt = torch.from_numpy(np.ascontiguousarray(qn.transpose(0, 2, 1, 3))).to(DEV).to(dt).transpose(1, 2) if rs.randint(3) else torch.from_numpy(qn).to(DEV).to(dt)
+            mu_g, cov_g = N.ea_qstats(qt, True)
+            dd = np.sqrt(np.einsum("bhii->bhi", cov_w))
+            e = float(np.max(np.abs(cov_g.cpu().numpy() - cov_w) / (dd[..., :, None] * dd[..., None, :])))
+            assert e <= 1e-3 and np.abs(mu_g.cpu().numpy() - mu_w).max() <= 1e-5 * np.abs(mu_w).max() + 1e-6, ("ea_qstats", e)
+            msg.append(f"qstats {e:.1e}")
         # gather + re-rotation in one pass == the oracle's gather then rerotate
         n = int(rs.randint(1, S + 1))
         pos = np.stack([np.sort(rs.choice(S, n, replace=False)) for _ in range(B * Hkv)]).reshape(B, Hkv, n).astype(np.int32)
