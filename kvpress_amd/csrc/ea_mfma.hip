@@ -569,48 +569,9 @@ __device__ __forceinline__ void el_tri_build(const float* __restrict__ cov_head,
         __builtin_amdgcn_sched_group_barrier(0x100, (4 + (nmfma) - (nmfma) / 2 - 1) / ((nmfma) - (nmfma) / 2), 0); \
     }
 
-// Round 6: the fragments of U depend on the HEAD only, yet every workgroup of a head (16 .. 32 key chunks) rebuilt its waves' 20 hi / lo pairs
-// from float32 Sigma -- strided reads of both triangles + ~70 VALU instructions per fragment: ~3000 per wave, a fifth of the kernel's vector
-// work on a SIMD where vector and matrix instructions do not overlap (LAB R6.5).  ea_tri_pack_kernel builds them ONCE per head (the two wave
-// types: strips (0, 3) and (1, 2)) into the score workspace, in the register layout; the PACKED kernel loads them with 20 coalesced 16-byte
-// reads per lane.  The same instructions on the same values: the same bits.  Used when a head has >= 4 key chunks.
-constexpr int EL_PACK_U4 = 20;   // uint4 per lane and wave type: fa.hi[NA], fa.lo[NA], fb.hi[NB], fb.lo[NB] (8 + 8 + 2 + 2 = 6 + 6 + 4 + 4)
-// one wave per (head, wave type, fragment): 640 short waves for 32 heads (a first version with one wave per (head, type) walked its 10
-// fragments' strided loads one after the other: 12 us under events where this one takes 2-3)
 template <int DT>
-__global__ __launch_bounds__(64) void ea_tri_pack_kernel(EaArgs a, uint4* __restrict__ pack) {
-    const uint32_t bhq = blockIdx.x, type = blockIdx.y / 10, task = blockIdx.y % 10, lane = threadIdx.x;
-    const uint32_t n = lane & 31, kg = lane >> 5;
-    const uint32_t SA = type, SB = 3 - type, NA = 8 - 2 * SA, NB = 8 - 2 * SB;   // wave types: strips (0, 3) and (1, 2)
-    const bool first = task < NA;
-    const uint32_t S = first ? SA : SB, i = first ? task : task - NA;
-    const uint32_t slot_hi = first ? i : 2 * NA + i, slot_lo = first ? NA + i : 2 * NA + NB + i;
-    // el_tri_build's loop body for (strip S, fragment i): the same operations in the same order -> the same bits
-    const float* cov_head = a.cov + (size_t)bhq * 128 * 128;
-    const uint32_t j = 32 * S + n, ks = 2 * S + i;
-    const float* crow = cov_head + (size_t)j * 128 + ks * 16 + kg * 8;
-    const float4 u = *reinterpret_cast<const float4*>(crow), w = *reinterpret_cast<const float4*>(crow + 4);
-    float x[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const uint32_t c = ks * 16 + kg * 8 + e;
-        const float tt = cov_head[(size_t)c * 128 + j];
-        x[e] = (c > j ? x[e] + tt : (c == j ? x[e] : 0.f)) * a.inv_2d;
-    }
-    uint32_t hw[4], lw[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        hw[p] = pack2<DT>(x[2 * p], x[2 * p + 1]);
-        lw[p] = pack2<DT>(x[2 * p] - lo16<DT>(hw[p]), x[2 * p + 1] - hi16<DT>(hw[p]));
-    }
-    uint4* out = pack + ((size_t)bhq * 2 + type) * EL_PACK_U4 * 64 + lane;
-    out[(size_t)slot_hi * 64] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-    out[(size_t)slot_lo * 64] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-}
-
-template <int DT, bool PACKED>
 __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_tri_kernel(EaArgs a, float* __restrict__ logits, uint32_t nblk, uint32_t chunk_keys,
-                                                                       float* __restrict__ part_m, float* __restrict__ part_z, const uint4* __restrict__ pack) {
+                                                                       float* __restrict__ part_m, float* __restrict__ part_z) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * EL_TILEB];
     __shared__ float red[3][8][EL_TILE];
     __shared__ __attribute__((aligned(16))) float mus[128];
@@ -685,17 +646,9 @@ __global__ __launch_bounds__(EM_THREADS, 2) void ea_logits_mfma_tri_kernel(EaArg
         constexpr int NA = 8 - 2 * SA, NB = 8 - 2 * SB, KS0 = 2 * (SA < SB ? SA : SB);
         ElTriFrag<DT, SA> fa;
         ElTriFrag<DT, SB> fb;
-        if (PACKED) {   // built once per head by ea_tri_pack_kernel, in this layout
-            const uint4* src = pack + ((size_t)bhq * 2 + (wv >> 1)) * EL_PACK_U4 * 64 + lane;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) { fa.hi[i] = src[(size_t)i * 64]; fa.lo[i] = src[(size_t)(NA + i) * 64]; }
-#pragma unroll
-            for (int i = 0; i < NB; ++i) { fb.hi[i] = src[(size_t)(2 * NA + i) * 64]; fb.lo[i] = src[(size_t)(2 * NA + NB + i) * 64]; }
-        } else {
-            const float* cov_head = a.cov + (size_t)bhq * 128 * 128;
-            el_tri_build<DT, SA>(cov_head, n, kg, a.inv_2d, fa);
-            el_tri_build<DT, SB>(cov_head, n, kg, a.inv_2d, fb);
-        }
+        const float* cov_head = a.cov + (size_t)bhq * 128 * 128;
+        el_tri_build<DT, SA>(cov_head, n, kg, a.inv_2d, fa);
+        el_tri_build<DT, SB>(cov_head, n, kg, a.inv_2d, fb);
         const uint32_t sa = 2 * (wv & 1), sb = sa + 1;
         auto frags = [&](const unsigned char* buf, uint32_t sub, uint4 (&kf)[8]) {
 #pragma unroll
@@ -1245,7 +1198,7 @@ bool ea_mfma_logits_eligible(const EaArgs& a, int dtype) {
     return (dtype == KVP_BF16 || dtype == KVP_F16) && (a.D == 128 || a.D == 64 || a.D == 96 || a.D == 256) && a.Sp >= 64 && (uintptr_t)a.k % 16 == 0 && aligned8(a.k_sb) &&
            aligned8(a.k_sh) && aligned8(a.k_ss) && a.G <= 65535;
 }
-size_t ea_mfma_logits_scratch_bytes(int64_t B, int64_t Hq, int64_t D) { return D == 128 ? (size_t)B * Hq * 2 * EL_PACK_U4 * 64 * 16 : 0; }   // ea_tri_pack_kernel's fragments
+size_t ea_mfma_logits_scratch_bytes(int64_t, int64_t, int64_t) { return 0; }
 // Keys per workgroup: 4096, doubled while the grid exceeds ONE resident round (two 4-wave workgroups per CU).  A workgroup's start-up
 // -- every wave packs its strips of the covariance into hi / lo MFMA fragments: ~3000 VALU instructions -- was a third of the
 // kernel's VALU work at 32 tiles per workgroup (10 432 instructions per wave against 204 per tile in the loop: round 6), and on this
@@ -1275,7 +1228,7 @@ static uint32_t ea_mfma_logits_chunk(const EaArgs& a) {
 }
 uint32_t ea_mfma_logits_nblk(const EaArgs& a) { const uint32_t c = ea_mfma_logits_chunk(a); return (a.Sp + c - 1) / c; }
 
-int ea_mfma_logits(const EaArgs& a, int dtype, float* logits, uint32_t nblk, float* part_m, float* part_z, void* scratch, hipStream_t stream) {
+int ea_mfma_logits(const EaArgs& a, int dtype, float* logits, uint32_t nblk, float* part_m, float* part_z, void*, hipStream_t stream) {
     const uint32_t ck = ea_mfma_logits_chunk(a);
     KVP_CHECK_ARG(nblk == (a.Sp + ck - 1) / ck, "ea_logits_mfma: nblk %u does not match the chunk plan", nblk);
     const uint64_t units = (uint64_t)nblk * a.B * a.Hkv;
@@ -1312,17 +1265,8 @@ int ea_mfma_logits(const EaArgs& a, int dtype, float* logits, uint32_t nblk, flo
         return KVP_OK;
     }
     if (a.cov) {   // the quadratic form on the doubled upper triangle of the covariance (2b): exact for any matrix, 40 instead of 64 MFMAs per tile and wave
-        // >= 4 key chunks per head: the fragments are built once per head (A/B on one box, profiles/r06_ab_ea_pack.txt: logits 192.2 -> 183.4 us under
-        // events, + 1.5-2 us of pack kernel, step -5 us); fewer chunks: every workgroup builds its own, no extra launch
-        const bool packed = scratch && nblk >= 4 && ((uintptr_t)scratch % 16) == 0;
-        uint4* pack = static_cast<uint4*>(scratch);
-        if (packed) {
-            if (dtype == KVP_BF16) KVP_LAUNCH("ea_tri_pack", stream, (ea_tri_pack_kernel<KVP_BF16><<<dim3(a.B * a.Hq, 20), 64, 0, stream>>>(a, pack)));
-            else KVP_LAUNCH("ea_tri_pack", stream, (ea_tri_pack_kernel<KVP_F16><<<dim3(a.B * a.Hq, 20), 64, 0, stream>>>(a, pack)));
-            if (dtype == KVP_BF16) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_BF16, true><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z, pack)));
-            else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_F16, true><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z, pack)));
-        } else if (dtype == KVP_BF16) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_BF16, false><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z, nullptr)));
-        else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_F16, false><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z, nullptr)));
+        if (dtype == KVP_BF16) KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_BF16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z)));
+        else KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_tri_kernel<KVP_F16><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z)));
     } else if (dtype == KVP_BF16) {   // use_covariance = False: the mean term only
         KVP_LAUNCH("ea_logits_mfma", stream, (ea_logits_mfma_kernel<KVP_BF16, false><<<grid, EM_THREADS, 0, stream>>>(a, logits, nblk, ck, part_m, part_z)));
     } else {
