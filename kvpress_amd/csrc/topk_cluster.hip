@@ -44,6 +44,7 @@
 // HIST1: the kernel that wrote the scores already accumulated the first digit's histogram (topk_internal.h): the first
 // step and its barrier are skipped.
 #include "kvp_common.h"
+#include <mutex>
 #include "topk_block.h"
 #include "topk_internal.h"
 
@@ -835,9 +836,56 @@ __global__ __launch_bounds__(TR_THREADS) void topk_cluster_kernel(ClusterArgs a)
     }
 }
 
+// ONE cluster select in flight per device (round 6, LAB R6.12).  Two of them dispatched at the same moment from different queues can each be handed
+// the CUs the other's rows wait for (a row's 32 workgroups sit on four CUs of every XCD; the XCDs' dispatchers pick queues independently): a circular
+// wait that only the time-out ends.  Within a process the library keeps the contract itself: a cluster launch on a stream OTHER than the previous
+// one's first waits (hipStreamWaitEvent: on the device, no host sync) for an event recorded after that previous launch.  A process that only ever
+// uses one stream -- the reference's hook -- pays a mutex and a pointer compare: no event is created, recorded or waited for.  Streams under graph
+// capture are left alone.  Across PROCESSES sharing a GPU nothing here helps: KVP_TK_CLUSTER=0.
+struct ClusterStreamGuard {
+    std::mutex mu;
+    hipStream_t last = nullptr;
+    hipEvent_t ev = nullptr;
+    bool have = false, multi = false;
+};
+ClusterStreamGuard g_cluster_guard[64];
+
+struct ClusterLaunchScope {   // held across the launch: enter (wait if the stream changed) .. leave (record once a second stream has been seen)
+    ClusterStreamGuard* g = nullptr;
+    hipStream_t s;
+    bool track = false;
+    explicit ClusterLaunchScope(hipStream_t stream) : s(stream) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+        g = &g_cluster_guard[dev];
+        g->mu.lock();
+        track = true;
+        if (g->have && g->last != s) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); track = false; return; }
+            if (!g->ev && hipEventCreateWithFlags(&g->ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); g->ev = nullptr; return; }
+            if (!g->multi) {   // first change of stream: nothing was recorded after the previous launch yet -- record behind everything enqueued on its stream so far
+                g->multi = true;
+                if (hipEventRecord(g->ev, g->last) != hipSuccess) { (void)hipGetLastError(); return; }   // (a destroyed stream: nothing left to wait for)
+            }
+            if (hipStreamWaitEvent(s, g->ev, 0) != hipSuccess) (void)hipGetLastError();
+        }
+    }
+    ~ClusterLaunchScope() {
+        if (!g) return;
+        if (track) {
+            if (g->multi && g->ev && hipEventRecord(g->ev, s) != hipSuccess) (void)hipGetLastError();
+            g->last = s;
+            g->have = true;
+        }
+        g->mu.unlock();
+    }
+};
+
 template <int PER, int MODE, bool HIST1>
 int launch_one(const ClusterArgs& a, hipStream_t stream) {
     if (!topk_cluster_launchable()) return 1;
+    ClusterLaunchScope scope(stream);
     ClusterArgs b = a;
     b.host_flag = kvp_async_flag();
     b.timeout_ticks = (uint32_t)std::min<int64_t>(std::max<int64_t>(kvp_env_int("KVP_TC_TIMEOUT_US", 1000000), 100), 20000000) * 100u;

@@ -52,6 +52,48 @@ def test_select_waits_for_cus_held_by_another_stream():
         assert np.array_equal(got.cpu().numpy(), want), f"rep {rep}"
 
 
+def test_cluster_selects_on_two_streams_of_one_process():
+    """Round 6 (LAB R6.12): two cluster selects dispatched at the same moment from different queues can deadlock each other until the
+    time-out (each holds CUs the other's rows wait for).  Within a process the library serialises them itself: a cluster launch on a
+    stream other than the previous one's waits on the device for that previous launch.  300 un-synchronised pairs on two streams -- plain
+    select, fused Knorm compress -- must all be right and leave no asynchronous failure; a third stream joins later."""
+    n = native()
+    a, b = _scores(seed=1), _scores(seed=2)
+    want_a, want_b = O.topk_select(a.numpy(), 65472), O.topk_select(b.numpy(), 30000)
+    da, db = a.to(DEV), b.to(DEV)
+    g = torch.Generator(device=DEV); g.manual_seed(3)
+    k = torch.randn((1, 8, 32768, 128), generator=g, device=DEV).to(torch.bfloat16)
+    v = torch.randn((1, 8, 32768, 128), generator=g, device=DEV).to(torch.bfloat16)
+    ko_ref, vo_ref = n.knorm_compress(k, v, 16384)
+    sa, sb, sc = (torch.cuda.Stream(device=DEV) for _ in range(3))
+    torch.cuda.synchronize()
+    got = []
+    for it in range(300):
+        with torch.cuda.stream(sa):
+            ga = n.topk_select(da, 65472)
+        with torch.cuda.stream(sb):
+            gb = n.topk_select(db, 30000) if it % 3 else None
+            kc = n.knorm_compress(k, v, 16384) if it % 3 == 0 else None
+        if it >= 150 and it % 5 == 0:
+            with torch.cuda.stream(sc):
+                got.append(("c", n.topk_select(db, 30000)))
+        if it % 25 == 0:
+            got.append(("a", ga))
+            if gb is not None:
+                got.append(("b", gb))
+            if kc is not None:
+                got.append(("k", kc))
+    torch.cuda.synchronize()
+    n.async_error_check()
+    for tag, x in got:
+        if tag == "a":
+            assert np.array_equal(x.cpu().numpy(), want_a)
+        elif tag in ("b", "c"):
+            assert np.array_equal(x.cpu().numpy(), want_b)
+        else:
+            assert torch.equal(x[0], ko_ref) and torch.equal(x[1], vo_ref)
+
+
 _CHILD = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, {root!r})
