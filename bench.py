@@ -644,6 +644,29 @@ def cpu_baseline(workload, press, att, rot, hidden, keys, values, kwargs, n_kept
             if dt == torch.float32 and restated:
                 sc32 = TP.SCORERS[kind](m, h, k, v, kw).numpy()
             del h, k, v, ko, vo
+    # SURVEY section 8(d)'s third column: the SAME reference code (pure PyTorch-ROCm, bf16) on this GPU -- what a user of NVIDIA/kvpress gets on an
+    # MI355X without this library.  1 warm-up + 3 runs, median, device-synchronised wall clock.
+    ref_gpu_ms = None
+    if ref is not None and hidden.is_cuda:
+        try:
+            with torch.no_grad():
+                ref_press = make_press(kind, ratio, ref)
+                if getattr(att, "rotary_emb", None) is None:
+                    att.rotary_emb = rot
+                tg = []
+                for i in range(4):
+                    torch.cuda.synchronize(hidden.device)
+                    t0 = time.perf_counter()
+                    ko, vo = ref_press.compress(att, hidden, keys, values, None, kwargs)
+                    torch.cuda.synchronize(hidden.device)
+                    if i:
+                        tg.append(time.perf_counter() - t0)
+                    assert tuple(ko.shape) == (keys.shape[0], H_KV, n_kept, D)
+                    del ko, vo
+                ref_gpu_ms = round(sorted(tg)[len(tg) // 2] * 1e3, 3)
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001 -- context only: never take the line down
+            print(f"[bench] the reference on the GPU failed ({e!r}): field omitted", file=sys.stderr)
     ok = None
     if sc32 is not None:   # GPU retained set vs the float32 CPU scores (tie-tolerant, 1e-3 band)
         gsc = press.score(att, hidden, keys, values, None, kwargs)
@@ -669,6 +692,7 @@ def cpu_baseline(workload, press, att, rot, hidden, keys, values, kwargs, n_kept
                       f"tok/s extrapolates one layer x {LAYERS}",
             "ms_per_layer": round(t * 1e3, 1), "ms_per_layer_fp32": round(res[torch.float32] * 1e3, 1),
             "restatement_bit_identical_to_reference": identical,
+            "reference_on_this_gpu_ms_per_layer": ref_gpu_ms,
             "numpy_port_ms_per_layer": port_ms, "gpu_topk_valid_vs_cpu_fp32_scores": ok}
 
 
